@@ -1,0 +1,19 @@
+"""lightgbm_amd: an MI355X-native gradient-boosted decision tree framework.
+
+LightGBM-style leaf-wise histogram boosting and random-forest mode with
+``Dataset`` / ``train`` / ``cv`` / ``predict`` entry points, early-stopped k-fold
+CV, a resumable parameter-grid CV search, and the LightGBM text model format.
+The compute path is hand-written HIP for gfx950 (``csrc/hip``) driven by a C++
+core; a same-numerics OpenMP engine serves CPU runs and as the test oracle.
+"""
+from .basic import Booster, Dataset, LightGBMError, default_device, params_to_string, resolve_alias
+from .callback import EarlyStopException, early_stopping, log_evaluation, print_evaluation, record_evaluation, reset_parameter
+from .engine import CVBooster, cv, make_folds, train
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "Dataset", "Booster", "CVBooster", "LightGBMError", "train", "cv", "make_folds",
+    "early_stopping", "log_evaluation", "print_evaluation", "record_evaluation", "reset_parameter",
+    "EarlyStopException", "default_device", "params_to_string", "resolve_alias",
+]

@@ -1,0 +1,676 @@
+"""Dataset and Booster: the Python face of the native core.
+
+Mirrors the calls the reference scripts make through the R binding -
+``lgb.Dataset(matrix, label=)`` (r/gridsearchCV.R:52-53), ``predict(booster,
+matrix)`` (r/gridsearchCV.R:63) and staged prediction with the first k trees
+(bagging_boosting.ipynb:136, ``ntree_limit``) - with LightGBM's Python names.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import warnings
+from typing import Any, Callable, Dict, Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import LightGBMError, c_str, check
+
+__all__ = ["Dataset", "Booster", "LightGBMError", "params_to_string", "resolve_alias", "default_device"]
+
+
+# ----------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------
+def _fmt_value(v: Any) -> str:
+    if isinstance(v, bool) or isinstance(v, np.bool_):
+        return "true" if v else "false"
+    if isinstance(v, (list, tuple, set)):
+        return ",".join(_fmt_value(x) for x in v)
+    if isinstance(v, (float, np.floating)):
+        return repr(float(v))
+    if isinstance(v, (int, np.integer)):
+        return str(int(v))
+    if v is None:
+        return ""
+    return str(v)
+
+
+def params_to_string(params: Optional[Dict[str, Any]]) -> str:
+    """``{"a": 1, "b": [1, 2]}`` -> ``"a=1 b=1,2"``; ``None`` values are dropped."""
+    if not params:
+        return ""
+    toks = []
+    for k, v in params.items():
+        if v is None or callable(v):
+            continue
+        s = _fmt_value(v)
+        if s == "" or any(ch.isspace() for ch in s):
+            if k in ("output_model", "input_model"):
+                continue
+            s = s.replace(" ", "")
+            if s == "":
+                continue
+        toks.append(f"{k}={s}")
+    return " ".join(toks)
+
+
+_alias_cache: Optional[Dict[str, str]] = None
+
+
+def _alias_map() -> Dict[str, str]:
+    global _alias_cache
+    if _alias_cache is None:
+        lib, _ = _lib.load()
+        table = json.loads(lib.lga_alias_table_json().decode())
+        m = {}
+        for canon, aliases in table.items():
+            m[canon] = canon
+            for a in aliases:
+                m[a] = canon
+        _alias_cache = m
+    return _alias_cache
+
+
+def resolve_alias(name: str) -> Optional[str]:
+    """Canonical parameter name for ``name`` or ``None`` when unknown."""
+    return _alias_map().get(name)
+
+
+def pop_param(params: Dict[str, Any], canonical: str, default: Any = None) -> Any:
+    """Removes every alias of ``canonical`` from ``params``; returns the value (canonical name wins)."""
+    found = default
+    seen = False
+    for k in list(params.keys()):
+        if resolve_alias(k) == canonical:
+            v = params.pop(k)
+            if k == canonical or not seen:
+                found = v
+            seen = True
+    return found
+
+
+def get_param(params: Dict[str, Any], canonical: str, default: Any = None) -> Any:
+    for k, v in params.items():
+        if k == canonical:
+            return v
+    for k, v in params.items():
+        if resolve_alias(k) == canonical:
+            return v
+    return default
+
+
+def default_device() -> str:
+    """``"gpu"`` when the HIP core is loaded (a GPU is visible), else ``"cpu"``."""
+    return "gpu" if _lib.is_hip() else "cpu"
+
+
+def _with_device(params: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+    p = dict(params or {})
+    if get_param(p, "device_type") is None:
+        p["device_type"] = default_device()
+    return p
+
+
+def _warn_unknown(params: Dict[str, Any]):
+    unknown = [k for k in params if resolve_alias(k) is None and not callable(params[k])]
+    if unknown:
+        warnings.warn("Unknown parameter(s) ignored: " + ", ".join(sorted(unknown)), stacklevel=3)
+
+
+# ----------------------------------------------------------------------------
+# data conversion
+# ----------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+def _to_matrix(data) -> Tuple[Any, List[str] | None]:
+    """Returns (2-D float32/float64 C- or F-contiguous ndarray | cuda tensor, column names or None)."""
+    names = None
+    if _is_torch(data):
+        import torch
+        if data.dim() != 2:
+            raise ValueError("data must be 2-dimensional")
+        if data.is_cuda:
+            if data.dtype not in (torch.float32, torch.float64):
+                data = data.float()
+            return data.contiguous(), None
+        data = data.detach().numpy()
+    if hasattr(data, "columns") and hasattr(data, "values"):   # pandas
+        names = [str(c) for c in data.columns]
+        data = data.values
+    if hasattr(data, "toarray") and not isinstance(data, np.ndarray):  # scipy sparse
+        data = data.toarray()
+    arr = np.asarray(data)
+    if arr.ndim == 1:
+        arr = arr.reshape(-1, 1)
+    if arr.ndim != 2:
+        raise ValueError("data must be 2-dimensional")
+    if arr.dtype not in (np.float32, np.float64):
+        arr = arr.astype(np.float64)
+    if not (arr.flags["C_CONTIGUOUS"] or arr.flags["F_CONTIGUOUS"]):
+        arr = np.ascontiguousarray(arr)
+    return arr, names
+
+
+def _to_1d(x, dtype) -> np.ndarray:
+    if _is_torch(x):
+        x = x.detach().cpu().numpy()
+    if hasattr(x, "values") and not isinstance(x, np.ndarray):
+        x = x.values
+    return np.ascontiguousarray(np.asarray(x).reshape(-1), dtype=dtype)
+
+
+def _mat_args(arr: np.ndarray):
+    dtype = 0 if arr.dtype == np.float32 else 1
+    row_major = 1 if arr.flags["C_CONTIGUOUS"] else 0
+    return arr.ctypes.data_as(ctypes.c_void_p), dtype, arr.shape[0], arr.shape[1], row_major
+
+
+# ----------------------------------------------------------------------------
+# Dataset
+# ----------------------------------------------------------------------------
+class Dataset:
+    """Binned training / validation data.
+
+    Construction is lazy like upstream: the matrix is binned at the first
+    ``construct()`` (called by ``train``/``cv``/``Booster``).  ``reference``
+    makes validation data share the training data's bin boundaries;
+    ``subset`` creates zero-copy row subsets (CV folds).
+    """
+
+    def __init__(self, data, label=None, reference: Optional["Dataset"] = None, weight=None, init_score=None,
+                 feature_name: Union[str, Sequence[str]] = "auto", params: Optional[Dict[str, Any]] = None,
+                 free_raw_data: bool = True):
+        self.data = data
+        self.label = label
+        self.reference = reference
+        self.weight = weight
+        self.init_score = init_score
+        self.feature_name = feature_name
+        self.params = dict(params or {})
+        self.free_raw_data = free_raw_data
+        self._handle: Optional[ctypes.c_void_p] = None
+        self._parent: Optional["Dataset"] = None
+        self._used_indices: Optional[np.ndarray] = None
+        self._predictor = None
+
+    # -- construction --
+    def construct(self) -> "Dataset":
+        if self._handle is not None:
+            return self
+        lib, hip = _lib.load()
+        if self._parent is not None:
+            self._parent.construct()
+            idx = np.ascontiguousarray(self._used_indices, dtype=np.int32)
+            h = ctypes.c_void_p()
+            check(lib.lga_dataset_subset(self._parent._handle, idx.ctypes.data_as(ctypes.c_void_p), len(idx),
+                                         ctypes.byref(h)))
+            self._handle = h
+            self._set_fields()
+            return self
+        if self.data is None:
+            raise LightGBMError("Cannot construct a Dataset whose raw data was freed")
+        mat, names = _to_matrix(self.data)
+        params = _with_device(self.params)
+        if self.reference is not None:
+            self.reference.construct()
+            # bin settings come from the reference
+        _warn_unknown(params)
+        pstr = params_to_string(params)
+        on_gpu = hip and get_param(params, "device_type") in ("gpu", "hip", "cuda", "rocm")
+        ref_h = self.reference._root_handle() if self.reference is not None else None
+        h = ctypes.c_void_p()
+        if _is_torch(mat):
+            if not hip:
+                mat = mat.cpu().numpy()
+            else:
+                from . import _device
+                _device.sync_stream(lib)
+                dtype = 0 if str(mat.dtype).endswith("float32") else 1
+                check(lib.lga_hip_dataset_from_device_mat(ctypes.c_void_p(mat.data_ptr()), dtype, mat.shape[0],
+                                                          mat.shape[1], c_str(pstr), ref_h, ctypes.byref(h)))
+                import torch
+                torch.cuda.synchronize()
+        if h.value is None:
+            ptr, dtype, nrow, ncol, rm = _mat_args(mat)
+            check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), ref_h, 0 if on_gpu else 1,
+                                           ctypes.byref(h)))
+            if on_gpu:
+                from . import _device
+                _device.sync_stream(lib)
+                check(lib.lga_hip_dataset_upload_raw(h, ptr, dtype, nrow, ncol, rm))
+        self._handle = h
+        self._num_total_features = mat.shape[1]
+        if isinstance(self.feature_name, (list, tuple)):
+            names = [str(n) for n in self.feature_name]
+        if names is not None and self.reference is None:
+            if len(names) != mat.shape[1]:
+                raise LightGBMError("Length of feature_name does not match the number of columns")
+            clean = [n.replace(" ", "_") for n in names]
+            check(lib.lga_dataset_set_feature_names(self._handle, c_str("\n".join(clean))))
+        self._set_fields()
+        if self.free_raw_data:
+            self.data = None
+        return self
+
+    def _root_handle(self):
+        self.construct()
+        return self._handle
+
+    def _set_fields(self):
+        if self.label is not None:
+            self.set_label(self.label)
+        if self.weight is not None:
+            self.set_weight(self.weight)
+        if self.init_score is not None:
+            self.set_init_score(self.init_score)
+
+    def _set_field(self, name: str, values, dtype):
+        lib, _ = _lib.load()
+        if values is None:
+            check(lib.lga_dataset_set_field(self._handle, c_str(name), None, 0, 1))
+            return
+        arr = _to_1d(values, dtype)
+        check(lib.lga_dataset_set_field(self._handle, c_str(name), arr.ctypes.data_as(ctypes.c_void_p), len(arr),
+                                        0 if dtype == np.float32 else 1))
+
+    def set_label(self, label) -> "Dataset":
+        self.label = label
+        if self._handle is not None and label is not None:
+            self._set_field("label", label, np.float32)
+        return self
+
+    def set_weight(self, weight) -> "Dataset":
+        self.weight = weight
+        if self._handle is not None:
+            self._set_field("weight", weight, np.float32)
+        return self
+
+    def set_init_score(self, init_score) -> "Dataset":
+        self.init_score = init_score
+        if self._handle is not None:
+            self._set_field("init_score", init_score, np.float64)
+        return self
+
+    def _get_field(self, name: str) -> Optional[np.ndarray]:
+        self.construct()
+        lib, _ = _lib.load()
+        n = ctypes.c_int64()
+        check(lib.lga_dataset_get_field(self._handle, c_str(name), None, 0, ctypes.byref(n)))
+        if n.value == 0:
+            return None
+        out = np.empty(n.value, dtype=np.float64)
+        check(lib.lga_dataset_get_field(self._handle, c_str(name), out.ctypes.data_as(ctypes.c_void_p), n.value,
+                                        ctypes.byref(n)))
+        return out
+
+    def get_label(self) -> Optional[np.ndarray]:
+        if self._handle is None:
+            return None if self.label is None else _to_1d(self.label, np.float64)
+        return self._get_field("label")
+
+    def get_weight(self) -> Optional[np.ndarray]:
+        if self._handle is None:
+            return None if self.weight is None else _to_1d(self.weight, np.float64)
+        return self._get_field("weight")
+
+    def get_init_score(self) -> Optional[np.ndarray]:
+        if self._handle is None:
+            return None if self.init_score is None else _to_1d(self.init_score, np.float64)
+        return self._get_field("init_score")
+
+    def get_data(self):
+        if self.data is None:
+            raise LightGBMError("Raw data was freed (free_raw_data=True)")
+        return self.data
+
+    # -- derived datasets --
+    def create_valid(self, data, label=None, weight=None, init_score=None, params=None) -> "Dataset":
+        return Dataset(data, label=label, reference=self, weight=weight, init_score=init_score,
+                       params=params if params is not None else self.params, free_raw_data=self.free_raw_data)
+
+    def subset(self, used_indices: Iterable[int], params: Optional[Dict[str, Any]] = None) -> "Dataset":
+        """Row subset sharing this dataset's bins (no re-binning, no copy)."""
+        ds = Dataset(None, params=params if params is not None else self.params, free_raw_data=self.free_raw_data)
+        ds._parent = self
+        ds._used_indices = np.sort(np.asarray(list(used_indices) if not isinstance(used_indices, np.ndarray)
+                                              else used_indices, dtype=np.int64))
+        ds.reference = self
+        return ds
+
+    # -- shape / names --
+    def num_data(self) -> int:
+        self.construct()
+        lib, _ = _lib.load()
+        n = ctypes.c_int64()
+        check(lib.lga_dataset_num_data(self._handle, ctypes.byref(n)))
+        return n.value
+
+    def num_feature(self) -> int:
+        self.construct()
+        lib, _ = _lib.load()
+        n = ctypes.c_int()
+        check(lib.lga_dataset_num_feature(self._handle, ctypes.byref(n)))
+        return n.value
+
+    def get_feature_name(self) -> List[str]:
+        self.construct()
+        lib, _ = _lib.load()
+        need = ctypes.c_int64()
+        check(lib.lga_dataset_get_feature_names(self._handle, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        check(lib.lga_dataset_get_feature_names(self._handle, buf, need.value, ctypes.byref(need)))
+        return buf.value.decode().split("\n")
+
+    def bin_info(self, feature: int) -> Dict[str, Any]:
+        """Bin boundaries of one (real) feature: ``num_bin``, ``missing_bin``, ``upper_bounds``."""
+        self.construct()
+        lib, _ = _lib.load()
+        nb, mb, nu = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        up = np.empty(257, dtype=np.float64)
+        check(lib.lga_dataset_bin_info(self._handle, feature, ctypes.byref(nb), ctypes.byref(mb),
+                                       up.ctypes.data_as(ctypes.c_void_p), 257, ctypes.byref(nu)))
+        return {"num_bin": nb.value, "missing_bin": mb.value, "upper_bounds": up[:nu.value].copy()}
+
+    def get_bins(self) -> np.ndarray:
+        """Feature-major bin matrix ``[used_features, rows]`` of the root dataset (for tests / inspection)."""
+        self.construct()
+        lib, _ = _lib.load()
+        nf = ctypes.c_int()
+        check(lib.lga_dataset_num_used_feature(self._handle, ctypes.byref(nf)))
+        root = self
+        while root._parent is not None:
+            root = root._parent
+        n = root.num_data()
+        out = np.empty((nf.value, n), dtype=np.uint8)
+        check(lib.lga_dataset_get_bins(self._handle, out.ctypes.data_as(ctypes.c_void_p), None))
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                lib, _ = _lib.load()
+                lib.lga_dataset_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------
+# Booster
+# ----------------------------------------------------------------------------
+class Booster:
+    """A gradient-boosted (or random-forest) tree ensemble."""
+
+    def __init__(self, params: Optional[Dict[str, Any]] = None, train_set: Optional[Dataset] = None,
+                 model_file: Optional[str] = None, model_str: Optional[str] = None, comm=None):
+        lib, hip = _lib.load()
+        self._handle = ctypes.c_void_p()
+        self.params = dict(params or {})
+        self.best_iteration = 0
+        self.best_score: Dict[str, Dict[str, float]] = {}
+        self.train_set = train_set
+        self.valid_sets: List[Dataset] = []
+        self.name_valid_sets: List[str] = []
+        self._train_data_name = "training"
+        self._comm = comm
+        self._init_predictor: Optional[Booster] = None
+        if train_set is not None:
+            if not isinstance(train_set, Dataset):
+                raise TypeError("train_set must be a Dataset")
+            p = _with_device(self.params)
+            _warn_unknown(p)
+            # the dataset decides where its bins live; keep the booster on the same device
+            train_set.params = {**p, **train_set.params} if train_set._handle is None else train_set.params
+            train_set.construct()
+            comm_h = comm.handle if comm is not None else None
+            check(lib.lga_booster_create(train_set._handle, c_str(params_to_string(p)), comm_h,
+                                         ctypes.byref(self._handle)))
+            self.params = p
+        elif model_file is not None:
+            with open(model_file, "r") as f:
+                self._load(f.read())
+        elif model_str is not None:
+            self._load(model_str)
+        else:
+            raise TypeError("Need at least one of train_set, model_file or model_str to create a Booster")
+        self._eval_names: Optional[List[Tuple[str, bool]]] = None
+
+    def _load(self, text: str):
+        lib, _ = _lib.load()
+        check(lib.lga_booster_from_string(c_str(text), ctypes.byref(self._handle)))
+
+    def __del__(self):
+        try:
+            if self._handle:
+                lib, _ = _lib.load()
+                lib.lga_booster_free(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # -- training --
+    def add_valid(self, data: Dataset, name: str) -> "Booster":
+        lib, _ = _lib.load()
+        if data.reference is None and data._parent is None and data is not self.train_set:
+            data.reference = self.train_set
+        data.construct()
+        check(lib.lga_booster_add_valid(self._handle, data._handle, c_str(name)))
+        self.valid_sets.append(data)
+        self.name_valid_sets.append(name)
+        return self
+
+    def update(self, train_set: Optional[Dataset] = None, fobj: Optional[Callable] = None) -> bool:
+        """One boosting iteration.  Returns True when training cannot continue (no split found)."""
+        lib, _ = _lib.load()
+        fin = ctypes.c_int()
+        if fobj is None:
+            check(lib.lga_booster_update(self._handle, ctypes.byref(fin)))
+        else:
+            preds = self._inner_predict(-1, raw=True)
+            grad, hess = fobj(preds, self.train_set)
+            return self.__boost(grad, hess)
+        return fin.value == 1
+
+    def __boost(self, grad, hess) -> bool:
+        lib, _ = _lib.load()
+        g = _to_1d(grad, np.float32)
+        h = _to_1d(hess, np.float32)
+        if len(g) != len(h):
+            raise ValueError("grad and hess have different lengths")
+        fin = ctypes.c_int()
+        check(lib.lga_booster_update_custom(self._handle, g.ctypes.data_as(ctypes.c_void_p),
+                                            h.ctypes.data_as(ctypes.c_void_p), len(g), ctypes.byref(fin)))
+        return fin.value == 1
+
+    def boost(self, grad, hess) -> bool:
+        return self.__boost(grad, hess)
+
+    def rollback_one_iter(self) -> "Booster":
+        lib, _ = _lib.load()
+        check(lib.lga_booster_rollback(self._handle))
+        return self
+
+    def reset_parameter(self, params: Dict[str, Any]) -> "Booster":
+        lib, _ = _lib.load()
+        check(lib.lga_booster_reset_parameter(self._handle, c_str(params_to_string(params))))
+        self.params.update(params)
+        return self
+
+    def current_iteration(self) -> int:
+        return self.num_trees()
+
+    def num_trees(self) -> int:
+        lib, _ = _lib.load()
+        n = ctypes.c_int()
+        check(lib.lga_booster_num_trees(self._handle, ctypes.byref(n)))
+        return n.value
+
+    def num_feature(self) -> int:
+        lib, _ = _lib.load()
+        n = ctypes.c_int()
+        check(lib.lga_booster_num_feature(self._handle, ctypes.byref(n)))
+        return n.value
+
+    def grow_stats(self) -> Dict[str, int]:
+        """Rounds / materialised / used splits of the last tree (batched best-first growth)."""
+        lib, _ = _lib.load()
+        a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(lib.lga_booster_stats(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"rounds": a.value, "materialized_splits": b.value, "used_splits": c.value}
+
+    def profile(self) -> Dict[str, Any]:
+        lib, _ = _lib.load()
+        out, n = ctypes.c_char_p(), ctypes.c_int64()
+        check(lib.lga_booster_profile_json(self._handle, ctypes.byref(out), ctypes.byref(n)))
+        return json.loads(ctypes.string_at(out, n.value).decode())
+
+    # -- evaluation --
+    def _metric_names(self) -> List[Tuple[str, bool]]:
+        if self._eval_names is None:
+            lib, _ = _lib.load()
+            buf = ctypes.create_string_buffer(1024)
+            check(lib.lga_booster_eval_names(self._handle, buf, 1024))
+            s = buf.value.decode()
+            self._eval_names = [(t.split(":")[0], t.split(":")[1] == "1") for t in s.split(",") if t]
+        return self._eval_names
+
+    def _inner_predict(self, which: int, raw: bool = False) -> np.ndarray:
+        lib, _ = _lib.load()
+        n = ctypes.c_int64()
+        check(lib.lga_booster_inner_nrows(self._handle, which, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        check(lib.lga_booster_inner_predict(self._handle, which, 1 if raw else 0, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def _eval(self, which: int, name: str, feval=None) -> List[Tuple[str, str, float, bool]]:
+        lib, _ = _lib.load()
+        names = self._metric_names()
+        res: List[Tuple[str, str, float, bool]] = []
+        if names:
+            vals = np.empty(len(names), dtype=np.float64)
+            n = ctypes.c_int()
+            check(lib.lga_booster_eval(self._handle, which, vals.ctypes.data_as(ctypes.c_void_p), len(names),
+                                       ctypes.byref(n)))
+            for (mn, hb), v in zip(names, vals[: n.value]):
+                res.append((name, mn, float(v), hb))
+        if feval is not None:
+            fevals = feval if isinstance(feval, (list, tuple)) else [feval]
+            data = self.train_set if which < 0 else self.valid_sets[which]
+            preds = self._inner_predict(which, raw=False)
+            for f in fevals:
+                r = f(preds, data)
+                rs = r if isinstance(r, list) else [r]
+                for (en, ev, ehb) in rs:
+                    res.append((name, en, float(ev), bool(ehb)))
+        return res
+
+    def eval_train(self, feval=None):
+        return self._eval(-1, self._train_data_name, feval)
+
+    def eval_valid(self, feval=None):
+        out = []
+        for i, n in enumerate(self.name_valid_sets):
+            out.extend(self._eval(i, n, feval))
+        return out
+
+    # -- prediction --
+    def predict(self, data, start_iteration: int = 0, num_iteration: Optional[int] = None, raw_score: bool = False,
+                pred_leaf: bool = False, device: Optional[str] = None, **kwargs) -> np.ndarray:
+        """Predicts a dense matrix.  ``num_iteration=k`` uses the first k trees (staged prediction)."""
+        lib, hip = _lib.load()
+        if isinstance(data, Dataset):
+            raise TypeError("Cannot predict a Dataset; pass the raw matrix")
+        if num_iteration is None:
+            num_iteration = self.best_iteration if self.best_iteration > 0 else -1
+        if num_iteration is None or num_iteration <= 0:
+            num_iteration = -1
+        mat, _ = _to_matrix(data)
+        ptype = 2 if pred_leaf else (1 if raw_score else 0)
+        used = ctypes.c_int()
+        check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
+        nrow = mat.shape[0]
+        use_gpu = hip and not pred_leaf and (device == "gpu" or _is_torch(mat) or
+                                             (device is None and nrow * max(used.value, 1) >= 2_000_000))
+        if use_gpu:
+            from . import _device
+            return _device.predict(lib, self._handle, mat, start_iteration, num_iteration, ptype)
+        if _is_torch(mat):
+            mat = mat.cpu().numpy()
+        out = np.empty(nrow * (used.value if pred_leaf else 1), dtype=np.float64)
+        ptr, dtype, nr, nc, rm = _mat_args(mat)
+        check(lib.lga_booster_predict(self._handle, ptr, dtype, nr, nc, rm, start_iteration, num_iteration, ptype,
+                                      out.ctypes.data_as(ctypes.c_void_p)))
+        if pred_leaf:
+            return out.reshape(nrow, used.value).astype(np.int32)
+        return out
+
+    # -- model IO --
+    def model_to_string(self, num_iteration: Optional[int] = None, start_iteration: int = 0,
+                        importance_type: str = "split") -> str:
+        lib, _ = _lib.load()
+        if num_iteration is None:
+            num_iteration = self.best_iteration if self.best_iteration > 0 else -1
+        out, n = ctypes.c_char_p(), ctypes.c_int64()
+        check(lib.lga_booster_save_string(self._handle, start_iteration, num_iteration or -1,
+                                          0 if importance_type == "split" else 1, ctypes.byref(out), ctypes.byref(n)))
+        return ctypes.string_at(out, n.value).decode()
+
+    def save_model(self, filename: str, num_iteration: Optional[int] = None, start_iteration: int = 0,
+                   importance_type: str = "split") -> "Booster":
+        text = self.model_to_string(num_iteration, start_iteration, importance_type)
+        tmp = f"{filename}.tmp.{os.getpid()}"
+        with open(tmp, "w") as f:
+            f.write(text)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, filename)
+        return self
+
+    def model_from_string(self, model_str: str) -> "Booster":
+        lib, _ = _lib.load()
+        if self._handle:
+            lib.lga_booster_free(self._handle)
+        self._handle = ctypes.c_void_p()
+        self._load(model_str)
+        self.train_set = None
+        self.valid_sets, self.name_valid_sets = [], []
+        self._eval_names = None
+        return self
+
+    def dump_model(self, num_iteration: Optional[int] = None, start_iteration: int = 0) -> Dict[str, Any]:
+        lib, _ = _lib.load()
+        out, n = ctypes.c_char_p(), ctypes.c_int64()
+        check(lib.lga_booster_dump_json(self._handle, start_iteration, num_iteration or -1, ctypes.byref(out),
+                                        ctypes.byref(n)))
+        return json.loads(ctypes.string_at(out, n.value).decode().replace("inf", "1e308"))
+
+    def feature_importance(self, importance_type: str = "split", iteration: Optional[int] = None) -> np.ndarray:
+        lib, _ = _lib.load()
+        out = np.zeros(self.num_feature(), dtype=np.float64)
+        check(lib.lga_booster_feature_importance(self._handle, iteration or -1, 0 if importance_type == "split" else 1,
+                                                 out.ctypes.data_as(ctypes.c_void_p)))
+        return out.astype(np.int32) if importance_type == "split" else out
+
+    def feature_name(self) -> List[str]:
+        return self.dump_model(num_iteration=1)["feature_names"] if self.num_trees() else \
+            json.loads(json.dumps(self.dump_model()))["feature_names"]
+
+    def objective_info(self) -> Dict[str, Any]:
+        lib, _ = _lib.load()
+        o, a, s = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_double()
+        check(lib.lga_booster_info(self._handle, ctypes.byref(o), ctypes.byref(a), ctypes.byref(s)))
+        return {"objective": o.value.decode(), "average_output": bool(a.value), "sigmoid": s.value}
+
+    def _prepend(self, first: "Booster"):
+        lib, _ = _lib.load()
+        check(lib.lga_booster_prepend(self._handle, first._handle))
+
+    def free_dataset(self) -> "Booster":
+        self.train_set = None
+        self.valid_sets = []
+        return self

@@ -1,0 +1,55 @@
+// Interface between the host-side tree grower and whatever executes the
+// row-level work (the OpenMP host backend or the HIP backend).  A backend
+// works in ROUNDS: every call splits a whole batch of leaves - partition rows,
+// build the smaller children's histograms, derive the siblings by
+// subtraction, scan all children for their best split - so that the number
+// of host<->device synchronisations per tree is the number of rounds
+// (about the tree depth) and not the number of leaves.
+#pragma once
+#include "common.hpp"
+#include <cstddef>
+#include <vector>
+
+namespace lga {
+
+// Collective operations used by the distributed learners.  The data-parallel
+// learner sums integer histograms (exact, order independent); the
+// feature-parallel learner gathers per-rank split candidates.
+class Comm {
+ public:
+  virtual ~Comm() {}
+  virtual int rank() const = 0;
+  virtual int size() const = 0;
+  // In-place sum over ranks.  `device` tells whether buf is device memory.
+  virtual void allreduce_sum_i64(int64_t* buf, size_t n, bool device, void* stream) = 0;
+  virtual void allreduce_sum_f64(double* buf, size_t n, bool device, void* stream) = 0;
+  virtual void allreduce_max_f32(float* buf, size_t n, bool device, void* stream) = 0;
+  // out must hold size()*nbytes; rank r's block lands at out + r*nbytes.
+  virtual void allgather_bytes(const void* in, void* out, size_t nbytes, bool device, void* stream) = 0;
+};
+
+struct LeafOutput {
+  int32_t node;    // backend node id of a final leaf
+  int32_t pad;
+  double value;    // already multiplied by the learning rate
+};
+
+class TreeBackend {
+ public:
+  virtual ~TreeBackend() {}
+  // Node/slot capacity the grower may use for one tree.
+  virtual int node_capacity() const = 0;
+  // Start a tree over the current bag with the current quantised gradients.
+  // meta[f].enabled carries this tree's feature_fraction mask.
+  virtual void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) = 0;
+  // Histogram + scan of the root (node 0, slot 0).
+  virtual void root_round(SplitInfo* out) = 0;
+  // Split every task's leaf; infos[2i] / infos[2i+1] are the best splits of
+  // task i's left / right child.  The backend fills the chunk fields of the tasks.
+  virtual void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) = 0;
+  virtual QuantScale quant_scale() const = 0;
+  // Local row count of a node (after the round that created it).
+  virtual int64_t node_local_count(int node) const = 0;
+};
+
+}  // namespace lga

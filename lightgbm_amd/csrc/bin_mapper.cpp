@@ -1,0 +1,52 @@
+#include "bin_mapper.hpp"
+#include "binning_core.hpp"
+#include <algorithm>
+#include <cmath>
+#include <sstream>
+
+namespace lga {
+
+std::vector<double> greedy_find_bounds(const std::vector<double>& distinct, const std::vector<int>& counts,
+                                       int max_bin, int64_t total_cnt, int min_data_in_bin) {
+  std::vector<double> out((size_t)std::max(max_bin, 1) + 1);
+  int nb = greedy_bounds_core(distinct.data(), counts.data(), (int)distinct.size(), max_bin, total_cnt,
+                              min_data_in_bin, out.data());
+  out.resize(nb);
+  return out;
+}
+
+void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing) {
+  // strip NaN
+  size_t n_all = values.size();
+  size_t w = 0;
+  for (size_t i = 0; i < n_all; ++i) if (values[i] == values[i]) values[w++] = values[i];
+  size_t n_nan = n_all - w;
+  values.resize(w);
+  std::sort(values.begin(), values.end());
+  std::vector<double> distinct;
+  std::vector<int> counts;
+  for (size_t i = 0; i < values.size(); ++i) {
+    if (i == 0 || values[i] != values[i - 1]) { distinct.push_back(values[i]); counts.push_back(1); }
+    else counts.back()++;
+  }
+  missing = (use_missing && n_nan > 0) ? MissingType::NaN : MissingType::None;
+  int value_bins = max_bin - (missing == MissingType::NaN ? 1 : 0);
+  if (value_bins < 1) value_bins = 1;
+  upper = greedy_find_bounds(distinct, counts, value_bins, (int64_t)values.size(), min_data_in_bin);
+  int nv = (int)upper.size();
+  if (missing == MissingType::NaN) { missing_bin = nv; num_bin = nv + 1; }
+  else { missing_bin = -1; num_bin = nv; }
+  if (!distinct.empty()) { min_val = distinct.front(); max_val = distinct.back(); }
+  else { min_val = max_val = 0.0; }
+  trivial = num_bin <= 1;
+}
+
+std::string BinMapper::info_string() const {
+  if (trivial) return "none";
+  std::ostringstream os;
+  os.precision(17);
+  os << "[" << min_val << ":" << max_val << "]";
+  return os.str();
+}
+
+}  // namespace lga

@@ -1,0 +1,79 @@
+// Bin-boundary search shared by the host BinMapper and the device binning
+// kernel (one feature per wave on the GPU runs exactly this routine).
+#pragma once
+#include "common.hpp"
+
+namespace lga {
+
+LGA_HD double bound_between(double a, double b) {
+  // a < b.  A value strictly inside [a, b) so that "x <= bound" keeps a left and b right.
+  double m = a + (b - a) * 0.5;
+  if (!(m < b)) m = a;
+  return m;
+}
+
+// distinct[0..n) ascending, counts[i] > 0.  Writes at most max_bin inclusive
+// upper bounds to `out` (the last one is +inf) and returns how many.
+LGA_HD int greedy_bounds_core(const double* distinct, const int* counts, int n, int max_bin,
+                              int64_t total_cnt, int min_data_in_bin, double* out) {
+  const double inf = std::numeric_limits<double>::infinity();
+  int nb = 0;
+  if (n <= 0) { out[nb++] = inf; return nb; }
+  if (max_bin < 1) max_bin = 1;
+  if (n <= max_bin) {
+    // one bin per distinct value, merging neighbours until a bin holds min_data_in_bin rows
+    int64_t cur = 0;
+    for (int i = 0; i + 1 < n; ++i) {
+      cur += counts[i];
+      if (cur >= min_data_in_bin) {
+        out[nb++] = bound_between(distinct[i], distinct[i + 1]);
+        cur = 0;
+      }
+    }
+    out[nb++] = inf;
+    return nb;
+  }
+  // equal-frequency: values at least as frequent as the mean bin size get a bin of their own
+  double mean = (double)total_cnt / (double)max_bin;
+  if (mean < (double)min_data_in_bin) mean = (double)min_data_in_bin;
+  int big = 0;
+  int64_t big_cnt = 0;
+  for (int i = 0; i < n; ++i) if ((double)counts[i] >= mean) { ++big; big_cnt += counts[i]; }
+  int rest_bins = max_bin - big;
+  int64_t rest_cnt = total_cnt - big_cnt;
+  double mean_small = rest_bins > 0 ? (double)rest_cnt / (double)rest_bins : (double)rest_cnt + 1.0;
+  if (mean_small < (double)min_data_in_bin) mean_small = (double)min_data_in_bin;
+  int64_t cur = 0;
+  for (int i = 0; i + 1 < n; ++i) {
+    bool big_i = (double)counts[i] >= mean;
+    bool big_next = (double)counts[i + 1] >= mean;
+    if (!big_i) rest_cnt -= counts[i];
+    cur += counts[i];
+    if (big_i || big_next || (double)cur >= mean_small) {
+      if (big_i || cur >= min_data_in_bin) {
+        out[nb++] = bound_between(distinct[i], distinct[i + 1]);
+        cur = 0;
+        if (nb >= max_bin - 1) break;
+        if (!big_i) {
+          --rest_bins;
+          mean_small = rest_bins > 0 ? (double)rest_cnt / (double)rest_bins : (double)rest_cnt + 1.0;
+          if (mean_small < (double)min_data_in_bin) mean_small = (double)min_data_in_bin;
+        }
+      }
+    }
+  }
+  out[nb++] = inf;
+  return nb;
+}
+
+// Branch-free-ish lower bound: first i with v <= upper[i]; upper[nv-1] = +inf.
+LGA_HD int search_bin(const double* upper, int nv, double v) {
+  int lo = 0, hi = nv - 1;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (v <= upper[mid]) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+}  // namespace lga

@@ -1,0 +1,216 @@
+// Shared plain-data types and arithmetic used by BOTH the host (g++) and the
+// device (hipcc, gfx950) builds.  Everything that decides the shape of a tree
+// (gradient quantisation, split gain, candidate ordering, count estimates)
+// lives here so the CPU oracle and the HIP kernels execute the same IEEE
+// operations on the same integers and therefore grow bit-identical trees.
+//
+// Build both sides with -ffp-contract=off: a fused multiply-add on one side
+// only would break that parity.
+#pragma once
+#include <cstdint>
+#include <cmath>
+#include <limits>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define LGA_HD __host__ __device__ __forceinline__
+#else
+#define LGA_HD inline
+#endif
+
+namespace lga {
+
+// ---- geometry constants -------------------------------------------------
+// Features are processed in tiles of 32: one row of one tile is a 32-byte
+// record (two 16-byte loads per lane) and the per-workgroup LDS histogram of a
+// tile is 32 x 256 x 8 B = 64 KiB, so two workgroups fit the 160 KiB LDS of a CU.
+constexpr int kTileFeatures = 32;
+constexpr int kMaxBins = 256;          // bins are stored as uint8
+// Gradients/hessians are quantised to |q| <= 2^kQuantBits.  A workgroup
+// accumulates packed (g:int32 | h:uint32) pairs in LDS, so it may add at most
+// kMaxRowsPerPass rows before flushing: 2^16 * 2^14 = 2^30 < 2^31.
+constexpr int kQuantBits = 16;
+constexpr int kMaxRowsPerPass = 16384;
+constexpr int kSlotHeader = 8;         // int64 words appended to every histogram slot
+
+// ---- plain data ----------------------------------------------------------
+struct SplitParams {
+  double lambda_l1;
+  double lambda_l2;
+  double min_gain_to_split;
+  double min_sum_hessian_in_leaf;
+  double max_delta_step;
+  int32_t min_data_in_leaf;
+  int32_t max_depth;  // <=0: unlimited
+};
+
+// Power-of-two scales of the current boosting iteration: real = q * 2^-k.
+struct QuantScale {
+  int32_t kg;
+  int32_t kh;
+};
+
+// Best split of one leaf (written by the scan, read by the host grower).
+struct SplitInfo {
+  double gain;          // improvement over the unsplit leaf; -inf when none
+  int32_t feature;      // inner (used-feature) index, -1 when none
+  int32_t threshold;    // rows with bin <= threshold go left
+  int32_t default_left; // side taken by the missing-value bin
+  int32_t pad0;
+  int64_t left_g, left_h;     // quantised sums of the left child
+  int64_t total_g, total_h;   // quantised sums of the leaf
+  int64_t left_cnt;           // estimated rows on the left (hessian-proportional)
+  int64_t total_cnt;          // exact rows in the leaf (global in data-parallel mode)
+};
+static_assert(sizeof(SplitInfo) == 72, "SplitInfo layout");
+
+// One leaf to split in a batched growth round.
+struct SplitTask {
+  int32_t parent_node;   // node-table index of the leaf being split
+  int32_t left_node;     // node-table indices that receive the children
+  int32_t right_node;
+  int32_t feature;       // inner feature
+  int32_t threshold;     // bin threshold
+  int32_t default_left;
+  int32_t missing_bin;   // bin holding missing values for that feature, -1 if none
+  int32_t hist_child;    // 0: build the left child's histogram, 1: the right one
+  int32_t parent_slot;   // histogram slot of the parent (inherited by the other child)
+  int32_t new_slot;      // fresh slot for hist_child
+  int32_t first_pchunk;  // first partition chunk of this task (prefix over tasks)
+  int32_t num_pchunk;
+  int32_t first_hchunk;  // first histogram chunk
+  int32_t num_hchunk;
+  int32_t depth;         // depth of the children
+  int32_t pad;
+};
+
+// Row range of a node inside the two ping-pong row-index arenas.
+struct NodeRange {
+  int32_t begin;
+  int32_t count;   // local rows
+  int32_t buf;     // which arena holds the rows
+  int32_t pad;
+};
+
+// One child whose best split is searched in a round.
+struct ScanTask {
+  int32_t node;        // node-table index (for the local row count)
+  int32_t slot;        // slot that holds / receives this node's histogram
+  int32_t parent_slot; // -1: histogram already in `slot`; else slot = parent - sibling
+  int32_t sibling_slot;
+  int32_t depth;
+  int32_t pad;
+};
+
+struct FeatureMeta {
+  int32_t num_bin;      // bins in use (<=256)
+  int32_t missing_bin;  // index of the NaN bin or -1
+  int32_t enabled;      // 0 when masked out by feature_fraction for this tree
+  int32_t pad;
+};
+
+// ---- arithmetic ----------------------------------------------------------
+LGA_HD double threshold_l1(double g, double l1) {
+  if (l1 <= 0.0) return g;
+  double a = fabs(g) - l1;
+  if (a <= 0.0) return 0.0;
+  return g > 0.0 ? a : -a;
+}
+
+// Un-normalised leaf objective reduction: T(G)^2 / (H + l2).
+LGA_HD double leaf_gain(double g, double h, double l1, double l2) {
+  double t = threshold_l1(g, l1);
+  double d = h + l2;
+  if (!(d > 0.0)) return 0.0;
+  return (t * t) / d;
+}
+
+LGA_HD double leaf_output(double g, double h, double l1, double l2, double max_delta_step) {
+  double d = h + l2;
+  if (!(d > 0.0)) return 0.0;
+  double out = -threshold_l1(g, l1) / d;
+  if (max_delta_step > 0.0 && fabs(out) > max_delta_step) out = out > 0.0 ? max_delta_step : -max_delta_step;
+  return out;
+}
+
+// 2^-k as an exact double.
+LGA_HD double unit_of(int k) { return ldexp(1.0, -k); }
+
+// Quantisation exponent: the largest k with vmax * 2^k < 2^kQuantBits.
+LGA_HD int quant_exponent(float vmax) {
+  if (!(vmax > 0.0f) || !(vmax < 3.0e38f)) return 0;
+  int e;
+  (void)frexpf(vmax, &e);  // vmax = m * 2^e, m in [0.5, 1)
+  return kQuantBits - e;
+}
+
+LGA_HD int32_t quantize(float v, int k) {
+  float s = ldexpf(v, k);
+  const float lim = (float)(1 << kQuantBits);
+  if (s > lim) s = lim;
+  if (s < -lim) s = -lim;
+  return (int32_t)rintf(s);
+}
+
+// (g,h) packed for a single 64-bit add: g in the high, h in the low word.
+// Sums stay separable while the low word does not carry (h >= 0, bounded rows).
+LGA_HD int64_t pack_gh(int32_t g, int32_t h) {
+  return (int64_t)(((uint64_t)(int64_t)g << 32) + (uint64_t)(uint32_t)h);
+}
+LGA_HD int32_t packed_g(int64_t p) { return (int32_t)(p >> 32); }
+LGA_HD uint32_t packed_h(int64_t p) { return (uint32_t)((uint64_t)p & 0xffffffffull); }
+
+// Ordering of split candidates: larger gain first; ties -> smaller key
+// (feature, threshold, default_left).  A strict total order, so a parallel
+// reduction and a sequential loop pick the same winner.
+LGA_HD uint64_t cand_key(int feature, int threshold, int default_left) {
+  return ((uint64_t)(uint32_t)feature << 16) | ((uint64_t)(uint32_t)threshold << 1) | (uint64_t)(default_left & 1);
+}
+LGA_HD bool cand_better(double gain_a, uint64_t key_a, double gain_b, uint64_t key_b) {
+  if (gain_a > gain_b) return true;
+  if (gain_a < gain_b) return false;
+  return key_a < key_b;
+}
+
+// Estimated row count of a part of a leaf from its hessian share.
+LGA_HD int64_t est_count(int64_t part_h, int64_t total_h, int64_t total_cnt) {
+  if (total_h <= 0) return 0;
+  double f = (double)total_cnt / (double)total_h;
+  return (int64_t)((double)part_h * f + 0.5);
+}
+
+// Gain of one candidate split or -inf when a constraint fails.
+LGA_HD double split_gain(int64_t lg, int64_t lh, int64_t tg, int64_t th, int64_t total_cnt,
+                         double gunit, double hunit, const SplitParams& p, double parent_gain) {
+  const double ninf = -std::numeric_limits<double>::infinity();
+  int64_t rg = tg - lg, rh = th - lh;
+  int64_t lc = est_count(lh, th, total_cnt);
+  int64_t rc = total_cnt - lc;
+  if (lc < p.min_data_in_leaf || rc < p.min_data_in_leaf) return ninf;
+  double lhr = (double)lh * hunit, rhr = (double)rh * hunit;
+  if (lhr < p.min_sum_hessian_in_leaf || rhr < p.min_sum_hessian_in_leaf) return ninf;
+  double lgr = (double)lg * gunit, rgr = (double)rg * gunit;
+  double gain = leaf_gain(lgr, lhr, p.lambda_l1, p.lambda_l2) + leaf_gain(rgr, rhr, p.lambda_l1, p.lambda_l2) - parent_gain;
+  if (!(gain > p.min_gain_to_split)) return ninf;
+  return gain;
+}
+
+// Counter-based RNG (splitmix64 finaliser over a (seed, stream, index) triple):
+// the same draw on host and device, independent of thread layout.
+LGA_HD uint64_t mix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+LGA_HD uint64_t rng_u64(uint64_t seed, uint64_t stream, uint64_t index) {
+  return mix64(mix64(seed * 0x2545f4914f6cdd1dull + stream) ^ (index * 0x9e3779b97f4a7c15ull));
+}
+// Uniform in [0,1) with 24 random bits (exactly representable in float).
+LGA_HD float rng_uniform(uint64_t seed, uint64_t stream, uint64_t index) {
+  return (float)(rng_u64(seed, stream, index) >> 40) * (1.0f / 16777216.0f);
+}
+
+LGA_HD double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+}  // namespace lga

@@ -1,0 +1,351 @@
+#include "config.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <sstream>
+#include <stdexcept>
+#include <limits>
+#include <cctype>
+
+namespace lga {
+namespace {
+
+enum class PType { Int, Double, Bool, String, StringList };
+
+struct ParamDef {
+  const char* name;
+  const char* aliases;  // comma separated
+  PType type;
+  size_t offset;        // offset of the member inside Config
+  double lo, hi;        // numeric range (inclusive), NaN = unbounded
+};
+
+const double kNone = std::numeric_limits<double>::quiet_NaN();
+#define P(member, aliases, type, lo, hi) \
+  { #member, aliases, PType::type, offsetof(Config, member), lo, hi }
+
+// Table order = order of the "parameters:" block in the model file.
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+const ParamDef kParams[] = {
+    P(boosting, "boosting_type,boost", String, kNone, kNone),
+    P(objective, "objective_type,app,application,loss", String, kNone, kNone),
+    P(metric, "metrics,metric_types", StringList, kNone, kNone),
+    P(tree_learner, "tree,tree_type,tree_learner_type", String, kNone, kNone),
+    P(device_type, "device", String, kNone, kNone),
+    P(num_iterations,
+      "num_iteration,n_iter,num_tree,num_trees,num_round,num_rounds,nrounds,num_boost_round,n_estimators,max_iter",
+      Int, 0, kNone),
+    P(learning_rate, "shrinkage_rate,eta", Double, 1e-300, kNone),
+    P(num_leaves, "num_leaf,max_leaves,max_leaf,max_leaf_nodes", Int, 2, 131072),
+    P(num_threads, "num_thread,nthread,nthreads,n_jobs", Int, kNone, kNone),
+    P(seed, "random_seed,random_state", Int, kNone, kNone),
+    P(deterministic, "", Bool, kNone, kNone),
+    P(max_depth, "", Int, kNone, kNone),
+    P(min_data_in_leaf, "min_data_per_leaf,min_data,min_child_samples,min_samples_leaf", Int, 0, kNone),
+    P(min_sum_hessian_in_leaf, "min_sum_hessian_per_leaf,min_sum_hessian,min_hessian,min_child_weight", Double, 0, kNone),
+    P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
+    P(bagging_freq, "subsample_freq", Int, 0, kNone),
+    P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
+    P(feature_fraction, "sub_feature,colsample_bytree", Double, 1e-300, 1.0),
+    P(feature_fraction_bynode, "sub_feature_bynode,colsample_bynode", Double, 1e-300, 1.0),
+    P(feature_fraction_seed, "", Int, kNone, kNone),
+    P(early_stopping_round, "early_stopping_rounds,early_stopping,n_iter_no_change", Int, kNone, kNone),
+    P(first_metric_only, "", Bool, kNone, kNone),
+    P(max_delta_step, "max_tree_output,max_leaf_output", Double, kNone, kNone),
+    P(lambda_l1, "reg_alpha,l1_regularization", Double, 0, kNone),
+    P(lambda_l2, "reg_lambda,lambda,l2_regularization", Double, 0, kNone),
+    P(min_gain_to_split, "min_split_gain", Double, 0, kNone),
+    P(verbosity, "verbose", Int, kNone, kNone),
+    P(max_bin, "max_bins", Int, 2, 255),
+    P(min_data_in_bin, "", Int, 1, kNone),
+    P(bin_construct_sample_cnt, "subsample_for_bin", Int, 1, kNone),
+    P(data_random_seed, "data_seed", Int, kNone, kNone),
+    P(use_missing, "", Bool, kNone, kNone),
+    P(zero_as_missing, "", Bool, kNone, kNone),
+    P(feature_pre_filter, "", Bool, kNone, kNone),
+    P(boost_from_average, "", Bool, kNone, kNone),
+    P(sigmoid, "", Double, 1e-300, kNone),
+    P(is_unbalance, "unbalance,unbalanced_sets", Bool, kNone, kNone),
+    P(scale_pos_weight, "", Double, 1e-300, kNone),
+    P(alpha, "", Double, 1e-300, kNone),
+    P(fair_c, "", Double, 1e-300, kNone),
+    P(poisson_max_delta_step, "", Double, 1e-300, kNone),
+    P(metric_freq, "output_freq", Int, 1, kNone),
+    P(is_provide_training_metric, "training_metric,is_training_metric,train_metric", Bool, kNone, kNone),
+    P(snapshot_freq, "save_period", Int, kNone, kNone),
+    P(output_model, "model_output,model_out", String, kNone, kNone),
+    P(input_model, "model_input,model_in", String, kNone, kNone),
+    P(num_machines, "num_machine", Int, 1, kNone),
+    P(gpu_device_id, "", Int, kNone, kNone),
+    P(max_batch_leaves, "", Int, 0, kNone),
+    P(profile, "", Bool, kNone, kNone),
+};
+#pragma GCC diagnostic pop
+#undef P
+
+std::vector<std::string> split(const std::string& s, char sep) {
+  std::vector<std::string> out;
+  std::string cur;
+  for (char c : s) {
+    if (c == sep) { if (!cur.empty()) out.push_back(cur); cur.clear(); }
+    else cur.push_back(c);
+  }
+  if (!cur.empty()) out.push_back(cur);
+  return out;
+}
+
+std::string trim(const std::string& s) {
+  size_t a = 0, b = s.size();
+  while (a < b && std::isspace((unsigned char)s[a])) ++a;
+  while (b > a && std::isspace((unsigned char)s[b - 1])) --b;
+  return s.substr(a, b - a);
+}
+
+std::string lower(std::string s) {
+  for (auto& c : s) c = (char)std::tolower((unsigned char)c);
+  return s;
+}
+
+const ParamDef* find_param(const std::string& name) {
+  for (const auto& p : kParams) {
+    if (name == p.name) return &p;
+    for (const auto& a : split(p.aliases, ',')) if (name == a) return &p;
+  }
+  return nullptr;
+}
+
+bool parse_bool(const std::string& v, const std::string& key) {
+  std::string s = lower(v);
+  if (s == "true" || s == "1" || s == "+" || s == "yes" || s == "t") return true;
+  if (s == "false" || s == "0" || s == "-" || s == "no" || s == "f") return false;
+  throw std::runtime_error("parameter " + key + " expects a boolean, got \"" + v + "\"");
+}
+
+template <typename T>
+T& field(Config* c, size_t off) { return *reinterpret_cast<T*>(reinterpret_cast<char*>(c) + off); }
+template <typename T>
+const T& cfield(const Config* c, size_t off) { return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(c) + off); }
+
+std::string fmt_double(double v) {
+  std::ostringstream os;
+  os.precision(17);
+  os << v;
+  return os.str();
+}
+
+}  // namespace
+
+std::string Config::resolve_alias(const std::string& name) {
+  const ParamDef* p = find_param(name);
+  return p ? p->name : "";
+}
+
+std::string Config::alias_table_json() {
+  std::ostringstream os;
+  os << "{";
+  bool first = true;
+  for (const auto& p : kParams) {
+    if (!first) os << ",";
+    first = false;
+    os << "\"" << p.name << "\":[";
+    bool f2 = true;
+    for (const auto& a : split(p.aliases, ',')) {
+      if (!f2) os << ",";
+      f2 = false;
+      os << "\"" << a << "\"";
+    }
+    os << "]";
+  }
+  os << "}";
+  return os.str();
+}
+
+void Config::set(const std::map<std::string, std::string>& kv) {
+  for (const auto& it : kv) {
+    const std::string key = trim(it.first);
+    const std::string val = trim(it.second);
+    const ParamDef* p = find_param(key);
+    if (!p) {
+      if (std::find(unknown_keys.begin(), unknown_keys.end(), key) == unknown_keys.end()) unknown_keys.push_back(key);
+      continue;
+    }
+    char* end = nullptr;
+    switch (p->type) {
+      case PType::Int: {
+        // accept "31", "31.0" (a data.frame row turns every column into a double)
+        double d = std::strtod(val.c_str(), &end);
+        if (end == val.c_str() || *end != '\0' || d != (double)(long long)d)
+          throw std::runtime_error("parameter " + key + " expects an integer, got \"" + val + "\"");
+        if ((p->lo == p->lo && d < p->lo) || (p->hi == p->hi && d > p->hi))
+          throw std::runtime_error("parameter " + key + "=" + val + " is out of range");
+        field<int>(this, p->offset) = (int)d;
+        break;
+      }
+      case PType::Double: {
+        double d = std::strtod(val.c_str(), &end);
+        if (end == val.c_str() || *end != '\0')
+          throw std::runtime_error("parameter " + key + " expects a number, got \"" + val + "\"");
+        if ((p->lo == p->lo && d < p->lo) || (p->hi == p->hi && d > p->hi))
+          throw std::runtime_error("parameter " + key + "=" + val + " is out of range");
+        field<double>(this, p->offset) = d;
+        break;
+      }
+      case PType::Bool:
+        field<bool>(this, p->offset) = parse_bool(val, key);
+        break;
+      case PType::String:
+        field<std::string>(this, p->offset) = val;
+        break;
+      case PType::StringList: {
+        auto& lst = field<std::vector<std::string>>(this, p->offset);
+        lst.clear();
+        for (auto& m : split(val, ',')) {
+          std::string t = trim(m);
+          if (!t.empty()) lst.push_back(t);
+        }
+        break;
+      }
+    }
+    if (std::find(explicit_keys.begin(), explicit_keys.end(), p->name) == explicit_keys.end())
+      explicit_keys.push_back(p->name);
+  }
+  check();
+}
+
+void Config::set(const std::string& params) {
+  // tokens are separated by whitespace; a token is key=value
+  std::map<std::string, std::string> kv;
+  std::vector<std::pair<std::string, std::string>> ordered;
+  std::istringstream is(params);
+  std::string tok;
+  while (is >> tok) {
+    size_t eq = tok.find('=');
+    if (eq == std::string::npos || eq == 0)
+      throw std::runtime_error("malformed parameter token \"" + tok + "\" (expected key=value)");
+    ordered.emplace_back(tok.substr(0, eq), tok.substr(eq + 1));
+  }
+  // canonical name wins over alias when both are given; otherwise last wins
+  std::map<std::string, std::string> by_canon;
+  std::map<std::string, bool> canon_direct;
+  for (auto& p : ordered) {
+    std::string canon = resolve_alias(p.first);
+    if (canon.empty()) { kv[p.first] = p.second; continue; }
+    bool direct = (canon == p.first);
+    if (by_canon.count(canon) && canon_direct[canon] && !direct) continue;
+    by_canon[canon] = p.second;
+    canon_direct[canon] = direct;
+  }
+  for (auto& p : by_canon) kv[p.first] = p.second;
+  set(kv);
+}
+
+std::string Config::canonical_objective(const std::string& name0) {
+  std::string name = lower(name0);
+  static const std::map<std::string, std::string> m = {
+      {"regression", "regression"}, {"regression_l2", "regression"}, {"l2", "regression"},
+      {"mean_squared_error", "regression"}, {"mse", "regression"}, {"l2_root", "regression"},
+      {"root_mean_squared_error", "regression"}, {"rmse", "regression"}, {"reg:linear", "regression"},
+      {"reg:squarederror", "regression"},
+      {"regression_l1", "regression_l1"}, {"l1", "regression_l1"}, {"mean_absolute_error", "regression_l1"},
+      {"mae", "regression_l1"},
+      {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
+      {"binary", "binary"}, {"binary_logloss", "binary"}, {"binary:logistic", "binary"},
+      {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
+      {"custom", "custom"}, {"none", "custom"}, {"null", "custom"}, {"na", "custom"},
+  };
+  auto it = m.find(name);
+  if (it == m.end()) throw std::runtime_error("unknown objective \"" + name0 + "\"");
+  return it->second;
+}
+
+std::string Config::canonical_metric(const std::string& name0) {
+  std::string name = lower(name0);
+  static const std::map<std::string, std::string> m = {
+      {"l2", "l2"}, {"mean_squared_error", "l2"}, {"mse", "l2"}, {"regression", "l2"}, {"regression_l2", "l2"},
+      {"rmse", "rmse"}, {"root_mean_squared_error", "rmse"}, {"l2_root", "rmse"},
+      {"l1", "l1"}, {"mean_absolute_error", "l1"}, {"mae", "l1"}, {"regression_l1", "l1"},
+      {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
+      {"binary_logloss", "binary_logloss"}, {"binary", "binary_logloss"}, {"logloss", "binary_logloss"},
+      {"binary_error", "binary_error"}, {"error", "binary_error"},
+      {"auc", "auc"},
+      {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
+      {"none", "none"}, {"null", "none"}, {"custom", "none"}, {"na", "none"}, {"", "none"},
+  };
+  auto it = m.find(name);
+  if (it == m.end()) throw std::runtime_error("unknown metric \"" + name0 + "\"");
+  return it->second;
+}
+
+std::vector<std::string> Config::resolved_metrics() const {
+  std::vector<std::string> out;
+  if (metric.empty()) {
+    std::string o = canonical_objective(objective);
+    if (o == "regression") out.push_back("l2");
+    else if (o == "regression_l1") out.push_back("l1");
+    else if (o == "huber") out.push_back("huber");
+    else if (o == "fair") out.push_back("fair");
+    else if (o == "poisson") out.push_back("poisson");
+    else if (o == "binary") out.push_back("binary_logloss");
+    else if (o == "cross_entropy") out.push_back("cross_entropy");
+    return out;
+  }
+  for (const auto& m : metric) {
+    std::string c = canonical_metric(m);
+    if (c == "none") continue;
+    if (std::find(out.begin(), out.end(), c) == out.end()) out.push_back(c);
+  }
+  return out;
+}
+
+void Config::check() {
+  std::string b = lower(boosting);
+  if (b == "gbrt" || b == "gbdt") boosting = "gbdt";
+  else if (b == "rf" || b == "random_forest") boosting = "rf";
+  else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf)");
+  (void)canonical_objective(objective);
+  for (const auto& m : metric) (void)canonical_metric(m);
+  std::string t = lower(tree_learner);
+  if (t == "serial") tree_learner = "serial";
+  else if (t == "feature" || t == "feature_parallel") tree_learner = "feature";
+  else if (t == "data" || t == "data_parallel") tree_learner = "data";
+  else if (t == "voting" || t == "voting_parallel") tree_learner = "data";  // served by the data-parallel learner
+  else throw std::runtime_error("unknown tree_learner \"" + tree_learner + "\"");
+  std::string d = lower(device_type);
+  if (d == "cpu") device_type = "cpu";
+  else if (d == "gpu" || d == "hip" || d == "cuda" || d == "rocm") device_type = "gpu";
+  else throw std::runtime_error("unknown device_type \"" + device_type + "\"");
+  if (boosting == "rf") {
+    bool row_sub = bagging_freq > 0 && bagging_fraction < 1.0;
+    bool col_sub = feature_fraction < 1.0 || feature_fraction_bynode < 1.0;
+    if (!row_sub && !col_sub)
+      throw std::runtime_error(
+          "boosting=rf needs row sub-sampling (bagging_freq > 0 and bagging_fraction < 1) "
+          "or column sub-sampling (feature_fraction < 1)");
+  }
+  if (max_depth > 0) {
+    // a tree of depth d has at most 2^d leaves
+    if (max_depth < 30) num_leaves = std::min(num_leaves, 1 << max_depth);
+  }
+}
+
+std::string Config::to_model_string() const {
+  std::ostringstream os;
+  for (const auto& p : kParams) {
+    os << "[" << p.name << ": ";
+    switch (p.type) {
+      case PType::Int: os << cfield<int>(this, p.offset); break;
+      case PType::Double: os << fmt_double(cfield<double>(this, p.offset)); break;
+      case PType::Bool: os << (cfield<bool>(this, p.offset) ? 1 : 0); break;
+      case PType::String: os << cfield<std::string>(this, p.offset); break;
+      case PType::StringList: {
+        const auto& l = cfield<std::vector<std::string>>(this, p.offset);
+        for (size_t i = 0; i < l.size(); ++i) os << (i ? "," : "") << l[i];
+        break;
+      }
+    }
+    os << "]\n";
+  }
+  return os.str();
+}
+
+}  // namespace lga

@@ -1,0 +1,97 @@
+// Parameter registry: one table (name, aliases, type, default, range) drives
+// alias resolution, validation, defaults and the "parameters:" block of the
+// text model.  Mirrors the flat named-list parameter style the reference
+// scripts use (r/gridsearchCV.R:55, 94-100, 108: `params` list + extra
+// named args + a data.frame row all end up in one namespace).
+#pragma once
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdint>
+
+namespace lga {
+
+struct Config {
+  // core
+  std::string objective = "regression";
+  std::string boosting = "gbdt";
+  std::string tree_learner = "serial";
+  std::string device_type = "cpu";
+  int num_iterations = 100;
+  double learning_rate = 0.1;
+  int num_leaves = 31;
+  int num_threads = 0;
+  int seed = 0;
+  bool deterministic = true;
+  // learning control
+  int max_depth = -1;
+  int min_data_in_leaf = 20;
+  double min_sum_hessian_in_leaf = 1e-3;
+  double bagging_fraction = 1.0;
+  int bagging_freq = 0;
+  int bagging_seed = 3;
+  double feature_fraction = 1.0;
+  double feature_fraction_bynode = 1.0;
+  int feature_fraction_seed = 2;
+  int early_stopping_round = 0;
+  bool first_metric_only = false;
+  double max_delta_step = 0.0;
+  double lambda_l1 = 0.0;
+  double lambda_l2 = 0.0;
+  double min_gain_to_split = 0.0;
+  int verbosity = 1;
+  // dataset
+  int max_bin = 255;
+  int min_data_in_bin = 3;
+  int bin_construct_sample_cnt = 200000;
+  int data_random_seed = 1;
+  bool use_missing = true;
+  bool zero_as_missing = false;
+  bool feature_pre_filter = true;
+  // objective
+  bool boost_from_average = true;
+  double sigmoid = 1.0;
+  bool is_unbalance = false;
+  double scale_pos_weight = 1.0;
+  double alpha = 0.9;          // huber / quantile
+  double fair_c = 1.0;
+  double poisson_max_delta_step = 0.7;
+  // metric
+  std::vector<std::string> metric;   // empty: derived from the objective
+  int metric_freq = 1;
+  bool is_provide_training_metric = false;
+  // io
+  int snapshot_freq = -1;
+  std::string output_model = "LightGBM_model.txt";
+  std::string input_model = "";
+  // distributed
+  int num_machines = 1;
+  // device
+  int gpu_device_id = 0;
+  int max_batch_leaves = 0;   // 0: as many leaves per growth round as the budget allows
+  bool profile = false;
+
+  // Names of parameters that were explicitly set (after alias resolution).
+  std::vector<std::string> explicit_keys;
+  // Unknown keys seen while parsing (reported as warnings, not errors).
+  std::vector<std::string> unknown_keys;
+
+  // Parse "k=v k2=v2" (whitespace or newline separated); later keys override.
+  // Throws std::runtime_error on a malformed or out-of-range value.
+  void set(const std::string& params);
+  void set(const std::map<std::string, std::string>& kv);
+  void check();   // cross-parameter validation (rf needs sub-sampling, ...)
+
+  // "[name: value]" lines, in table order, for the model file.
+  std::string to_model_string() const;
+  // Canonical objective name ("regression", "binary") and its metric default.
+  static std::string canonical_objective(const std::string& name);
+  static std::string canonical_metric(const std::string& name);
+  std::vector<std::string> resolved_metrics() const;
+
+  // Alias handling, usable from the bindings.
+  static std::string resolve_alias(const std::string& name);  // "" if unknown
+  static std::string alias_table_json();
+};
+
+}  // namespace lga

@@ -1,0 +1,196 @@
+#include "dataset.hpp"
+#include "binning_core.hpp"
+#include <algorithm>
+#include <stdexcept>
+#include <cstring>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace lga {
+
+namespace {
+inline double load_value(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, int64_t r, int c) {
+  int64_t off = row_major ? r * (int64_t)ncol + c : (int64_t)c * nrow + r;
+  return dtype == 0 ? (double)((const float*)data)[off] : ((const double*)data)[off];
+}
+}  // namespace
+
+void Dataset::finish_mappers() {
+  used_feature_.clear();
+  inner_of_real_.assign(mappers_.size(), -1);
+  for (size_t f = 0; f < mappers_.size(); ++f) {
+    if (!mappers_[f].trivial) {
+      inner_of_real_[f] = (int32_t)used_feature_.size();
+      used_feature_.push_back((int32_t)f);
+    }
+  }
+  if (feature_names.size() != mappers_.size()) {
+    feature_names.resize(mappers_.size());
+    for (size_t f = 0; f < mappers_.size(); ++f) feature_names[f] = "Column_" + std::to_string(f);
+  }
+}
+
+std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsample, int ncol, int64_t nrow,
+                                              const Config& cfg) {
+  auto ds = std::make_shared<Dataset>();
+  ds->root_rows_ = nrow;
+  ds->mappers_.resize(ncol);
+#pragma omp parallel for schedule(dynamic)
+  for (int f = 0; f < ncol; ++f) {
+    std::vector<double> col((size_t)nsample);
+    for (int64_t i = 0; i < nsample; ++i) col[(size_t)i] = sample[i * ncol + f];
+    ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing);
+  }
+  ds->finish_mappers();
+  return ds;
+}
+
+std::shared_ptr<Dataset> Dataset::from_matrix(const void* data, int dtype, int64_t nrow, int ncol, bool row_major,
+                                              const Config& cfg, const Dataset* reference, bool bin_on_host) {
+  if (nrow <= 0 || ncol <= 0) throw std::runtime_error("Dataset: empty matrix");
+  if (nrow > 2147483000LL) throw std::runtime_error("Dataset: more than 2^31 rows per device is not supported");
+  std::shared_ptr<Dataset> ds;
+  if (reference) {
+    const Dataset* r = reference->root();
+    if (r->num_total_features() != ncol)
+      throw std::runtime_error("Dataset: reference has a different number of features");
+    ds = std::make_shared<Dataset>();
+    ds->root_rows_ = nrow;
+    ds->mappers_ = r->mappers_;
+    ds->feature_names = r->feature_names;
+    ds->finish_mappers();
+  } else {
+    // row sample for bin finding
+    int64_t want = cfg.bin_construct_sample_cnt;
+    std::vector<int64_t> rows;
+    if (nrow <= want) {
+      rows.resize((size_t)nrow);
+      for (int64_t i = 0; i < nrow; ++i) rows[(size_t)i] = i;
+    } else {
+      float p = (float)((double)want / (double)nrow);
+      rows.reserve((size_t)(want + want / 8));
+      for (int64_t i = 0; i < nrow; ++i)
+        if (rng_uniform((uint64_t)cfg.data_random_seed, 0x5a17u, (uint64_t)i) < p) rows.push_back(i);
+    }
+    int64_t ns = (int64_t)rows.size();
+    std::vector<double> sample((size_t)ns * ncol);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < ns; ++i)
+      for (int c = 0; c < ncol; ++c)
+        sample[(size_t)(i * ncol + c)] = load_value(data, dtype, nrow, ncol, row_major, rows[(size_t)i], c);
+    ds = from_sample(sample.data(), ns, ncol, nrow, cfg);
+  }
+  if (bin_on_host) {
+    int F = ds->num_features();
+    int T = ds->num_tiles();
+    std::vector<uint8_t> rt((size_t)T * nrow * kTileFeatures, 0), fm((size_t)F * nrow, 0);
+    ds->bin_rows(data, dtype, nrow, ncol, row_major, rt.data(), fm.data(), nrow, 0);
+    ds->adopt_host_bins(std::move(rt), std::move(fm));
+  }
+  return ds;
+}
+
+void Dataset::bin_rows(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, uint8_t* rt, uint8_t* fm,
+                       int64_t total_rows, int64_t row_offset) const {
+  const Dataset* r = root();
+  int F = r->num_features();
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < nrow; ++i) {
+    int64_t row = row_offset + i;
+    for (int f = 0; f < F; ++f) {
+      const BinMapper& m = r->mappers_[r->used_feature_[f]];
+      double v = load_value(data, dtype, nrow, ncol, row_major, i, r->used_feature_[f]);
+      uint8_t b = (uint8_t)m.value_to_bin(v);
+      int t = f / kTileFeatures, k = f % kTileFeatures;
+      rt[((size_t)t * total_rows + row) * kTileFeatures + k] = b;
+      fm[(size_t)f * total_rows + row] = b;
+    }
+  }
+}
+
+void Dataset::adopt_host_bins(std::vector<uint8_t>&& rt, std::vector<uint8_t>&& fm) {
+  if (parent_) throw std::runtime_error("adopt_host_bins on a subset");
+  bins_rt_ = std::move(rt);
+  bins_fm_ = std::move(fm);
+}
+
+std::shared_ptr<Dataset> Dataset::subset(const int32_t* indices, int64_t n) const {
+  auto ds = std::make_shared<Dataset>();
+  std::shared_ptr<const Dataset> rootp = parent_ ? parent_ : shared_from_this();
+  ds->parent_ = rootp;
+  ds->root_rows_ = rootp->root_rows_;
+  auto idx = std::make_shared<std::vector<int32_t>>((size_t)n);
+  int64_t local_n = num_data();
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t v = indices[i];
+    if (v < 0 || v >= local_n) throw std::runtime_error("subset: index out of range");
+    (*idx)[(size_t)i] = used_indices_ ? (*used_indices_)[(size_t)v] : v;
+  }
+  // the learners keep row lists ascending (stable partitions preserve it)
+  std::sort(idx->begin(), idx->end());
+  if (std::adjacent_find(idx->begin(), idx->end()) != idx->end())
+    throw std::runtime_error("subset: duplicate row index");
+  ds->used_indices_ = idx;
+  return ds;
+}
+
+std::vector<FeatureMeta> Dataset::feature_meta() const {
+  int F = num_features();
+  std::vector<FeatureMeta> m((size_t)F);
+  for (int f = 0; f < F; ++f) {
+    const BinMapper& bm = inner_mapper(f);
+    m[(size_t)f].num_bin = bm.num_bin;
+    m[(size_t)f].missing_bin = bm.missing_bin;
+    m[(size_t)f].enabled = 1;
+    m[(size_t)f].pad = 0;
+  }
+  return m;
+}
+
+namespace {
+template <typename T>
+void scatter_field(std::vector<T>& dst, int64_t root_rows, const std::vector<int32_t>* used, const T* v, int64_t n,
+                   int64_t local_n, const char* what) {
+  if (n == 0) { if (!used) dst.clear(); return; }
+  if (n != local_n) throw std::runtime_error(std::string("length of ") + what + " differs from the number of rows");
+  if (!used) { dst.assign(v, v + n); return; }
+  if (dst.empty()) dst.assign((size_t)root_rows, (T)0);
+  for (int64_t i = 0; i < n; ++i) dst[(size_t)(*used)[(size_t)i]] = v[i];
+}
+}  // namespace
+
+void Dataset::set_label(const float* v, int64_t n) {
+  scatter_field(root_mut()->label_, root_rows_, used_indices_.get(), v, n, num_data(), "label");
+}
+void Dataset::set_weight(const float* v, int64_t n) {
+  for (int64_t i = 0; i < n; ++i)
+    if (!(v[i] >= 0.0f)) throw std::runtime_error("weights must be non-negative");
+  scatter_field(root_mut()->weight_, root_rows_, used_indices_.get(), v, n, num_data(), "weight");
+}
+void Dataset::set_init_score(const double* v, int64_t n) {
+  scatter_field(root_mut()->init_score_, root_rows_, used_indices_.get(), v, n, num_data(), "init_score");
+}
+
+std::vector<float> Dataset::local_label() const {
+  const auto& l = root_label();
+  if (!used_indices_) return l;
+  std::vector<float> out(used_indices_->size());
+  if (l.empty()) { out.clear(); return out; }
+  for (size_t i = 0; i < out.size(); ++i) out[i] = l[(size_t)(*used_indices_)[i]];
+  return out;
+}
+std::vector<float> Dataset::local_weight() const {
+  const auto& l = root_weight();
+  if (!used_indices_ || l.empty()) return l;
+  std::vector<float> out(used_indices_->size());
+  for (size_t i = 0; i < out.size(); ++i) out[i] = l[(size_t)(*used_indices_)[i]];
+  return out;
+}
+
+void Dataset::set_feature_names(const std::vector<std::string>& names) {
+  if ((int)names.size() != num_total_features()) throw std::runtime_error("feature_name length mismatch");
+  root_mut()->feature_names = names;
+}
+
+}  // namespace lga

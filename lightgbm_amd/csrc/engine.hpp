@@ -1,0 +1,61 @@
+// Execution engine of one booster: owns scores, gradients, the current bag
+// and the tree backend for one training dataset (+ validation datasets).
+// The boosting driver (gbdt.cpp) is written against this interface; the host
+// (OpenMP) and HIP engines implement it with the same numerics.
+#pragma once
+#include "backend.hpp"
+#include "config.hpp"
+#include "dataset.hpp"
+#include "grower.hpp"
+#include "objective.hpp"
+#include "tree.hpp"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace lga {
+
+struct EvalResult {
+  std::string name;
+  double value;
+  bool higher_better;
+};
+
+class Engine {
+ public:
+  virtual ~Engine() {}
+  virtual const char* name() const = 0;
+  // which: -1 training data, >=0 validation set index
+  virtual int add_valid(std::shared_ptr<Dataset> ds) = 0;
+  virtual int num_valid() const = 0;
+  virtual int64_t num_rows(int which) const = 0;
+
+  // Sum of weight*label and sum of weight over the (global) training rows.
+  virtual void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) = 0;
+  // scores = dataset init_score (or 0) + v, for training and validation data.
+  virtual void reset_scores(double v) = 0;
+  virtual void scale_scores(int which, double factor) = 0;
+  virtual void add_constant(int which, double v) = 0;
+
+  virtual void compute_gradients(const ObjectiveSpec& obj) = 0;
+  // Gradients supplied by the caller, ordered like the training dataset's rows.
+  virtual void set_gradients(const float* g, const float* h, int64_t n) = 0;
+  // Draw a new bag (every row when fraction >= 1).
+  virtual void resample(double fraction, uint64_t seed, uint64_t iter) = 0;
+
+  // Grow a tree on the current gradients/bag.  Leaf values are unshrunk.
+  virtual Tree train_tree(const std::vector<FeatureMeta>& meta) = 0;
+  // Add `tree` (final leaf values) to the training scores, using the row
+  // ranges of the tree just grown for in-bag rows and traversal for the rest.
+  virtual void add_trained_tree_to_train_scores(const Tree& tree) = 0;
+  // Add (sign=+1) or remove (sign=-1) a tree's output by traversal of the binned rows.
+  virtual void add_tree_by_traversal(int which, const Tree& tree, double sign) = 0;
+
+  virtual std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) = 0;
+  virtual void get_scores(int which, double* out) = 0;   // dataset-local row order
+  virtual void get_gradients(float* g, float* h) = 0;    // dataset-local row order
+  virtual std::string profile_json() const { return "{}"; }
+  virtual GrowStats grow_stats() const = 0;
+};
+
+}  // namespace lga

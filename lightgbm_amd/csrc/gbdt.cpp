@@ -1,0 +1,282 @@
+#include "gbdt.hpp"
+#include "metric.hpp"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <sstream>
+#include <stdexcept>
+
+namespace lga {
+
+Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, const EngineFactory& factory)
+    : train_(train) {
+  cfg_.set(params);
+  if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
+  is_rf_ = cfg_.boosting == "rf";
+  average_output_ = is_rf_;
+  setup_objective();
+  for (const auto& m : cfg_.resolved_metrics()) metrics_.push_back(metric_kind_from_name(m));
+  engine_ = factory(train_, cfg_);
+  max_feature_idx_ = train_->num_total_features() - 1;
+  feature_names_ = train_->names();
+  feature_infos_.clear();
+  for (const auto& m : train_->mappers()) feature_infos_.push_back(m.info_string());
+}
+
+Booster::Booster(const std::string& model_text) { load_model_from_string(model_text); }
+
+void Booster::setup_objective() {
+  std::string o = Config::canonical_objective(cfg_.objective);
+  obj_ = ObjectiveSpec{};
+  obj_.sigmoid = cfg_.sigmoid;
+  obj_.pos_weight = 1.0;
+  obj_.neg_weight = 1.0;
+  obj_.alpha = cfg_.alpha;
+  obj_.fair_c = cfg_.fair_c;
+  obj_.poisson_max_delta = cfg_.poisson_max_delta_step;
+  if (o == "regression") { obj_.kind = kObjRegression; objective_str_ = "regression"; }
+  else if (o == "regression_l1") { obj_.kind = kObjRegressionL1; objective_str_ = "regression_l1"; }
+  else if (o == "huber") { obj_.kind = kObjHuber; objective_str_ = "huber"; }
+  else if (o == "fair") { obj_.kind = kObjFair; objective_str_ = "fair"; }
+  else if (o == "poisson") { obj_.kind = kObjPoisson; objective_str_ = "poisson"; }
+  else if (o == "binary") {
+    obj_.kind = kObjBinary;
+    std::ostringstream os;
+    os << "binary sigmoid:" << cfg_.sigmoid;
+    objective_str_ = os.str();
+  } else if (o == "cross_entropy") { obj_.kind = kObjCrossEntropy; objective_str_ = "cross_entropy"; }
+  else { obj_.kind = kObjCustom; objective_str_ = "custom"; }
+}
+
+void Booster::add_valid(std::shared_ptr<Dataset> ds, const std::string& name) {
+  if (!engine_) throw std::runtime_error("add_valid on a prediction-only booster");
+  if (scores_initialised_) throw std::runtime_error("validation data must be added before the first boosting iteration");
+  engine_->add_valid(ds);
+  valid_sets_.push_back(ds);
+  valid_names_.push_back(name);
+}
+
+double Booster::boost_from_average() {
+  if (!cfg_.boost_from_average) return 0.0;
+  if (!train_->root_init_score().empty()) return 0.0;
+  double swy, sw, swp;
+  engine_->label_stats(&swy, &sw, &swp);
+  if (!(sw > 0.0)) return 0.0;
+  switch (obj_.kind) {
+    case kObjRegression:
+    case kObjHuber:
+    case kObjFair:
+    case kObjRegressionL1:   // mean instead of the median: a constant start either way
+      return swy / sw;
+    case kObjPoisson: {
+      double m = swy / sw;
+      return std::log(m > 1e-10 ? m : 1e-10);
+    }
+    case kObjBinary: {
+      double pos = swp * obj_.pos_weight, neg = (sw - swp) * obj_.neg_weight;
+      double p = pos / (pos + neg);
+      p = std::min(std::max(p, 1e-15), 1.0 - 1e-15);
+      return std::log(p / (1.0 - p)) / obj_.sigmoid;
+    }
+    case kObjCrossEntropy: {
+      double p = std::min(std::max(swy / sw, 1e-15), 1.0 - 1e-15);
+      return std::log(p / (1.0 - p));
+    }
+    default: return 0.0;
+  }
+}
+
+std::vector<FeatureMeta> Booster::sample_features() {
+  std::vector<FeatureMeta> meta = train_->feature_meta();
+  int F = (int)meta.size();
+  double ff = cfg_.feature_fraction;
+  if (ff >= 1.0 || F <= 1) return meta;
+  int k = std::max(1, (int)(F * ff + 0.5));
+  std::vector<int> perm((size_t)F);
+  std::iota(perm.begin(), perm.end(), 0);
+  for (int j = 0; j < k; ++j) {
+    uint64_t r = rng_u64((uint64_t)cfg_.feature_fraction_seed, (uint64_t)iter_, (uint64_t)j);
+    int pick = j + (int)(r % (uint64_t)(F - j));
+    std::swap(perm[(size_t)j], perm[(size_t)pick]);
+  }
+  for (auto& m : meta) m.enabled = 0;
+  for (int j = 0; j < k; ++j) meta[(size_t)perm[(size_t)j]].enabled = 1;
+  return meta;
+}
+
+bool Booster::update_one_iter() {
+  if (!engine_) throw std::runtime_error("update on a prediction-only booster");
+  if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
+  if (!scores_initialised_) {
+    if (obj_.kind == kObjBinary) {
+      double swy, sw, swp;
+      engine_->label_stats(&swy, &sw, &swp);
+      double cp = swp, cn = sw - swp;
+      if (cfg_.is_unbalance && cp > 0 && cn > 0) {
+        if (cp > cn) { obj_.pos_weight = 1.0; obj_.neg_weight = cp / cn; }
+        else { obj_.pos_weight = cn / cp; obj_.neg_weight = 1.0; }
+      }
+      obj_.pos_weight *= cfg_.scale_pos_weight;
+    }
+    init_score_ = boost_from_average();
+    engine_->reset_scores(init_score_);
+    scores_initialised_ = true;
+    if (is_rf_) engine_->compute_gradients(obj_);
+  }
+  if (!is_rf_) engine_->compute_gradients(obj_);
+  bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
+  if (bagging && (iter_ % cfg_.bagging_freq == 0)) engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
+  Tree tree = engine_->train_tree(sample_features());
+  return finish_iteration(std::move(tree));
+}
+
+bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64_t n) {
+  if (!engine_) throw std::runtime_error("update on a prediction-only booster");
+  if (is_rf_) throw std::runtime_error("custom gradients are not supported with boosting=rf");
+  if (!scores_initialised_) {
+    init_score_ = 0.0;
+    engine_->reset_scores(0.0);
+    scores_initialised_ = true;
+  }
+  engine_->set_gradients(grad, hess, n);
+  bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
+  if (bagging && (iter_ % cfg_.bagging_freq == 0)) engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
+  Tree tree = engine_->train_tree(sample_features());
+  return finish_iteration(std::move(tree));
+}
+
+bool Booster::finish_iteration(Tree&& tree) {
+  ++iter_;
+  if (tree.num_leaves <= 1) {
+    if (!trees_.empty()) return true;   // nothing learnable any more: drop this iteration
+    tree.leaf_value[0] = 0.0;
+    tree.add_bias(init_score_);
+    trees_.push_back(std::move(tree));
+    return true;
+  }
+  int nv = engine_->num_valid();
+  if (!is_rf_) {
+    tree.apply_shrinkage(cfg_.learning_rate);
+    engine_->add_trained_tree_to_train_scores(tree);
+    for (int v = 0; v < nv; ++v) engine_->add_tree_by_traversal(v, tree, 1.0);
+    if (trees_.empty() && init_score_ != 0.0) tree.add_bias(init_score_);
+  } else {
+    // running average of (init + tree) over the forest
+    double t = (double)trees_.size();
+    tree.add_bias(init_score_);
+    Tree scaled = tree;
+    for (auto& v : scaled.leaf_value) v /= (t + 1.0);
+    engine_->scale_scores(-1, t / (t + 1.0));
+    engine_->add_trained_tree_to_train_scores(scaled);
+    for (int v = 0; v < nv; ++v) {
+      engine_->scale_scores(v, t / (t + 1.0));
+      engine_->add_tree_by_traversal(v, scaled, 1.0);
+    }
+  }
+  trees_.push_back(std::move(tree));
+  return false;
+}
+
+void Booster::rollback_one_iter() {
+  if (!engine_ || trees_.empty()) return;
+  Tree last = trees_.back();
+  int nv = engine_->num_valid();
+  if (!is_rf_) {
+    if (trees_.size() == 1 && init_score_ != 0.0) last.add_bias(-init_score_);
+    for (int w = -1; w < nv; ++w) engine_->add_tree_by_traversal(w, last, -1.0);
+  } else {
+    double t = (double)trees_.size();
+    if (trees_.size() == 1) {
+      engine_->reset_scores(init_score_);
+    } else {
+      for (int w = -1; w < nv; ++w) {
+        engine_->add_tree_by_traversal(w, last, -1.0 / t);
+        engine_->scale_scores(w, t / (t - 1.0));
+      }
+    }
+  }
+  trees_.pop_back();
+  --iter_;
+}
+
+void Booster::reset_parameter(const std::string& params) {
+  Config c = cfg_;
+  c.set(params);
+  // only parameters that do not change the engine's buffers may be reset
+  if (c.num_leaves != cfg_.num_leaves || c.max_bin != cfg_.max_bin || c.boosting != cfg_.boosting ||
+      c.device_type != cfg_.device_type || c.tree_learner != cfg_.tree_learner)
+    throw std::runtime_error("reset_parameter: num_leaves / max_bin / boosting / device / tree_learner cannot change");
+  cfg_.learning_rate = c.learning_rate;
+  cfg_.bagging_fraction = c.bagging_fraction;
+  cfg_.bagging_freq = c.bagging_freq;
+  cfg_.feature_fraction = c.feature_fraction;
+}
+
+std::vector<EvalResult> Booster::eval(int which) {
+  if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
+  if (!scores_initialised_) {
+    init_score_ = 0.0;
+    engine_->reset_scores(0.0);
+  }
+  return engine_->eval(which, metrics_, obj_);
+}
+
+void Booster::inner_predict(int which, bool raw, double* out) {
+  engine_->get_scores(which, out);
+  if (!raw) {
+    int64_t n = engine_->num_rows(which);
+    for (int64_t i = 0; i < n; ++i) out[i] = transform_score(obj_.kind, obj_.sigmoid, out[i]);
+  }
+}
+
+int Booster::used_iterations(int start_iter, int num_iter) const {
+  int total = (int)trees_.size();
+  start_iter = std::max(0, std::min(start_iter, total));
+  int n = num_iter > 0 ? std::min(num_iter, total - start_iter) : total - start_iter;
+  return n;
+}
+
+void Booster::predict(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, int start_iter,
+                      int num_iter, int type, double* out) const {
+  if (ncol <= max_feature_idx_)
+    throw std::runtime_error("predict: the data has " + std::to_string(ncol) + " features, the model needs " +
+                             std::to_string(max_feature_idx_ + 1));
+  int total = (int)trees_.size();
+  start_iter = std::max(0, std::min(start_iter, total));
+  int n_it = used_iterations(start_iter, num_iter);
+#pragma omp parallel
+  {
+    std::vector<double> row((size_t)ncol);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < nrow; ++i) {
+      for (int c = 0; c < ncol; ++c) {
+        int64_t off = row_major ? i * (int64_t)ncol + c : (int64_t)c * nrow + i;
+        row[(size_t)c] = dtype == 0 ? (double)((const float*)data)[off] : ((const double*)data)[off];
+      }
+      if (type == kPredictLeaf) {
+        for (int t = 0; t < n_it; ++t)
+          out[i * (int64_t)n_it + t] = (double)trees_[(size_t)(start_iter + t)].predict_leaf(row.data());
+      } else {
+        double s = 0.0;
+        for (int t = 0; t < n_it; ++t) s += trees_[(size_t)(start_iter + t)].predict(row.data());
+        if (average_output_ && n_it > 0) s /= (double)n_it;
+        out[i] = type == kPredictRaw ? s : transform_score(obj_.kind, obj_.sigmoid, s);
+      }
+    }
+  }
+}
+
+std::vector<double> Booster::feature_importance(int num_iter, int importance_type) const {
+  std::vector<double> imp((size_t)(max_feature_idx_ + 1), 0.0);
+  int n = num_iter > 0 ? std::min(num_iter, (int)trees_.size()) : (int)trees_.size();
+  for (int t = 0; t < n; ++t) {
+    const Tree& tr = trees_[(size_t)t];
+    for (int i = 0; i + 1 < tr.num_leaves; ++i) {
+      if (tr.split_gain[(size_t)i] <= 0.0 && importance_type == 1) continue;
+      imp[(size_t)tr.split_feature[(size_t)i]] += importance_type == 0 ? 1.0 : tr.split_gain[(size_t)i];
+    }
+  }
+  return imp;
+}
+
+}  // namespace lga

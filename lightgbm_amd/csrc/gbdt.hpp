@@ -1,0 +1,97 @@
+// Boosting drivers: gradient boosting (`lgb.train`, r/gridsearchCV.R:57-61,
+// 134-138) and the random-forest / bagging mode that
+// bagging_boosting.ipynb:10-13 contrasts it with.  One Booster = one model +
+// (when training) one execution engine.
+#pragma once
+#include "config.hpp"
+#include "dataset.hpp"
+#include "engine.hpp"
+#include "tree.hpp"
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace lga {
+
+using EngineFactory = std::function<std::unique_ptr<Engine>(std::shared_ptr<Dataset>, const Config&)>;
+
+enum PredictType : int { kPredictNormal = 0, kPredictRaw = 1, kPredictLeaf = 2 };
+
+class Booster {
+ public:
+  // Training booster.
+  Booster(std::shared_ptr<Dataset> train, const std::string& params, const EngineFactory& factory);
+  // Prediction-only booster from a LightGBM text model.
+  explicit Booster(const std::string& model_text);
+
+  void add_valid(std::shared_ptr<Dataset> ds, const std::string& name);
+  // One boosting iteration; returns true when no further split was possible
+  // (the iteration's tree is then discarded, except for the very first one).
+  bool update_one_iter();
+  bool update_one_iter_custom(const float* grad, const float* hess, int64_t n);
+  void rollback_one_iter();
+  void reset_parameter(const std::string& params);
+  // Put `first`'s trees in front of this booster's (continued training from init_model).
+  void prepend_trees(const Booster& first) { trees_.insert(trees_.begin(), first.trees_.begin(), first.trees_.end()); }
+
+  int current_iteration() const { return (int)trees_.size(); }
+  int num_trees() const { return (int)trees_.size(); }
+  int num_features() const { return max_feature_idx_ + 1; }
+  int num_valid() const { return engine_ ? engine_->num_valid() : 0; }
+  const std::vector<std::string>& valid_names() const { return valid_names_; }
+  std::vector<EvalResult> eval(int which);
+  // Current (transformed unless raw) predictions for training (-1) / validation data.
+  void inner_predict(int which, bool raw, double* out);
+  int64_t inner_num_rows(int which) const { return engine_->num_rows(which); }
+  void get_gradients(float* g, float* h) { engine_->get_gradients(g, h); }
+
+  // Dense prediction on the host.  out: nrow doubles (or nrow * used_trees ints-as-doubles for leaf indices).
+  void predict(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, int start_iter, int num_iter,
+               int type, double* out) const;
+  int used_iterations(int start_iter, int num_iter) const;
+
+  std::string save_model_to_string(int start_iter, int num_iter, int importance_type) const;
+  std::string dump_json(int start_iter, int num_iter) const;
+  std::vector<double> feature_importance(int num_iter, int importance_type) const;  // 0 split, 1 gain
+  const std::vector<std::string>& feature_names() const { return feature_names_; }
+  const std::vector<Tree>& trees() const { return trees_; }
+  const Config& config() const { return cfg_; }
+  const std::string& objective_string() const { return objective_str_; }
+  bool average_output() const { return average_output_; }
+  ObjectiveSpec objective_spec() const { return obj_; }
+  std::string last_profile() const { return engine_ ? engine_->profile_json() : "{}"; }
+  GrowStats last_grow_stats() const { return engine_ ? engine_->grow_stats() : GrowStats(); }
+  Engine* engine() { return engine_.get(); }
+  double init_score_value() const { return init_score_; }
+
+ private:
+  void setup_objective();
+  double boost_from_average();
+  std::vector<FeatureMeta> sample_features();
+  bool finish_iteration(Tree&& tree);
+  void load_model_from_string(const std::string& text);
+
+  Config cfg_;
+  std::shared_ptr<Dataset> train_;
+  std::unique_ptr<Engine> engine_;
+  std::vector<std::shared_ptr<Dataset>> valid_sets_;
+  std::vector<std::string> valid_names_;
+  std::vector<int32_t> metrics_;
+  ObjectiveSpec obj_{};
+  std::string objective_str_;
+  bool is_rf_ = false;
+  bool average_output_ = false;
+  bool scores_initialised_ = false;
+  double init_score_ = 0.0;
+  int iter_ = 0;                 // iterations attempted (drives bagging / feature sampling streams)
+  std::vector<Tree> trees_;
+  // model meta
+  int max_feature_idx_ = -1;
+  int label_index_ = 0;
+  std::vector<std::string> feature_names_;
+  std::vector<std::string> feature_infos_;
+  std::string loaded_parameters_;
+};
+
+}  // namespace lga

@@ -1,0 +1,486 @@
+#include "host_engine.hpp"
+#include "metric.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace lga {
+
+void quantize_rows_host(const float* g, const float* h, const int32_t* rows, int64_t n, QuantScale qs,
+                        int64_t* packed) {
+#pragma omp parallel for schedule(static) if (n > 65536)
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t r = rows ? rows[i] : i;
+    packed[r] = pack_gh(quantize(g[r], qs.kg), quantize(h[r], qs.kh));
+  }
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Host backend
+// ---------------------------------------------------------------------------
+class HostBackend : public TreeBackend {
+ public:
+  HostBackend(const Dataset* ds, const Config& cfg, Comm* comm, ParallelMode mode)
+      : root_(ds->root()), comm_(comm), mode_(mode) {
+    F_ = root_->num_features();
+    TF_ = root_->num_tiles() * kTileFeatures;
+    N_ = root_->root_rows();
+    plane_ = (size_t)TF_ * kMaxBins;
+    slot_words_ = 2 * plane_ + kSlotHeader;
+    int L = std::max(cfg.num_leaves, 2);
+    capacity_splits_ = 2 * (L - 1) + 1;
+    pool_.assign((size_t)(capacity_splits_ + 1) * slot_words_, 0);
+    ranges_.resize((size_t)(2 * capacity_splits_ + 1));
+    if (comm_ && comm_->size() > 1 && mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
+    if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
+  }
+
+  void set_bag(const int32_t* rows, int64_t n) { bag_ = rows; bag_n_ = n; }
+  void set_gradients(const int64_t* packed, QuantScale qs) { packed_ = packed; qs_ = qs; }
+
+  int node_capacity() const override { return 2 * capacity_splits_ + 1; }
+  QuantScale quant_scale() const override { return qs_; }
+  int64_t node_local_count(int node) const override { return ranges_[(size_t)node].count; }
+  const NodeRange& range(int node) const { return ranges_[(size_t)node]; }
+  const int32_t* arena(int buf) const { return arena_[buf].data(); }
+
+  void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
+    meta_ = meta;
+    sp_ = params;
+    for (int b = 0; b < 2; ++b)
+      if ((int64_t)arena_[b].size() < bag_n_) arena_[b].resize((size_t)bag_n_);
+    std::memcpy(arena_[0].data(), bag_, (size_t)bag_n_ * sizeof(int32_t));
+    ranges_[0] = NodeRange{0, (int32_t)bag_n_, 0, 0};
+  }
+
+  void root_round(SplitInfo* out) override {
+    build_hist(0, 0);
+    reduce_slots(0, 1);
+    ScanTask st{0, 0, -1, -1, 0, 0};
+    scan_nodes(&st, 1, out);
+  }
+
+  void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) override {
+    size_t B = tasks.size();
+    if (B == 0) return;
+    // 1. partition
+#pragma omp parallel for schedule(dynamic) if (B > 1)
+    for (size_t i = 0; i < B; ++i) partition(tasks[i]);
+    // 2. histograms of the chosen children (fresh, contiguous slots)
+    for (size_t i = 0; i < B; ++i) {
+      const SplitTask& t = tasks[i];
+      build_hist(t.hist_child == 0 ? t.left_node : t.right_node, t.new_slot);
+    }
+    reduce_slots(tasks[0].new_slot, (int)B);
+    // 3. scan both children of every task (the sibling by subtraction, in place in the parent's slot)
+    std::vector<ScanTask> st(B * 2);
+    for (size_t i = 0; i < B; ++i) {
+      const SplitTask& t = tasks[i];
+      for (int side = 0; side < 2; ++side) {
+        ScanTask& s = st[i * 2 + (size_t)side];
+        s.node = side == 0 ? t.left_node : t.right_node;
+        s.depth = t.depth;
+        if (side == t.hist_child) { s.slot = t.new_slot; s.parent_slot = -1; s.sibling_slot = -1; }
+        else { s.slot = t.parent_slot; s.parent_slot = t.parent_slot; s.sibling_slot = t.new_slot; }
+      }
+    }
+    scan_nodes(st.data(), (int)st.size(), infos);
+  }
+
+ private:
+  int64_t* slot(int s) { return pool_.data() + (size_t)s * slot_words_; }
+
+  bool owns_feature(int f) const {
+    if (mode_ != ParallelMode::Feature) return true;
+    return ((f / kTileFeatures) % comm_->size()) == comm_->rank();
+  }
+
+  void partition(const SplitTask& t) {
+    const NodeRange p = ranges_[(size_t)t.parent_node];
+    const int32_t* src = arena_[p.buf].data() + p.begin;
+    int32_t* dst = arena_[1 - p.buf].data() + p.begin;
+    const uint8_t* col = root_->bins_fm() + (size_t)t.feature * (size_t)N_;
+    int32_t nl = 0;
+    for (int32_t i = 0; i < p.count; ++i) {
+      int b = col[src[i]];
+      bool left = (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+      nl += left ? 1 : 0;
+    }
+    int32_t li = 0, ri = nl;
+    for (int32_t i = 0; i < p.count; ++i) {
+      int32_t row = src[i];
+      int b = col[row];
+      bool left = (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+      if (left) dst[li++] = row; else dst[ri++] = row;
+    }
+    ranges_[(size_t)t.left_node] = NodeRange{p.begin, nl, 1 - p.buf, 0};
+    ranges_[(size_t)t.right_node] = NodeRange{p.begin + nl, p.count - nl, 1 - p.buf, 0};
+  }
+
+  void build_hist(int node, int s) {
+    const NodeRange r = ranges_[(size_t)node];
+    int64_t* base = slot(s);
+    std::memset(base, 0, slot_words_ * sizeof(int64_t));
+    const int32_t* rows = arena_[r.buf].data() + r.begin;
+    const int64_t n = r.count;
+    int64_t* gp = base;
+    int64_t* hp = base + plane_;
+    const uint8_t* fm = root_->bins_fm();
+#pragma omp parallel for schedule(dynamic) if (n * (int64_t)F_ > 100000)
+    for (int f = 0; f < F_; ++f) {
+      if (!owns_feature(f)) continue;
+      const uint8_t* col = fm + (size_t)f * (size_t)N_;
+      int64_t* g = gp + (size_t)f * kMaxBins;
+      int64_t* h = hp + (size_t)f * kMaxBins;
+      for (int64_t i = 0; i < n; ++i) {
+        int32_t row = rows[i];
+        int64_t p = packed_[row];
+        int b = col[row];
+        g[b] += packed_g(p);
+        h[b] += packed_h(p);
+      }
+    }
+    int64_t tg = 0, th = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      int64_t p = packed_[rows[i]];
+      tg += packed_g(p);
+      th += packed_h(p);
+    }
+    int64_t* hd = base + 2 * plane_;
+    hd[0] = n; hd[1] = tg; hd[2] = th;
+  }
+
+  void reduce_slots(int first, int count) {
+    if (mode_ != ParallelMode::Data) return;
+    comm_->allreduce_sum_i64(slot(first), (size_t)count * slot_words_, false, nullptr);
+  }
+
+  struct Cand {
+    double gain;
+    uint64_t key;
+    int64_t lg, lh;
+  };
+
+  void scan_feature(const int64_t* g, const int64_t* h, int f, int64_t tg, int64_t th, int64_t tc, double gunit,
+                    double hunit, double parent_gain, Cand* best) const {
+    const FeatureMeta& m = meta_[(size_t)f];
+    int nb = m.num_bin, mb = m.missing_bin;
+    int vb = mb >= 0 ? nb - 1 : nb;   // value bins
+    int64_t mg = mb >= 0 ? g[mb] : 0, mh = mb >= 0 ? h[mb] : 0;
+    int64_t lg = 0, lh = 0;
+    int last = mb >= 0 ? vb - 1 : vb - 2;
+    for (int t = 0; t <= last; ++t) {
+      lg += g[t];
+      lh += h[t];
+      double ga = split_gain(lg, lh, tg, th, tc, gunit, hunit, sp_, parent_gain);
+      uint64_t ka = cand_key(f, t, 0);
+      if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, lg, lh};
+      if (mb >= 0 && t <= vb - 2) {
+        double gb = split_gain(lg + mg, lh + mh, tg, th, tc, gunit, hunit, sp_, parent_gain);
+        uint64_t kb = cand_key(f, t, 1);
+        if (cand_better(gb, kb, best->gain, best->key)) *best = Cand{gb, kb, lg + mg, lh + mh};
+      }
+    }
+  }
+
+  void scan_nodes(const ScanTask* st, int n, SplitInfo* out) {
+    const double gunit = unit_of(qs_.kg), hunit = unit_of(qs_.kh);
+    const double ninf = -std::numeric_limits<double>::infinity();
+    const uint64_t worst_key = ~0ull;
+    std::vector<Cand> local((size_t)n);
+#pragma omp parallel for schedule(dynamic) if (n * F_ > 64)
+    for (int i = 0; i < n; ++i) {
+      const ScanTask& s = st[i];
+      int64_t* self = slot(s.slot);
+      if (s.parent_slot >= 0) {
+        // self (== parent's storage) = parent - sibling, element-wise, header included
+        const int64_t* sib = slot(s.sibling_slot);
+        for (size_t w = 0; w < slot_words_; ++w) self[w] -= sib[w];
+      }
+      const int64_t* hd = self + 2 * plane_;
+      int64_t tc = hd[0], tg = hd[1], th = hd[2];
+      double parent_gain = leaf_gain((double)tg * gunit, (double)th * hunit, sp_.lambda_l1, sp_.lambda_l2);
+      Cand best{ninf, worst_key, 0, 0};
+      for (int f = 0; f < F_; ++f) {
+        if (!meta_[(size_t)f].enabled || !owns_feature(f)) continue;
+        scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, tg, th, tc, gunit, hunit,
+                     parent_gain, &best);
+      }
+      local[(size_t)i] = best;
+      SplitInfo& o = out[i];
+      o.total_g = tg; o.total_h = th; o.total_cnt = tc;
+    }
+    if (mode_ == ParallelMode::Feature) {
+      // exchange per-rank winners; every rank applies the same total order
+      int P = comm_->size();
+      std::vector<Cand> all((size_t)n * P);
+      comm_->allgather_bytes(local.data(), all.data(), (size_t)n * sizeof(Cand), false, nullptr);
+      for (int i = 0; i < n; ++i) {
+        Cand best = all[(size_t)i];
+        for (int r = 1; r < P; ++r) {
+          const Cand& c = all[(size_t)r * n + i];
+          if (cand_better(c.gain, c.key, best.gain, best.key)) best = c;
+        }
+        local[(size_t)i] = best;
+      }
+    }
+    for (int i = 0; i < n; ++i) {
+      const Cand& b = local[(size_t)i];
+      SplitInfo& o = out[i];
+      o.pad0 = 0;
+      if (b.gain == ninf) {
+        o.gain = ninf; o.feature = -1; o.threshold = 0; o.default_left = 0; o.left_g = o.left_h = 0; o.left_cnt = 0;
+      } else {
+        o.gain = b.gain;
+        o.feature = (int32_t)(b.key >> 16);
+        o.threshold = (int32_t)((b.key >> 1) & 0x7fff);
+        o.default_left = (int32_t)(b.key & 1);
+        o.left_g = b.lg; o.left_h = b.lh;
+        o.left_cnt = est_count(b.lh, o.total_h, o.total_cnt);
+      }
+    }
+  }
+
+  const Dataset* root_;
+  Comm* comm_;
+  ParallelMode mode_;
+  int F_, TF_;
+  int64_t N_;
+  size_t plane_, slot_words_;
+  int capacity_splits_;
+  std::vector<int64_t> pool_;
+  std::vector<int32_t> arena_[2];
+  std::vector<NodeRange> ranges_;
+  std::vector<FeatureMeta> meta_;
+  SplitParams sp_{};
+  const int32_t* bag_ = nullptr;
+  int64_t bag_n_ = 0;
+  const int64_t* packed_ = nullptr;
+  QuantScale qs_{0, 0};
+};
+
+// ---------------------------------------------------------------------------
+// Host engine
+// ---------------------------------------------------------------------------
+std::vector<int32_t> base_rows_of(const Dataset& ds) {
+  if (ds.used_indices()) return *ds.used_indices();
+  std::vector<int32_t> r((size_t)ds.root_rows());
+  std::iota(r.begin(), r.end(), 0);
+  return r;
+}
+
+class HostEngine : public Engine {
+ public:
+  HostEngine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm, ParallelMode mode)
+      : train_(train), cfg_(cfg), comm_(comm), backend_(train.get(), cfg, comm, mode), grower_(cfg, train.get()) {
+    if (!train_->has_host_bins()) throw std::runtime_error("host engine: the dataset has no host bin matrices");
+    if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
+    N_ = train_->root_rows();
+    base_ = base_rows_of(*train_);
+    scores_.assign((size_t)N_, 0.0);
+    grad_.assign((size_t)N_, 0.f);
+    hess_.assign((size_t)N_, 0.f);
+    packed_.assign((size_t)N_, 0);
+    bag_ = base_;
+    int F = train_->num_features();
+    missing_bin_.resize((size_t)F);
+    for (int f = 0; f < F; ++f) missing_bin_[(size_t)f] = train_->inner_mapper(f).missing_bin;
+#ifdef _OPENMP
+    if (cfg.num_threads > 0) omp_set_num_threads(cfg.num_threads);
+#endif
+  }
+
+  const char* name() const override { return "host"; }
+
+  int add_valid(std::shared_ptr<Dataset> ds) override {
+    if (ds->num_total_features() != train_->num_total_features())
+      throw std::runtime_error("validation data has a different number of features");
+    if (!ds->has_host_bins()) throw std::runtime_error("host engine: validation data has no host bin matrices");
+    if (ds->root_label().empty()) throw std::runtime_error("validation data has no label");
+    Valid v;
+    v.ds = ds;
+    v.rows = base_rows_of(*ds);
+    v.scores.assign((size_t)ds->root_rows(), 0.0);
+    valid_.push_back(std::move(v));
+    return (int)valid_.size() - 1;
+  }
+  int num_valid() const override { return (int)valid_.size(); }
+  int64_t num_rows(int which) const override {
+    return which < 0 ? (int64_t)base_.size() : (int64_t)valid_[(size_t)which].rows.size();
+  }
+
+  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) override {
+    const auto& y = train_->root_label();
+    const auto& w = train_->root_weight();
+    double a = 0, b = 0, c = 0;
+    for (int32_t r : base_) {
+      double ww = w.empty() ? 1.0 : w[(size_t)r];
+      a += ww * y[(size_t)r];
+      b += ww;
+      if (y[(size_t)r] > 0.0f) c += ww;
+    }
+    if (dist()) {
+      double buf[3] = {a, b, c};
+      comm_->allreduce_sum_f64(buf, 3, false, nullptr);
+      a = buf[0]; b = buf[1]; c = buf[2];
+    }
+    *sum_wy = a; *sum_w = b; *sum_w_pos = c;
+  }
+
+  void reset_scores(double v) override {
+    const auto& is = train_->root_init_score();
+    for (int32_t r : base_) scores_[(size_t)r] = v + (is.empty() ? 0.0 : is[(size_t)r]);
+    for (auto& vs : valid_) {
+      const auto& vis = vs.ds->root_init_score();
+      for (int32_t r : vs.rows) vs.scores[(size_t)r] = v + (vis.empty() ? 0.0 : vis[(size_t)r]);
+    }
+  }
+  void scale_scores(int which, double f) override {
+    if (which < 0) { for (int32_t r : base_) scores_[(size_t)r] *= f; }
+    else { auto& v = valid_[(size_t)which]; for (int32_t r : v.rows) v.scores[(size_t)r] *= f; }
+  }
+  void add_constant(int which, double c) override {
+    if (which < 0) { for (int32_t r : base_) scores_[(size_t)r] += c; }
+    else { auto& v = valid_[(size_t)which]; for (int32_t r : v.rows) v.scores[(size_t)r] += c; }
+  }
+
+  void compute_gradients(const ObjectiveSpec& obj) override {
+    const auto& y = train_->root_label();
+    const auto& w = train_->root_weight();
+    int64_t n = (int64_t)base_.size();
+#pragma omp parallel for schedule(static) if (n > 16384)
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t r = base_[(size_t)i];
+      grad_hess(obj, scores_[(size_t)r], y[(size_t)r], w.empty() ? 1.0f : w[(size_t)r], &grad_[(size_t)r],
+                &hess_[(size_t)r]);
+    }
+  }
+  void set_gradients(const float* g, const float* h, int64_t n) override {
+    if (n != (int64_t)base_.size()) throw std::runtime_error("custom gradients: wrong length");
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t r = base_[(size_t)i];
+      grad_[(size_t)r] = g[i];
+      hess_[(size_t)r] = h[i];
+    }
+  }
+  void get_gradients(float* g, float* h) override {
+    for (size_t i = 0; i < base_.size(); ++i) { g[i] = grad_[(size_t)base_[i]]; h[i] = hess_[(size_t)base_[i]]; }
+  }
+
+  void resample(double fraction, uint64_t seed, uint64_t iter) override {
+    if (fraction >= 1.0) { bag_ = base_; oob_.clear(); return; }
+    bag_.clear(); oob_.clear();
+    uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
+    float fr = (float)fraction;
+    for (int32_t r : base_) {
+      if (rng_uniform(seed, iter, salt + (uint64_t)r) < fr) bag_.push_back(r); else oob_.push_back(r);
+    }
+  }
+
+  Tree train_tree(const std::vector<FeatureMeta>& meta) override {
+    // quantisation scale from the largest |g| and h of the training rows
+    float mx[2] = {0.f, 0.f};
+    for (int32_t r : base_) {
+      mx[0] = std::max(mx[0], std::fabs(grad_[(size_t)r]));
+      mx[1] = std::max(mx[1], hess_[(size_t)r]);
+    }
+    if (dist()) comm_->allreduce_max_f32(mx, 2, false, nullptr);
+    QuantScale qs{quant_exponent(mx[0]), quant_exponent(mx[1])};
+    quantize_rows_host(grad_.data(), hess_.data(), bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
+    backend_.set_bag(bag_.data(), (int64_t)bag_.size());
+    backend_.set_gradients(packed_.data(), qs);
+    return grower_.grow(backend_, meta, &leaf_nodes_);
+  }
+
+  void add_trained_tree_to_train_scores(const Tree& tree) override {
+    for (int l = 0; l < tree.num_leaves; ++l) {
+      const NodeRange& r = backend_.range(leaf_nodes_[(size_t)l]);
+      const int32_t* rows = backend_.arena(r.buf) + r.begin;
+      double v = tree.leaf_value[(size_t)l];
+      for (int32_t i = 0; i < r.count; ++i) scores_[(size_t)rows[i]] += v;
+    }
+    if (!oob_.empty()) traverse_add(train_->root(), oob_, scores_, tree, 1.0);
+  }
+
+  void add_tree_by_traversal(int which, const Tree& tree, double sign) override {
+    if (which < 0) traverse_add(train_->root(), base_, scores_, tree, sign);
+    else { auto& v = valid_[(size_t)which]; traverse_add(v.ds->root(), v.rows, v.scores, tree, sign); }
+  }
+
+  std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
+    if (which < 0) {
+      const auto& w = train_->root_weight();
+      return eval_metrics_host(scores_.data(), train_->root_label().data(), w.empty() ? nullptr : w.data(),
+                               base_.data(), (int64_t)base_.size(), metrics, obj, comm_);
+    }
+    auto& v = valid_[(size_t)which];
+    const auto& w = v.ds->root_weight();
+    return eval_metrics_host(v.scores.data(), v.ds->root_label().data(), w.empty() ? nullptr : w.data(),
+                             v.rows.data(), (int64_t)v.rows.size(), metrics, obj, comm_);
+  }
+
+  void get_scores(int which, double* out) override {
+    if (which < 0) { for (size_t i = 0; i < base_.size(); ++i) out[i] = scores_[(size_t)base_[i]]; }
+    else { auto& v = valid_[(size_t)which]; for (size_t i = 0; i < v.rows.size(); ++i) out[i] = v.scores[(size_t)v.rows[i]]; }
+  }
+  GrowStats grow_stats() const override { return grower_.last_stats(); }
+
+ private:
+  struct Valid {
+    std::shared_ptr<Dataset> ds;
+    std::vector<int32_t> rows;
+    std::vector<double> scores;
+  };
+  bool dist() const { return comm_ && comm_->size() > 1; }
+
+  void traverse_add(const Dataset* root, const std::vector<int32_t>& rows, std::vector<double>& scores,
+                    const Tree& tree, double sign) {
+    if (tree.num_leaves <= 1) {
+      double v = tree.leaf_value[0] * sign;
+      for (int32_t r : rows) scores[(size_t)r] += v;
+      return;
+    }
+    if (tree.split_feature_inner.empty() || tree.split_feature_inner[0] < 0)
+      throw std::runtime_error("tree has no bin thresholds (loaded from a model file); cannot traverse binned data");
+    const uint8_t* fm = root->bins_fm();
+    int64_t NR = root->root_rows();
+    int64_t n = (int64_t)rows.size();
+#pragma omp parallel for schedule(static) if (n > 16384)
+    for (int64_t i = 0; i < n; ++i) {
+      int32_t r = rows[(size_t)i];
+      int leaf = tree.predict_leaf_binned([&](int f) { return (int)fm[(size_t)f * (size_t)NR + (size_t)r]; },
+                                          missing_bin_.data());
+      scores[(size_t)r] += sign * tree.leaf_value[(size_t)leaf];
+    }
+  }
+
+  std::shared_ptr<Dataset> train_;
+  Config cfg_;
+  Comm* comm_;
+  HostBackend backend_;
+  TreeGrower grower_;
+  int64_t N_ = 0;
+  std::vector<int32_t> base_, bag_, oob_;
+  std::vector<double> scores_;
+  std::vector<float> grad_, hess_;
+  std::vector<int64_t> packed_;
+  std::vector<int32_t> leaf_nodes_;
+  std::vector<int32_t> missing_bin_;
+  std::vector<Valid> valid_;
+};
+
+}  // namespace
+
+std::unique_ptr<Engine> make_host_engine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm,
+                                         ParallelMode mode) {
+  return std::unique_ptr<Engine>(new HostEngine(train, cfg, comm, mode));
+}
+
+}  // namespace lga

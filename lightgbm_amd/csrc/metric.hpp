@@ -1,0 +1,28 @@
+// Host evaluation metrics.  `eval = "rmse"` (r/gridsearchCV.R:75) and the
+// default l2 of the grid loop (r/gridsearchCV.R:108-115) are the two the
+// reference exercises; auc / binary_logloss serve the binary configs.
+#pragma once
+#include "backend.hpp"
+#include "engine.hpp"
+#include "objective.hpp"
+#include <string>
+#include <vector>
+
+namespace lga {
+
+int32_t metric_kind_from_name(const std::string& canonical);
+const char* metric_name(int32_t kind);
+bool metric_higher_better(int32_t kind);
+
+// scores/label/weight are root-indexed; rows lists the rows to evaluate
+// (nullptr: 0..n-1).  weight may be null.  With comm != nullptr sums are
+// reduced over ranks (AUC: exact over gathered (score,label,weight) triples is
+// not attempted; each rank's rank-sum is combined through a global score grid).
+std::vector<EvalResult> eval_metrics_host(const double* scores, const float* label, const float* weight,
+                                          const int32_t* rows, int64_t n, const std::vector<int32_t>& metrics,
+                                          const ObjectiveSpec& obj, Comm* comm);
+
+// Weighted AUC of (score, label>0) pairs, ties counted half.
+double auc_host(std::vector<std::pair<double, std::pair<float, float>>>& items);
+
+}  // namespace lga

@@ -1,0 +1,138 @@
+// Objective (gradient / hessian) and pointwise metric formulas, shared by the
+// host engine and the HIP kernels.  `objective = "regression"` is what every
+// training call of the reference passes (r/gridsearchCV.R:60,74,112,137);
+// `binary` serves the Higgs-shaped benchmark configs.
+#pragma once
+#include "common.hpp"
+
+namespace lga {
+
+enum ObjectiveKind : int32_t {
+  kObjRegression = 0,
+  kObjRegressionL1 = 1,
+  kObjHuber = 2,
+  kObjFair = 3,
+  kObjPoisson = 4,
+  kObjBinary = 5,
+  kObjCrossEntropy = 6,
+  kObjCustom = 7,
+};
+
+enum MetricKind : int32_t {
+  kMetL2 = 0,
+  kMetRmse = 1,
+  kMetL1 = 2,
+  kMetHuber = 3,
+  kMetFair = 4,
+  kMetPoisson = 5,
+  kMetBinaryLogloss = 6,
+  kMetBinaryError = 7,
+  kMetAuc = 8,
+  kMetCrossEntropy = 9,
+};
+
+struct ObjectiveSpec {
+  int32_t kind;
+  int32_t pad;
+  double sigmoid;            // binary
+  double pos_weight;         // binary: weight multiplier of positive rows
+  double neg_weight;
+  double alpha;              // huber delta
+  double fair_c;
+  double poisson_max_delta;  // poisson safety term
+};
+
+// label is the raw label; for binary any label > 0 is positive.
+LGA_HD void grad_hess(const ObjectiveSpec& o, double score, float label, float weight, float* g, float* h) {
+  double gg, hh;
+  switch (o.kind) {
+    case kObjRegression: {
+      gg = score - (double)label; hh = 1.0; break;
+    }
+    case kObjRegressionL1: {
+      double d = score - (double)label;
+      gg = d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0); hh = 1.0; break;
+    }
+    case kObjHuber: {
+      double d = score - (double)label;
+      if (fabs(d) <= o.alpha) gg = d; else gg = d > 0.0 ? o.alpha : -o.alpha;
+      hh = 1.0; break;
+    }
+    case kObjFair: {
+      double d = score - (double)label;
+      double c = o.fair_c;
+      gg = c * d / (fabs(d) + c);
+      hh = c * c / ((fabs(d) + c) * (fabs(d) + c)); break;
+    }
+    case kObjPoisson: {
+      double e = exp(score);
+      gg = e - (double)label;
+      hh = e * exp(o.poisson_max_delta); break;
+    }
+    case kObjBinary: {
+      // y in {-1,+1}: g = -y*s/(1+exp(y*s*score)), h = |g|*(s-|g|)
+      double y = label > 0.0f ? 1.0 : -1.0;
+      double lw = label > 0.0f ? o.pos_weight : o.neg_weight;
+      double resp = -y * o.sigmoid / (1.0 + exp(y * o.sigmoid * score));
+      double ar = fabs(resp);
+      gg = resp * lw; hh = ar * (o.sigmoid - ar) * lw; break;
+    }
+    case kObjCrossEntropy: {
+      double p = 1.0 / (1.0 + exp(-score));
+      gg = p - (double)label; hh = p * (1.0 - p); break;
+    }
+    default: gg = 0.0; hh = 1.0; break;
+  }
+  *g = (float)(gg * (double)weight);
+  *h = (float)(hh * (double)weight);
+}
+
+// score -> prediction (link function)
+LGA_HD double transform_score(int32_t obj_kind, double sigmoid, double score) {
+  switch (obj_kind) {
+    case kObjBinary: return 1.0 / (1.0 + exp(-sigmoid * score));
+    case kObjCrossEntropy: return 1.0 / (1.0 + exp(-score));
+    case kObjPoisson: return exp(score);
+    default: return score;
+  }
+}
+
+// Pointwise loss of a metric (AUC is rank based and handled separately).
+// `pred` is the transformed prediction, `raw` the raw score.
+LGA_HD double point_loss(int32_t metric, double pred, double raw, float label, const ObjectiveSpec& o) {
+  const double eps = 1e-15;
+  switch (metric) {
+    case kMetL2:
+    case kMetRmse: { double d = pred - (double)label; return d * d; }
+    case kMetL1: return fabs(pred - (double)label);
+    case kMetHuber: {
+      double d = fabs(pred - (double)label);
+      return d <= o.alpha ? 0.5 * d * d : o.alpha * (d - 0.5 * o.alpha);
+    }
+    case kMetFair: {
+      double x = fabs(pred - (double)label), c = o.fair_c;
+      return c * x - c * c * log(1.0 + x / c);
+    }
+    case kMetPoisson: {
+      double p = pred < 1e-10 ? 1e-10 : pred;
+      return p - (double)label * log(p);
+    }
+    case kMetBinaryLogloss: {
+      double p = pred;
+      if (label > 0.0f) return -log(p > eps ? p : eps);
+      return -log(1.0 - p > eps ? 1.0 - p : eps);
+    }
+    case kMetBinaryError: {
+      bool pos = pred > 0.5;
+      return (pos != (label > 0.0f)) ? 1.0 : 0.0;
+    }
+    case kMetCrossEntropy: {
+      double p = pred, y = (double)label;
+      double a = p > eps ? p : eps, b = 1.0 - p > eps ? 1.0 - p : eps;
+      return -(y * log(a) + (1.0 - y) * log(b));
+    }
+    default: (void)raw; return 0.0;
+  }
+}
+
+}  // namespace lga

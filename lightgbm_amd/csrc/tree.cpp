@@ -1,0 +1,248 @@
+#include "tree.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace lga {
+
+void Tree::reset(int max_leaves) {
+  num_leaves = 1;
+  int m = std::max(max_leaves, 1);
+  auto rs = [&](auto& v, size_t n) { v.clear(); v.reserve(n); };
+  rs(split_feature, m); rs(split_feature_inner, m); rs(split_gain, m); rs(threshold, m); rs(threshold_bin, m);
+  rs(decision_type, m); rs(left_child, m); rs(right_child, m); rs(internal_value, m); rs(internal_weight, m);
+  rs(internal_count, m);
+  leaf_value.assign(1, 0.0); leaf_weight.assign(1, 0.0); leaf_count.assign(1, 0);
+  leaf_depth.assign(1, 0); leaf_parent.assign(1, -1);
+  shrinkage = 1.0;
+}
+
+int Tree::split(int leaf, int feature_real, int feature_inner, int thr_bin, double thr, bool default_left,
+                int missing_type, double gain, double left_value, double right_value, int64_t left_cnt,
+                int64_t right_cnt, double left_weight, double right_weight) {
+  int node = num_leaves - 1;       // new internal node
+  int parent = leaf_parent[(size_t)leaf];
+  if (parent >= 0) {
+    if (left_child[(size_t)parent] == ~leaf) left_child[(size_t)parent] = node;
+    else right_child[(size_t)parent] = node;
+  }
+  split_feature.push_back(feature_real);
+  split_feature_inner.push_back(feature_inner);
+  split_gain.push_back(gain);
+  threshold.push_back(thr);
+  threshold_bin.push_back(thr_bin);
+  int8_t dt = 0;
+  if (default_left) dt |= kDefaultLeftMask;
+  dt |= (int8_t)((missing_type & 3) << 2);
+  decision_type.push_back(dt);
+  left_child.push_back(~leaf);
+  right_child.push_back(~num_leaves);
+  internal_value.push_back(leaf_value[(size_t)leaf]);
+  internal_weight.push_back(leaf_weight[(size_t)leaf]);
+  internal_count.push_back(left_cnt + right_cnt);
+  int depth = leaf_depth[(size_t)leaf] + 1;
+  // left child reuses the leaf slot
+  leaf_value[(size_t)leaf] = left_value;
+  leaf_weight[(size_t)leaf] = left_weight;
+  leaf_count[(size_t)leaf] = left_cnt;
+  leaf_depth[(size_t)leaf] = depth;
+  leaf_parent[(size_t)leaf] = node;
+  leaf_value.push_back(right_value);
+  leaf_weight.push_back(right_weight);
+  leaf_count.push_back(right_cnt);
+  leaf_depth.push_back(depth);
+  leaf_parent.push_back(node);
+  return num_leaves++;
+}
+
+void Tree::apply_shrinkage(double rate) {
+  for (auto& v : leaf_value) v *= rate;
+  for (auto& v : internal_value) v *= rate;
+  shrinkage *= rate;
+}
+
+void Tree::add_bias(double b) {
+  for (auto& v : leaf_value) v += b;
+  for (auto& v : internal_value) v += b;
+}
+
+int Tree::predict_leaf(const double* row) const {
+  if (num_leaves <= 1) return 0;
+  int node = 0;
+  while (node >= 0) {
+    double v = row[split_feature[(size_t)node]];
+    node = go_left(v, threshold[(size_t)node], decision_type[(size_t)node]) ? left_child[(size_t)node]
+                                                                             : right_child[(size_t)node];
+  }
+  return ~node;
+}
+
+int Tree::max_depth() const {
+  int d = 0;
+  for (int v : leaf_depth) d = std::max(d, v);
+  return d;
+}
+
+namespace {
+std::string g17(double v) {
+  char buf[64];
+  std::snprintf(buf, sizeof(buf), "%.17g", v);
+  return buf;
+}
+template <typename T, typename F>
+void join(std::ostringstream& os, const char* key, const std::vector<T>& v, size_t n, F fmt) {
+  os << key << "=";
+  for (size_t i = 0; i < n; ++i) { if (i) os << " "; os << fmt(v[i]); }
+  os << "\n";
+}
+std::vector<std::string> tokens(const std::string& s) {
+  std::vector<std::string> out;
+  std::istringstream is(s);
+  std::string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+}  // namespace
+
+std::string Tree::to_string(int index) const {
+  std::ostringstream os;
+  os << "Tree=" << index << "\n";
+  os << "num_leaves=" << num_leaves << "\n";
+  os << "num_cat=0\n";
+  size_t ni = (size_t)num_leaves - 1, nl = (size_t)num_leaves;
+  auto id = [](auto v) { return std::to_string((long long)v); };
+  auto dd = [](double v) { return g17(v); };
+  if (num_leaves > 1) {
+    join(os, "split_feature", split_feature, ni, id);
+    join(os, "split_gain", split_gain, ni, [](double v) { char b[64]; std::snprintf(b, 64, "%g", v); return std::string(b); });
+    join(os, "threshold", threshold, ni, dd);
+    join(os, "decision_type", decision_type, ni, id);
+    join(os, "left_child", left_child, ni, id);
+    join(os, "right_child", right_child, ni, id);
+    join(os, "leaf_value", leaf_value, nl, dd);
+    join(os, "leaf_weight", leaf_weight, nl, dd);
+    join(os, "leaf_count", leaf_count, nl, id);
+    join(os, "internal_value", internal_value, ni, dd);
+    join(os, "internal_weight", internal_weight, ni, dd);
+    join(os, "internal_count", internal_count, ni, id);
+  } else {
+    join(os, "leaf_value", leaf_value, 1, dd);
+  }
+  os << "is_linear=0\n";
+  os << "shrinkage=" << g17(shrinkage) << "\n";
+  os << "\n\n";
+  return os.str();
+}
+
+Tree Tree::from_string(const std::string& block) {
+  std::map<std::string, std::string> kv;
+  std::istringstream is(block);
+  std::string line;
+  while (std::getline(is, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+    size_t eq = line.find('=');
+    if (eq == std::string::npos) continue;
+    kv[line.substr(0, eq)] = line.substr(eq + 1);
+  }
+  auto need = [&](const char* k) -> const std::string& {
+    auto it = kv.find(k);
+    if (it == kv.end()) throw std::runtime_error(std::string("model parse: tree block lacks \"") + k + "\"");
+    return it->second;
+  };
+  Tree t;
+  t.num_leaves = std::atoi(need("num_leaves").c_str());
+  if (t.num_leaves < 1) throw std::runtime_error("model parse: num_leaves < 1");
+  if (kv.count("num_cat") && std::atoi(kv["num_cat"].c_str()) != 0)
+    throw std::runtime_error("model parse: categorical splits are not supported");
+  size_t ni = (size_t)t.num_leaves - 1, nl = (size_t)t.num_leaves;
+  auto ints = [&](const std::string& s, size_t n, auto& out, const char* k) {
+    auto tk = tokens(s);
+    if (tk.size() != n) throw std::runtime_error(std::string("model parse: wrong length of ") + k);
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) out[i] = (typename std::decay<decltype(out[0])>::type)std::strtoll(tk[i].c_str(), nullptr, 10);
+  };
+  auto dbls = [&](const std::string& s, size_t n, std::vector<double>& out, const char* k) {
+    auto tk = tokens(s);
+    if (tk.size() != n) throw std::runtime_error(std::string("model parse: wrong length of ") + k);
+    out.resize(n);
+    for (size_t i = 0; i < n; ++i) out[i] = std::strtod(tk[i].c_str(), nullptr);
+  };
+  dbls(need("leaf_value"), nl, t.leaf_value, "leaf_value");
+  if (t.num_leaves > 1) {
+    ints(need("split_feature"), ni, t.split_feature, "split_feature");
+    dbls(need("threshold"), ni, t.threshold, "threshold");
+    ints(need("decision_type"), ni, t.decision_type, "decision_type");
+    ints(need("left_child"), ni, t.left_child, "left_child");
+    ints(need("right_child"), ni, t.right_child, "right_child");
+    if (kv.count("split_gain")) dbls(kv["split_gain"], ni, t.split_gain, "split_gain"); else t.split_gain.assign(ni, 0.0);
+    if (kv.count("leaf_weight")) dbls(kv["leaf_weight"], nl, t.leaf_weight, "leaf_weight"); else t.leaf_weight.assign(nl, 0.0);
+    if (kv.count("leaf_count")) ints(kv["leaf_count"], nl, t.leaf_count, "leaf_count"); else t.leaf_count.assign(nl, 0);
+    if (kv.count("internal_value")) dbls(kv["internal_value"], ni, t.internal_value, "internal_value"); else t.internal_value.assign(ni, 0.0);
+    if (kv.count("internal_weight")) dbls(kv["internal_weight"], ni, t.internal_weight, "internal_weight"); else t.internal_weight.assign(ni, 0.0);
+    if (kv.count("internal_count")) ints(kv["internal_count"], ni, t.internal_count, "internal_count"); else t.internal_count.assign(ni, 0);
+    for (size_t i = 0; i < ni; ++i) {
+      if (t.decision_type[i] & kCategoricalMask) throw std::runtime_error("model parse: categorical splits are not supported");
+      auto ok = [&](int c) { return (c >= 0 && c < (int)ni) || (c < 0 && ~c < (int)nl); };
+      if (!ok(t.left_child[i]) || !ok(t.right_child[i])) throw std::runtime_error("model parse: child index out of range");
+    }
+  } else {
+    t.leaf_weight.assign(1, 0.0);
+    t.leaf_count.assign(1, 0);
+  }
+  if (kv.count("is_linear") && std::atoi(kv["is_linear"].c_str()) != 0)
+    throw std::runtime_error("model parse: linear trees are not supported");
+  t.shrinkage = kv.count("shrinkage") ? std::strtod(kv["shrinkage"].c_str(), nullptr) : 1.0;
+  // derived, not serialised
+  t.split_feature_inner.assign(ni, -1);
+  t.threshold_bin.assign(ni, -1);
+  t.leaf_depth.assign(nl, 0);
+  t.leaf_parent.assign(nl, -1);
+  if (t.num_leaves > 1) {
+    std::vector<int> depth(ni, 0);
+    for (size_t i = 0; i < ni; ++i) {
+      for (int c : {t.left_child[i], t.right_child[i]}) {
+        if (c >= 0) depth[(size_t)c] = depth[i] + 1;
+        else { t.leaf_depth[(size_t)~c] = depth[i] + 1; t.leaf_parent[(size_t)~c] = (int)i; }
+      }
+    }
+  }
+  return t;
+}
+
+std::string Tree::to_json(int index) const {
+  std::ostringstream os;
+  os << "{\"tree_index\":" << index << ",\"num_leaves\":" << num_leaves << ",\"num_cat\":0,\"shrinkage\":" << g17(shrinkage)
+     << ",\"tree_structure\":";
+  // recursive lambda over nodes
+  struct Rec {
+    const Tree& t;
+    std::ostringstream& os;
+    void leaf(int l) {
+      os << "{\"leaf_index\":" << l << ",\"leaf_value\":" << g17(t.leaf_value[(size_t)l])
+         << ",\"leaf_weight\":" << g17(t.leaf_weight[(size_t)l]) << ",\"leaf_count\":" << t.leaf_count[(size_t)l] << "}";
+    }
+    void node(int n) {
+      if (n < 0) { leaf(~n); return; }
+      size_t i = (size_t)n;
+      int mt = (t.decision_type[i] >> 2) & 3;
+      os << "{\"split_index\":" << n << ",\"split_feature\":" << t.split_feature[i] << ",\"split_gain\":" << g17(t.split_gain[i])
+         << ",\"threshold\":" << g17(t.threshold[i]) << ",\"decision_type\":\"<=\",\"default_left\":"
+         << ((t.decision_type[i] & kDefaultLeftMask) ? "true" : "false") << ",\"missing_type\":\""
+         << (mt == 0 ? "None" : mt == 1 ? "Zero" : "NaN") << "\",\"internal_value\":" << g17(t.internal_value[i])
+         << ",\"internal_weight\":" << g17(t.internal_weight[i]) << ",\"internal_count\":" << t.internal_count[i]
+         << ",\"left_child\":";
+      node(t.left_child[i]);
+      os << ",\"right_child\":";
+      node(t.right_child[i]);
+      os << "}";
+    }
+  } rec{*this, os};
+  if (num_leaves <= 1) rec.leaf(0); else rec.node(0);
+  os << "}";
+  return os.str();
+}
+
+}  // namespace lga

@@ -1,0 +1,325 @@
+"""``train`` and ``cv``: the two training entry points the reference uses.
+
+* ``train``  <- ``lgb.train(params, data, nrounds, objective=, verbose=)``
+  (r/gridsearchCV.R:57-61, 134-138)
+* ``cv``     <- ``lgb.cv(params, data, nrounds, nfold, objective=, eval=, showsd=,
+  early_stopping_rounds=, verbose=)`` (r/gridsearchCV.R:70-78, 108-115): k fold
+  boosters share ONE binned dataset (folds are row-index subsets), advance in
+  lock-step, and early stopping watches the mean of the fold metrics.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import callback as cb
+from .basic import Booster, Dataset, LightGBMError, get_param, pop_param, resolve_alias
+
+__all__ = ["train", "cv", "CVBooster", "make_folds"]
+
+
+def _split_callbacks(callbacks):
+    cbs = set(callbacks or [])
+    before = {c for c in cbs if getattr(c, "before_iteration", False)}
+    after = cbs - before
+    key = lambda c: getattr(c, "order", 0)
+    return sorted(before, key=key), sorted(after, key=key)
+
+
+def _prepare_params(params: Optional[Dict[str, Any]], kwargs: Dict[str, Any]) -> Dict[str, Any]:
+    """params + extra named arguments share one namespace (the R binding's `...`, r/gridsearchCV.R:60)."""
+    p = copy.deepcopy(dict(params or {}))
+    for k, v in kwargs.items():
+        if resolve_alias(k) is not None:
+            p[k] = v
+        else:
+            raise TypeError(f"unexpected keyword argument {k!r}")
+    return p
+
+
+def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: int = 100,
+          valid_sets: Optional[List[Dataset]] = None, valid_names: Optional[List[str]] = None,
+          fobj: Optional[Callable] = None, feval=None, init_model: Union[str, Booster, None] = None,
+          early_stopping_rounds: Optional[int] = None, evals_result: Optional[dict] = None,
+          verbose_eval: Union[bool, int] = False, keep_training_booster: bool = False,
+          callbacks: Optional[List[Callable]] = None, comm=None, **kwargs) -> Booster:
+    """Trains a booster for ``num_boost_round`` iterations (fewer if stopped early)."""
+    params = _prepare_params(params, kwargs)
+    nit = pop_param(params, "num_iterations")
+    if nit is not None:
+        num_boost_round = int(nit)
+    esr = pop_param(params, "early_stopping_round")
+    if esr is not None and early_stopping_rounds is None:
+        early_stopping_rounds = int(esr)
+    first_metric_only = bool(get_param(params, "first_metric_only", False))
+    if num_boost_round <= 0:
+        raise ValueError("num_boost_round should be greater than zero.")
+    if callable(params.get("objective")):
+        fobj = params.pop("objective")
+    if fobj is not None:
+        params["objective"] = "custom"
+
+    predictor: Optional[Booster] = None
+    if isinstance(init_model, str):
+        predictor = Booster(model_file=init_model)
+    elif isinstance(init_model, Booster):
+        predictor = init_model
+    if predictor is not None:
+        # continue training: the old model's raw predictions become the data's initial scores
+        raw = train_set.data
+        if raw is None:
+            raise LightGBMError("init_model needs the raw training data (construct the Dataset with free_raw_data=False)")
+        train_set.set_init_score(predictor.predict(raw, raw_score=True, num_iteration=-1))
+
+    booster = Booster(params=params, train_set=train_set, comm=comm)
+    is_valid_contain_train = False
+    train_data_name = "training"
+    if valid_sets is not None:
+        if isinstance(valid_sets, Dataset):
+            valid_sets = [valid_sets]
+        if isinstance(valid_names, str):
+            valid_names = [valid_names]
+        for i, vd in enumerate(valid_sets):
+            name = valid_names[i] if valid_names is not None and len(valid_names) > i else f"valid_{i}"
+            if vd is train_set:
+                is_valid_contain_train = True
+                train_data_name = name if valid_names is not None and len(valid_names) > i else "training"
+                continue
+            if predictor is not None and vd.data is not None:
+                vd.set_init_score(predictor.predict(vd.data, raw_score=True, num_iteration=-1))
+            booster.add_valid(vd, name)
+    booster._train_data_name = train_data_name
+
+    callbacks = list(callbacks or [])
+    if verbose_eval is True:
+        callbacks.append(cb.log_evaluation())
+    elif isinstance(verbose_eval, int) and not isinstance(verbose_eval, bool) and verbose_eval > 0:
+        callbacks.append(cb.log_evaluation(verbose_eval))
+    if early_stopping_rounds is not None and early_stopping_rounds > 0:
+        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=bool(verbose_eval)))
+    if evals_result is not None:
+        callbacks.append(cb.record_evaluation(evals_result))
+    cb_before, cb_after = _split_callbacks(callbacks)
+
+    need_eval = bool(booster.valid_sets) or is_valid_contain_train
+    booster.best_iteration = 0
+    evaluation_result_list: List[Tuple] = []
+    for i in range(num_boost_round):
+        for c in cb_before:
+            c(cb.CallbackEnv(booster, params, i, 0, num_boost_round, None))
+        finished = booster.update(fobj=fobj)
+        evaluation_result_list = []
+        if need_eval:
+            if is_valid_contain_train:
+                evaluation_result_list.extend(booster.eval_train(feval))
+            evaluation_result_list.extend(booster.eval_valid(feval))
+        try:
+            for c in cb_after:
+                c(cb.CallbackEnv(booster, params, i, 0, num_boost_round, evaluation_result_list))
+        except cb.EarlyStopException as es:
+            booster.best_iteration = es.best_iteration + 1
+            evaluation_result_list = es.best_score
+            break
+        if finished:
+            break
+    booster.best_score = {}
+    for item in evaluation_result_list or []:
+        booster.best_score.setdefault(item[0], {})[item[1]] = item[2]
+    if predictor is not None:
+        booster._prepend(predictor)
+        if booster.best_iteration > 0:
+            booster.best_iteration += predictor.num_trees()
+    if not keep_training_booster:
+        booster = _carry(booster)
+    return booster
+
+
+def _carry(trained: Booster) -> Booster:
+    """Turns a training booster into a light prediction booster, keeping its bookkeeping."""
+    out = Booster(model_str=trained.model_to_string(num_iteration=-1))
+    out.best_iteration = trained.best_iteration
+    out.best_score = trained.best_score
+    out.params = trained.params
+    return out
+
+
+
+# ----------------------------------------------------------------------------
+# cross-validation
+# ----------------------------------------------------------------------------
+class CVBooster:
+    """The k fold boosters of one ``cv`` run.
+
+    ``best_iteration`` is 1-based like upstream's Python API; the R-style
+    accessors used by the reference (``best_iter``, ``best_score`` with flipped
+    sign for losses) are provided by :mod:`lightgbm_amd.rstyle`.
+    """
+
+    def __init__(self):
+        self.boosters: List[Booster] = []
+        self.best_iteration = -1
+
+    def append(self, booster: Booster):
+        self.boosters.append(booster)
+
+    def __getattr__(self, name):
+        def handler(*args, **kwargs):
+            return [getattr(b, name)(*args, **kwargs) for b in self.boosters]
+        return handler
+
+
+def _stratify_labels(y: np.ndarray, nfold: int, classification: bool) -> np.ndarray:
+    """Group id per row to stratify on: the class, or (numeric labels) a quantile group, caret style."""
+    if classification:
+        _, inv = np.unique(y, return_inverse=True)
+        return inv
+    n = len(y)
+    groups = min(5, max(2, n // nfold))
+    qs = np.quantile(y, np.linspace(0, 1, groups + 1)[1:-1])
+    return np.searchsorted(np.unique(qs), y, side="right")
+
+
+def make_folds(n: int, nfold: int, label: Optional[np.ndarray] = None, stratified: bool = True,
+               shuffle: bool = True, seed: int = 0, classification: bool = False) -> List[Tuple[np.ndarray, np.ndarray]]:
+    """(train_idx, test_idx) pairs: disjoint test folds that cover 0..n-1, sizes differing by at most one per stratum."""
+    if nfold < 2:
+        raise ValueError("nfold must be at least 2")
+    if n < nfold:
+        raise ValueError("more folds than rows")
+    rng = np.random.RandomState(seed)
+    fold_of = np.empty(n, dtype=np.int64)
+    if stratified and label is not None:
+        strata = _stratify_labels(np.asarray(label), nfold, classification)
+        offset = 0
+        for g in np.unique(strata):
+            idx = np.flatnonzero(strata == g)
+            if shuffle:
+                rng.shuffle(idx)
+            # continue dealing where the previous stratum stopped so fold sizes stay balanced
+            fold_of[idx] = (np.arange(len(idx)) + offset) % nfold
+            offset = (offset + len(idx)) % nfold
+    else:
+        idx = np.arange(n)
+        if shuffle:
+            rng.shuffle(idx)
+        bounds = np.linspace(0, n, nfold + 1).astype(np.int64)
+        for k in range(nfold):
+            fold_of[idx[bounds[k]:bounds[k + 1]]] = k
+    all_idx = np.arange(n)
+    return [(all_idx[fold_of != k], all_idx[fold_of == k]) for k in range(nfold)]
+
+
+def _agg_cv_result(raw_results: List[List[Tuple]], eval_train_metric: bool):
+    """Mean / stdv over folds of every (data, metric) pair, in first-seen order."""
+    cvmap: Dict[str, List[float]] = {}
+    metric_type: Dict[str, bool] = {}
+    order: List[str] = []
+    for one_result in raw_results:
+        for one_line in one_result:
+            key = f"{one_line[0]} {one_line[1]}" if eval_train_metric else one_line[1]
+            if key not in cvmap:
+                order.append(key)
+                cvmap[key] = []
+            metric_type[key] = one_line[3]
+            cvmap[key].append(one_line[2])
+    return [("cv_agg", k, float(np.mean(cvmap[k])), metric_type[k], float(np.std(cvmap[k]))) for k in order]
+
+
+def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: int = 100, folds=None, nfold: int = 5,
+       stratified: bool = True, shuffle: bool = True, metrics: Union[str, List[str], None] = None,
+       fobj: Optional[Callable] = None, feval=None, init_model=None, early_stopping_rounds: Optional[int] = None,
+       fpreproc=None, verbose_eval: Union[bool, int, None] = None, show_stdv: bool = True, seed: int = 0,
+       callbacks: Optional[List[Callable]] = None, eval_train_metric: bool = False, return_cvbooster: bool = False,
+       **kwargs) -> Dict[str, Any]:
+    """k-fold cross-validation; returns ``{"<metric>-mean": [...], "<metric>-stdv": [...]}`` (+ ``"cvbooster"``)."""
+    if not isinstance(train_set, Dataset):
+        raise TypeError("Training only accepts Dataset object")
+    params = _prepare_params(params, kwargs)
+    nit = pop_param(params, "num_iterations")
+    if nit is not None:
+        num_boost_round = int(nit)
+    esr = pop_param(params, "early_stopping_round")
+    if esr is not None and early_stopping_rounds is None:
+        early_stopping_rounds = int(esr)
+    first_metric_only = bool(get_param(params, "first_metric_only", False))
+    if num_boost_round <= 0:
+        raise ValueError("num_boost_round should be greater than zero.")
+    if callable(params.get("objective")):
+        fobj = params.pop("objective")
+    if fobj is not None:
+        params["objective"] = "custom"
+    if metrics is not None:
+        pop_param(params, "metric")
+        params["metric"] = metrics
+    if init_model is not None:
+        raise LightGBMError("cv(init_model=...) is not supported")
+
+    train_set.params = {**params, **train_set.params} if train_set._handle is None else train_set.params
+    train_set.construct()
+    n = train_set.num_data()
+    objective = str(get_param(params, "objective", "regression"))
+    classification = objective in ("binary", "binary_logloss", "binary:logistic")
+    if folds is not None:
+        if hasattr(folds, "split"):
+            y = train_set.get_label()
+            folds = list(folds.split(X=np.empty((n, 1)), y=y))
+        else:
+            folds = [(np.asarray(a), np.asarray(b)) for a, b in folds]
+    else:
+        label = train_set.get_label() if stratified else None
+        folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)
+
+    cvbooster = CVBooster()
+    for tr_idx, te_idx in folds:
+        tr = train_set.subset(tr_idx)
+        te = train_set.subset(te_idx)
+        fold_params = params
+        if fpreproc is not None:
+            tr, te, fold_params = fpreproc(tr, te, dict(params))
+        b = Booster(fold_params, tr)
+        if eval_train_metric:
+            b._train_data_name = "train"
+        b.add_valid(te, "valid")
+        cvbooster.append(b)
+
+    callbacks = list(callbacks or [])
+    if early_stopping_rounds is not None and early_stopping_rounds > 0:
+        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=False))
+    if verbose_eval is True:
+        callbacks.append(cb.log_evaluation(show_stdv=show_stdv))
+    elif isinstance(verbose_eval, int) and not isinstance(verbose_eval, bool) and verbose_eval and verbose_eval > 0:
+        callbacks.append(cb.log_evaluation(verbose_eval, show_stdv=show_stdv))
+    cb_before, cb_after = _split_callbacks(callbacks)
+
+    results: Dict[str, List[float]] = {}
+    for i in range(num_boost_round):
+        for c in cb_before:
+            c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
+        finished = [b.update(fobj=fobj) for b in cvbooster.boosters]
+        raw = []
+        for b in cvbooster.boosters:
+            one = []
+            if eval_train_metric:
+                one.extend(b.eval_train(feval))
+            one.extend(b.eval_valid(feval))
+            raw.append(one)
+        res = _agg_cv_result(raw, eval_train_metric)
+        for _, key, mean, _, std in res:
+            results.setdefault(f"{key}-mean", []).append(mean)
+            results.setdefault(f"{key}-stdv", []).append(std)
+        try:
+            for c in cb_after:
+                c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))
+        except cb.EarlyStopException as es:
+            cvbooster.best_iteration = es.best_iteration + 1
+            for k in results:
+                results[k] = results[k][: cvbooster.best_iteration]
+            break
+        if all(finished):
+            break
+    out: Dict[str, Any] = dict(results)
+    if return_cvbooster:
+        out["cvbooster"] = cvbooster
+    return out
