@@ -90,14 +90,13 @@ def _declare(lib, hip: bool):
         sig.update({
             "lga_hip_set_allocator": (c_int, [ALLOC_FN, FREE_FN]),
             "lga_hip_set_stream": (c_int, [c_void_p]),
-            "lga_hip_dataset_from_device_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_char_p, c_void_p, P(c_void_p)]),
-            "lga_hip_dataset_upload": (c_int, [c_void_p]),
-            "lga_hip_predict": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
-            "lga_hip_booster_scores_ptr": (c_int, [c_void_p, c_int, P(c_void_p), P(c_int64)]),
-            "lga_hip_comm_create_rccl": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),
-            "lga_hip_rccl_unique_id": (c_int, [c_void_p, c_int, P(c_int)]),
-            "lga_hip_op": (c_int, [c_char_p, P(c_void_p), c_int, P(c_int64), c_int]),
             "lga_hip_device_info": (c_int, [P(c_int), P(c_int64), P(c_int)]),
+            "lga_hip_dataset_from_device_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_char_p, c_void_p, P(c_void_p)]),
+            "lga_hip_dataset_upload_raw": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+            "lga_hip_predict": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int]),
+            "lga_hip_rccl_unique_id": (c_int, [c_void_p, c_int, P(c_int)]),
+            "lga_hip_comm_create_rccl": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),
+            "lga_hip_op": (c_int, [c_char_p, P(c_void_p), c_int, P(c_int64), c_int]),
         })
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

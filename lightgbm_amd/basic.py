@@ -428,6 +428,9 @@ class Booster:
             train_set.params = {**p, **train_set.params} if train_set._handle is None else train_set.params
             train_set.construct()
             comm_h = comm.handle if comm is not None else None
+            if hip:
+                from . import _device
+                _device.sync_stream(lib)
             check(lib.lga_booster_create(train_set._handle, c_str(params_to_string(p)), comm_h,
                                          ctypes.byref(self._handle)))
             self.params = p

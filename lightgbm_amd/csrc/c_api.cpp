@@ -51,6 +51,7 @@ Booster* B(LgaBooster h) { if (!h) throw std::runtime_error("null booster handle
 extern "C" {
 
 const char* lga_last_error() { return g_error.c_str(); }
+void lga_set_last_error(const char* msg) { g_error = msg ? msg : ""; }
 const char* lga_build_info() { return engine_build_name(); }
 const char* lga_alias_table_json() {
   g_str = Config::alias_table_json();

@@ -10,6 +10,7 @@ typedef void* LgaBooster;
 typedef void* LgaComm;
 
 const char* lga_last_error();
+void lga_set_last_error(const char* msg);
 const char* lga_build_info();          // "host" or "hip"
 const char* lga_alias_table_json();
 int lga_resolve_alias(const char* name, char* out, int out_len);

@@ -172,25 +172,40 @@ LGA_HD bool cand_better(double gain_a, uint64_t key_a, double gain_b, uint64_t k
   return key_a < key_b;
 }
 
+// Per-leaf constants of a split search, computed once per (leaf) and shared by
+// every candidate of that leaf.
+struct LeafScanCtx {
+  int64_t total_g, total_h, total_cnt;
+  double gunit, hunit;
+  double cnt_factor;    // rows per quantised hessian unit
+  double parent_gain;
+};
+
+LGA_HD LeafScanCtx make_scan_ctx(int64_t tg, int64_t th, int64_t tc, double gunit, double hunit, const SplitParams& p) {
+  LeafScanCtx c;
+  c.total_g = tg; c.total_h = th; c.total_cnt = tc;
+  c.gunit = gunit; c.hunit = hunit;
+  c.cnt_factor = th > 0 ? (double)tc / (double)th : 0.0;
+  c.parent_gain = leaf_gain((double)tg * gunit, (double)th * hunit, p.lambda_l1, p.lambda_l2);
+  return c;
+}
+
 // Estimated row count of a part of a leaf from its hessian share.
-LGA_HD int64_t est_count(int64_t part_h, int64_t total_h, int64_t total_cnt) {
-  if (total_h <= 0) return 0;
-  double f = (double)total_cnt / (double)total_h;
-  return (int64_t)((double)part_h * f + 0.5);
+LGA_HD int64_t est_count(int64_t part_h, const LeafScanCtx& c) {
+  return (int64_t)((double)part_h * c.cnt_factor + 0.5);
 }
 
 // Gain of one candidate split or -inf when a constraint fails.
-LGA_HD double split_gain(int64_t lg, int64_t lh, int64_t tg, int64_t th, int64_t total_cnt,
-                         double gunit, double hunit, const SplitParams& p, double parent_gain) {
+LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const SplitParams& p) {
   const double ninf = -std::numeric_limits<double>::infinity();
-  int64_t rg = tg - lg, rh = th - lh;
-  int64_t lc = est_count(lh, th, total_cnt);
-  int64_t rc = total_cnt - lc;
+  int64_t rg = c.total_g - lg, rh = c.total_h - lh;
+  int64_t lc = est_count(lh, c);
+  int64_t rc = c.total_cnt - lc;
   if (lc < p.min_data_in_leaf || rc < p.min_data_in_leaf) return ninf;
-  double lhr = (double)lh * hunit, rhr = (double)rh * hunit;
+  double lhr = (double)lh * c.hunit, rhr = (double)rh * c.hunit;
   if (lhr < p.min_sum_hessian_in_leaf || rhr < p.min_sum_hessian_in_leaf) return ninf;
-  double lgr = (double)lg * gunit, rgr = (double)rg * gunit;
-  double gain = leaf_gain(lgr, lhr, p.lambda_l1, p.lambda_l2) + leaf_gain(rgr, rhr, p.lambda_l1, p.lambda_l2) - parent_gain;
+  double lgr = (double)lg * c.gunit, rgr = (double)rg * c.gunit;
+  double gain = leaf_gain(lgr, lhr, p.lambda_l1, p.lambda_l2) + leaf_gain(rgr, rhr, p.lambda_l1, p.lambda_l2) - c.parent_gain;
   if (!(gain > p.min_gain_to_split)) return ninf;
   return gain;
 }

@@ -29,6 +29,8 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   // finds bins from `sample` (row-major float64, nsample x ncol).
   static std::shared_ptr<Dataset> from_sample(const double* sample, int64_t nsample, int ncol, int64_t nrow,
                                               const Config& cfg);
+  // Mapper-only dataset with `nrow` rows that shares `ref`'s bin boundaries (bins are filled later).
+  static std::shared_ptr<Dataset> from_reference(const Dataset* ref, int64_t nrow);
   std::shared_ptr<Dataset> subset(const int32_t* indices, int64_t n) const;
 
   // ---- shape ----

@@ -1,0 +1,707 @@
+// HIP backend + engine: everything row-sized stays in HBM for the whole
+// training run; per growth round the host sends one descriptor block down and
+// receives the children's best splits back (one synchronisation per round).
+#include "hip_engine.hpp"
+#include "kernels.hpp"
+#include "../metric.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <sstream>
+
+namespace lga {
+
+// ---------------------------------------------------------------------------
+// allocator / stream hooks
+// ---------------------------------------------------------------------------
+namespace {
+DeviceAllocFn g_alloc = nullptr;
+DeviceFreeFn g_free = nullptr;
+hipStream_t g_stream = nullptr;
+}  // namespace
+
+void set_device_allocator(DeviceAllocFn a, DeviceFreeFn f) { g_alloc = a; g_free = f; }
+void* device_alloc(size_t nbytes) {
+  if (nbytes == 0) nbytes = 16;
+  if (g_alloc) {
+    void* p = g_alloc((int64_t)nbytes);
+    if (!p) throw std::runtime_error("device allocation of " + std::to_string(nbytes) + " bytes failed");
+    return p;
+  }
+  void* p = nullptr;
+  LGA_HIP_CHECK(hipMalloc(&p, nbytes));
+  return p;
+}
+void device_free(void* p) {
+  if (!p) return;
+  if (g_free) g_free(p); else (void)hipFree(p);
+}
+void set_current_stream(hipStream_t s) { g_stream = s; }
+hipStream_t current_stream() { return g_stream; }
+
+namespace {
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// profiling: HIP events around the phases of a round (profile=true only)
+// ---------------------------------------------------------------------------
+struct PhaseProfile {
+  bool on = false;
+  enum { kUpload, kPartition, kHist, kComm, kScan, kFetch, kCount };
+  double ms[kCount] = {0, 0, 0, 0, 0, 0};
+  double host_ms = 0;
+  int64_t rounds = 0, trees = 0, tasks = 0;
+  hipEvent_t ev[kCount + 1];
+  bool created = false;
+  void init() {
+    if (!on || created) return;
+    for (auto& e : ev) LGA_HIP_CHECK(hipEventCreate(&e));
+    created = true;
+  }
+  void mark(int i, hipStream_t s) { if (on) LGA_HIP_CHECK(hipEventRecord(ev[i], s)); }
+  void collect(int upto) {
+    if (!on) return;
+    for (int i = 0; i < upto; ++i) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms[i] += t;
+    }
+  }
+  ~PhaseProfile() { if (created) for (auto& e : ev) (void)hipEventDestroy(e); }
+  std::string json() const {
+    std::ostringstream os;
+    os << "{\"rounds\":" << rounds << ",\"trees\":" << trees << ",\"split_tasks\":" << tasks << ",\"upload_ms\":" << ms[kUpload]
+       << ",\"partition_ms\":" << ms[kPartition] << ",\"hist_ms\":" << ms[kHist] << ",\"comm_ms\":" << ms[kComm]
+       << ",\"scan_ms\":" << ms[kScan] << ",\"fetch_ms\":" << ms[kFetch] << "}";
+    return os.str();
+  }
+};
+
+// ---------------------------------------------------------------------------
+// backend
+// ---------------------------------------------------------------------------
+class HipBackend : public TreeBackend {
+ public:
+  HipBackend(const Dataset* ds, DeviceMirror* mirror, const Config& cfg, Comm* comm, ParallelMode mode,
+             int64_t max_rows)
+      : root_(ds->root()), mir_(mirror), comm_(comm), mode_(mode) {
+    F_ = root_->num_features();
+    T_ = root_->num_tiles();
+    N_ = root_->root_rows();
+    plane_ = (int64_t)T_ * kTileFeatures * kMaxBins;
+    slot_words_ = 2 * plane_ + kSlotHeader;
+    int L = std::max(cfg.num_leaves, 2);
+    max_batch_ = L - 1;
+    capacity_splits_ = 3 * (L - 1) + 1;
+    // keep the histogram pool below ~24 GiB
+    while (capacity_splits_ > (L - 1) + 1 && (double)(capacity_splits_ + 1) * slot_words_ * 8.0 > 24.0 * (1u << 30))
+      capacity_splits_ -= 1;
+    if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
+    else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
+    stream_ = current_stream();
+    pool_.resize((size_t)(capacity_splits_ + 1) * slot_words_);
+    int n_nodes = 2 * capacity_splits_ + 2;
+    nodes_.resize((size_t)n_nodes);
+    node_totals_.resize((size_t)n_nodes * 4);
+    ranges_host_.resize((size_t)n_nodes);
+    arena_[0].resize((size_t)std::max<int64_t>(max_rows, 1));
+    arena_[1].resize((size_t)std::max<int64_t>(max_rows, 1));
+    max_pchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), k::kPartChunk) + max_batch_ + 1;
+    max_hchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), 1024) + max_batch_ + 1;
+    mask_.resize((size_t)max_pchunks_ * (k::kPartChunk / 64));
+    chunk_left_.resize((size_t)max_pchunks_);
+    task_left_.resize((size_t)max_batch_ + 1);
+    // one staging block: [tasks | scan tasks | pchunk table | hchunk table]
+    off_tasks_ = 64;   // the first 64 bytes stage one NodeRange
+    off_scan_ = off_tasks_ + sizeof(SplitTask) * (size_t)(max_batch_ + 1);
+    off_pch_ = off_scan_ + sizeof(k::ScanTaskDev) * (size_t)(2 * max_batch_ + 2);
+    off_hch_ = off_pch_ + sizeof(int32_t) * (size_t)max_pchunks_;
+    stage_bytes_ = off_hch_ + sizeof(int32_t) * (size_t)max_hchunks_;
+    stage_bytes_ = (stage_bytes_ + 255) & ~(size_t)255;
+    stage_host_.resize(stage_bytes_);
+    stage_dev_.resize(stage_bytes_);
+    cands_.resize((size_t)(2 * max_batch_ + 2) * (size_t)std::max(F_, 1));
+    results_dev_.resize((size_t)(2 * max_batch_ + 2));
+    // fetch block: [SplitInfo x 2B | task_left x B | QuantScale]
+    fetch_host_.resize(sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+    meta_dev_.resize((size_t)std::max(F_, 1));
+    qs_dev_.resize(1);
+    if (mode_ == ParallelMode::Feature) {
+      best_local_.resize((size_t)(2 * max_batch_ + 2));
+      best_all_.resize((size_t)(2 * max_batch_ + 2) * (size_t)comm_->size());
+    }
+    prof.on = cfg.profile;
+    prof.init();
+  }
+
+  void set_bag(const int32_t* rows_dev, int64_t n) { bag_ = rows_dev; bag_n_ = n; }
+  void set_packed(const int64_t* packed_dev) { packed_ = packed_dev; }
+  QuantScale* qs_device() { return qs_dev_.get(); }
+
+  int node_capacity() const override { return 2 * capacity_splits_ + 1; }
+  QuantScale quant_scale() const override { return qs_host_; }
+  int64_t node_local_count(int node) const override { return ranges_host_[(size_t)node].count; }
+  const NodeRange& range(int node) const { return ranges_host_[(size_t)node]; }
+  const int32_t* arena(int b) const { return arena_[b].get(); }
+  ParallelMode mode() const { return mode_; }
+  PhaseProfile prof;
+
+  void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
+    sp_ = params;
+    if (meta.size() != meta_host_.size() ||
+        std::memcmp(meta.data(), meta_host_.data(), sizeof(FeatureMeta) * meta.size()) != 0) {
+      meta_host_ = meta;
+      LGA_HIP_CHECK(hipMemcpyAsync(meta_dev_.get(), meta_host_.data(), sizeof(FeatureMeta) * meta_host_.size(),
+                                   hipMemcpyHostToDevice, stream_));
+      // meta_host_ stays alive and unchanged until the copy has run (next sync is in root_round)
+    }
+    LGA_HIP_CHECK(hipMemcpyAsync(arena_[0].get(), bag_, sizeof(int32_t) * (size_t)bag_n_, hipMemcpyDeviceToDevice, stream_));
+    ranges_host_[0] = NodeRange{0, (int32_t)bag_n_, 0, 0};
+    ++prof.trees;
+  }
+
+  void root_round(SplitInfo* out) override {
+    SplitTask t{};
+    t.parent_node = 0; t.left_node = 0; t.right_node = 0; t.feature = 0; t.hist_child = 0;
+    t.parent_slot = 0; t.new_slot = 0; t.first_pchunk = 0; t.num_pchunk = 0; t.first_hchunk = 0;
+    int hch = pick_hist_chunk(bag_n_);
+    t.num_hchunk = std::max(1, ceil_div(bag_n_, hch));
+    char* st = stage_host_.get();
+    std::memcpy(st + off_tasks_, &t, sizeof(t));
+    k::ScanTaskDev sd{0, 0, -1, -1, -1, 0};
+    std::memcpy(st + off_scan_, &sd, sizeof(sd));
+    int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
+    for (int i = 0; i < t.num_hchunk; ++i) hc[i] = 0;
+    std::memcpy(st, &ranges_host_[0], sizeof(NodeRange));
+    prof.mark(PhaseProfile::kUpload, stream_);
+    upload_stage(off_hch_ + sizeof(int32_t) * (size_t)t.num_hchunk);
+    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), stage_dev_.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
+    LGA_HIP_CHECK(hipMemsetAsync(pool_.get(), 0, sizeof(int64_t) * (size_t)slot_words_, stream_));
+    prof.mark(PhaseProfile::kPartition, stream_);
+    prof.mark(PhaseProfile::kHist, stream_);
+    run_hist(1, t.num_hchunk, hch);
+    prof.mark(PhaseProfile::kComm, stream_);
+    reduce_slots(0, 1);
+    prof.mark(PhaseProfile::kScan, stream_);
+    run_scan(1);
+    prof.mark(PhaseProfile::kFetch, stream_);
+    fetch(1, 0, true);
+    prof.mark(PhaseProfile::kCount, stream_);
+    sync();
+    prof.collect(PhaseProfile::kCount);
+    ++prof.rounds;
+    std::memcpy(out, fetch_host_.get(), sizeof(SplitInfo));
+    std::memcpy(&qs_host_, fetch_host_.get() + sizeof(SplitInfo), sizeof(QuantScale));
+  }
+
+  void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) override {
+    const int B = (int)tasks.size();
+    if (B == 0) return;
+    if (B > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
+    int64_t total_rows = 0;
+    for (const auto& t : tasks) total_rows += ranges_host_[(size_t)t.parent_node].count;
+    const int hch = pick_hist_chunk(total_rows);
+    char* st = stage_host_.get();
+    int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
+    int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
+    int np = 0, nh = 0;
+    for (int i = 0; i < B; ++i) {
+      SplitTask& t = tasks[(size_t)i];
+      int64_t cnt = ranges_host_[(size_t)t.parent_node].count;
+      t.first_pchunk = np;
+      t.num_pchunk = std::max(1, ceil_div(cnt, k::kPartChunk));
+      t.first_hchunk = nh;
+      t.num_hchunk = std::max(1, ceil_div(cnt, hch));
+      if (np + t.num_pchunk > max_pchunks_ || nh + t.num_hchunk > max_hchunks_)
+        throw std::runtime_error("chunk table overflow");
+      for (int c = 0; c < t.num_pchunk; ++c) pc[np++] = i;
+      for (int c = 0; c < t.num_hchunk; ++c) hc[nh++] = i;
+    }
+    std::memcpy(st + off_tasks_, tasks.data(), sizeof(SplitTask) * (size_t)B);
+    k::ScanTaskDev* sd = reinterpret_cast<k::ScanTaskDev*>(st + off_scan_);
+    for (int i = 0; i < B; ++i) {
+      const SplitTask& t = tasks[(size_t)i];
+      for (int side = 0; side < 2; ++side) {
+        k::ScanTaskDev& s = sd[i * 2 + side];
+        s.node = side == 0 ? t.left_node : t.right_node;
+        s.parent_node = t.parent_node;
+        s.pad = 0;
+        if (side == t.hist_child) { s.slot = t.new_slot; s.parent_slot = -1; s.sibling_slot = -1; }
+        else { s.slot = t.parent_slot; s.parent_slot = t.parent_slot; s.sibling_slot = t.new_slot; }
+      }
+    }
+    prof.mark(PhaseProfile::kUpload, stream_);
+    upload_stage(off_hch_ + sizeof(int32_t) * (size_t)nh);
+    LGA_HIP_CHECK(hipMemsetAsync(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, 0,
+                                 sizeof(int64_t) * (size_t)slot_words_ * (size_t)B, stream_));
+    prof.mark(PhaseProfile::kPartition, stream_);
+    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
+    const int32_t* dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
+    k::partition(dt, dpc, np, nodes_.get(), arena_[0].get(), arena_[1].get(), arena_[0].get(), arena_[1].get(),
+                 mir_->bins_fm.get(), N_, mask_.get(), chunk_left_.get(), task_left_.get(), k::BagParams{0, 0, 0, 0.f},
+                 stream_);
+    prof.mark(PhaseProfile::kHist, stream_);
+    run_hist(B, nh, hch);
+    prof.mark(PhaseProfile::kComm, stream_);
+    reduce_slots(tasks[0].new_slot, B);
+    prof.mark(PhaseProfile::kScan, stream_);
+    run_scan(2 * B);
+    prof.mark(PhaseProfile::kFetch, stream_);
+    fetch(2 * B, B, false);
+    prof.mark(PhaseProfile::kCount, stream_);
+    sync();
+    prof.collect(PhaseProfile::kCount);
+    ++prof.rounds;
+    prof.tasks += B;
+    std::memcpy(infos, fetch_host_.get(), sizeof(SplitInfo) * (size_t)(2 * B));
+    const int32_t* tl = reinterpret_cast<const int32_t*>(fetch_host_.get() + sizeof(SplitInfo) * (size_t)(2 * B));
+    for (int i = 0; i < B; ++i) {
+      const SplitTask& t = tasks[(size_t)i];
+      const NodeRange p = ranges_host_[(size_t)t.parent_node];
+      ranges_host_[(size_t)t.left_node] = NodeRange{p.begin, tl[i], 1 - p.buf, 0};
+      ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
+    }
+  }
+
+  // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
+  int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
+                        uint64_t iter, uint64_t salt) {
+    if (n == 0) return 0;
+    SplitTask t{};
+    const int node_id = 2 * capacity_splits_ + 1;   // scratch node entry beyond the grower's range
+    t.parent_node = node_id; t.left_node = node_id; t.right_node = node_id;
+    t.feature = -1; t.first_pchunk = 0; t.num_pchunk = ceil_div(n, k::kPartChunk);
+    if (t.num_pchunk > max_pchunks_) throw std::runtime_error("bagging chunk table overflow");
+    char* st = stage_host_.get();
+    std::memcpy(st + off_tasks_, &t, sizeof(t));
+    int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
+    for (int c = 0; c < t.num_pchunk; ++c) pc[c] = 0;
+    NodeRange r{0, (int32_t)n, 0, 0};
+    std::memcpy(st, &r, sizeof(NodeRange));
+    upload_stage(off_pch_ + sizeof(int32_t) * (size_t)t.num_pchunk);
+    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get() + node_id, stage_dev_.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
+    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
+    const int32_t* dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
+    k::partition(dt, dpc, t.num_pchunk, nodes_.get(), base_rows, nullptr, nullptr, out, nullptr, N_, mask_.get(),
+                 chunk_left_.get(), task_left_.get(), k::BagParams{seed, iter, salt, (float)fraction}, stream_);
+    int32_t nl = 0;
+    LGA_HIP_CHECK(hipMemcpyAsync(&nl, task_left_.get(), sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    sync();
+    return nl;
+  }
+
+  void sync() { LGA_HIP_CHECK(hipStreamSynchronize(stream_)); }
+  hipStream_t stream() const { return stream_; }
+
+ private:
+  int pick_hist_chunk(int64_t total_rows) const {
+    // aim at >= ~1024 workgroups when there is enough work; never exceed the LDS accumulator range
+    int64_t c = (total_rows + 1023) / 1024;
+    c = ((c + 511) / 512) * 512;
+    if (c < 1024) c = 1024;
+    if (c > kMaxRowsPerPass) c = kMaxRowsPerPass;
+    return (int)c;
+  }
+
+  void upload_stage(size_t bytes) {
+    LGA_HIP_CHECK(hipMemcpyAsync(stage_dev_.get(), stage_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
+  }
+
+  void run_hist(int n_tasks, int n_chunks, int hch) {
+    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
+    const int32_t* dhc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_hch_);
+    int tile_first = 0, tile_step = 1, tile_count = T_;
+    if (mode_ == ParallelMode::Feature) {
+      int P = comm_->size(), r = comm_->rank();
+      int owned = r < T_ ? (T_ - r + P - 1) / P : 0;
+      if (owned > 0) { tile_first = r; tile_step = P; tile_count = owned; }
+      else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
+    }
+    (void)n_tasks;
+    k::histogram(dt, dhc, n_chunks, hch, nodes_.get(), arena_[0].get(), arena_[1].get(), mir_->bins_rt.get(), N_,
+                 packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count, stream_);
+  }
+
+  void reduce_slots(int first_slot, int count) {
+    if (mode_ != ParallelMode::Data) return;
+    comm_->allreduce_sum_i64(pool_.get() + (size_t)first_slot * slot_words_, (size_t)count * slot_words_, true, stream_);
+  }
+
+  void run_scan(int n_scan) {
+    const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(stage_dev_.get() + off_scan_);
+    int first = 0, step = 1;
+    if (mode_ == ParallelMode::Feature) { first = comm_->rank(); step = comm_->size(); }
+    k::scan(ds, n_scan, meta_dev_.get(), F_, first, step, pool_.get(), slot_words_, plane_, node_totals_.get(),
+            qs_dev_.get(), sp_, cands_.get(), stream_);
+    if (mode_ == ParallelMode::Feature) {
+      k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(),
+                best_local_.get(), stream_);
+      comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, stream_);
+      k::merge_winners(best_all_.get(), comm_->size(), n_scan, ds, node_totals_.get(), qs_dev_.get(), sp_,
+                       results_dev_.get(), stream_);
+    } else {
+      k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(), nullptr,
+                stream_);
+    }
+  }
+
+  void fetch(int n_scan, int n_tasks, bool with_qs) {
+    char* h = fetch_host_.get();
+    LGA_HIP_CHECK(hipMemcpyAsync(h, results_dev_.get(), sizeof(SplitInfo) * (size_t)n_scan, hipMemcpyDeviceToHost, stream_));
+    size_t off = sizeof(SplitInfo) * (size_t)n_scan;
+    if (n_tasks > 0)
+      LGA_HIP_CHECK(hipMemcpyAsync(h + off, task_left_.get(), sizeof(int32_t) * (size_t)n_tasks, hipMemcpyDeviceToHost, stream_));
+    if (with_qs)
+      LGA_HIP_CHECK(hipMemcpyAsync(h + off, qs_dev_.get(), sizeof(QuantScale), hipMemcpyDeviceToHost, stream_));
+  }
+
+  const Dataset* root_;
+  DeviceMirror* mir_;
+  Comm* comm_;
+  ParallelMode mode_;
+  hipStream_t stream_ = nullptr;
+  int F_ = 0, T_ = 0;
+  int64_t N_ = 0, plane_ = 0, slot_words_ = 0;
+  int capacity_splits_ = 0, max_batch_ = 0, max_pchunks_ = 0, max_hchunks_ = 0;
+  DeviceBuffer<int64_t> pool_;
+  DeviceBuffer<NodeRange> nodes_;
+  DeviceBuffer<int64_t> node_totals_;
+  DeviceBuffer<int32_t> arena_[2];
+  DeviceBuffer<uint64_t> mask_;
+  DeviceBuffer<int32_t> chunk_left_, task_left_;
+  DeviceBuffer<char> stage_dev_;
+  PinnedBuffer<char> stage_host_, fetch_host_;
+  DeviceBuffer<k::Cand> cands_, best_local_, best_all_;
+  DeviceBuffer<SplitInfo> results_dev_;
+  DeviceBuffer<FeatureMeta> meta_dev_;
+  DeviceBuffer<QuantScale> qs_dev_;
+  std::vector<FeatureMeta> meta_host_;
+  std::vector<NodeRange> ranges_host_;
+  size_t off_tasks_ = 0, off_scan_ = 0, off_pch_ = 0, off_hch_ = 0, stage_bytes_ = 0;
+  SplitParams sp_{};
+  QuantScale qs_host_{0, 0};
+  const int32_t* bag_ = nullptr;
+  int64_t bag_n_ = 0;
+  const int64_t* packed_ = nullptr;
+};
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+class HipEngine : public Engine {
+ public:
+  HipEngine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm, ParallelMode mode)
+      : train_(train), cfg_(cfg), comm_(comm), grower_(cfg, train.get()) {
+    if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
+    stream_ = current_stream();
+    mir_ = ensure_device_mirror(train_->root());
+    N_ = train_->root_rows();
+    upload_meta(train_->root(), mir_);
+    n_base_ = train_->num_data();
+    base_rows_.resize((size_t)std::max<int64_t>(n_base_, 1));
+    if (train_->used_indices())
+      LGA_HIP_CHECK(hipMemcpyAsync(base_rows_.get(), train_->used_indices()->data(), sizeof(int32_t) * (size_t)n_base_,
+                                   hipMemcpyHostToDevice, stream_));
+    else
+      k::iota(base_rows_.get(), n_base_, stream_);
+    bag_rows_.resize((size_t)std::max<int64_t>(n_base_, 1));
+    scores_.resize((size_t)N_);
+    grad_.resize((size_t)N_);
+    hess_.resize((size_t)N_);
+    packed_.resize((size_t)N_);
+    maxbits_.resize(2);
+    red_dev_.resize(8);
+    red_host_.resize(8);
+    if (!train_->root_init_score().empty()) {
+      init_score_dev_.upload(train_->root_init_score().data(), (size_t)N_, stream_);
+      has_init_ = true;
+    }
+    backend_.reset(new HipBackend(train_.get(), mir_, cfg, comm, mode, n_base_));
+    bag_ptr_ = base_rows_.get();
+    bag_n_ = n_base_;
+    oob_n_ = 0;
+    int F = train_->num_features();
+    std::vector<int32_t> mb((size_t)std::max(F, 1), -1);
+    for (int f = 0; f < F; ++f) mb[(size_t)f] = train_->inner_mapper(f).missing_bin;
+    missing_bin_dev_.upload(mb.data(), mb.size(), stream_);
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
+  const char* name() const override { return "hip"; }
+
+  int add_valid(std::shared_ptr<Dataset> ds) override {
+    if (ds->num_total_features() != train_->num_total_features())
+      throw std::runtime_error("validation data has a different number of features");
+    if (ds->root_label().empty()) throw std::runtime_error("validation data has no label");
+    std::unique_ptr<Valid> v(new Valid());
+    v->ds = ds;
+    v->mir = ensure_device_mirror(ds->root());
+    upload_meta(ds->root(), v->mir);
+    v->n = ds->num_data();
+    v->N = ds->root_rows();
+    v->rows.resize((size_t)std::max<int64_t>(v->n, 1));
+    if (ds->used_indices())
+      LGA_HIP_CHECK(hipMemcpyAsync(v->rows.get(), ds->used_indices()->data(), sizeof(int32_t) * (size_t)v->n,
+                                   hipMemcpyHostToDevice, stream_));
+    else
+      k::iota(v->rows.get(), v->n, stream_);
+    v->shared_scores = false;
+    if (!v->shared_scores) v->scores.resize((size_t)v->N);
+    if (!ds->root_init_score().empty() && !v->shared_scores) {
+      v->init.upload(ds->root_init_score().data(), (size_t)v->N, stream_);
+      v->has_init = true;
+    }
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    valid_.push_back(std::move(v));
+    return (int)valid_.size() - 1;
+  }
+  int num_valid() const override { return (int)valid_.size(); }
+  int64_t num_rows(int which) const override { return which < 0 ? n_base_ : valid_[(size_t)which]->n; }
+
+  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) override {
+    k::label_sums(mir_->label.get(), weight_ptr(mir_), base_rows_.get(), n_base_, red_dev_.get(), stream_);
+    red_dev_.download(red_host_.get(), 3, stream_);
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    double b[3] = {red_host_[0], red_host_[1], red_host_[2]};
+    if (dist()) comm_->allreduce_sum_f64(b, 3, false, stream_);
+    *sum_wy = b[0]; *sum_w = b[1]; *sum_w_pos = b[2];
+  }
+
+  void reset_scores(double v) override {
+    k::init_scores(scores_.get(), has_init_ ? init_score_dev_.get() : nullptr, base_rows_.get(), n_base_, v, stream_);
+    for (auto& vs : valid_)
+      k::init_scores(score_ptr(*vs), (vs->has_init ? vs->init.get() : (vs->shared_scores && has_init_ ? init_score_dev_.get() : nullptr)),
+                     vs->rows.get(), vs->n, v, stream_);
+  }
+  void scale_scores(int which, double f) override {
+    if (which < 0) k::scale_add(scores_.get(), base_rows_.get(), n_base_, f, 0.0, stream_);
+    else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, f, 0.0, stream_); }
+  }
+  void add_constant(int which, double c) override {
+    if (which < 0) k::scale_add(scores_.get(), base_rows_.get(), n_base_, 1.0, c, stream_);
+    else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, 1.0, c, stream_); }
+  }
+
+  void compute_gradients(const ObjectiveSpec& obj) override {
+    k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_rows_.get(), n_base_, grad_.get(),
+                 hess_.get(), maxbits_.get(), stream_);
+    have_max_ = true;
+  }
+  void set_gradients(const float* g, const float* h, int64_t n) override {
+    if (n != n_base_) throw std::runtime_error("custom gradients: wrong length");
+    tmp_f32_.resize((size_t)n * 2);
+    LGA_HIP_CHECK(hipMemcpyAsync(tmp_f32_.get(), g, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream_));
+    LGA_HIP_CHECK(hipMemcpyAsync(tmp_f32_.get() + n, h, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream_));
+    k::scatter_f32(tmp_f32_.get(), base_rows_.get(), n, grad_.get(), stream_);
+    k::scatter_f32(tmp_f32_.get() + n, base_rows_.get(), n, hess_.get(), stream_);
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));   // g/h are caller memory
+    have_max_ = false;
+  }
+  void get_gradients(float* g, float* h) override {
+    tmp_f32_.resize((size_t)n_base_ * 2);
+    k::gather_f32(grad_.get(), base_rows_.get(), n_base_, tmp_f32_.get(), stream_);
+    k::gather_f32(hess_.get(), base_rows_.get(), n_base_, tmp_f32_.get() + n_base_, stream_);
+    LGA_HIP_CHECK(hipMemcpyAsync(g, tmp_f32_.get(), sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipMemcpyAsync(h, tmp_f32_.get() + n_base_, sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
+  void resample(double fraction, uint64_t seed, uint64_t iter) override {
+    if (fraction >= 1.0) { bag_ptr_ = base_rows_.get(); bag_n_ = n_base_; oob_n_ = 0; return; }
+    uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
+    bag_n_ = backend_->bag_partition(base_rows_.get(), n_base_, bag_rows_.get(), fraction, seed, iter, salt);
+    bag_ptr_ = bag_rows_.get();
+    oob_n_ = n_base_ - bag_n_;
+  }
+
+  Tree train_tree(const std::vector<FeatureMeta>& meta) override {
+    if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_rows_.get(), n_base_, maxbits_.get(), stream_);
+    if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
+    k::quantize(grad_.get(), hess_.get(), bag_ptr_, bag_n_, maxbits_.get(), backend_->qs_device(), packed_.get(), stream_);
+    backend_->set_bag(bag_ptr_, bag_n_);
+    backend_->set_packed(packed_.get());
+    return grower_.grow(*backend_, meta, &leaf_nodes_);
+  }
+
+  void add_trained_tree_to_train_scores(const Tree& tree) override {
+    int L = tree.num_leaves;
+    std::vector<k::LeafSpan> spans((size_t)L);
+    for (int l = 0; l < L; ++l) {
+      const NodeRange& r = backend_->range(leaf_nodes_[(size_t)l]);
+      spans[(size_t)l] = k::LeafSpan{r.begin, r.begin + r.count, r.buf, 0, tree.leaf_value[(size_t)l]};
+    }
+    std::sort(spans.begin(), spans.end(), [](const k::LeafSpan& a, const k::LeafSpan& b) {
+      if (a.begin != b.begin) return a.begin < b.begin;
+      return a.end < b.end;   // empty leaves first so the last entry with begin <= p is the non-empty one
+    });
+    wait_upload();
+    span_host_.resize((size_t)L);
+    std::memcpy(span_host_.get(), spans.data(), sizeof(k::LeafSpan) * (size_t)L);
+    span_dev_.resize((size_t)L);
+    LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
+    mark_upload();
+    k::leaf_add(span_dev_.get(), L, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(), stream_);
+    if (oob_n_ > 0) {
+      k::TreeDev td = upload_tree(tree);
+      k::traverse_add(td, mir_->bins_fm.get(), N_, missing_bin_dev_.get(), bag_ptr_ + bag_n_, oob_n_, 1.0, scores_.get(), stream_);
+    }
+  }
+
+  void add_tree_by_traversal(int which, const Tree& tree, double sign) override {
+    if (tree.num_leaves > 1 && (tree.split_feature_inner.empty() || tree.split_feature_inner[0] < 0))
+      throw std::runtime_error("tree has no bin thresholds (loaded from a model file); cannot traverse binned data");
+    k::TreeDev td = upload_tree(tree);
+    if (which < 0) {
+      k::traverse_add(td, mir_->bins_fm.get(), N_, missing_bin_dev_.get(), base_rows_.get(), n_base_, sign, scores_.get(), stream_);
+    } else {
+      auto& v = *valid_[(size_t)which];
+      k::traverse_add(td, v.mir->bins_fm.get(), v.N, missing_bin_dev_.get(), v.rows.get(), v.n, sign, score_ptr(v), stream_);
+    }
+  }
+
+  std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
+    const double* sc; const DeviceMirror* m; const int32_t* rows; int64_t n; const Dataset* ds;
+    if (which < 0) { sc = scores_.get(); m = mir_; rows = base_rows_.get(); n = n_base_; ds = train_.get(); }
+    else { auto& v = *valid_[(size_t)which]; sc = score_ptr(v); m = v.mir; rows = v.rows.get(); n = v.n; ds = v.ds.get(); }
+    std::vector<EvalResult> out;
+    for (int32_t mk : metrics) {
+      EvalResult r;
+      r.name = metric_name(mk);
+      r.higher_better = metric_higher_better(mk);
+      if (mk == kMetAuc) {
+        // rank statistic: scores come back to the host, which sorts them
+        std::vector<double> hs((size_t)n);
+        tmp_f64_.resize((size_t)std::max<int64_t>(n, 1));
+        k::gather_f64(sc, rows, n, tmp_f64_.get(), stream_);
+        LGA_HIP_CHECK(hipMemcpyAsync(hs.data(), tmp_f64_.get(), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream_));
+        LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+        std::vector<float> lab = ds->local_label();
+        std::vector<float> w = ds->local_weight();
+        std::vector<int32_t> met{kMetAuc};
+        auto rr = eval_metrics_host(hs.data(), lab.data(), w.empty() ? nullptr : w.data(), nullptr, n, met, obj, comm_);
+        r.value = rr[0].value;
+      } else {
+        k::metric_sum(mk, obj, sc, m->label.get(), weight_ptr(m), rows, n, red_dev_.get(), stream_);
+        red_dev_.download(red_host_.get(), 2, stream_);
+        LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+        double b[2] = {red_host_[0], red_host_[1]};
+        if (dist()) comm_->allreduce_sum_f64(b, 2, false, stream_);
+        double v = b[1] > 0.0 ? b[0] / b[1] : 0.0;
+        if (mk == kMetRmse) v = std::sqrt(v);
+        r.value = v;
+      }
+      out.push_back(r);
+    }
+    return out;
+  }
+
+  void get_scores(int which, double* out) override {
+    const double* sc; const int32_t* rows; int64_t n;
+    if (which < 0) { sc = scores_.get(); rows = base_rows_.get(); n = n_base_; }
+    else { auto& v = *valid_[(size_t)which]; sc = score_ptr(v); rows = v.rows.get(); n = v.n; }
+    tmp_f64_.resize((size_t)std::max<int64_t>(n, 1));
+    k::gather_f64(sc, rows, n, tmp_f64_.get(), stream_);
+    LGA_HIP_CHECK(hipMemcpyAsync(out, tmp_f64_.get(), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
+  std::string profile_json() const override { return backend_->prof.json(); }
+  GrowStats grow_stats() const override { return grower_.last_stats(); }
+
+  // raw device pointers (used by the bindings for zero-copy access)
+  double* scores_device() { return scores_.get(); }
+  int64_t root_rows() const { return N_; }
+
+ private:
+  struct Valid {
+    std::shared_ptr<Dataset> ds;
+    DeviceMirror* mir = nullptr;
+    int64_t n = 0, N = 0;
+    DeviceBuffer<int32_t> rows;
+    DeviceBuffer<double> scores, init;
+    bool shared_scores = false, has_init = false;
+  };
+  bool dist() const { return comm_ && comm_->size() > 1; }
+  double* score_ptr(Valid& v) { return v.shared_scores ? scores_.get() : v.scores.get(); }
+  static const float* weight_ptr(const DeviceMirror* m) { return m->has_weight ? m->weight.get() : nullptr; }
+
+  void upload_meta(const Dataset* root, DeviceMirror* m) {
+    const auto& y = root->root_label();
+    if (!y.empty()) m->label.upload(y.data(), y.size(), stream_);
+    const auto& w = root->root_weight();
+    m->has_weight = !w.empty();
+    if (m->has_weight) m->weight.upload(w.data(), w.size(), stream_);
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+  }
+
+  void wait_upload() { if (upload_pending_) { LGA_HIP_CHECK(hipEventSynchronize(upload_ev_)); upload_pending_ = false; } }
+  void mark_upload() {
+    if (!upload_ev_) LGA_HIP_CHECK(hipEventCreateWithFlags(&upload_ev_, hipEventDisableTiming));
+    LGA_HIP_CHECK(hipEventRecord(upload_ev_, stream_));
+    upload_pending_ = true;
+  }
+
+  k::TreeDev upload_tree(const Tree& tree) {
+    int L = tree.num_leaves, ni = L - 1;
+    size_t ints = (size_t)std::max(ni, 1) * 5;
+    size_t bytes = ((ints * sizeof(int32_t) + 7) & ~(size_t)7) + sizeof(double) * (size_t)L;
+    wait_upload();
+    tree_host_.resize(bytes);
+    tree_dev_.resize(bytes);
+    int32_t* ip = reinterpret_cast<int32_t*>(tree_host_.get());
+    size_t stride = (size_t)std::max(ni, 1);
+    for (int i = 0; i < ni; ++i) {
+      ip[i] = tree.split_feature_inner[(size_t)i];
+      ip[stride + i] = tree.threshold_bin[(size_t)i];
+      ip[2 * stride + i] = (tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 1 : 0;
+      ip[3 * stride + i] = tree.left_child[(size_t)i];
+      ip[4 * stride + i] = tree.right_child[(size_t)i];
+    }
+    size_t doff = (ints * sizeof(int32_t) + 7) & ~(size_t)7;
+    std::memcpy(tree_host_.get() + doff, tree.leaf_value.data(), sizeof(double) * (size_t)L);
+    LGA_HIP_CHECK(hipMemcpyAsync(tree_dev_.get(), tree_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
+    mark_upload();
+    const int32_t* dp = reinterpret_cast<const int32_t*>(tree_dev_.get());
+    k::TreeDev td;
+    td.feature = dp; td.threshold = dp + stride; td.default_left = dp + 2 * stride; td.left = dp + 3 * stride;
+    td.right = dp + 4 * stride;
+    td.leaf_value = reinterpret_cast<const double*>(tree_dev_.get() + doff);
+    td.num_leaves = L;
+    return td;
+  }
+
+  std::shared_ptr<Dataset> train_;
+  Config cfg_;
+  Comm* comm_;
+  TreeGrower grower_;
+  hipStream_t stream_ = nullptr;
+  DeviceMirror* mir_ = nullptr;
+  std::unique_ptr<HipBackend> backend_;
+  int64_t N_ = 0, n_base_ = 0, bag_n_ = 0, oob_n_ = 0;
+  const int32_t* bag_ptr_ = nullptr;
+  DeviceBuffer<int32_t> base_rows_, bag_rows_, missing_bin_dev_;
+  DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
+  DeviceBuffer<float> grad_, hess_, tmp_f32_;
+  DeviceBuffer<int64_t> packed_;
+  DeviceBuffer<uint32_t> maxbits_;
+  DeviceBuffer<k::LeafSpan> span_dev_;
+  DeviceBuffer<char> tree_dev_;
+  PinnedBuffer<double> red_host_;
+  PinnedBuffer<k::LeafSpan> span_host_;
+  PinnedBuffer<char> tree_host_;
+  hipEvent_t upload_ev_ = nullptr;
+  bool upload_pending_ = false;
+  bool has_init_ = false, have_max_ = false;
+  std::vector<int32_t> leaf_nodes_;
+  std::vector<std::unique_ptr<Valid>> valid_;
+};
+
+}  // namespace
+
+std::unique_ptr<Engine> make_hip_engine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm,
+                                        ParallelMode mode) {
+  return std::unique_ptr<Engine>(new HipEngine(train, cfg, comm, mode));
+}
+
+}  // namespace lga

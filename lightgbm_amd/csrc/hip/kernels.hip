@@ -1,0 +1,738 @@
+// Training kernels for gfx950 (CDNA4, wave64).
+//
+//  * histogram:  one lane = one row; the row's 32 bins of a feature tile arrive
+//    as two 16-byte loads; (g,h) are added as ONE packed 64-bit integer with an
+//    LDS atomic (ds_add_u64) into a 64 KiB per-workgroup histogram; the
+//    workgroup then merges its non-zero cells into the int64 global slot.
+//    Integer sums make the result independent of thread order.
+//  * partition:  ballot bit masks + popcount ranks give a stable split of a
+//    leaf's row list without sorting; two launches (count, scatter) per round
+//    for ALL leaves of the round.
+//  * scan:       one wave per (leaf, feature): 4 bins per lane, wave prefix sum
+//    by shuffles, fp64 gains, wave arg-max; sibling histograms are derived in
+//    place (parent - smaller child) on the way in.
+#include "kernels.hpp"
+#include "device.hpp"
+
+namespace lga {
+namespace k {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int64_t shfl_i64(int64_t v, int src) {
+  int lo = __shfl((int)(uint32_t)((uint64_t)v & 0xffffffffull), src, kWave);
+  int hi = __shfl((int)(uint32_t)((uint64_t)v >> 32), src, kWave);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+__device__ __forceinline__ int64_t shfl_up_i64(int64_t v, int d) {
+  int lo = __shfl_up((int)(uint32_t)((uint64_t)v & 0xffffffffull), d, kWave);
+  int hi = __shfl_up((int)(uint32_t)((uint64_t)v >> 32), d, kWave);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+__device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
+  int lo = __shfl_xor((int)(uint32_t)((uint64_t)v & 0xffffffffull), m, kWave);
+  int hi = __shfl_xor((int)(uint32_t)((uint64_t)v >> 32), m, kWave);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  return __longlong_as_double(shfl_xor_i64(__double_as_longlong(v), m));
+}
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_i64(v, m);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_f64(v, m);
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, kWave));
+  return v;
+}
+
+inline int grid_for(int64_t n, int threads, int max_blocks = 2048) {
+  int64_t b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------
+// gradients / quantisation
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gradients_kernel(ObjectiveSpec obj, const double* __restrict__ scores,
+                                                        const float* __restrict__ label,
+                                                        const float* __restrict__ weight,
+                                                        const int32_t* __restrict__ rows, int64_t n,
+                                                        float* __restrict__ g, float* __restrict__ h,
+                                                        uint32_t* maxbits) {
+  float mg = 0.f, mh = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = rows ? rows[i] : i;
+    float gg, hh;
+    grad_hess(obj, scores[r], label[r], weight ? weight[r] : 1.0f, &gg, &hh);
+    g[r] = gg;
+    h[r] = hh;
+    mg = fmaxf(mg, fabsf(gg));
+    mh = fmaxf(mh, hh);
+  }
+  mg = wave_max_f32(mg);
+  mh = wave_max_f32(mh);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&maxbits[0], __float_as_uint(mg));   // non-negative floats order like their bit patterns
+    atomicMax(&maxbits[1], __float_as_uint(mh));
+  }
+}
+
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                     const int32_t* __restrict__ rows, int64_t n, uint32_t* maxbits) {
+  float mg = 0.f, mh = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = rows ? rows[i] : i;
+    mg = fmaxf(mg, fabsf(g[r]));
+    mh = fmaxf(mh, h[r]);
+  }
+  mg = wave_max_f32(mg);
+  mh = wave_max_f32(mh);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&maxbits[0], __float_as_uint(mg));
+    atomicMax(&maxbits[1], __float_as_uint(mh));
+  }
+}
+
+__global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                       const int32_t* __restrict__ rows, int64_t n,
+                                                       const uint32_t* __restrict__ maxbits, QuantScale* qs,
+                                                       int64_t* __restrict__ packed) {
+  const int kg = quant_exponent(__uint_as_float(maxbits[0]));
+  const int kh = quant_exponent(__uint_as_float(maxbits[1]));
+  if (blockIdx.x == 0 && threadIdx.x == 0) { qs->kg = kg; qs->kh = kh; }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = rows ? rows[i] : i;
+    packed[r] = pack_gh(lga::quantize(g[r], kg), lga::quantize(h[r], kh));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// partition
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __restrict__ bins_fm, int64_t N,
+                                          int32_t row, const BagParams& bag) {
+  if (t.feature < 0) return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < bag.fraction;
+  int b = bins_fm[(int64_t)t.feature * N + row];
+  return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+}
+
+__global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, const NodeRange* __restrict__ nodes,
+    const int32_t* __restrict__ a0, const int32_t* __restrict__ a1, const uint8_t* __restrict__ bins_fm, int64_t N,
+    uint64_t* __restrict__ mask, int32_t* __restrict__ chunk_left, BagParams bag) {
+  __shared__ int wave_cnt[kPartThreads / kWave];
+  const int wg = blockIdx.x;
+  const SplitTask t = tasks[chunk_task[wg]];
+  const int c = wg - t.first_pchunk;
+  const NodeRange p = nodes[t.parent_node];
+  const int32_t* src = (p.buf ? a1 : a0) + p.begin;
+  const int base = c * kPartChunk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int cnt = 0;
+#pragma unroll
+  for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
+    int pos = base + kk * kPartThreads + threadIdx.x;
+    bool left = false;
+    if (pos < p.count) left = goes_left(t, bins_fm, N, src[pos], bag);
+    unsigned long long m = __ballot(left);
+    if (lane == 0) {
+      mask[(int64_t)wg * (kPartChunk / kWave) + kk * (kPartThreads / kWave) + wave] = m;
+      cnt += __popcll(m);
+    }
+  }
+  if (lane == 0) wave_cnt[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+#pragma unroll
+    for (int w = 0; w < kPartThreads / kWave; ++w) s += wave_cnt[w];
+    chunk_left[wg] = s;
+  }
+}
+
+__global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, NodeRange* __restrict__ nodes,
+    const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src, int32_t* __restrict__ a0_dst,
+    int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask, const int32_t* __restrict__ chunk_left,
+    int32_t* __restrict__ task_left) {
+  constexpr int kWords = kPartChunk / kWave;   // 32 mask words per chunk
+  __shared__ int red_before[kPartThreads / kWave], red_all[kPartThreads / kWave];
+  __shared__ int word_prefix[kWords];
+  const int wg = blockIdx.x;
+  const int ti = chunk_task[wg];
+  const SplitTask t = tasks[ti];
+  const int c = wg - t.first_pchunk;
+  const NodeRange p = nodes[t.parent_node];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // lefts in earlier chunks of this task, and in all of them
+  int before = 0, all = 0;
+  for (int j = threadIdx.x; j < t.num_pchunk; j += kPartThreads) {
+    int v = chunk_left[t.first_pchunk + j];
+    all += v;
+    if (j < c) before += v;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    before += __shfl_xor(before, m, kWave);
+    all += __shfl_xor(all, m, kWave);
+  }
+  if (lane == 0) { red_before[wave] = before; red_all[wave] = all; }
+  // exclusive prefix of the popcounts of this chunk's mask words
+  if (threadIdx.x < kWave) {
+    int pc = 0;
+    if (threadIdx.x < kWords) pc = __popcll(mask[(int64_t)wg * kWords + threadIdx.x]);
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < kWords; d <<= 1) {
+      int o = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += o;
+    }
+    if (threadIdx.x < kWords) word_prefix[threadIdx.x] = incl - pc;
+  }
+  __syncthreads();
+  before = 0; all = 0;
+#pragma unroll
+  for (int w = 0; w < kPartThreads / kWave; ++w) { before += red_before[w]; all += red_all[w]; }
+  const int32_t* src = (p.buf ? a1_src : a0_src) + p.begin;
+  int32_t* dst = (p.buf ? a0_dst : a1_dst) + p.begin;   // the OTHER buffer
+  const int base = c * kPartChunk;
+  const int right_before = base - before;
+#pragma unroll
+  for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
+    int w = kk * (kPartThreads / kWave) + wave;
+    int pos = base + w * kWave + lane;
+    if (pos < p.count) {
+      unsigned long long m = mask[(int64_t)wg * kWords + w];
+      bool left = (m >> lane) & 1ull;
+      int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
+      int in_chunk = w * kWave + lane;
+      int d = left ? (before + lrank) : (all + right_before + (in_chunk - lrank));
+      dst[d] = src[pos];
+    }
+  }
+  if (c == 0 && threadIdx.x == 0) {
+    nodes[t.left_node] = NodeRange{p.begin, all, 1 - p.buf, 0};
+    nodes[t.right_node] = NodeRange{p.begin + all, p.count - all, 1 - p.buf, 0};
+    task_left[ti] = all;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// histogram
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kHistThreads) void hist_kernel(
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, int rows_per_chunk,
+    const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+    const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, int64_t* __restrict__ pool,
+    int64_t slot_words, int64_t plane, int F, int tile_first, int tile_step) {
+  __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
+  __shared__ long long red[3][kHistThreads / kWave];
+  const int x = blockIdx.x;
+  const int tile = tile_first + (int)blockIdx.y * tile_step;
+  const SplitTask t = tasks[chunk_task[x]];
+  const int c = x - t.first_hchunk;
+  const int node = t.hist_child ? t.right_node : t.left_node;
+  const NodeRange r = nodes[node];
+  const int lo = c * rows_per_chunk;
+  if (lo >= r.count) return;   // the child turned out smaller than the grid was sized for
+  const int hi = min(lo + rows_per_chunk, r.count);
+  for (int i = threadIdx.x; i < kTileFeatures * kMaxBins; i += kHistThreads) lds[i] = 0ull;
+  __syncthreads();
+  const int32_t* rows = (r.buf ? a1 : a0) + r.begin;
+  const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
+  const int nf = min(kTileFeatures, F - tile * kTileFeatures);
+  long long sg = 0, sh = 0;
+  for (int i = lo + threadIdx.x; i < hi; i += kHistThreads) {
+    const int row = rows[i];
+    const unsigned long long p = (unsigned long long)packed[row];
+    const uint4 ra = recs[(int64_t)row * 2];
+    const uint4 rb = recs[(int64_t)row * 2 + 1];
+    sg += (long long)(int32_t)(p >> 32);
+    sh += (long long)(p & 0xffffffffull);
+    const unsigned w[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+    for (int k = 0; k < kTileFeatures; ++k) {
+      if (k < nf) {
+        unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+        atomicAdd(&lds[k * kMaxBins + bin], p);
+      }
+    }
+  }
+  __syncthreads();
+  int64_t* slot = pool + (int64_t)t.new_slot * slot_words;
+  unsigned long long* gp = reinterpret_cast<unsigned long long*>(slot + (int64_t)tile * kTileFeatures * kMaxBins);
+  unsigned long long* hp = reinterpret_cast<unsigned long long*>(slot + plane + (int64_t)tile * kTileFeatures * kMaxBins);
+  for (int e = threadIdx.x; e < nf * kMaxBins; e += kHistThreads) {
+    unsigned long long v = lds[e];
+    if (v != 0ull) {
+      atomicAdd(&gp[e], (unsigned long long)(long long)(int32_t)(v >> 32));
+      atomicAdd(&hp[e], v & 0xffffffffull);
+    }
+  }
+  if (blockIdx.y == 0) {
+    // header: rows, sum g, sum h of this child (tile 0's workgroups see every row once)
+    sg = wave_sum_i64(sg);
+    sh = wave_sum_i64(sh);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[0][wave] = sg; red[1][wave] = sh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long tg = 0, th = 0;
+#pragma unroll
+      for (int w = 0; w < kHistThreads / kWave; ++w) { tg += red[0][w]; th += red[1][w]; }
+      unsigned long long* hd = reinterpret_cast<unsigned long long*>(slot + 2 * plane);
+      atomicAdd(&hd[0], (unsigned long long)(hi - lo));
+      atomicAdd(&hd[1], (unsigned long long)tg);
+      atomicAdd(&hd[2], (unsigned long long)th);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// split scan
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void take_better(double& g, uint64_t& key, int64_t& lg, int64_t& lh, double g2,
+                                            uint64_t k2, int64_t lg2, int64_t lh2) {
+  if (cand_better(g2, k2, g, key)) { g = g2; key = k2; lg = lg2; lh = lh2; }
+}
+
+__global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict__ tasks,
+                                                   const FeatureMeta* __restrict__ meta, int F, int f_first_tile,
+                                                   int tile_step, int64_t* __restrict__ pool, int64_t slot_words,
+                                                   int64_t plane, int64_t* __restrict__ node_totals,
+                                                   const QuantScale* __restrict__ qs, SplitParams sp,
+                                                   Cand* __restrict__ cands) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f = blockIdx.x * 4 + wave;
+  const int s = blockIdx.y;
+  if (f >= F) return;
+  const ScanTaskDev t = tasks[s];
+  const double ninf = -std::numeric_limits<double>::infinity();
+  int64_t* self = pool + (int64_t)t.slot * slot_words;
+  // leaf totals
+  int64_t tc, tg, th;
+  if (t.parent_slot < 0) {
+    const int64_t* hd = self + 2 * plane;
+    tc = hd[0]; tg = hd[1]; th = hd[2];
+  } else {
+    const int64_t* sib = pool + (int64_t)t.sibling_slot * slot_words + 2 * plane;
+    const int64_t* pt = node_totals + (int64_t)t.parent_node * 4;
+    tc = pt[0] - sib[0]; tg = pt[1] - sib[1]; th = pt[2] - sib[2];
+  }
+  if (f == 0 && lane == 0) {
+    int64_t* nt = node_totals + (int64_t)t.node * 4;
+    nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
+  }
+  Cand* out = cands + (int64_t)s * F + f;
+  const FeatureMeta m = meta[f];
+  const int my_tile = f / kTileFeatures;
+  const bool owned = tile_step <= 1 || ((my_tile - f_first_tile) % tile_step == 0 && my_tile >= f_first_tile);
+  if (!m.enabled || !owned) {
+    if (lane == 0) *out = Cand{ninf, ~0ull, 0, 0};
+    return;
+  }
+  // 4 consecutive bins per lane
+  const int64_t e = (int64_t)f * kMaxBins + lane * 4;
+  int64_t g[4], h[4];
+  {
+    const longlong2* gs = reinterpret_cast<const longlong2*>(self + e);
+    const longlong2* hs = reinterpret_cast<const longlong2*>(self + plane + e);
+    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+    g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
+    h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
+  }
+  if (t.parent_slot >= 0) {
+    // self aliases the parent's storage: self = parent - sibling, cell by cell
+    const int64_t* sb = pool + (int64_t)t.sibling_slot * slot_words;
+    const longlong2* gs = reinterpret_cast<const longlong2*>(sb + e);
+    const longlong2* hs = reinterpret_cast<const longlong2*>(sb + plane + e);
+    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+    g[0] -= g01.x; g[1] -= g01.y; g[2] -= g23.x; g[3] -= g23.y;
+    h[0] -= h01.x; h[1] -= h01.y; h[2] -= h23.x; h[3] -= h23.y;
+    longlong2* go = reinterpret_cast<longlong2*>(self + e);
+    longlong2* ho = reinterpret_cast<longlong2*>(self + plane + e);
+    go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
+    ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
+  }
+  const int nb = m.num_bin, mb = m.missing_bin;
+  const int vb = mb >= 0 ? nb - 1 : nb;
+  // stats of the missing-value bin, broadcast from the lane that holds it
+  int64_t mg = 0, mh = 0;
+  if (mb >= 0) {
+    const int j = mb & 3;
+    int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
+    int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
+    mg = shfl_i64(og, mb >> 2);
+    mh = shfl_i64(oh, mb >> 2);
+  }
+  // inclusive prefix inside the lane, exclusive prefix across lanes
+  g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
+  h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
+  int64_t ig = g[3], ih = h[3];
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    int64_t og = shfl_up_i64(ig, d), oh = shfl_up_i64(ih, d);
+    if (lane >= d) { ig += og; ih += oh; }
+  }
+  const int64_t eg = ig - g[3], eh = ih - h[3];
+  const QuantScale q = *qs;
+  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp);
+  const int last = mb >= 0 ? vb - 1 : vb - 2;
+  double bg = ninf;
+  uint64_t bkey = ~0ull;
+  int64_t blg = 0, blh = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int thr = lane * 4 + j;
+    if (thr <= last) {
+      const int64_t lg = eg + g[j], lh = eh + h[j];
+      take_better(bg, bkey, blg, blh, split_gain(lg, lh, ctx, sp), cand_key(f, thr, 0), lg, lh);
+      if (mb >= 0 && thr <= vb - 2)
+        take_better(bg, bkey, blg, blh, split_gain(lg + mg, lh + mh, ctx, sp), cand_key(f, thr, 1), lg + mg, lh + mh);
+    }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    double g2 = shfl_xor_f64(bg, msk);
+    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
+    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
+    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
+  }
+  if (lane == 0) *out = Cand{bg, bkey, blg, blh};
+}
+
+__device__ __forceinline__ void write_split(SplitInfo* o, double bg, uint64_t bkey, int64_t blg, int64_t blh, int64_t tc,
+                                            int64_t tg, int64_t th, const QuantScale& q, const SplitParams& sp) {
+  const double ninf = -std::numeric_limits<double>::infinity();
+  o->total_cnt = tc; o->total_g = tg; o->total_h = th; o->pad0 = 0;
+  if (bg == ninf) {
+    o->gain = ninf; o->feature = -1; o->threshold = 0; o->default_left = 0; o->left_g = 0; o->left_h = 0; o->left_cnt = 0;
+  } else {
+    o->gain = bg;
+    o->feature = (int32_t)(bkey >> 16);
+    o->threshold = (int32_t)((bkey >> 1) & 0x7fff);
+    o->default_left = (int32_t)(bkey & 1);
+    o->left_g = blg; o->left_h = blh;
+    o->left_cnt = est_count(blh, make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp));
+  }
+}
+
+__global__ __launch_bounds__(64) void select_kernel(const ScanTaskDev* __restrict__ tasks, int F,
+                                                    const Cand* __restrict__ cands,
+                                                    const int64_t* __restrict__ node_totals,
+                                                    const QuantScale* __restrict__ qs, SplitParams sp,
+                                                    SplitInfo* __restrict__ out, Cand* __restrict__ best_out) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  double bg = ninf;
+  uint64_t bkey = ~0ull;
+  int64_t blg = 0, blh = 0;
+  for (int f = lane; f < F; f += kWave) {
+    const Cand c = cands[(int64_t)s * F + f];
+    take_better(bg, bkey, blg, blh, c.gain, c.key, c.lg, c.lh);
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    double g2 = shfl_xor_f64(bg, msk);
+    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
+    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
+    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
+  }
+  if (lane == 0) {
+    const int64_t* nt = node_totals + (int64_t)tasks[s].node * 4;
+    if (best_out) best_out[s] = Cand{bg, bkey, blg, blh};
+    write_split(&out[s], bg, bkey, blg, blh, nt[0], nt[1], nt[2], *qs, sp);
+  }
+}
+
+__global__ __launch_bounds__(64) void merge_winners_kernel(const Cand* __restrict__ gathered, int ranks, int n_tasks,
+                                                           const ScanTaskDev* __restrict__ tasks,
+                                                           const int64_t* __restrict__ node_totals,
+                                                           const QuantScale* __restrict__ qs, SplitParams sp,
+                                                           SplitInfo* __restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_tasks) return;
+  Cand b = gathered[s];
+  for (int r = 1; r < ranks; ++r) {
+    const Cand c = gathered[(int64_t)r * n_tasks + s];
+    if (cand_better(c.gain, c.key, b.gain, b.key)) b = c;
+  }
+  const int64_t* nt = node_totals + (int64_t)tasks[s].node * 4;
+  write_split(&out[s], b.gain, b.key, b.lg, b.lh, nt[0], nt[1], nt[2], *qs, sp);
+}
+
+// ---------------------------------------------------------------------------
+// score updates
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void leaf_add_kernel(const LeafSpan* __restrict__ leaves, int n_leaves,
+                                                       const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                       int64_t n_rows, double* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* begins = reinterpret_cast<int32_t*>(smem);
+  for (int i = threadIdx.x; i < n_leaves; i += blockDim.x) begins[i] = leaves[i].begin;
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * blockDim.x) {
+    // last leaf with begin <= p (leaves are sorted by begin and tile [0, n_rows))
+    int lo = 0, hi = n_leaves - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (begins[mid] <= (int32_t)p) lo = mid; else hi = mid - 1;
+    }
+    const LeafSpan l = leaves[lo];
+    const int32_t row = (l.buf ? a1 : a0)[p];
+    scores[row] += l.value;
+  }
+}
+
+__global__ __launch_bounds__(256) void traverse_add_kernel(TreeDev tree, const uint8_t* __restrict__ bins_fm, int64_t N,
+                                                           const int32_t* __restrict__ missing_bin,
+                                                           const int32_t* __restrict__ rows, int64_t n, double sign,
+                                                           double* __restrict__ scores) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    int node = 0;
+    if (tree.num_leaves <= 1) node = ~0;
+    while (node >= 0) {
+      const int f = tree.feature[node];
+      const int b = bins_fm[(int64_t)f * N + r];
+      const bool left = (b == missing_bin[f]) ? (tree.default_left[node] != 0) : (b <= tree.threshold[node]);
+      node = left ? tree.left[node] : tree.right[node];
+    }
+    scores[r] += sign * tree.leaf_value[~node];
+  }
+}
+
+__global__ __launch_bounds__(256) void scale_add_kernel(double* __restrict__ scores, const int32_t* __restrict__ rows,
+                                                        int64_t n, double scale, double add) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    scores[r] = scores[r] * scale + add;
+  }
+}
+
+__global__ __launch_bounds__(256) void init_scores_kernel(double* __restrict__ scores, const double* __restrict__ init,
+                                                          const int32_t* __restrict__ rows, int64_t n, double v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    scores[r] = v + (init ? init[r] : 0.0);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void metric_sum_kernel(int32_t metric, ObjectiveSpec obj,
+                                                         const double* __restrict__ scores,
+                                                         const float* __restrict__ label,
+                                                         const float* __restrict__ weight,
+                                                         const int32_t* __restrict__ rows, int64_t n, double* out2) {
+  double s = 0.0, sw = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    const double w = weight ? (double)weight[r] : 1.0;
+    const double raw = scores[r];
+    const double pred = transform_score(obj.kind, obj.sigmoid, raw);
+    s += w * point_loss(metric, pred, raw, label[r], obj);
+    sw += w;
+  }
+  s = wave_sum_f64(s);
+  sw = wave_sum_f64(sw);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out2[0], s);
+    atomicAdd(&out2[1], sw);
+  }
+}
+
+__global__ __launch_bounds__(256) void label_sums_kernel(const float* __restrict__ label,
+                                                         const float* __restrict__ weight,
+                                                         const int32_t* __restrict__ rows, int64_t n, double* out3) {
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    const double w = weight ? (double)weight[r] : 1.0;
+    a += w * (double)label[r];
+    b += w;
+    if (label[r] > 0.0f) c += w;
+  }
+  a = wave_sum_f64(a); b = wave_sum_f64(b); c = wave_sum_f64(c);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out3[0], a);
+    atomicAdd(&out3[1], b);
+    atomicAdd(&out3[2], c);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kernel(const T* __restrict__ src, const int32_t* __restrict__ rows,
+                                                     int64_t n, T* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = src[rows ? rows[i] : i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_kernel(const T* __restrict__ src, const int32_t* __restrict__ rows,
+                                                      int64_t n, T* __restrict__ dst) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[rows ? rows[i] : i] = src[i];
+}
+__global__ __launch_bounds__(256) void iota_kernel(int32_t* dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (int32_t)i;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// launch wrappers
+// ---------------------------------------------------------------------------
+#define LGA_LAUNCH_CHECK() LGA_HIP_CHECK(hipGetLastError())
+
+void gradients(const ObjectiveSpec& obj, const double* scores, const float* label, const float* weight,
+               const int32_t* rows, int64_t n, float* g, float* h, uint32_t* maxbits, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(maxbits, 0, 2 * sizeof(uint32_t), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gradients_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, obj, scores, label, weight, rows, n, g,
+                     h, maxbits);
+  LGA_LAUNCH_CHECK();
+}
+
+void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(maxbits, 0, 2 * sizeof(uint32_t), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits);
+  LGA_LAUNCH_CHECK();
+}
+
+void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
+              int64_t* packed, hipStream_t s) {
+  hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
+  LGA_LAUNCH_CHECK();
+}
+
+void partition(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, NodeRange* nodes,
+               const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint8_t* bins_fm,
+               int64_t N, uint64_t* mask, int32_t* chunk_left, int32_t* task_left, BagParams bag, hipStream_t s) {
+  if (total_chunks <= 0) return;
+  hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, nodes,
+                     a0_src, a1_src, bins_fm, N, mask, chunk_left, bag);
+  LGA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, nodes,
+                     a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left);
+  LGA_LAUNCH_CHECK();
+}
+
+void histogram(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, int rows_per_chunk,
+               const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
+               const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
+               int tile_step, int tile_count, hipStream_t s) {
+  if (total_chunks <= 0 || tile_count <= 0) return;
+  if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
+  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task,
+                     rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, tile_first,
+                     tile_step);
+  LGA_LAUNCH_CHECK();
+}
+
+void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F, int f_first_tile, int tile_step,
+          int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
+          const SplitParams& sp, Cand* cands, hipStream_t s) {
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(scan_kernel, dim3((F + 3) / 4, n_tasks), dim3(256), 0, s, tasks, meta, F, f_first_tile, tile_step,
+                     pool, slot_words, plane, node_totals, qs, sp, cands);
+  LGA_LAUNCH_CHECK();
+}
+
+void select(const ScanTaskDev* tasks, int n_tasks, int F, const Cand* cands, const int64_t* node_totals,
+            const QuantScale* qs, const SplitParams& sp, SplitInfo* out, Cand* best_out, hipStream_t s) {
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(select_kernel, dim3(n_tasks), dim3(64), 0, s, tasks, F, cands, node_totals, qs, sp, out, best_out);
+  LGA_LAUNCH_CHECK();
+}
+
+void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskDev* tasks, const int64_t* node_totals,
+                   const QuantScale* qs, const SplitParams& sp, SplitInfo* out, hipStream_t s) {
+  if (n_tasks <= 0) return;
+  hipLaunchKernelGGL(merge_winners_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, gathered, ranks, n_tasks, tasks,
+                     node_totals, qs, sp, out);
+  LGA_LAUNCH_CHECK();
+}
+
+void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+              double* scores, hipStream_t s) {
+  if (n_rows <= 0 || n_leaves <= 0) return;
+  size_t sm = ((size_t)n_leaves * sizeof(int32_t) + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(leaf_add_kernel, dim3(grid_for(n_rows, 256)), dim3(256), sm, s, leaves, n_leaves, a0, a1, n_rows,
+                     scores);
+  LGA_LAUNCH_CHECK();
+}
+
+void traverse_add(const TreeDev& tree, const uint8_t* bins_fm, int64_t N, const int32_t* missing_bin,
+                  const int32_t* rows, int64_t n, double sign, double* scores, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(traverse_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tree, bins_fm, N, missing_bin, rows,
+                     n, sign, scores);
+  LGA_LAUNCH_CHECK();
+}
+
+void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, scores, rows, n, scale, add);
+  LGA_LAUNCH_CHECK();
+}
+
+void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(init_scores_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, scores, init, rows, n, v);
+  LGA_LAUNCH_CHECK();
+}
+
+void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
+                const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(double), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(metric_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, metric, obj, scores, label,
+                     weight, rows, n, out2);
+  LGA_LAUNCH_CHECK();
+}
+
+void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(out3, 0, 3 * sizeof(double), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(label_sums_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, label, weight, rows, n, out3);
+  LGA_LAUNCH_CHECK();
+}
+
+void gather_f64(const double* src, const int32_t* rows, int64_t n, double* dst, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_kernel<double>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, rows, n, dst);
+  LGA_LAUNCH_CHECK();
+}
+void gather_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, rows, n, dst);
+  LGA_LAUNCH_CHECK();
+}
+void scatter_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(scatter_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, src, rows, n, dst);
+  LGA_LAUNCH_CHECK();
+}
+void iota(int32_t* dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dst, n);
+  LGA_LAUNCH_CHECK();
+}
+
+}  // namespace k
+}  // namespace lga

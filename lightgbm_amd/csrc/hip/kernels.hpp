@@ -1,0 +1,88 @@
+// Launch wrappers of the gfx950 training kernels (definitions in kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "../common.hpp"
+#include "../objective.hpp"
+
+namespace lga {
+namespace k {
+
+constexpr int kPartChunk = 2048;    // rows per partition workgroup (256 threads x 8)
+constexpr int kPartThreads = 256;
+constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
+
+// Best candidate of one (leaf, feature) pair.
+struct Cand {
+  double gain;
+  uint64_t key;
+  int64_t lg, lh;
+};
+
+// Device scan task: ScanTask + the parent's node id (for its totals).
+struct ScanTaskDev {
+  int32_t node;
+  int32_t slot;
+  int32_t parent_slot;    // -1: histogram already in `slot`
+  int32_t sibling_slot;
+  int32_t parent_node;
+  int32_t pad;
+};
+
+struct TreeDev {           // device arrays of one tree for binned traversal
+  const int32_t* feature;      // inner feature per internal node
+  const int32_t* threshold;    // bin threshold
+  const int32_t* default_left;
+  const int32_t* left;
+  const int32_t* right;
+  const double* leaf_value;
+  int32_t num_leaves;
+};
+
+struct LeafSpan {          // final leaf of a grown tree
+  int32_t begin, end, buf, pad;
+  double value;
+};
+
+void gradients(const ObjectiveSpec& obj, const double* scores, const float* label, const float* weight,
+               const int32_t* rows, int64_t n, float* g, float* h, uint32_t* maxbits, hipStream_t s);
+void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s);
+void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
+              int64_t* packed, hipStream_t s);
+
+// Partition (or bagging when task.feature < 0): a0/a1 are the two row-index buffers a node's `buf` selects.
+struct BagParams { uint64_t seed, iter, salt; float fraction; };
+void partition(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, NodeRange* nodes,
+               const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint8_t* bins_fm,
+               int64_t N, uint64_t* mask, int32_t* chunk_left, int32_t* task_left, BagParams bag, hipStream_t s);
+
+void histogram(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, int rows_per_chunk,
+               const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
+               const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
+               int tile_step, int tile_count, hipStream_t s);
+
+void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F, int f_first_tile, int tile_step,
+          int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
+          const SplitParams& sp, Cand* cands, hipStream_t s);
+void select(const ScanTaskDev* tasks, int n_tasks, int F, const Cand* cands, const int64_t* node_totals,
+            const QuantScale* qs, const SplitParams& sp, SplitInfo* out, Cand* best_out, hipStream_t s);
+// Feature-parallel: merge P ranks' winners (gathered [rank][task]) into SplitInfo.
+void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskDev* tasks, const int64_t* node_totals,
+                   const QuantScale* qs, const SplitParams& sp, SplitInfo* out, hipStream_t s);
+
+void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+              double* scores, hipStream_t s);
+void traverse_add(const TreeDev& tree, const uint8_t* bins_fm, int64_t N, const int32_t* missing_bin,
+                  const int32_t* rows, int64_t n, double sign, double* scores, hipStream_t s);
+void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s);
+void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s);
+void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
+                const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s);
+void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s);
+void gather_f64(const double* src, const int32_t* rows, int64_t n, double* dst, hipStream_t s);
+void gather_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s);
+void scatter_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s);
+void iota(int32_t* dst, int64_t n, hipStream_t s);
+
+}  // namespace k
+}  // namespace lga

@@ -5,6 +5,9 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -21,6 +24,17 @@ void quantize_rows_host(const float* g, const float* h, const int32_t* rows, int
 }
 
 namespace {
+
+struct PhaseTimer {
+  double part = 0, hist = 0, scan = 0, reduce = 0;
+  bool on = std::getenv("LGA_HOST_PROFILE") != nullptr;
+  ~PhaseTimer() {
+    if (on) std::fprintf(stderr, "[lga host] partition %.3fs hist %.3fs reduce %.3fs scan %.3fs\n", part, hist, reduce, scan);
+  }
+};
+inline double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 // ---------------------------------------------------------------------------
 // Host backend
@@ -70,15 +84,20 @@ class HostBackend : public TreeBackend {
   void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) override {
     size_t B = tasks.size();
     if (B == 0) return;
+    double t0 = now_s();
     // 1. partition
 #pragma omp parallel for schedule(dynamic) if (B > 1)
     for (size_t i = 0; i < B; ++i) partition(tasks[i]);
+    double t1 = now_s();
     // 2. histograms of the chosen children (fresh, contiguous slots)
     for (size_t i = 0; i < B; ++i) {
       const SplitTask& t = tasks[i];
       build_hist(t.hist_child == 0 ? t.left_node : t.right_node, t.new_slot);
     }
+    double t2 = now_s();
     reduce_slots(tasks[0].new_slot, (int)B);
+    double t3 = now_s();
+    timer_.part += t1 - t0; timer_.hist += t2 - t1; timer_.reduce += t3 - t2;
     // 3. scan both children of every task (the sibling by subtraction, in place in the parent's slot)
     std::vector<ScanTask> st(B * 2);
     for (size_t i = 0; i < B; ++i) {
@@ -92,9 +111,11 @@ class HostBackend : public TreeBackend {
       }
     }
     scan_nodes(st.data(), (int)st.size(), infos);
+    timer_.scan += now_s() - t3;
   }
 
  private:
+  PhaseTimer timer_;
   int64_t* slot(int s) { return pool_.data() + (size_t)s * slot_words_; }
 
   bool owns_feature(int f) const {
@@ -168,8 +189,7 @@ class HostBackend : public TreeBackend {
     int64_t lg, lh;
   };
 
-  void scan_feature(const int64_t* g, const int64_t* h, int f, int64_t tg, int64_t th, int64_t tc, double gunit,
-                    double hunit, double parent_gain, Cand* best) const {
+  void scan_feature(const int64_t* g, const int64_t* h, int f, const LeafScanCtx& ctx, Cand* best) const {
     const FeatureMeta& m = meta_[(size_t)f];
     int nb = m.num_bin, mb = m.missing_bin;
     int vb = mb >= 0 ? nb - 1 : nb;   // value bins
@@ -179,11 +199,11 @@ class HostBackend : public TreeBackend {
     for (int t = 0; t <= last; ++t) {
       lg += g[t];
       lh += h[t];
-      double ga = split_gain(lg, lh, tg, th, tc, gunit, hunit, sp_, parent_gain);
+      double ga = split_gain(lg, lh, ctx, sp_);
       uint64_t ka = cand_key(f, t, 0);
       if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, lg, lh};
       if (mb >= 0 && t <= vb - 2) {
-        double gb = split_gain(lg + mg, lh + mh, tg, th, tc, gunit, hunit, sp_, parent_gain);
+        double gb = split_gain(lg + mg, lh + mh, ctx, sp_);
         uint64_t kb = cand_key(f, t, 1);
         if (cand_better(gb, kb, best->gain, best->key)) *best = Cand{gb, kb, lg + mg, lh + mh};
       }
@@ -206,12 +226,11 @@ class HostBackend : public TreeBackend {
       }
       const int64_t* hd = self + 2 * plane_;
       int64_t tc = hd[0], tg = hd[1], th = hd[2];
-      double parent_gain = leaf_gain((double)tg * gunit, (double)th * hunit, sp_.lambda_l1, sp_.lambda_l2);
+      LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_);
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
         if (!meta_[(size_t)f].enabled || !owns_feature(f)) continue;
-        scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, tg, th, tc, gunit, hunit,
-                     parent_gain, &best);
+        scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, &best);
       }
       local[(size_t)i] = best;
       SplitInfo& o = out[i];
@@ -243,7 +262,7 @@ class HostBackend : public TreeBackend {
         o.threshold = (int32_t)((b.key >> 1) & 0x7fff);
         o.default_left = (int32_t)(b.key & 1);
         o.left_g = b.lg; o.left_h = b.lh;
-        o.left_cnt = est_count(b.lh, o.total_h, o.total_cnt);
+        o.left_cnt = est_count(b.lh, make_scan_ctx(o.total_g, o.total_h, o.total_cnt, gunit, hunit, sp_));
       }
     }
   }
