@@ -1,0 +1,131 @@
+"""Headline benchmark: Higgs-shaped binary training (10.5 M x 28, 255 bins, 255 leaves).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" is one boosting iteration (one 255-leaf tree over the whole matrix,
+including gradients, histogram building, split search, partitioning and score
+update).  The data is synthetic of the Higgs shape (no network for the real
+set).  With N > 1 (launched through torch.distributed.run, one rank per GPU)
+the SAME 10.5 M rows are sharded over the ranks (strong scaling) and trained
+data-parallel with RCCL histogram all-reduces.
+
+The reported metric is the wall-clock training time of the reference
+configuration - 500 trees - derived from the timed steps
+(value = ms_per_step * 500 / 1000; exact when --steps 500).  Lower is better;
+vs_baseline = upstream LightGBM's published 238.5 s divided by ours.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+BASELINE_SECONDS = 238.5   # upstream LightGBM CPU, Higgs, 500 iterations (docs/Experiments.rst, recalled)
+N_ROWS = 10_500_000
+N_TREES_REF = 500
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=N_ROWS)
+    ap.add_argument("--leaves", type=int, default=255)
+    ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--auc", action="store_true", help="also report train AUC after the timed steps")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import lightgbm_amd as lgb
+    from lightgbm_amd.utils.datasets import make_higgs_like
+    from lightgbm_amd.parallel import default_comm, distributed_dataset
+
+    n_total = args.rows
+    lo = n_total * rank // world
+    hi = n_total * (rank + 1) // world
+    X, y = make_higgs_like(hi - lo, seed=1234 + rank, device="cuda")
+    params = {
+        "objective": "binary", "num_leaves": args.leaves, "max_bin": 255, "learning_rate": 0.1,
+        "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 100.0, "verbose": -1, "device_type": "gpu",
+        "tree_learner": "data" if distributed else "serial", "profile": bool(args.profile),
+    }
+    t0 = time.time()
+    if distributed:
+        ds = distributed_dataset(X, y, params=params)
+        comm = default_comm()
+    else:
+        ds = lgb.Dataset(X, label=y, params=params)
+        comm = None
+    ds.construct()
+    torch.cuda.synchronize()
+    t_bin = time.time() - t0
+    del X
+    booster = lgb.Booster(params, ds, comm=comm)
+
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        booster.update()
+    sync()
+    t1 = time.time()
+    for _ in range(args.steps):
+        booster.update()
+    sync()
+    elapsed = time.time() - t1
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1000.0 / max(args.steps, 1)
+    value = ms_per_step * N_TREES_REF / 1000.0
+    out = {
+        "metric": "higgs_10.5Mx28_train_seconds_500_trees",
+        "value": round(value, 4),
+        "unit": "s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": False,
+        "scaling": "strong",
+        "vs_baseline": round(BASELINE_SECONDS / value, 3) if value > 0 else None,
+        "dtype": "int64-fixed-point histograms / fp64 split gain (no reduced precision; reference is fp32/fp64)",
+        "data": "synthetic Higgs-shaped (make_higgs_like), random labels from a non-linear score; no real Higgs download possible",
+        "config": {"model": "gbdt binary, 255 leaves, 255 bins, lr 0.1, min_sum_hessian 100", "rows": n_total,
+                   "features": 28, "trees_timed": args.steps, "parallelism": f"dp{world}" if distributed else "single",
+                   "binning_seconds": round(t_bin, 3)},
+    }
+    if args.auc:
+        res = dict((m, v) for _, m, v, _ in booster._eval(-1, "training"))
+        out["config"]["train_metric"] = res
+    if args.profile:
+        out["config"]["profile"] = booster.profile()
+        out["config"]["last_tree"] = booster.grow_stats()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

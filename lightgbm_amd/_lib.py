@@ -48,6 +48,8 @@ def _declare(lib, hip: bool):
         "lga_resolve_alias": (c_int, [c_char_p, c_char_p, c_int]),
         "lga_dataset_from_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_char_p, c_void_p, c_int, P(c_void_p)]),
         "lga_dataset_from_sample": (c_int, [c_void_p, c_int64, c_int, c_int64, c_char_p, P(c_void_p)]),
+        "lga_dataset_bin_matrix": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+        "lga_dataset_from_reference": (c_int, [c_void_p, c_int64, P(c_void_p)]),
         "lga_dataset_subset": (c_int, [c_void_p, c_void_p, c_int64, P(c_void_p)]),
         "lga_dataset_set_field": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_int]),
         "lga_dataset_get_field": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, P(c_int64)]),
@@ -93,6 +95,7 @@ def _declare(lib, hip: bool):
             "lga_hip_device_info": (c_int, [P(c_int), P(c_int64), P(c_int)]),
             "lga_hip_dataset_from_device_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_char_p, c_void_p, P(c_void_p)]),
             "lga_hip_dataset_upload_raw": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
+            "lga_hip_dataset_bin_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int]),
             "lga_hip_predict": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int]),
             "lga_hip_rccl_unique_id": (c_int, [c_void_p, c_int, P(c_int)]),
             "lga_hip_comm_create_rccl": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),

@@ -184,8 +184,11 @@ class Dataset:
 
     def __init__(self, data, label=None, reference: Optional["Dataset"] = None, weight=None, init_score=None,
                  feature_name: Union[str, Sequence[str]] = "auto", params: Optional[Dict[str, Any]] = None,
-                 free_raw_data: bool = True):
+                 free_raw_data: bool = True, bin_sample=None):
         self.data = data
+        # rows to derive the bin boundaries from instead of this matrix (data-parallel ranks pass the
+        # same gathered sample so that every shard is binned identically)
+        self.bin_sample = bin_sample
         self.label = label
         self.reference = reference
         self.weight = weight
@@ -217,32 +220,50 @@ class Dataset:
         mat, names = _to_matrix(self.data)
         params = _with_device(self.params)
         if self.reference is not None:
-            self.reference.construct()
-            # bin settings come from the reference
+            self.reference.construct()   # bin boundaries come from the reference
         _warn_unknown(params)
         pstr = params_to_string(params)
         on_gpu = hip and get_param(params, "device_type") in ("gpu", "hip", "cuda", "rocm")
-        ref_h = self.reference._root_handle() if self.reference is not None else None
+        if _is_torch(mat) and not on_gpu:
+            mat = mat.cpu().numpy()
+        nrow, ncol = int(mat.shape[0]), int(mat.shape[1])
         h = ctypes.c_void_p()
-        if _is_torch(mat):
-            if not hip:
-                mat = mat.cpu().numpy()
-            else:
-                from . import _device
-                _device.sync_stream(lib)
-                dtype = 0 if str(mat.dtype).endswith("float32") else 1
-                check(lib.lga_hip_dataset_from_device_mat(ctypes.c_void_p(mat.data_ptr()), dtype, mat.shape[0],
-                                                          mat.shape[1], c_str(pstr), ref_h, ctypes.byref(h)))
-                import torch
-                torch.cuda.synchronize()
-        if h.value is None:
-            ptr, dtype, nrow, ncol, rm = _mat_args(mat)
-            check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), ref_h, 0 if on_gpu else 1,
+        if on_gpu:
+            from . import _device
+            _device.sync_stream(lib)
+        # 1. bin boundaries: from the reference, from an explicit sample, or from this matrix
+        if self.reference is not None:
+            check(lib.lga_dataset_from_reference(self.reference._root_handle(), nrow, ctypes.byref(h)))
+        elif self.bin_sample is not None:
+            smp = np.ascontiguousarray(np.asarray(self.bin_sample, dtype=np.float64))
+            if smp.ndim != 2 or smp.shape[1] != ncol:
+                raise LightGBMError("bin_sample must be a 2-D array with the data's number of columns")
+            check(lib.lga_dataset_from_sample(smp.ctypes.data_as(ctypes.c_void_p), smp.shape[0], ncol, nrow,
+                                              c_str(pstr), ctypes.byref(h)))
+        elif _is_torch(mat):
+            dtype = 0 if str(mat.dtype).endswith("float32") else 1
+            check(lib.lga_hip_dataset_from_device_mat(ctypes.c_void_p(mat.data_ptr()), dtype, nrow, ncol, c_str(pstr),
+                                                      None, ctypes.byref(h)))
+            mat_binned = True
+        else:
+            ptr, dtype, _, _, rm = _mat_args(mat)
+            check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), None, 0 if on_gpu else 1,
                                            ctypes.byref(h)))
-            if on_gpu:
-                from . import _device
-                _device.sync_stream(lib)
-                check(lib.lga_hip_dataset_upload_raw(h, ptr, dtype, nrow, ncol, rm))
+            mat_binned = not on_gpu
+        # 2. bins
+        if not locals().get("mat_binned", False):
+            if _is_torch(mat):
+                dtype = 0 if str(mat.dtype).endswith("float32") else 1
+                check(lib.lga_hip_dataset_bin_device(h, ctypes.c_void_p(mat.data_ptr()), dtype, nrow, ncol))
+            else:
+                ptr, dtype, _, _, rm = _mat_args(mat)
+                if on_gpu:
+                    check(lib.lga_hip_dataset_upload_raw(h, ptr, dtype, nrow, ncol, rm))
+                else:
+                    check(lib.lga_dataset_bin_matrix(h, ptr, dtype, nrow, ncol, rm))
+        if on_gpu:
+            import torch
+            torch.cuda.synchronize()
         self._handle = h
         self._num_total_features = mat.shape[1]
         if isinstance(self.feature_name, (list, tuple)):

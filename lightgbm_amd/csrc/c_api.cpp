@@ -85,6 +85,22 @@ int lga_dataset_from_sample(const double* sample, int64_t nsample, int ncol, int
   });
 }
 
+int lga_dataset_bin_matrix(LgaDataset ds, const void* data, int dtype, int64_t nrow, int ncol, int row_major) {
+  return guard([&] {
+    Dataset* d = D(ds);
+    if (d->is_subset()) throw std::runtime_error("cannot bin into a subset");
+    if (nrow != d->root_rows()) throw std::runtime_error("row count differs from the dataset's");
+    if (ncol != d->num_total_features()) throw std::runtime_error("column count differs from the dataset's");
+    std::vector<uint8_t> rt((size_t)d->num_tiles() * (size_t)nrow * kTileFeatures, 0), fm((size_t)d->num_features() * (size_t)nrow, 0);
+    d->bin_rows(data, dtype, nrow, ncol, row_major != 0, rt.data(), fm.data(), nrow, 0);
+    d->adopt_host_bins(std::move(rt), std::move(fm));
+  });
+}
+
+int lga_dataset_from_reference(LgaDataset ref, int64_t nrow, LgaDataset* out) {
+  return guard([&] { *out = new DatasetBox{Dataset::from_reference(D(ref), nrow)}; });
+}
+
 int lga_dataset_subset(LgaDataset ds, const int32_t* idx, int64_t n, LgaDataset* out) {
   return guard([&] { *out = new DatasetBox{D(ds)->subset(idx, n)}; });
 }

@@ -20,6 +20,9 @@ int lga_dataset_from_mat(const void* data, int dtype, int64_t nrow, int ncol, in
                          LgaDataset reference, int bin_on_host, LgaDataset* out);
 int lga_dataset_from_sample(const double* sample, int64_t nsample, int ncol, int64_t nrow, const char* params,
                             LgaDataset* out);
+// Bins a raw host matrix into a dataset that only holds bin mappers so far (from_sample / reference).
+int lga_dataset_bin_matrix(LgaDataset ds, const void* data, int dtype, int64_t nrow, int ncol, int row_major);
+int lga_dataset_from_reference(LgaDataset ref, int64_t nrow, LgaDataset* out);
 int lga_dataset_subset(LgaDataset ds, const int32_t* idx, int64_t n, LgaDataset* out);
 int lga_dataset_set_field(LgaDataset ds, const char* name, const void* data, int64_t n, int dtype);
 int lga_dataset_get_field(LgaDataset ds, const char* name, double* out, int64_t cap, int64_t* n);

@@ -100,6 +100,15 @@ int lga_hip_dataset_upload_raw(LgaDataset h, const void* data, int dtype, int64_
   });
 }
 
+// Bins a raw row-major DEVICE matrix into a dataset that only holds bin mappers so far.
+int lga_hip_dataset_bin_device(LgaDataset h, const void* dev_data, int dtype, int64_t nrow, int ncol) {
+  return hguard([&] {
+    Dataset* ds = ((DatasetBox*)h)->ds.get();
+    if (ncol != ds->num_total_features()) throw std::runtime_error("column count differs from the dataset's");
+    bin_device_matrix(ds, dev_data, dtype, nrow, ncol);
+  });
+}
+
 int lga_hip_predict(LgaBooster b, const void* data, int on_device, int dtype, int64_t nrow, int ncol, int start_iter,
                     int num_iter, int type, double* out, int out_on_device) {
   return hguard([&] {

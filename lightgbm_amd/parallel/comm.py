@@ -1,0 +1,167 @@
+"""Communicators for the distributed tree learners.
+
+* :class:`RcclComm` - the production path: one process per GPU, RCCL over xGMI.
+  The native core binds librccl itself and enqueues every collective on the
+  learner's HIP stream; ``torch.distributed`` is only used once, to hand
+  rank 0's RCCL unique id to the other ranks.
+* :class:`TorchComm` - collectives through ``torch.distributed`` on host buffers
+  (``gloo``): used by the CPU engine and by the multi-process CPU tests.
+* :class:`ThreadComm` - an in-process loop-back communicator: P learners run in
+  P threads of one process and reduce through shared host buffers.  It tests
+  the sharding logic without any process group.
+
+Payloads per growth round (data-parallel): ONE integer all-reduce of the
+round's new histogram slots (counts and gradient totals ride in each slot's
+header), i.e. about tree-depth collectives per tree instead of one per leaf.
+Integer sums make the result independent of rank order and bit-identical to
+serial training.  Feature-parallel exchanges only the per-leaf winners.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from typing import List, Optional
+
+import numpy as np
+
+from .. import _lib
+
+_DT = {0: np.int64, 1: np.float64, 2: np.float32}
+
+
+class _CallbackComm:
+    """Base: wraps Python collectives into the native callback communicator."""
+
+    def __init__(self, rank: int, size: int):
+        lib, _ = _lib.load()
+        self.rank, self.size = rank, size
+        self._ar = _lib.ALLREDUCE_FN(self._allreduce)
+        self._ag = _lib.ALLGATHER_FN(self._allgather)
+        h = ctypes.c_void_p()
+        _lib.check(lib.lga_comm_create_callback(rank, size, self._ar, self._ag, ctypes.byref(h)))
+        self.handle = h
+
+    # buffers arrive as raw pointers
+    def _allreduce(self, buf, n, dtype, op):
+        arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_byte)), shape=(n * np.dtype(_DT[dtype]).itemsize,))
+        view = arr.view(_DT[dtype])
+        self.allreduce(view, "max" if op == 1 else "sum")
+
+    def _allgather(self, inp, out, nbytes):
+        a = np.ctypeslib.as_array(ctypes.cast(inp, ctypes.POINTER(ctypes.c_ubyte)), shape=(nbytes,))
+        o = np.ctypeslib.as_array(ctypes.cast(out, ctypes.POINTER(ctypes.c_ubyte)), shape=(nbytes * self.size,))
+        self.allgather(a, o)
+
+    def allreduce(self, view: np.ndarray, op: str):
+        raise NotImplementedError
+
+    def allgather(self, a: np.ndarray, out: np.ndarray):
+        raise NotImplementedError
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib, _ = _lib.load()
+            lib.lga_comm_free(self.handle)
+            self.handle = None
+
+
+class TorchComm(_CallbackComm):
+    """Host-buffer collectives through a ``torch.distributed`` process group (gloo)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self._group = group
+        super().__init__(dist.get_rank(group), dist.get_world_size(group))
+
+    def allreduce(self, view, op):
+        import torch
+        t = torch.from_numpy(view)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM,
+                              group=self._group)
+
+    def allgather(self, a, out):
+        import torch
+        outs = [torch.empty(len(a), dtype=torch.uint8) for _ in range(self.size)]
+        self._dist.all_gather(outs, torch.from_numpy(a.copy()), group=self._group)
+        out[:] = torch.cat(outs).numpy()
+
+
+class _ThreadHub:
+    def __init__(self, size: int):
+        self.size = size
+        self.barrier = threading.Barrier(size)
+        self.slots: List[Optional[np.ndarray]] = [None] * size
+
+
+class ThreadComm(_CallbackComm):
+    """Loop-back communicator: create one hub, then one ThreadComm per rank (each used from its own thread)."""
+
+    @staticmethod
+    def make_group(size: int) -> List["ThreadComm"]:
+        hub = _ThreadHub(size)
+        return [ThreadComm(hub, r) for r in range(size)]
+
+    def __init__(self, hub: _ThreadHub, rank: int):
+        self._hub = hub
+        super().__init__(rank, hub.size)
+
+    def allreduce(self, view, op):
+        hub = self._hub
+        hub.slots[self.rank] = view.copy()
+        hub.barrier.wait()
+        acc = hub.slots[0].copy()
+        for r in range(1, hub.size):       # fixed rank order
+            acc = np.maximum(acc, hub.slots[r]) if op == "max" else acc + hub.slots[r]
+        hub.barrier.wait()
+        view[:] = acc
+
+    def allgather(self, a, out):
+        hub = self._hub
+        hub.slots[self.rank] = a.copy()
+        hub.barrier.wait()
+        out[:] = np.concatenate([hub.slots[r] for r in range(hub.size)])
+        hub.barrier.wait()
+
+
+class RcclComm:
+    """RCCL communicator owned by the native core (HIP build only)."""
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        lib, hip = _lib.load()
+        if not hip:
+            raise _lib.LightGBMError("RcclComm needs the HIP build and a visible GPU")
+        self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
+        uid = np.zeros(128, dtype=np.uint8)
+        if self.rank == 0:
+            n = ctypes.c_int()
+            _lib.check(lib.lga_hip_rccl_unique_id(uid.ctypes.data_as(ctypes.c_void_p), 128, ctypes.byref(n)))
+        # hand rank 0's id to everyone (works on any backend: the tensor lives where the backend needs it)
+        backend = dist.get_backend(group)
+        t = torch.from_numpy(uid)
+        if backend == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = t.cpu().numpy()
+        from .. import _device
+        _device.sync_stream(lib)
+        h = ctypes.c_void_p()
+        _lib.check(lib.lga_hip_comm_create_rccl(self.rank, self.size, uid.ctypes.data_as(ctypes.c_void_p), 128,
+                                                ctypes.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib, _ = _lib.load()
+            lib.lga_comm_free(self.handle)
+            self.handle = None
+
+
+def default_comm(group=None):
+    """RCCL when training on GPUs, torch.distributed host collectives otherwise; None when not distributed."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return None
+    return RcclComm(group) if _lib.is_hip() else TorchComm(group)
