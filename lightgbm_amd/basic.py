@@ -671,7 +671,7 @@ class Booster:
         out, n = ctypes.c_char_p(), ctypes.c_int64()
         check(lib.lga_booster_dump_json(self._handle, start_iteration, num_iteration or -1, ctypes.byref(out),
                                         ctypes.byref(n)))
-        return json.loads(ctypes.string_at(out, n.value).decode().replace("inf", "1e308"))
+        return json.loads(ctypes.string_at(out, n.value).decode())
 
     def feature_importance(self, importance_type: str = "split", iteration: Optional[int] = None) -> np.ndarray:
         lib, _ = _lib.load()

@@ -159,8 +159,11 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     double rv = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
     // exact child counts come from the children's own scans
     int64_t lc = nodes[(size_t)n.left].best.total_cnt, rc = nodes[(size_t)n.right].best.total_cnt;
+    // "every value left, only missing right" has an infinite bin bound: keep the model text finite
+    double real_thr = bm.bin_to_threshold(s.threshold);
+    if (std::isinf(real_thr)) real_thr = 1e300;
     int right_leaf = tree.split(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
-                                bm.bin_to_threshold(s.threshold), s.default_left != 0, (int)bm.missing, s.gain, lv, rv,
+                                real_thr, s.default_left != 0, (int)bm.missing, s.gain, lv, rv,
                                 lc, rc, lh, rh);
     leaf_of_node[(size_t)n.left] = leaf;
     leaf_of_node[(size_t)n.right] = right_leaf;

@@ -86,7 +86,9 @@ class HostBackend : public TreeBackend {
     if (B == 0) return;
     double t0 = now_s();
     // 1. partition
-#pragma omp parallel for schedule(dynamic) if (B > 1)
+    int64_t batch_rows = 0;
+    for (size_t i = 0; i < B; ++i) batch_rows += ranges_[(size_t)tasks[i].parent_node].count;
+#pragma omp parallel for schedule(dynamic) if (B > 1 && batch_rows > 200000)
     for (size_t i = 0; i < B; ++i) partition(tasks[i]);
     double t1 = now_s();
     // 2. histograms of the chosen children (fresh, contiguous slots)
@@ -154,7 +156,7 @@ class HostBackend : public TreeBackend {
     int64_t* gp = base;
     int64_t* hp = base + plane_;
     const uint8_t* fm = root_->bins_fm();
-#pragma omp parallel for schedule(dynamic) if (n * (int64_t)F_ > 100000)
+#pragma omp parallel for schedule(dynamic) if (n * (int64_t)F_ > 400000)
     for (int f = 0; f < F_; ++f) {
       if (!owns_feature(f)) continue;
       const uint8_t* col = fm + (size_t)f * (size_t)N_;
@@ -215,7 +217,7 @@ class HostBackend : public TreeBackend {
     const double ninf = -std::numeric_limits<double>::infinity();
     const uint64_t worst_key = ~0ull;
     std::vector<Cand> local((size_t)n);
-#pragma omp parallel for schedule(dynamic) if (n * F_ > 64)
+#pragma omp parallel for schedule(dynamic) if (n * F_ >= 512)
     for (int i = 0; i < n; ++i) {
       const ScanTask& s = st[i];
       int64_t* self = slot(s.slot);

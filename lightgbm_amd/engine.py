@@ -160,6 +160,7 @@ class CVBooster:
     def __init__(self):
         self.boosters: List[Booster] = []
         self.best_iteration = -1
+        self.iterations_run = 0
 
     def append(self, booster: Booster):
         self.boosters.append(booster)
@@ -298,6 +299,7 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
         for c in cb_before:
             c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
         finished = [b.update(fobj=fobj) for b in cvbooster.boosters]
+        cvbooster.iterations_run = i + 1
         raw = []
         for b in cvbooster.boosters:
             one = []

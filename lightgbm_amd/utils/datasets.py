@@ -87,8 +87,9 @@ def make_diamonds_like(n: int = 53940, seed: int = 0) -> Tuple[np.ndarray, np.nd
     color_eff = np.array([0.0, -0.05, -0.09, -0.16, -0.25, -0.37, -0.51])[color.astype(int) - 1]
     clar_eff = np.array([0.0, 0.42, 0.59, 0.74, 0.81, 0.94, 1.02, 1.11])[clarity.astype(int) - 1]
     cut_eff = np.array([0.0, 0.08, 0.12, 0.14, 0.16])[cut.astype(int) - 1]
-    y = (8.45 + 1.88 * log_carat + color_eff + clar_eff + cut_eff - 0.05 * np.maximum(log_carat, 0) ** 2
-         - 0.002 * (depth - 61.75) ** 2 + 0.03 * clar_eff * log_carat + rng.normal(0, 0.095, n))
+    y = (8.45 + 1.88 * log_carat + color_eff + clar_eff + cut_eff - 0.16 * log_carat ** 2
+         - 0.004 * (depth - 61.75) ** 2 - 0.10 * clar_eff * log_carat + 0.35 * color_eff * clar_eff
+         + 0.08 * np.tanh(4.0 * (log_carat + 0.35)) + rng.normal(0, 0.092, n))
     X = np.column_stack([log_carat, cut, color, clarity, depth, table])
     return X, y
 

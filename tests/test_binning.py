@@ -1,0 +1,75 @@
+"""Bin construction and value->bin mapping."""
+import numpy as np
+
+import lightgbm_amd as lgb
+
+
+def _ds(X, **params):
+    d = lgb.Dataset(X, label=np.zeros(len(X)), params={"device_type": "cpu", **params})
+    d.construct()
+    return d
+
+
+def test_distinct_values_get_one_bin_each():
+    rng = np.random.RandomState(0)
+    col = rng.choice([1.0, 2.0, 3.0, 4.0, 5.0], size=1000)     # an ordinal like `cut`
+    d = _ds(np.column_stack([col, rng.randn(1000)]), min_data_in_bin=1)
+    info = d.bin_info(0)
+    assert info["num_bin"] == 5 and info["missing_bin"] == -1
+    np.testing.assert_allclose(info["upper_bounds"][:4], [1.5, 2.5, 3.5, 4.5])
+    assert np.isinf(info["upper_bounds"][-1])
+    bins = d.get_bins()
+    np.testing.assert_array_equal(bins[0], (col - 1).astype(np.uint8))
+
+
+def test_equal_frequency_bins_and_max_bin():
+    rng = np.random.RandomState(1)
+    x = rng.randn(20000)
+    d = _ds(x.reshape(-1, 1), max_bin=63)
+    info = d.bin_info(0)
+    assert 50 <= info["num_bin"] <= 63
+    counts = np.bincount(d.get_bins()[0], minlength=info["num_bin"])
+    assert counts.min() > 0 and counts.max() < 3 * counts.mean()
+    ub = info["upper_bounds"]
+    assert np.all(np.diff(ub[:-1]) > 0)
+    # first i with x <= upper[i]
+    expect = np.searchsorted(ub, x, side="left")
+    np.testing.assert_array_equal(d.get_bins()[0], expect.astype(np.uint8))
+
+
+def test_nan_gets_its_own_last_bin_and_constant_feature_is_dropped():
+    rng = np.random.RandomState(2)
+    x = rng.randn(3000)
+    x[::7] = np.nan
+    X = np.column_stack([x, np.full(3000, 3.0), rng.randn(3000)])
+    d = _ds(X)
+    info = d.bin_info(0)
+    assert info["missing_bin"] == info["num_bin"] - 1
+    bins = d.get_bins()
+    assert bins.shape[0] == 2                     # the constant column is not a used feature
+    assert np.all(bins[0][::7] == info["missing_bin"])
+    assert d.bin_info(1)["num_bin"] == 1
+
+
+def test_reference_shares_boundaries_and_subset_shares_bins():
+    rng = np.random.RandomState(3)
+    X = rng.randn(5000, 4)
+    y = X[:, 0]
+    d = lgb.Dataset(X, label=y, params={"device_type": "cpu"})
+    v = d.create_valid(X[:1000] * 2.0, label=y[:1000])
+    v.construct()
+    for f in range(4):
+        np.testing.assert_array_equal(d.bin_info(f)["upper_bounds"], v.bin_info(f)["upper_bounds"])
+    idx = np.arange(0, 5000, 3)
+    s = d.subset(idx)
+    assert s.num_data() == len(idx) and s.num_feature() == 4
+    np.testing.assert_allclose(s.get_label(), y[idx], rtol=1e-6)
+
+
+def test_bin_sample_controls_boundaries():
+    rng = np.random.RandomState(4)
+    X = rng.randn(4000, 3)
+    a = lgb.Dataset(X[:2000], label=np.zeros(2000), bin_sample=X, params={"device_type": "cpu"}).construct()
+    b = lgb.Dataset(X[2000:], label=np.zeros(2000), bin_sample=X, params={"device_type": "cpu"}).construct()
+    for f in range(3):
+        np.testing.assert_array_equal(a.bin_info(f)["upper_bounds"], b.bin_info(f)["upper_bounds"])

@@ -1,0 +1,64 @@
+"""Parameter registry: aliases, defaults, validation, merging (SURVEY 4B unit tier)."""
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+from lightgbm_amd.basic import get_param, params_to_string, pop_param, resolve_alias
+
+
+def test_aliases_used_by_the_reference():
+    # r/gridsearchCV.R passes nthread, nrounds (as arg), eval; xgboost-style names appear in the notebook
+    assert resolve_alias("nthread") == "num_threads"
+    assert resolve_alias("nrounds") == "num_iterations"
+    assert resolve_alias("eta") == "learning_rate"
+    assert resolve_alias("subsample") == "bagging_fraction"
+    assert resolve_alias("colsample_bytree") == "feature_fraction"
+    assert resolve_alias("max_leaf_nodes") == "num_leaves"
+    assert resolve_alias("random_state") == "seed"
+    assert resolve_alias("early_stopping_rounds") == "early_stopping_round"
+    assert resolve_alias("no_such_param") is None
+
+
+def test_params_to_string_and_pop():
+    s = params_to_string({"learning_rate": 0.05, "metric": ["l2", "rmse"], "use_missing": False, "skip": None})
+    assert "learning_rate=0.05" in s and "metric=l2,rmse" in s and "use_missing=false" in s and "skip" not in s
+    p = {"eta": 0.3, "learning_rate": 0.1, "nrounds": 7}
+    assert pop_param(p, "learning_rate") == 0.1 and "eta" not in p and "learning_rate" not in p
+    assert get_param({"n_estimators": 12}, "num_iterations") == 12
+
+
+def test_unknown_parameter_warns_not_fails():
+    X = np.random.RandomState(0).randn(200, 3)
+    y = X[:, 0]
+    with pytest.warns(UserWarning, match="Unknown parameter"):
+        lgb.train({"verbose": -1, "definitely_unknown": 3, "min_data_in_leaf": 5}, lgb.Dataset(X, label=y), 2)
+
+
+def test_validation_errors():
+    X = np.random.RandomState(0).randn(200, 3)
+    y = X[:, 0]
+    with pytest.raises(lgb.LightGBMError, match="rf"):
+        lgb.train({"boosting": "rf", "verbose": -1}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="out of range"):
+        lgb.train({"bagging_fraction": 1.5, "verbose": -1}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="objective"):
+        lgb.train({"objective": "nonsense", "verbose": -1}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="integer"):
+        lgb.train({"num_leaves": 7.5, "verbose": -1}, lgb.Dataset(X, label=y), 2)
+
+
+def test_grid_row_of_doubles_is_accepted():
+    # as.list(paramGrid[i, -(1:2)]) yields doubles for every column (num_leaves = 31.0, nthread = 4.0)
+    X = np.random.RandomState(0).randn(300, 3)
+    y = X[:, 0]
+    b = lgb.train({"num_leaves": 7.0, "min_data_in_leaf": 5.0, "bagging_freq": 4.0, "nthread": 4.0, "verbose": -1},
+                  lgb.Dataset(X, label=y), 3)
+    assert b.num_trees() == 3
+
+
+def test_parameters_block_in_model():
+    X = np.random.RandomState(0).randn(300, 3)
+    y = X[:, 0]
+    b = lgb.train({"learning_rate": 0.07, "num_leaves": 5, "verbose": -1, "min_data_in_leaf": 5}, lgb.Dataset(X, label=y), 2)
+    s = b.model_to_string()
+    assert "[learning_rate: 0.07" in s and "[num_leaves: 5]" in s and "[boosting: gbdt]" in s

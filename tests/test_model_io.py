@@ -1,0 +1,127 @@
+"""LightGBM text model format: writer / parser round trip, golden string, decision rule."""
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+
+GOLDEN = """tree
+version=v3
+num_class=1
+num_tree_per_iteration=1
+label_index=0
+max_feature_idx=1
+objective=regression
+feature_names=Column_0 Column_1
+feature_infos=[-1:1] [0:3]
+tree_sizes=300 120
+
+Tree=0
+num_leaves=3
+num_cat=0
+split_feature=0 1
+split_gain=10 5
+threshold=0.5 1.5
+decision_type=2 8
+left_child=1 -1
+right_child=-2 -3
+leaf_value=1 2 3
+leaf_weight=10 20 30
+leaf_count=10 20 30
+internal_value=0 0
+internal_weight=0 0
+internal_count=60 30
+shrinkage=0.1
+
+
+Tree=1
+num_leaves=1
+num_cat=0
+leaf_value=0.25
+shrinkage=1
+
+
+end of trees
+
+feature_importances:
+Column_0=1
+Column_1=1
+
+parameters:
+[boosting: gbdt]
+[objective: regression]
+end of parameters
+
+pandas_categorical:null
+"""
+
+
+def test_golden_model_parses_and_predicts_by_upstream_rules():
+    b = lgb.Booster(model_str=GOLDEN)
+    assert b.num_trees() == 2 and b.num_feature() == 2
+    # node0: x0 <= 0.5 -> node1 else leaf1(=2.0); node1: x1 <= 1.5 -> leaf0(=1.0) else leaf2(=3.0); NaN in x1 (missing NaN, default right)
+    X = np.array([[0.0, 1.0], [0.0, 2.0], [1.0, 0.0], [0.5, 1.5], [0.0, np.nan], [np.nan, 0.0]])
+    #                leaf0      leaf2       leaf1       leaf0       NaN->right=leaf2   NaN (missing none) -> 0.0 <= .5 -> node1 -> leaf0
+    np.testing.assert_allclose(b.predict(X), np.array([1, 3, 2, 1, 3, 1]) + 0.25)
+    np.testing.assert_allclose(b.predict(X, num_iteration=1), [1, 3, 2, 1, 3, 1])
+    leaves = b.predict(X, pred_leaf=True)
+    np.testing.assert_array_equal(leaves[:, 0], [0, 2, 1, 0, 2, 0])
+
+
+def test_round_trip_is_exact():
+    rng = np.random.RandomState(0)
+    X = rng.randn(3000, 5)
+    X[::11, 2] = np.nan
+    y = X[:, 0] + np.where(np.isnan(X[:, 2]), 1.0, X[:, 2]) ** 2 + 0.1 * rng.randn(3000)
+    b = lgb.train({"verbose": -1, "num_leaves": 15, "learning_rate": 0.1}, lgb.Dataset(X, label=y), 20)
+    s = b.model_to_string()
+    b2 = lgb.Booster(model_str=s)
+    assert b2.model_to_string() == s
+    np.testing.assert_array_equal(b.predict(X), b2.predict(X))
+    # tree_sizes are byte counts of the blocks
+    sizes = [int(t) for t in s.split("tree_sizes=")[1].split("\n")[0].split()]
+    body = s[s.index("Tree=0"):s.index("end of trees")]
+    assert sum(sizes) == len(body)
+    assert "end of parameters" in s and "feature_importances:" in s
+
+
+def test_save_and_load_file(tmp_path):
+    rng = np.random.RandomState(1)
+    X = rng.randn(1000, 3)
+    y = (X[:, 0] + X[:, 1] > 0).astype(float)
+    b = lgb.train({"objective": "binary", "verbose": -1, "num_leaves": 7}, lgb.Dataset(X, label=y), 10)
+    path = str(tmp_path / "model.txt")
+    b.save_model(path)
+    b2 = lgb.Booster(model_file=path)
+    assert "binary sigmoid:1" in open(path).read()
+    p = b2.predict(X)
+    assert p.min() >= 0 and p.max() <= 1
+    np.testing.assert_array_equal(p, b.predict(X))
+    raw = b2.predict(X, raw_score=True)
+    np.testing.assert_allclose(1 / (1 + np.exp(-raw)), p)
+
+
+def test_parser_rejects_broken_models():
+    with pytest.raises(lgb.LightGBMError):
+        lgb.Booster(model_str="this is not a model")
+    bad = GOLDEN.replace("left_child=1 -1", "left_child=1 -7")
+    with pytest.raises(lgb.LightGBMError, match="out of range"):
+        lgb.Booster(model_str=bad)
+    bad = GOLDEN.replace("tree_sizes=300 120", "tree_sizes=300 120 99")
+    with pytest.raises(lgb.LightGBMError, match="tree_sizes"):
+        lgb.Booster(model_str=bad)
+    # missing tree_sizes is tolerated (sequential scan)
+    ok = GOLDEN.replace("tree_sizes=300 120\n", "")
+    assert lgb.Booster(model_str=ok).num_trees() == 2
+
+
+def test_feature_importance_and_dump():
+    rng = np.random.RandomState(2)
+    X = rng.randn(2000, 4)
+    y = 3 * X[:, 1] + 0.01 * rng.randn(2000)
+    b = lgb.train({"verbose": -1, "num_leaves": 7}, lgb.Dataset(X, label=y), 5)
+    imp = b.feature_importance()
+    assert imp.argmax() == 1 and imp.sum() == 5 * 6
+    gain = b.feature_importance("gain")
+    assert gain.argmax() == 1
+    d = b.dump_model()
+    assert len(d["tree_info"]) == 5 and d["tree_info"][0]["num_leaves"] == 7

@@ -1,0 +1,208 @@
+"""End-to-end training on the CPU engine: quality, determinism, growth-order exactness, objectives, callbacks."""
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+from lightgbm_amd.utils.datasets import make_diamonds_like, make_regression
+
+CPU = {"device_type": "cpu", "verbose": -1}
+
+
+def rmse(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a) - np.asarray(b)) ** 2)))
+
+
+def trees_of(b):
+    s = b.model_to_string()
+    return s[s.index("Tree=0"):s.index("end of trees")]
+
+
+def test_regression_quality_matches_sklearn_histgb():
+    # SURVEY 7.2 step 1 exit criterion: diamonds-like regression within 2 % of sklearn's histogram GBDT
+    from sklearn.ensemble import HistGradientBoostingRegressor
+    X, y = make_diamonds_like(20000, seed=3)
+    tr, te = slice(0, 16000), slice(16000, None)
+    b = lgb.train({**CPU, "learning_rate": 0.1, "objective": "regression"}, lgb.Dataset(X[tr], label=y[tr]), 200)
+    ours = rmse(b.predict(X[te]), y[te])
+    sk = HistGradientBoostingRegressor(max_iter=200, learning_rate=0.1, max_leaf_nodes=31, min_samples_leaf=20,
+                                       early_stopping=False).fit(X[tr], y[tr])
+    theirs = rmse(sk.predict(X[te]), y[te])
+    lin = np.linalg.lstsq(np.c_[X[tr], np.ones(16000)], y[tr], rcond=None)[0]
+    linear = rmse(np.c_[X[te], np.ones(len(y[te]))] @ lin, y[te])
+    assert ours < 1.02 * theirs
+    assert ours < 0.8 * linear       # boosting beats the linear model (R:46 vs R:64)
+
+
+def test_binary_quality_matches_sklearn_histgb():
+    from sklearn.ensemble import HistGradientBoostingClassifier
+    from sklearn.metrics import roc_auc_score
+    from lightgbm_amd.utils.datasets import make_higgs_like
+    X, y = make_higgs_like(30000, seed=5, device="numpy")
+    tr, te = slice(0, 24000), slice(24000, None)
+    ev = {}
+    d = lgb.Dataset(X[tr], label=y[tr])
+    v = d.create_valid(X[te], label=y[te])
+    b = lgb.train({**CPU, "objective": "binary", "metric": ["auc", "binary_logloss"], "num_leaves": 31}, d, 100,
+                  valid_sets=[v], evals_result=ev)
+    p = b.predict(X[te])
+    ours = roc_auc_score(y[te], p)
+    assert abs(ev["valid_0"]["auc"][-1] - ours) < 1e-9          # our AUC metric == sklearn's on the same scores
+    sk = HistGradientBoostingClassifier(max_iter=100, learning_rate=0.1, max_leaf_nodes=31, min_samples_leaf=20,
+                                        early_stopping=False).fit(X[tr], y[tr])
+    theirs = roc_auc_score(y[te], sk.predict_proba(X[te])[:, 1])
+    assert ours > theirs - 0.005
+    ll = -np.mean(y[te] * np.log(p) + (1 - y[te]) * np.log(1 - p))
+    assert abs(ev["valid_0"]["binary_logloss"][-1] - ll) < 1e-9
+
+
+def test_training_is_deterministic_and_thread_count_independent():
+    X, y = make_regression(5000, 10, seed=1)
+    a = lgb.train({**CPU, "num_threads": 1}, lgb.Dataset(X, label=y), 15)
+    b = lgb.train({**CPU, "num_threads": 4}, lgb.Dataset(X, label=y), 15)
+    assert trees_of(a) == trees_of(b)
+
+
+@pytest.mark.parametrize("leaves,extra", [(31, {}), (63, {"min_data_in_leaf": 5}), (15, {"max_depth": 4}),
+                                          (127, {"lambda_l2": 1.0, "min_gain_to_split": 0.01})])
+def test_batched_growth_equals_strict_best_first(leaves, extra):
+    # max_batch_leaves=1 splits one leaf per round = textbook best-first; the default batches every
+    # frontier leaf that can still be reached.  Both must give the same trees.
+    X, y = make_regression(6000, 8, seed=2)
+    p = {**CPU, "num_leaves": leaves, **extra}
+    strict = lgb.train({**p, "max_batch_leaves": 1}, lgb.Dataset(X, label=y), 8, keep_training_booster=True)
+    batched = lgb.train(p, lgb.Dataset(X, label=y), 8, keep_training_booster=True)
+    assert trees_of(strict) == trees_of(batched)
+    assert batched.grow_stats()["rounds"] < strict.grow_stats()["rounds"]
+    assert batched.grow_stats()["used_splits"] == strict.grow_stats()["used_splits"]
+
+
+def test_num_leaves_and_min_data_constraints_hold():
+    X, y = make_regression(4000, 6, seed=4)
+    b = lgb.train({**CPU, "num_leaves": 20, "min_data_in_leaf": 100}, lgb.Dataset(X, label=y), 5)
+    for t in b.dump_model()["tree_info"]:
+        assert t["num_leaves"] <= 20
+        counts = []
+
+        def walk(n):
+            if "leaf_index" in n:
+                counts.append(n["leaf_count"])
+            else:
+                walk(n["left_child"]); walk(n["right_child"])
+        walk(t["tree_structure"])
+        assert min(counts) >= 100 and sum(counts) == 4000
+
+
+def test_leaf_values_are_newton_steps():
+    # one tree, lr 1, L2: each leaf value = mean residual of its rows (+ init score)
+    X, y = make_regression(3000, 5, seed=6)
+    b = lgb.train({**CPU, "num_leaves": 8, "learning_rate": 1.0, "min_data_in_leaf": 50}, lgb.Dataset(X, label=y), 1)
+    leaf = b.predict(X, pred_leaf=True)[:, 0]
+    pred = b.predict(X)
+    for l in np.unique(leaf):
+        m = leaf == l
+        assert abs(pred[m][0] - y[m].mean()) < 2e-3 * max(1.0, abs(y[m].mean()))   # 16-bit gradient quantisation
+
+
+def test_weights_and_init_score():
+    X, y = make_regression(3000, 5, seed=7)
+    w = np.where(X[:, 0] > 0, 2.0, 0.5)
+    b = lgb.train({**CPU, "num_leaves": 8}, lgb.Dataset(X, label=y, weight=w), 5)
+    b0 = lgb.train({**CPU, "num_leaves": 8}, lgb.Dataset(X, label=y), 5)
+    assert trees_of(b) != trees_of(b0)
+    # init_score: training on residuals of a constant offset gives the same trees as boost_from_average off
+    d = lgb.Dataset(X, label=y, init_score=np.full(len(y), 3.0))
+    bi = lgb.train({**CPU, "num_leaves": 8}, d, 3)
+    br = lgb.train({**CPU, "num_leaves": 8, "boost_from_average": False}, lgb.Dataset(X, label=y - 3.0), 3)
+    np.testing.assert_allclose(bi.predict(X), br.predict(X), atol=1e-5)   # labels are stored as float32
+
+
+def test_early_stopping_and_best_iteration():
+    X, y = make_regression(4000, 8, seed=8, noise=1.0)
+    d = lgb.Dataset(X[:3000], label=y[:3000])
+    v = d.create_valid(X[3000:], label=y[3000:])
+    ev = {}
+    b = lgb.train({**CPU, "learning_rate": 0.3, "metric": "rmse"}, d, 500, valid_sets=[v], early_stopping_rounds=5,
+                  evals_result=ev)
+    hist = ev["valid_0"]["rmse"]
+    assert 0 < b.best_iteration < 500
+    assert b.best_iteration == int(np.argmin(hist)) + 1
+    assert len(hist) == b.best_iteration + 5
+    np.testing.assert_allclose(b.best_score["valid_0"]["rmse"], min(hist))
+    # predict uses best_iteration by default
+    np.testing.assert_array_equal(b.predict(X[3000:]), b.predict(X[3000:], num_iteration=b.best_iteration))
+
+
+def test_staged_prediction_and_rollback():
+    X, y = make_regression(2000, 5, seed=9)
+    b = lgb.train(CPU, lgb.Dataset(X, label=y), 20, keep_training_booster=True)
+    p10 = b.predict(X, num_iteration=10)
+    p20 = b.predict(X)
+    assert rmse(p20, y) < rmse(p10, y) < rmse(b.predict(X, num_iteration=1), y)   # NBB:136 staged prediction
+    np.testing.assert_allclose(b.predict(X, start_iteration=10, num_iteration=10, raw_score=True) + p10, p20, atol=1e-9)
+    before = b._inner_predict(-1, raw=True)
+    np.testing.assert_allclose(before, p20, atol=1e-9)
+    b.rollback_one_iter()
+    assert b.num_trees() == 19
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X), atol=1e-9)
+
+
+def test_custom_objective_and_metric():
+    X, y = make_regression(3000, 6, seed=10)
+
+    def l2(preds, data):
+        return preds - data.get_label(), np.ones_like(preds)
+
+    def mae(preds, data):
+        return "mae", float(np.mean(np.abs(preds - data.get_label()))), False
+    d = lgb.Dataset(X, label=y)
+    ev = {}
+    b = lgb.train({**CPU, "boost_from_average": False}, d, 10, fobj=l2, feval=mae, valid_sets=[d], evals_result=ev)
+    ref = lgb.train({**CPU, "boost_from_average": False}, lgb.Dataset(X, label=y), 10)
+    np.testing.assert_allclose(b.predict(X), ref.predict(X), atol=1e-9)
+    assert "mae" in ev["training"] and ev["training"]["mae"][-1] < ev["training"]["mae"][0]
+
+
+def test_continue_training_from_init_model(tmp_path):
+    X, y = make_regression(3000, 6, seed=11)
+    d = lgb.Dataset(X, label=y, free_raw_data=False)
+    b1 = lgb.train(CPU, d, 10)
+    path = str(tmp_path / "m.txt")
+    b1.save_model(path)
+    b2 = lgb.train(CPU, lgb.Dataset(X, label=y, free_raw_data=False), 10, init_model=path)
+    assert b2.num_trees() == 20
+    assert rmse(b2.predict(X), y) < rmse(b1.predict(X), y)
+    full = lgb.train(CPU, lgb.Dataset(X, label=y), 20)
+    assert abs(rmse(b2.predict(X), y) - rmse(full.predict(X), y)) < 0.05 * rmse(full.predict(X), y)
+
+
+def test_other_objectives_train():
+    rng = np.random.RandomState(12)
+    X = rng.randn(3000, 5)
+    y = np.exp(0.5 * X[:, 0]) + 0.1 * rng.rand(3000)
+    for obj in ("regression_l1", "huber", "fair", "poisson"):
+        b = lgb.train({**CPU, "objective": obj, "num_leaves": 15}, lgb.Dataset(X, label=y), 30)
+        assert np.corrcoef(b.predict(X), y)[0, 1] > 0.8, obj
+    yb = (X[:, 0] + X[:, 1] > 0).astype(float)
+    b = lgb.train({**CPU, "objective": "cross_entropy", "num_leaves": 15}, lgb.Dataset(X, label=yb), 30)
+    assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
+
+
+def test_feature_fraction_and_bagging_change_trees_but_stay_deterministic():
+    X, y = make_regression(4000, 10, seed=13)
+    p = {**CPU, "feature_fraction": 0.6, "bagging_fraction": 0.7, "bagging_freq": 2}
+    a = lgb.train(p, lgb.Dataset(X, label=y), 10)
+    b = lgb.train(p, lgb.Dataset(X, label=y), 10)
+    c = lgb.train({**p, "bagging_seed": 11}, lgb.Dataset(X, label=y), 10)
+    plain = lgb.train(CPU, lgb.Dataset(X, label=y), 10)
+    assert trees_of(a) == trees_of(b) != trees_of(c)
+    assert trees_of(a) != trees_of(plain)
+    assert rmse(a.predict(X), y) < 1.6 * rmse(plain.predict(X), y)
+
+
+def test_pandas_and_names():
+    import pandas as pd
+    X, y = make_regression(1000, 4, seed=14)
+    df = pd.DataFrame(X, columns=["a", "b", "c d", "e"])
+    b = lgb.train({**CPU, "num_leaves": 7}, lgb.Dataset(df, label=pd.Series(y)), 3)
+    assert "feature_names=a b c_d e" in b.model_to_string()
+    np.testing.assert_array_equal(b.predict(df), b.predict(X))
