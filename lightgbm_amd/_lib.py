@@ -99,6 +99,7 @@ def _declare(lib, hip: bool):
             "lga_hip_predict": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int]),
             "lga_hip_rccl_unique_id": (c_int, [c_void_p, c_int, P(c_int)]),
             "lga_hip_comm_create_rccl": (c_int, [c_int, c_int, c_void_p, c_int, P(c_void_p)]),
+            "lga_hip_comm_create_loopback_group": (c_int, [c_int, P(c_void_p)]),
             "lga_hip_op": (c_int, [c_char_p, P(c_void_p), c_int, P(c_int64), c_int]),
         })
     for name, (res, args) in sig.items():

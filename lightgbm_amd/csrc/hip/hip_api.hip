@@ -8,6 +8,7 @@
 #include "rccl_comm.hpp"
 #include <cstring>
 #include <string>
+#include <vector>
 
 using namespace lga;
 
@@ -120,6 +121,14 @@ int lga_hip_predict(LgaBooster b, const void* data, int on_device, int dtype, in
 int lga_hip_rccl_unique_id(void* out, int cap, int* len) { return hguard([&] { rccl_unique_id(out, cap, len); }); }
 int lga_hip_comm_create_rccl(int rank, int size, const void* unique_id, int id_len, LgaComm* out) {
   return hguard([&] { *out = make_rccl_comm(rank, size, unique_id, id_len); });
+}
+
+int lga_hip_comm_create_loopback_group(int size, LgaComm* out) {
+  return hguard([&] {
+    std::vector<Comm*> v((size_t)size);
+    make_loopback_group(size, v.data());
+    for (int r = 0; r < size; ++r) out[r] = v[(size_t)r];
+  });
 }
 
 int lga_hip_op(const char* name, void** ptrs, int nptr, const int64_t* ints, int nint) {

@@ -1,0 +1,158 @@
+"""Single-kernel entry points (HIP build): run ONE training kernel on torch CUDA tensors.
+
+The training loop never goes through these - it drives the kernels from C++ -
+they exist so that every hot kernel can be checked against a plain NumPy /
+PyTorch reference in isolation:
+
+* :func:`hist_build`      - gradient histogram of a row list (LDS packed 64-bit atomics)
+* :func:`partition_rows`  - stable split of a row list by ``bin <= threshold``
+* :func:`split_scan`      - best split of one leaf histogram (wave prefix scan + fp64 gain)
+* :func:`pack_gradients`  - the (g, h) -> packed int64 quantisation used by the histograms
+
+Without a GPU every function raises ``LightGBMError``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Any, Dict, Tuple
+
+import numpy as np
+
+from .. import _lib
+
+TILE = 32
+BINS = 256
+QUANT_BITS = 16
+SLOT_HEADER = 8
+
+
+def _need_hip():
+    lib, hip = _lib.load()
+    if not hip:
+        raise _lib.LightGBMError("lightgbm_amd.ops needs the HIP build and a visible GPU")
+    from .. import _device
+    _device.sync_stream(lib)
+    return lib
+
+
+def _op(lib, name: str, ptrs, ints):
+    import torch
+    P = (ctypes.c_void_p * len(ptrs))(*[ctypes.c_void_p(p) for p in ptrs])
+    I = (ctypes.c_int64 * len(ints))(*[int(i) for i in ints])
+    _lib.check(lib.lga_hip_op(name.encode(), P, len(ptrs), I, len(ints)))
+    torch.cuda.synchronize()
+
+
+def _i32(values, device="cuda"):
+    import torch
+    return torch.tensor(np.asarray(values, dtype=np.int32), device=device)
+
+
+def quant_exponent(vmax: float) -> int:
+    """Largest k with vmax * 2^k < 2^16 (0 for vmax == 0)."""
+    if not (vmax > 0):
+        return 0
+    m, e = np.frexp(np.float32(vmax))
+    return QUANT_BITS - int(e)
+
+
+def pack_gradients(g: np.ndarray, h: np.ndarray) -> Tuple[np.ndarray, int, int]:
+    """NumPy reference of the device quantisation: returns (packed int64, kg, kh)."""
+    g = np.asarray(g, dtype=np.float32)
+    h = np.asarray(h, dtype=np.float32)
+    kg, kh = quant_exponent(float(np.abs(g).max(initial=0))), quant_exponent(float(h.max(initial=0)))
+    lim = float(1 << QUANT_BITS)
+    gq = np.rint(np.clip(np.ldexp(g, kg), -lim, lim)).astype(np.int64)
+    hq = np.rint(np.clip(np.ldexp(h, kh), -lim, lim)).astype(np.int64)
+    packed = (gq << 32) + hq
+    return packed, kg, kh
+
+
+def hist_build(bins_rt, rows, packed, num_features: int, rows_per_chunk: int = 4096):
+    """bins_rt uint8 [tiles, N, 32], rows int32 [n], packed int64 [N] -> (g int64 [tiles*32, 256], h, header[8])."""
+    import torch
+    lib = _need_hip()
+    T, N = int(bins_rt.shape[0]), int(bins_rt.shape[1])
+    n = int(rows.numel())
+    plane = T * TILE * BINS
+    slot_words = 2 * plane + SLOT_HEADER
+    nch = max(1, -(-n // rows_per_chunk))
+    task = np.zeros(16, dtype=np.int32)
+    task[13] = nch   # num_hchunk; left_node = 0, hist_child = 0, new_slot = 0, first_hchunk = 0
+    tasks = _i32(task)
+    chunk_task = torch.zeros(nch, dtype=torch.int32, device="cuda")
+    nodes = _i32([0, n, 0, 0])
+    pool = torch.zeros(slot_words, dtype=torch.int64, device="cuda")
+    rows = rows.contiguous()
+    _op(lib, "histogram",
+        [tasks.data_ptr(), chunk_task.data_ptr(), nodes.data_ptr(), rows.data_ptr(), rows.data_ptr(),
+         bins_rt.data_ptr(), packed.data_ptr(), pool.data_ptr()],
+        [nch, rows_per_chunk, N, slot_words, plane, num_features, 0, 1, T])
+    g = pool[:plane].view(T * TILE, BINS)
+    h = pool[plane:2 * plane].view(T * TILE, BINS)
+    return g, h, pool[2 * plane:]
+
+
+def partition_rows(rows, bins_fm, feature: int, threshold: int, missing_bin: int = -1, default_left: bool = False):
+    """Stable partition of ``rows`` (int32 [n]) by bins_fm[feature, row] <= threshold.  Returns (new rows, n_left)."""
+    import torch
+    lib = _need_hip()
+    n = int(rows.numel())
+    N = int(bins_fm.shape[1])
+    nch = max(1, -(-n // 2048))
+    task = np.zeros(16, dtype=np.int32)
+    task[0], task[1], task[2] = 0, 1, 2
+    task[3], task[4], task[5], task[6] = feature, threshold, int(default_left), missing_bin
+    task[10], task[11] = 0, nch
+    tasks = _i32(task)
+    chunk_task = torch.zeros(nch, dtype=torch.int32, device="cuda")
+    nodes = _i32([0, n, 0, 0] + [0] * 8)
+    src = rows.contiguous().clone()
+    dst = torch.full_like(src, -1)
+    mask = torch.zeros(nch * 32, dtype=torch.int64, device="cuda")
+    chunk_left = torch.zeros(nch, dtype=torch.int32, device="cuda")
+    task_left = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _op(lib, "partition",
+        [tasks.data_ptr(), chunk_task.data_ptr(), nodes.data_ptr(), src.data_ptr(), dst.data_ptr(), bins_fm.data_ptr(),
+         mask.data_ptr(), chunk_left.data_ptr(), task_left.data_ptr()], [nch, N])
+    nd = nodes.cpu().numpy().reshape(3, 4)
+    nl = int(task_left.item())
+    assert nd[1, 1] == nl and nd[2, 0] == nl and nd[2, 1] == n - nl
+    return dst, nl
+
+
+class _SplitParams(ctypes.Structure):
+    _fields_ = [("lambda_l1", ctypes.c_double), ("lambda_l2", ctypes.c_double), ("min_gain_to_split", ctypes.c_double),
+                ("min_sum_hessian_in_leaf", ctypes.c_double), ("max_delta_step", ctypes.c_double),
+                ("min_data_in_leaf", ctypes.c_int32), ("max_depth", ctypes.c_int32)]
+
+
+def split_scan(g, h, count: int, total_g: int, total_h: int, num_bins, missing_bins, kg: int, kh: int,
+               lambda_l1: float = 0.0, lambda_l2: float = 0.0, min_gain_to_split: float = 0.0,
+               min_sum_hessian_in_leaf: float = 1e-3, min_data_in_leaf: int = 20) -> Dict[str, Any]:
+    """g, h int64 [F_pad, 256] (F_pad a multiple of 32); returns the winning split as a dict."""
+    import torch
+    lib = _need_hip()
+    F = len(num_bins)
+    plane = int(g.numel())
+    slot_words = 2 * plane + SLOT_HEADER
+    pool = torch.zeros(slot_words, dtype=torch.int64, device="cuda")
+    pool[:plane] = g.reshape(-1)
+    pool[plane:2 * plane] = h.reshape(-1)
+    pool[2 * plane + 0], pool[2 * plane + 1], pool[2 * plane + 2] = int(count), int(total_g), int(total_h)
+    meta = np.zeros((F, 4), dtype=np.int32)
+    meta[:, 0], meta[:, 1], meta[:, 2] = num_bins, missing_bins, 1
+    meta_t = _i32(meta.reshape(-1))
+    st = _i32([0, 0, -1, -1, -1, 0])
+    totals = torch.zeros(4, dtype=torch.int64, device="cuda")
+    qs = _i32([kg, kh])
+    sp = _SplitParams(lambda_l1, lambda_l2, min_gain_to_split, min_sum_hessian_in_leaf, 0.0, min_data_in_leaf, -1)
+    cands = torch.zeros(F * 4, dtype=torch.int64, device="cuda")
+    out = torch.zeros(9, dtype=torch.int64, device="cuda")
+    _op(lib, "scan", [st.data_ptr(), meta_t.data_ptr(), pool.data_ptr(), totals.data_ptr(), qs.data_ptr(),
+                      ctypes.addressof(sp), cands.data_ptr(), out.data_ptr()], [1, F, slot_words, plane])
+    raw = out.cpu().numpy()
+    ints = raw[1:3].view(np.int32)
+    return {"gain": float(raw[:1].view(np.float64)[0]), "feature": int(ints[0]), "threshold": int(ints[1]),
+            "default_left": int(ints[2]), "left_g": int(raw[3]), "left_h": int(raw[4]), "total_g": int(raw[5]),
+            "total_h": int(raw[6]), "left_cnt": int(raw[7]), "total_cnt": int(raw[8])}

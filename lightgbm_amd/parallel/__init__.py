@@ -1,6 +1,6 @@
 """Multi-GPU training: data-parallel / feature-parallel learners (RCCL over xGMI) and task-parallel grid sharding."""
-from .comm import RcclComm, ThreadComm, TorchComm, default_comm
+from .comm import DeviceLoopbackComm, RcclComm, ThreadComm, TorchComm, default_comm
 from .data_parallel import distributed_dataset, gather_bin_sample, train_data_parallel
 
-__all__ = ["RcclComm", "TorchComm", "ThreadComm", "default_comm", "distributed_dataset", "gather_bin_sample",
+__all__ = ["DeviceLoopbackComm", "RcclComm", "TorchComm", "ThreadComm", "default_comm", "distributed_dataset", "gather_bin_sample",
            "train_data_parallel"]

@@ -159,6 +159,28 @@ class RcclComm:
             self.handle = None
 
 
+class DeviceLoopbackComm:
+    """In-process loop-back group for the HIP engine: P learners in P threads on ONE GPU (tests only)."""
+
+    def __init__(self, handle, rank, size):
+        self.handle, self.rank, self.size = handle, rank, size
+
+    @staticmethod
+    def make_group(size: int) -> List["DeviceLoopbackComm"]:
+        lib, hip = _lib.load()
+        if not hip:
+            raise _lib.LightGBMError("DeviceLoopbackComm needs the HIP build and a visible GPU")
+        arr = (ctypes.c_void_p * size)()
+        _lib.check(lib.lga_hip_comm_create_loopback_group(size, arr))
+        return [DeviceLoopbackComm(ctypes.c_void_p(arr[r]), r, size) for r in range(size)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib, _ = _lib.load()
+            lib.lga_comm_free(self.handle)
+            self.handle = None
+
+
 def default_comm(group=None):
     """RCCL when training on GPUs, torch.distributed host collectives otherwise; None when not distributed."""
     import torch.distributed as dist

@@ -1,0 +1,307 @@
+"""MI355X tests: every hot kernel against a NumPy/PyTorch reference, and the device engine against the CPU oracle.
+
+Run with ``pytest -m gpu`` on a GPU box.  The HIP core must be the loaded library (no silent fallback).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+from lightgbm_amd.utils.datasets import make_diamonds_like, make_higgs_like, make_regression
+
+pytestmark = pytest.mark.gpu
+
+GPU = {"device_type": "gpu", "verbose": -1}
+CPU = {"device_type": "cpu", "verbose": -1}
+
+
+def trees_of(b):
+    s = b.model_to_string() if hasattr(b, "model_to_string") else b
+    return s[s.index("Tree=0"):s.index("end of trees")]
+
+
+def test_hip_core_is_loaded():
+    from lightgbm_amd import _lib
+    lib, hip = _lib.load()
+    assert hip and lib.lga_build_info() == b"hip"
+
+
+# ----------------------------------------------------------------------------- kernels
+def _random_bins(n, F, seed, low_card=()):
+    rng = np.random.RandomState(seed)
+    T = (F + 31) // 32
+    bins = rng.randint(0, 256, size=(n, F)).astype(np.uint8)
+    for f in low_card:
+        bins[:, f] = rng.randint(0, 5, size=n)
+    rt = np.zeros((T, n, 32), dtype=np.uint8)
+    for f in range(F):
+        rt[f // 32, :, f % 32] = bins[:, f]
+    return bins, rt
+
+
+@pytest.mark.parametrize("n,F,chunk", [(1000, 28, 4096), (70000, 28, 4096), (50000, 70, 16384), (3, 5, 1024)])
+def test_histogram_kernel_matches_numpy(n, F, chunk):
+    import torch
+    from lightgbm_amd import ops
+    N = n + 500
+    bins, rt = _random_bins(N, F, seed=n, low_card=(1, 3))
+    rng = np.random.RandomState(1)
+    g = rng.randn(N).astype(np.float32)
+    h = rng.rand(N).astype(np.float32)
+    packed, kg, kh = ops.pack_gradients(g, h)
+    rows = np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32)
+    gq, hq = packed >> 32, packed & 0xffffffff
+    G, H, hd = ops.hist_build(torch.from_numpy(rt).cuda(), torch.from_numpy(rows).cuda(),
+                              torch.from_numpy(packed).cuda(), F, rows_per_chunk=chunk)
+    G, H, hd = G.cpu().numpy(), H.cpu().numpy(), hd.cpu().numpy()
+    for f in range(F):
+        eg = np.bincount(bins[rows, f], weights=None, minlength=256) * 0
+        eg = np.zeros(256, dtype=np.int64); eh = np.zeros(256, dtype=np.int64)
+        np.add.at(eg, bins[rows, f], gq[rows]); np.add.at(eh, bins[rows, f], hq[rows])
+        np.testing.assert_array_equal(G[f], eg)      # integer sums: exact
+        np.testing.assert_array_equal(H[f], eh)
+    assert G[F:].sum() == 0 and H[F:].sum() == 0     # padding features untouched
+    assert hd[0] == n and hd[1] == gq[rows].sum() and hd[2] == hq[rows].sum()
+
+
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100000])
+def test_partition_kernel_is_a_stable_split(n):
+    import torch
+    from lightgbm_amd import ops
+    rng = np.random.RandomState(n)
+    N = n + 300
+    fm = rng.randint(0, 40, size=(3, N)).astype(np.uint8)
+    rows = np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32)
+    for (f, thr, mb, dl) in [(1, 17, -1, False), (2, 9, 39, True), (0, 0, 39, False)]:
+        out, nl = ops.partition_rows(torch.from_numpy(rows).cuda(), torch.from_numpy(fm).cuda(), f, thr, mb, dl)
+        b = fm[f, rows]
+        left = np.where(b == mb, dl, b <= thr)
+        np.testing.assert_array_equal(out.cpu().numpy(), np.concatenate([rows[left], rows[~left]]))   # stable: exact
+        assert nl == int(left.sum())
+
+
+def _scan_reference(G, H, cnt, nb, mb, kg, kh, l1, l2, min_gain, min_h, min_data):
+    gu, hu = 2.0 ** -kg, 2.0 ** -kh
+    tg, th = int(G[0, :].sum()), int(H[0, :].sum())
+    factor = cnt / th
+    def lg(g, hh):
+        t = np.sign(g) * max(abs(g) - l1, 0.0)
+        return t * t / (hh + l2)
+    parent = lg(tg * gu, th * hu)
+    best = (-np.inf, None)
+    for f in range(len(nb)):
+        vb = nb[f] - 1 if mb[f] >= 0 else nb[f]
+        cg, ch = np.cumsum(G[f, :vb]), np.cumsum(H[f, :vb])
+        last = vb - 1 if mb[f] >= 0 else vb - 2
+        for t in range(last + 1):
+            cands = [(int(cg[t]), int(ch[t]), 0)]
+            if mb[f] >= 0 and t <= vb - 2:
+                cands.append((int(cg[t] + G[f, mb[f]]), int(ch[t] + H[f, mb[f]]), 1))
+            for a, b, dl in cands:
+                lc = int(b * factor + 0.5); rc = cnt - lc
+                if lc < min_data or rc < min_data or b * hu < min_h or (th - b) * hu < min_h:
+                    continue
+                gain = lg(a * gu, b * hu) + lg((tg - a) * gu, (th - b) * hu) - parent
+                if not gain > min_gain:
+                    continue
+                key = (f << 16) | (t << 1) | dl
+                if gain > best[0] or (gain == best[0] and key < best[1][0]):
+                    best = (gain, (key, f, t, dl, a, b))
+    return best
+
+
+@pytest.mark.parametrize("seed,l1,l2", [(0, 0.0, 0.0), (1, 0.5, 1.0), (2, 0.0, 10.0)])
+def test_scan_kernel_picks_the_reference_split(seed, l1, l2):
+    import torch
+    from lightgbm_amd import ops
+    rng = np.random.RandomState(seed)
+    F = 9
+    nb = np.array([256, 5, 64, 256, 17, 2, 100, 255, 33])
+    mb = np.array([-1, -1, 63, 255, -1, -1, -1, -1, 32])
+    n = 20000
+    g = rng.randn(n).astype(np.float32); h = (rng.rand(n) + 0.1).astype(np.float32)
+    packed, kg, kh = ops.pack_gradients(g, h)
+    gq, hq = packed >> 32, packed & 0xffffffff
+    G = np.zeros((32, 256), dtype=np.int64); H = np.zeros((32, 256), dtype=np.int64)
+    for f in range(F):
+        b = rng.randint(0, nb[f], size=n)
+        if f == 0:
+            gq2 = gq + (b < 100) * 3000        # plant a strong split
+            np.add.at(G[f], b, gq2); np.add.at(H[f], b, hq)
+            G[f] -= 0
+        else:
+            np.add.at(G[f], b, gq); np.add.at(H[f], b, hq)
+    # every feature must sum to the same totals (they describe the same rows)
+    tg, th = int(G[1].sum()), int(H[1].sum())
+    G[0, 255] += tg - int(G[0].sum())
+    ref = _scan_reference(G, H, n, nb, mb, kg, kh, l1, l2, 0.0, 1e-3, 20)
+    got = ops.split_scan(torch.from_numpy(G).cuda(), torch.from_numpy(H).cuda(), n, tg, th, nb, mb, kg, kh,
+                         lambda_l1=l1, lambda_l2=l2)
+    key, f, t, dl, a, b = ref[1]
+    assert (got["feature"], got["threshold"], got["default_left"]) == (f, t, dl)
+    assert got["left_g"] == a and got["left_h"] == b and got["total_cnt"] == n
+    assert abs(got["gain"] - ref[0]) <= 1e-9 * abs(ref[0])
+
+
+def test_device_binning_equals_host_binning():
+    import torch
+    rng = np.random.RandomState(0)
+    X = rng.randn(30000, 37)
+    X[:, 3] = rng.randint(0, 4, 30000)
+    X[::9, 5] = np.nan
+    X[:, 7] = 1.0
+    for arr in (X, X.astype(np.float32), np.asfortranarray(X)):
+        dc = lgb.Dataset(arr, label=np.zeros(30000), params=CPU).construct()
+        dg = lgb.Dataset(arr, label=np.zeros(30000), params=GPU).construct()
+        np.testing.assert_array_equal(dc.get_bins(), dg.get_bins())
+    dt = lgb.Dataset(torch.from_numpy(X).cuda(), label=np.zeros(30000), params=GPU).construct()
+    np.testing.assert_array_equal(dt.get_bins(), dc.get_bins())
+
+
+# ----------------------------------------------------------------------------- engine parity
+@pytest.mark.parametrize("params", [
+    {"num_leaves": 31},
+    {"num_leaves": 127, "min_data_in_leaf": 5, "lambda_l2": 0.5},
+    {"num_leaves": 63, "max_depth": 5, "feature_fraction": 0.7},
+    {"num_leaves": 31, "bagging_fraction": 0.6, "bagging_freq": 2},
+    {"num_leaves": 15, "max_bin": 63, "lambda_l1": 0.1, "min_gain_to_split": 0.05},
+])
+def test_gpu_regression_trees_equal_cpu_trees(params):
+    X, y = make_regression(40000, 12, seed=3)
+    X[::13, 4] = np.nan
+    w = np.where(X[:, 0] > 0, 1.5, 0.5)
+    a = lgb.train({**CPU, **params}, lgb.Dataset(X, label=y, weight=w, params=CPU), 12)
+    b = lgb.train({**GPU, **params}, lgb.Dataset(X, label=y, weight=w, params=GPU), 12)
+    assert trees_of(a) == trees_of(b)
+
+
+def test_gpu_binary_matches_cpu_quality_and_first_tree():
+    X, y = make_higgs_like(60000, seed=2, device="numpy")
+    p = {"objective": "binary", "num_leaves": 63, "metric": ["auc", "binary_logloss"], "min_sum_hessian_in_leaf": 10.0}
+    ec, eg = {}, {}
+    dc = lgb.Dataset(X, label=y, params=CPU); dg = lgb.Dataset(X, label=y, params=GPU)
+    a = lgb.train({**CPU, **p}, dc, 30, valid_sets=[dc], evals_result=ec)
+    b = lgb.train({**GPU, **p}, dg, 30, valid_sets=[dg], evals_result=eg)
+    sa, sb = a.model_to_string(), b.model_to_string()
+    assert sa[sa.index("Tree=0"):sa.index("Tree=1")] == sb[sb.index("Tree=0"):sb.index("Tree=1")]
+    # exp() differs in the last bits between libm and the device, so later trees may differ in ties only
+    assert abs(ec["training"]["auc"][-1] - eg["training"]["auc"][-1]) < 1e-3
+    assert abs(ec["training"]["binary_logloss"][-1] - eg["training"]["binary_logloss"][-1]) < 1e-3
+
+
+def test_gpu_predictor_matches_host_predictor():
+    import torch
+    X, y = make_regression(30000, 20, seed=5)
+    X[::7, 2] = np.nan
+    b = lgb.train({**GPU, "num_leaves": 255, "min_data_in_leaf": 3}, lgb.Dataset(X, label=y, params=GPU), 60)
+    host = b.predict(X, device="cpu")
+    np.testing.assert_allclose(b.predict(X, device="gpu"), host, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.predict(torch.from_numpy(X).cuda()), host, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.predict(X.astype(np.float32), device="gpu"), b.predict(X.astype(np.float32), device="cpu"),
+                               rtol=0, atol=1e-12)
+    np.testing.assert_allclose(b.predict(X, device="gpu", num_iteration=7), b.predict(X, device="cpu", num_iteration=7),
+                               atol=1e-12)
+    yb = (y > 0).astype(float)
+    bb = lgb.train({**GPU, "objective": "binary"}, lgb.Dataset(X, label=yb, params=GPU), 10)
+    np.testing.assert_allclose(bb.predict(X, device="gpu"), bb.predict(X, device="cpu"), atol=1e-12)
+    rf = lgb.train({**GPU, "boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1},
+                   lgb.Dataset(X, label=y, params=GPU), 10)
+    np.testing.assert_allclose(rf.predict(X, device="gpu"), rf.predict(X, device="cpu"), atol=1e-12)
+
+
+def test_gpu_cv_and_rstyle_grid_row():
+    from lightgbm_amd.rstyle import lgb_cv, lgb_Dataset
+    X, y = make_diamonds_like(20000, seed=4)
+    kw = dict(nrounds=200, nfold=5, objective="regression", eval="rmse", showsd=False, early_stopping_rounds=5,
+              verbose=0, seed=3)
+    g = lgb_cv({"learning_rate": 0.1}, lgb_Dataset(X, label=y, params=GPU), **kw)
+    c = lgb_cv({"learning_rate": 0.1}, lgb_Dataset(X, label=y, params=CPU), **kw)
+    assert g.best_iter == c.best_iter and abs(g.best_score - c.best_score) < 1e-9
+
+
+def test_gpu_rf_and_rollback_and_custom_objective():
+    X, y = make_regression(20000, 8, seed=6)
+    p = {"boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1, "feature_fraction": 0.8, "num_leaves": 63}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 8)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 8)
+    assert trees_of(a) == trees_of(b)
+    bst = lgb.train(GPU, lgb.Dataset(X, label=y, params=GPU), 6, keep_training_booster=True)
+    bst.rollback_one_iter()
+    np.testing.assert_allclose(bst._inner_predict(-1, raw=True), bst.predict(X), atol=1e-9)
+    fobj = lambda preds, data: (preds - data.get_label(), np.ones_like(preds))
+    c = lgb.train({**GPU, "boost_from_average": False}, lgb.Dataset(X, label=y, params=GPU), 5, fobj=fobj)
+    d = lgb.train({**GPU, "boost_from_average": False}, lgb.Dataset(X, label=y, params=GPU), 5)
+    np.testing.assert_allclose(c.predict(X), d.predict(X), atol=1e-9)
+
+
+def test_many_features_use_several_tiles():
+    X, y = make_regression(8000, 150, seed=7)
+    a = lgb.train({**CPU, "num_leaves": 31}, lgb.Dataset(X, label=y, params=CPU), 5)
+    b = lgb.train({**GPU, "num_leaves": 31}, lgb.Dataset(X, label=y, params=GPU), 5)
+    assert trees_of(a) == trees_of(b)
+
+
+# ----------------------------------------------------------------------------- distributed code paths on one GPU
+def _run_ranks(P, fn):
+    from lightgbm_amd.parallel import DeviceLoopbackComm
+    comms = DeviceLoopbackComm.make_group(P)
+    out, err = [None] * P, [None] * P
+
+    def work(r):
+        try:
+            out[r] = fn(r, comms[r])
+        except BaseException as e:   # noqa
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for e in err:
+        if e is not None:
+            raise e
+    [c.close() for c in comms]
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_gpu_data_parallel_equals_serial(P):
+    X, y = make_regression(40000, 10, seed=8)
+    params = {**GPU, "num_leaves": 63}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X[:20000], params=GPU), 10)
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X[:20000], params=GPU)
+        return lgb.train({**params, "tree_learner": "data"}, d, 10, comm=comm).model_to_string()
+    for s in _run_ranks(P, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
+def test_gpu_feature_parallel_equals_serial():
+    X, y = make_regression(10000, 100, seed=9)
+    params = {**GPU, "num_leaves": 31}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, params=GPU), 6)
+    res = _run_ranks(2, lambda r, c: lgb.train({**params, "tree_learner": "feature"},
+                                               lgb.Dataset(X, label=y, params=GPU), 6, comm=c).model_to_string())
+    for s in res:
+        assert trees_of(s) == trees_of(serial)
+
+
+def test_rccl_single_rank_communicator(tmp_path):
+    # RCCL itself needs one GPU per rank; with one GPU we can still bring a 1-rank communicator up and train through it
+    import os, socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"})
+    dist.init_process_group("gloo")
+    try:
+        from lightgbm_amd.parallel import RcclComm
+        comm = RcclComm()
+        X, y = make_regression(5000, 6, seed=10)
+        a = lgb.train({**GPU, "tree_learner": "data"}, lgb.Dataset(X, label=y, params=GPU), 3, comm=comm)
+        b = lgb.train(GPU, lgb.Dataset(X, label=y, params=GPU), 3)
+        assert trees_of(a) == trees_of(b)
+        comm.close()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,152 @@
+"""Distributed learners on the CPU engine: data-parallel and feature-parallel training must grow the SAME
+trees as serial training (integer histograms make the reduction exact).  Covered two ways:
+an in-process loop-back communicator (threads) and real torch.distributed/gloo processes."""
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+from lightgbm_amd.parallel import ThreadComm
+from lightgbm_amd.utils.datasets import make_higgs_like, make_regression
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = {"device_type": "cpu", "verbose": -1}
+
+
+def trees_of(b):
+    s = b.model_to_string() if hasattr(b, "model_to_string") else b
+    return s[s.index("Tree=0"):s.index("end of trees")]
+
+
+def run_ranks(P, fn):
+    comms = ThreadComm.make_group(P)
+    out, err = [None] * P, [None] * P
+
+    def work(r):
+        try:
+            out[r] = fn(r, comms[r])
+        except BaseException as e:   # noqa
+            err[r] = e
+            comms[r]._hub.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    [c.close() for c in comms]
+    return out
+
+
+@pytest.mark.parametrize("P", [2, 3, 4])
+def test_data_parallel_equals_serial_regression(P):
+    X, y = make_regression(6000, 9, seed=0)
+    params = {**CPU, "num_leaves": 31, "min_data_in_leaf": 20}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X), 12)
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X)
+        ev = {}
+        b = lgb.train({**params, "tree_learner": "data", "metric": "l2"}, d, 12, comm=comm, valid_sets=[d],
+                      evals_result=ev)
+        return b.model_to_string(), ev["training"]["l2"][-1]
+    res = run_ranks(P, rank)
+    for s, _ in res:
+        assert trees_of(s) == trees_of(serial)
+    # the distributed metric is the global one
+    global_l2 = float(np.mean((serial.predict(X) - y) ** 2))
+    assert all(abs(m - global_l2) < 1e-6 for _, m in res)
+
+
+def test_data_parallel_equals_serial_binary_first_trees_and_auc():
+    X, y = make_higgs_like(8000, seed=1, device="numpy")
+    params = {**CPU, "objective": "binary", "num_leaves": 15, "min_sum_hessian_in_leaf": 5.0, "metric": "auc"}
+    ds = lgb.Dataset(X, label=y, bin_sample=X)
+    ev0 = {}
+    serial = lgb.train(params, ds, 10, valid_sets=[ds], evals_result=ev0)
+
+    def rank(r, comm):
+        sl = slice(r * 4000, (r + 1) * 4000)
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X)
+        ev = {}
+        b = lgb.train({**params, "tree_learner": "data"}, d, 10, comm=comm, valid_sets=[d], evals_result=ev)
+        return b.model_to_string(), ev["training"]["auc"][-1]
+    res = run_ranks(2, rank)
+    assert trees_of(res[0][0]) == trees_of(res[1][0]) == trees_of(serial)
+    # AUC over ranks goes through a shared score grid: equal to the exact one within 1e-4
+    assert abs(res[0][1] - ev0["training"]["auc"][-1]) < 1e-4 and res[0][1] == res[1][1]
+
+
+@pytest.mark.parametrize("P,F", [(2, 70), (3, 100)])
+def test_feature_parallel_equals_serial(P, F):
+    X, y = make_regression(3000, F, seed=2)
+    params = {**CPU, "num_leaves": 15}
+    serial = lgb.train(params, lgb.Dataset(X, label=y), 6)
+
+    def rank(r, comm):
+        b = lgb.train({**params, "tree_learner": "feature"}, lgb.Dataset(X, label=y), 6, comm=comm)
+        return b.model_to_string()
+    for s in run_ranks(P, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
+def test_feature_parallel_with_fewer_tiles_than_ranks():
+    X, y = make_regression(2000, 10, seed=3)     # one 32-feature tile, two ranks: rank 1 owns nothing
+    serial = lgb.train({**CPU, "num_leaves": 7}, lgb.Dataset(X, label=y), 4)
+    res = run_ranks(2, lambda r, c: lgb.train({**CPU, "num_leaves": 7, "tree_learner": "feature"},
+                                              lgb.Dataset(X, label=y), 4, comm=c).model_to_string())
+    assert trees_of(res[0]) == trees_of(res[1]) == trees_of(serial)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gloo_two_processes_data_parallel(tmp_path):
+    out = str(tmp_path / "model_rank{}.txt")
+    script = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ["LGA_FORCE_HOST"] = "1"
+import numpy as np, torch.distributed as dist
+dist.init_process_group("gloo")
+import lightgbm_amd as lgb
+from lightgbm_amd.parallel import train_data_parallel
+from lightgbm_amd.utils.datasets import make_regression
+X, y = make_regression(5000, 8, seed=7)
+r, P = dist.get_rank(), dist.get_world_size()
+sl = slice(r * 2500, (r + 1) * 2500)
+b = train_data_parallel({{"device_type": "cpu", "verbose": -1, "num_leaves": 15, "bin_construct_sample_cnt": 5000}},
+                        X[sl], y[sl], num_boost_round=8)
+b.save_model({out!r}.format(r))
+dist.destroy_process_group()
+"""
+    port = _free_port()
+    path = str(tmp_path / "worker.py")
+    with open(path, "w") as f:
+        f.write(script)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), path],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m0, m1 = open(out.format(0)).read(), open(out.format(1)).read()
+    assert trees_of(m0) == trees_of(m1)
+    # the gathered sample holds every row here, so serial training with the same sample must match
+    X, y = make_regression(5000, 8, seed=7)
+    order = np.concatenate([np.arange(0, 2500), np.arange(2500, 5000)])
+    serial = lgb.train({**CPU, "num_leaves": 15}, lgb.Dataset(X, label=y, bin_sample=X[order]), 8)
+    assert trees_of(serial) == trees_of(m0)

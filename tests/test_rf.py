@@ -1,0 +1,52 @@
+"""Random-forest / bagging mode vs boosting (bagging_boosting.ipynb)."""
+import numpy as np
+
+import lightgbm_amd as lgb
+from lightgbm_amd.utils.datasets import make_curve_1d, make_regression
+
+CPU = {"device_type": "cpu", "verbose": -1}
+
+
+def test_rf_prediction_is_the_tree_average():
+    X, y = make_regression(3000, 6, seed=0)
+    p = {**CPU, "boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1, "feature_fraction": 0.8, "num_leaves": 31}
+    b = lgb.train(p, lgb.Dataset(X, label=y), 20)
+    s = b.model_to_string()
+    assert "average_output" in s.split("feature_names")[0]
+    single = np.column_stack([b.predict(X, start_iteration=i, num_iteration=1) for i in range(20)])
+    np.testing.assert_allclose(b.predict(X), single.mean(axis=1), atol=1e-9)
+    # the flag survives a round trip
+    b2 = lgb.Booster(model_str=s)
+    np.testing.assert_allclose(b2.predict(X), b.predict(X), atol=1e-12)
+    # trees are independent fits of the label (not of residuals): each alone is a decent model
+    assert all(np.corrcoef(single[:, i], y)[0, 1] > 0.6 for i in range(20))
+
+
+def test_rf_eval_tracks_running_average():
+    X, y = make_regression(3000, 6, seed=1)
+    d = lgb.Dataset(X[:2000], label=y[:2000])
+    v = d.create_valid(X[2000:], label=y[2000:])
+    ev = {}
+    p = {**CPU, "boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1, "metric": "rmse"}
+    b = lgb.train(p, d, 15, valid_sets=[v], evals_result=ev)
+    final = np.sqrt(np.mean((b.predict(X[2000:]) - y[2000:]) ** 2))
+    assert abs(ev["valid_0"]["rmse"][-1] - final) < 1e-6   # labels are float32 inside the engine
+    assert ev["valid_0"]["rmse"][-1] < ev["valid_0"]["rmse"][0]      # averaging more trees reduces variance
+
+
+def test_bagging_vs_boosting_on_the_toy_curve():
+    # NBB:118-137 (boosting, staged prediction) and NBB:194-212 (forest of 1 / 3 / 100 trees)
+    xg, yg, xt, yt = make_curve_1d()
+    d = lgb.Dataset(xt, label=yt)
+    boost = lgb.train({**CPU, "learning_rate": 0.02, "num_leaves": 31, "max_depth": 6, "min_data_in_leaf": 5}, d, 500)
+    err = [np.sqrt(np.mean((boost.predict(xg, num_iteration=k) - yg) ** 2)) for k in (1, 20, 50, 100, 300)]
+    assert all(a > b for a, b in zip(err, err[1:]))                 # more trees -> closer to the curve
+    assert err[-1] < 0.05
+    rf_err = {}
+    for n in (1, 3, 100):
+        rf = lgb.train({**CPU, "boosting": "rf", "num_leaves": 20, "bagging_fraction": 0.632, "bagging_freq": 1,
+                        "min_data_in_leaf": 5, "seed": 345, "bagging_seed": 345}, lgb.Dataset(xt, label=yt), n)
+        rf_err[n] = np.sqrt(np.mean((rf.predict(xg) - yg) ** 2))
+    assert rf_err[100] < rf_err[1] and rf_err[100] < 0.08
+    # one boosted tree at eta 0.02 is still far from the curve; one deep bagged tree is already close
+    assert rf_err[1] < err[0]
