@@ -104,25 +104,34 @@ std::vector<FeatureMeta> Booster::sample_features() {
   return meta;
 }
 
+void Booster::ensure_scores() {
+  if (scores_initialised_) return;
+  if (obj_.kind == kObjCustom) {
+    init_score_ = 0.0;
+    engine_->reset_scores(0.0);
+    scores_initialised_ = true;
+    return;
+  }
+  if (obj_.kind == kObjBinary) {
+    double swy, sw, swp;
+    engine_->label_stats(&swy, &sw, &swp);
+    double cp = swp, cn = sw - swp;
+    if (cfg_.is_unbalance && cp > 0 && cn > 0) {
+      if (cp > cn) { obj_.pos_weight = 1.0; obj_.neg_weight = cp / cn; }
+      else { obj_.pos_weight = cn / cp; obj_.neg_weight = 1.0; }
+    }
+    obj_.pos_weight *= cfg_.scale_pos_weight;
+  }
+  init_score_ = boost_from_average();
+  engine_->reset_scores(init_score_);
+  scores_initialised_ = true;
+  if (is_rf_) engine_->compute_gradients(obj_);
+}
+
 bool Booster::update_one_iter() {
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
-  if (!scores_initialised_) {
-    if (obj_.kind == kObjBinary) {
-      double swy, sw, swp;
-      engine_->label_stats(&swy, &sw, &swp);
-      double cp = swp, cn = sw - swp;
-      if (cfg_.is_unbalance && cp > 0 && cn > 0) {
-        if (cp > cn) { obj_.pos_weight = 1.0; obj_.neg_weight = cp / cn; }
-        else { obj_.pos_weight = cn / cp; obj_.neg_weight = 1.0; }
-      }
-      obj_.pos_weight *= cfg_.scale_pos_weight;
-    }
-    init_score_ = boost_from_average();
-    engine_->reset_scores(init_score_);
-    scores_initialised_ = true;
-    if (is_rf_) engine_->compute_gradients(obj_);
-  }
+  ensure_scores();
   if (!is_rf_) engine_->compute_gradients(obj_);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
   if (bagging && (iter_ % cfg_.bagging_freq == 0)) engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
@@ -134,6 +143,7 @@ bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (is_rf_) throw std::runtime_error("custom gradients are not supported with boosting=rf");
   if (!scores_initialised_) {
+    // gradients come from the caller: no boost-from-average, scores start at the data's init_score (or 0)
     init_score_ = 0.0;
     engine_->reset_scores(0.0);
     scores_initialised_ = true;
@@ -214,14 +224,12 @@ void Booster::reset_parameter(const std::string& params) {
 
 std::vector<EvalResult> Booster::eval(int which) {
   if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
-  if (!scores_initialised_) {
-    init_score_ = 0.0;
-    engine_->reset_scores(0.0);
-  }
+  ensure_scores();
   return engine_->eval(which, metrics_, obj_);
 }
 
 void Booster::inner_predict(int which, bool raw, double* out) {
+  ensure_scores();
   engine_->get_scores(which, out);
   if (!raw) {
     int64_t n = engine_->num_rows(which);

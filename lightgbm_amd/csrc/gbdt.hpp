@@ -67,6 +67,7 @@ class Booster {
 
  private:
   void setup_objective();
+  void ensure_scores();
   double boost_from_average();
   std::vector<FeatureMeta> sample_features();
   bool finish_iteration(Tree&& tree);
