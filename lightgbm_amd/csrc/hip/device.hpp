@@ -91,6 +91,31 @@ class PinnedBuffer {
   size_t n_ = 0;
 };
 
+// Host memory the device can write directly (fine-grained, mapped): results of a growth round land
+// here without a copy command.
+class MappedBuffer {
+ public:
+  MappedBuffer() {}
+  ~MappedBuffer() { if (p_) (void)hipHostFree(p_); }
+  MappedBuffer(const MappedBuffer&) = delete;
+  MappedBuffer& operator=(const MappedBuffer&) = delete;
+  void resize(size_t n) {
+    if (n <= n_) return;
+    if (p_) (void)hipHostFree(p_);
+    LGA_HIP_CHECK(hipHostMalloc((void**)&p_, n, hipHostMallocMapped | hipHostMallocCoherent));
+    LGA_HIP_CHECK(hipHostGetDevicePointer((void**)&d_, p_, 0));
+    n_ = n;
+  }
+  char* get() const { return p_; }
+  char* device_ptr() const { return d_; }
+  size_t size() const { return n_; }
+
+ private:
+  char* p_ = nullptr;
+  char* d_ = nullptr;
+  size_t n_ = 0;
+};
+
 // Device copy of a root dataset's bin matrices.
 struct DeviceMirror {
   int64_t rows = 0;

@@ -123,8 +123,13 @@ class HipBackend : public TreeBackend {
     stage_dev_.resize(stage_bytes_);
     cands_.resize((size_t)(2 * max_batch_ + 2) * (size_t)std::max(F_, 1));
     results_dev_.resize((size_t)(2 * max_batch_ + 2));
-    // fetch block: [SplitInfo x 2B | task_left x B | QuantScale]
-    fetch_host_.resize(sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+    // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
+    host_block_.resize(k::kHostDataOffset + sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) +
+                       sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+    std::memset(host_block_.get(), 0, host_block_.size());
+    host_block_dev_ = host_block_.device_ptr();
+    done_counter_.resize(4);
+    done_counter_.zero(stream_);
     meta_dev_.resize((size_t)std::max(F_, 1));
     qs_dev_.resize(1);
     if (mode_ == ParallelMode::Feature) {
@@ -162,106 +167,22 @@ class HipBackend : public TreeBackend {
   }
 
   void root_round(SplitInfo* out) override {
-    SplitTask t{};
-    t.parent_node = 0; t.left_node = 0; t.right_node = 0; t.feature = 0; t.hist_child = 0;
-    t.parent_slot = 0; t.new_slot = 0; t.first_pchunk = 0; t.num_pchunk = 0; t.first_hchunk = 0;
-    int hch = pick_hist_chunk(bag_n_);
-    t.num_hchunk = std::max(1, ceil_div(bag_n_, hch));
-    char* st = stage_host_.get();
-    std::memcpy(st + off_tasks_, &t, sizeof(t));
-    k::ScanTaskDev sd{0, 0, -1, -1, -1, 0};
-    std::memcpy(st + off_scan_, &sd, sizeof(sd));
-    int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
-    for (int i = 0; i < t.num_hchunk; ++i) hc[i] = 0;
-    std::memcpy(st, &ranges_host_[0], sizeof(NodeRange));
-    prof.mark(PhaseProfile::kUpload, stream_);
-    upload_stage(off_hch_ + sizeof(int32_t) * (size_t)t.num_hchunk);
-    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), stage_dev_.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
+    std::vector<SplitTask> tasks(1);
+    SplitTask& t = tasks[0];
+    t = SplitTask{};
+    t.parent_node = -1; t.left_node = 0; t.right_node = 0; t.feature = 0; t.hist_child = 0;
+    t.parent_slot = 0; t.new_slot = 0;
+    // the root's row range goes to the device through the staging block's first bytes
+    std::memcpy(stage_host_.get(), &ranges_host_[0], sizeof(NodeRange));
+    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), stage_host_.get(), sizeof(NodeRange), hipMemcpyHostToDevice, stream_));
     LGA_HIP_CHECK(hipMemsetAsync(pool_.get(), 0, sizeof(int64_t) * (size_t)slot_words_, stream_));
-    prof.mark(PhaseProfile::kPartition, stream_);
-    prof.mark(PhaseProfile::kHist, stream_);
-    run_hist(1, t.num_hchunk, hch);
-    prof.mark(PhaseProfile::kComm, stream_);
-    reduce_slots(0, 1);
-    prof.mark(PhaseProfile::kScan, stream_);
-    run_scan(1);
-    prof.mark(PhaseProfile::kFetch, stream_);
-    fetch(1, 0, true);
-    prof.mark(PhaseProfile::kCount, stream_);
-    sync();
-    prof.collect(PhaseProfile::kCount);
-    ++prof.rounds;
-    std::memcpy(out, fetch_host_.get(), sizeof(SplitInfo));
-    std::memcpy(&qs_host_, fetch_host_.get() + sizeof(SplitInfo), sizeof(QuantScale));
+    run_round(tasks, true, out);
   }
 
   void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) override {
-    const int B = (int)tasks.size();
-    if (B == 0) return;
-    if (B > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
-    int64_t total_rows = 0;
-    for (const auto& t : tasks) total_rows += ranges_host_[(size_t)t.parent_node].count;
-    const int hch = pick_hist_chunk(total_rows);
-    char* st = stage_host_.get();
-    int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
-    int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
-    int np = 0, nh = 0;
-    for (int i = 0; i < B; ++i) {
-      SplitTask& t = tasks[(size_t)i];
-      int64_t cnt = ranges_host_[(size_t)t.parent_node].count;
-      t.first_pchunk = np;
-      t.num_pchunk = std::max(1, ceil_div(cnt, k::kPartChunk));
-      t.first_hchunk = nh;
-      t.num_hchunk = std::max(1, ceil_div(cnt, hch));
-      if (np + t.num_pchunk > max_pchunks_ || nh + t.num_hchunk > max_hchunks_)
-        throw std::runtime_error("chunk table overflow");
-      for (int c = 0; c < t.num_pchunk; ++c) pc[np++] = i;
-      for (int c = 0; c < t.num_hchunk; ++c) hc[nh++] = i;
-    }
-    std::memcpy(st + off_tasks_, tasks.data(), sizeof(SplitTask) * (size_t)B);
-    k::ScanTaskDev* sd = reinterpret_cast<k::ScanTaskDev*>(st + off_scan_);
-    for (int i = 0; i < B; ++i) {
-      const SplitTask& t = tasks[(size_t)i];
-      for (int side = 0; side < 2; ++side) {
-        k::ScanTaskDev& s = sd[i * 2 + side];
-        s.node = side == 0 ? t.left_node : t.right_node;
-        s.parent_node = t.parent_node;
-        s.pad = 0;
-        if (side == t.hist_child) { s.slot = t.new_slot; s.parent_slot = -1; s.sibling_slot = -1; }
-        else { s.slot = t.parent_slot; s.parent_slot = t.parent_slot; s.sibling_slot = t.new_slot; }
-      }
-    }
-    prof.mark(PhaseProfile::kUpload, stream_);
-    upload_stage(off_hch_ + sizeof(int32_t) * (size_t)nh);
-    LGA_HIP_CHECK(hipMemsetAsync(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, 0,
-                                 sizeof(int64_t) * (size_t)slot_words_ * (size_t)B, stream_));
-    prof.mark(PhaseProfile::kPartition, stream_);
-    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
-    const int32_t* dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
-    k::partition(dt, dpc, np, nodes_.get(), arena_[0].get(), arena_[1].get(), arena_[0].get(), arena_[1].get(),
-                 mir_->bins_fm.get(), N_, mask_.get(), chunk_left_.get(), task_left_.get(), k::BagParams{0, 0, 0, 0.f},
-                 stream_);
-    prof.mark(PhaseProfile::kHist, stream_);
-    run_hist(B, nh, hch);
-    prof.mark(PhaseProfile::kComm, stream_);
-    reduce_slots(tasks[0].new_slot, B);
-    prof.mark(PhaseProfile::kScan, stream_);
-    run_scan(2 * B);
-    prof.mark(PhaseProfile::kFetch, stream_);
-    fetch(2 * B, B, false);
-    prof.mark(PhaseProfile::kCount, stream_);
-    sync();
-    prof.collect(PhaseProfile::kCount);
-    ++prof.rounds;
-    prof.tasks += B;
-    std::memcpy(infos, fetch_host_.get(), sizeof(SplitInfo) * (size_t)(2 * B));
-    const int32_t* tl = reinterpret_cast<const int32_t*>(fetch_host_.get() + sizeof(SplitInfo) * (size_t)(2 * B));
-    for (int i = 0; i < B; ++i) {
-      const SplitTask& t = tasks[(size_t)i];
-      const NodeRange p = ranges_host_[(size_t)t.parent_node];
-      ranges_host_[(size_t)t.left_node] = NodeRange{p.begin, tl[i], 1 - p.buf, 0};
-      ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
-    }
+    if (tasks.empty()) return;
+    if ((int)tasks.size() > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
+    run_round(tasks, false, infos);
   }
 
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
@@ -283,8 +204,10 @@ class HipBackend : public TreeBackend {
     LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get() + node_id, stage_dev_.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
     const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
     const int32_t* dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
-    k::partition(dt, dpc, t.num_pchunk, nodes_.get(), base_rows, nullptr, nullptr, out, nullptr, N_, mask_.get(),
-                 chunk_left_.get(), task_left_.get(), k::BagParams{seed, iter, salt, (float)fraction}, stream_);
+    k::InlineTasks none{};
+    k::partition(dt, dpc, none, t.num_pchunk, t.num_pchunk > 1, nodes_.get(), base_rows, nullptr, nullptr, out, nullptr,
+                 N_, mask_.get(), chunk_left_.get(), task_left_.get(), k::BagParams{seed, iter, salt, (float)fraction},
+                 nullptr, 0, stream_);
     int32_t nl = 0;
     LGA_HIP_CHECK(hipMemcpyAsync(&nl, task_left_.get(), sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     sync();
@@ -308,52 +231,161 @@ class HipBackend : public TreeBackend {
     LGA_HIP_CHECK(hipMemcpyAsync(stage_dev_.get(), stage_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
   }
 
-  void run_hist(int n_tasks, int n_chunks, int hch) {
-    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
-    const int32_t* dhc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_hch_);
-    int tile_first = 0, tile_step = 1, tile_count = T_;
-    if (mode_ == ParallelMode::Feature) {
-      int P = comm_->size(), r = comm_->rank();
-      int owned = r < T_ ? (T_ - r + P - 1) / P : 0;
-      if (owned > 0) { tile_first = r; tile_step = P; tile_count = owned; }
-      else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
+  // One growth round.  root: no partition, a single scan task.  Small rounds (<= kInlineTasks leaves) carry
+  // their descriptors in the kernel arguments; results come back through host-mapped memory and a
+  // completion flag the host polls, so such a round costs 3-4 kernel launches and no copy or stream sync.
+  void run_round(std::vector<SplitTask>& tasks, bool root, SplitInfo* infos) {
+    const int B = (int)tasks.size();
+    const int n_scan = root ? 1 : 2 * B;
+    const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
+    const bool inline_tasks = fused && B <= k::kInlineTasks;
+    int64_t total_rows = 0;
+    for (const auto& t : tasks) total_rows += root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
+    const int hch = pick_hist_chunk(total_rows);
+    char* st = stage_host_.get();
+    int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
+    int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
+    int np = 0, nh = 0;
+    bool any_multi = false;
+    for (int i = 0; i < B; ++i) {
+      SplitTask& t = tasks[(size_t)i];
+      int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
+      t.first_pchunk = np;
+      t.num_pchunk = root ? 0 : std::max(1, ceil_div(cnt, k::kPartChunk));
+      t.first_hchunk = nh;
+      t.num_hchunk = std::max(1, ceil_div(cnt, hch));
+      if (np + t.num_pchunk > max_pchunks_ || nh + t.num_hchunk > max_hchunks_)
+        throw std::runtime_error("chunk table overflow");
+      any_multi = any_multi || t.num_pchunk > 1;
+      if (!inline_tasks) {
+        for (int c = 0; c < t.num_pchunk; ++c) pc[np + c] = i;
+        for (int c = 0; c < t.num_hchunk; ++c) hc[nh + c] = i;
+      }
+      np += t.num_pchunk;
+      nh += t.num_hchunk;
     }
-    (void)n_tasks;
-    k::histogram(dt, dhc, n_chunks, hch, nodes_.get(), arena_[0].get(), arena_[1].get(), mir_->bins_rt.get(), N_,
-                 packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count, stream_);
-  }
-
-  void reduce_slots(int first_slot, int count) {
-    if (mode_ != ParallelMode::Data) return;
-    comm_->allreduce_sum_i64(pool_.get() + (size_t)first_slot * slot_words_, (size_t)count * slot_words_, true, stream_);
-  }
-
-  void run_scan(int n_scan) {
-    const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(stage_dev_.get() + off_scan_);
-    int first = 0, step = 1;
-    if (mode_ == ParallelMode::Feature) { first = comm_->rank(); step = comm_->size(); }
-    k::scan(ds, n_scan, meta_dev_.get(), F_, first, step, pool_.get(), slot_words_, plane_, node_totals_.get(),
-            qs_dev_.get(), sp_, cands_.get(), stream_);
-    if (mode_ == ParallelMode::Feature) {
-      k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(),
-                best_local_.get(), stream_);
-      comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, stream_);
-      k::merge_winners(best_all_.get(), comm_->size(), n_scan, ds, node_totals_.get(), qs_dev_.get(), sp_,
-                       results_dev_.get(), stream_);
+    k::InlineTasks inl{};
+    const SplitTask* dt = nullptr;
+    const int32_t* dpc = nullptr;
+    const int32_t* dhc = nullptr;
+    prof.mark(PhaseProfile::kUpload, stream_);
+    if (inline_tasks) {
+      inl.count = B;
+      std::memcpy(inl.t, tasks.data(), sizeof(SplitTask) * (size_t)B);
     } else {
-      k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(), nullptr,
-                stream_);
+      std::memcpy(st + off_tasks_, tasks.data(), sizeof(SplitTask) * (size_t)B);
+      if (!fused) {
+        k::ScanTaskDev* sd = reinterpret_cast<k::ScanTaskDev*>(st + off_scan_);
+        for (int i = 0; i < n_scan; ++i) {
+          const SplitTask& t = tasks[(size_t)(i >> 1)];
+          const int side = i & 1;
+          k::ScanTaskDev& sdt = sd[i];
+          sdt.node = side == 0 ? t.left_node : t.right_node;
+          sdt.parent_node = t.parent_node;
+          sdt.pad = 0;
+          if (side == t.hist_child) { sdt.slot = t.new_slot; sdt.parent_slot = -1; sdt.sibling_slot = -1; }
+          else { sdt.slot = t.parent_slot; sdt.parent_slot = t.parent_slot; sdt.sibling_slot = t.new_slot; }
+        }
+      }
+      upload_stage(off_hch_ + sizeof(int32_t) * (size_t)nh);
+      dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
+      dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
+      dhc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_hch_);
+    }
+    prof.mark(PhaseProfile::kPartition, stream_);
+    if (!root)
+      k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), arena_[0].get(), arena_[1].get(), arena_[0].get(),
+                   arena_[1].get(), mir_->bins_fm.get(), N_, mask_.get(), chunk_left_.get(), task_left_.get(),
+                   k::BagParams{0, 0, 0, 0.f}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
+                   (int64_t)slot_words_ * B, stream_);
+    prof.mark(PhaseProfile::kHist, stream_);
+    {
+      int tile_first = 0, tile_step = 1, tile_count = T_;
+      if (mode_ == ParallelMode::Feature) {
+        int P = comm_->size(), r = comm_->rank();
+        int owned = r < T_ ? (T_ - r + P - 1) / P : 0;
+        if (owned > 0) { tile_first = r; tile_step = P; tile_count = owned; }
+        else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
+      }
+      k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), arena_[0].get(), arena_[1].get(), mir_->bins_rt.get(), N_,
+                   packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count, stream_);
+    }
+    prof.mark(PhaseProfile::kComm, stream_);
+    if (mode_ == ParallelMode::Data)
+      comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true,
+                               stream_);
+    prof.mark(PhaseProfile::kScan, stream_);
+    char* hres = host_block_.get() + k::kHostDataOffset;
+    if (fused) {
+      const unsigned seq = ++round_seq_ ? round_seq_ : ++round_seq_;   // never 0
+      k::scan_fused(dt, inl, n_scan, root ? 0 : B, meta_dev_.get(), F_, pool_.get(), slot_words_, plane_,
+                    node_totals_.get(), qs_dev_.get(), sp_, task_left_.get(), host_block_dev_, done_counter_.get(), seq,
+                    stream_);
+      prof.mark(PhaseProfile::kFetch, stream_);
+      prof.mark(PhaseProfile::kCount, stream_);
+      wait_flag(seq);
+      if (prof.on) sync();
+    } else {
+      const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(stage_dev_.get() + off_scan_);
+      int first = 0, step = 1;
+      if (mode_ == ParallelMode::Feature) { first = comm_->rank(); step = comm_->size(); }
+      k::scan(ds, n_scan, meta_dev_.get(), F_, first, step, pool_.get(), slot_words_, plane_, node_totals_.get(),
+              qs_dev_.get(), sp_, cands_.get(), stream_);
+      if (mode_ == ParallelMode::Feature) {
+        k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(),
+                  best_local_.get(), stream_);
+        comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, stream_);
+        k::merge_winners(best_all_.get(), comm_->size(), n_scan, ds, node_totals_.get(), qs_dev_.get(), sp_,
+                         results_dev_.get(), stream_);
+      } else {
+        k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(), nullptr,
+                  stream_);
+      }
+      prof.mark(PhaseProfile::kFetch, stream_);
+      size_t off = sizeof(SplitInfo) * (size_t)n_scan;
+      LGA_HIP_CHECK(hipMemcpyAsync(hres, results_dev_.get(), off, hipMemcpyDeviceToHost, stream_));
+      if (!root)
+        LGA_HIP_CHECK(hipMemcpyAsync(hres + off, task_left_.get(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(hres + off + sizeof(int32_t) * (size_t)(root ? 0 : B), qs_dev_.get(),
+                                   sizeof(QuantScale), hipMemcpyDeviceToHost, stream_));
+      prof.mark(PhaseProfile::kCount, stream_);
+      sync();
+    }
+    prof.collect(PhaseProfile::kCount);
+    ++prof.rounds;
+    if (!root) prof.tasks += B;
+    std::memcpy(infos, hres, sizeof(SplitInfo) * (size_t)n_scan);
+    const int32_t* tl = reinterpret_cast<const int32_t*>(hres + sizeof(SplitInfo) * (size_t)n_scan);
+    if (root) {
+      std::memcpy(&qs_host_, tl, sizeof(QuantScale));
+    } else {
+      for (int i = 0; i < B; ++i) {
+        const SplitTask& t = tasks[(size_t)i];
+        const NodeRange p = ranges_host_[(size_t)t.parent_node];
+        ranges_host_[(size_t)t.left_node] = NodeRange{p.begin, tl[i], 1 - p.buf, 0};
+        ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
+      }
     }
   }
 
-  void fetch(int n_scan, int n_tasks, bool with_qs) {
-    char* h = fetch_host_.get();
-    LGA_HIP_CHECK(hipMemcpyAsync(h, results_dev_.get(), sizeof(SplitInfo) * (size_t)n_scan, hipMemcpyDeviceToHost, stream_));
-    size_t off = sizeof(SplitInfo) * (size_t)n_scan;
-    if (n_tasks > 0)
-      LGA_HIP_CHECK(hipMemcpyAsync(h + off, task_left_.get(), sizeof(int32_t) * (size_t)n_tasks, hipMemcpyDeviceToHost, stream_));
-    if (with_qs)
-      LGA_HIP_CHECK(hipMemcpyAsync(h + off, qs_dev_.get(), sizeof(QuantScale), hipMemcpyDeviceToHost, stream_));
+  // Polls the completion flag the last scan workgroup writes into host-mapped memory.  The stream is
+  // queried now and then so that a failed launch surfaces as an error instead of an endless wait.
+  void wait_flag(unsigned seq) {
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(host_block_.get());
+    unsigned spins = 0;
+    while (*flag != seq) {
+      if ((++spins & 4095u) == 0) {
+        hipError_t q = hipStreamQuery(stream_);
+        if (q == hipSuccess) {
+          if (*flag == seq) break;
+          throw std::runtime_error("growth round finished without raising its completion flag");
+        }
+        if (q != hipErrorNotReady) LGA_HIP_CHECK(q);
+      }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
   }
 
   const Dataset* root_;
@@ -371,9 +403,13 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<uint64_t> mask_;
   DeviceBuffer<int32_t> chunk_left_, task_left_;
   DeviceBuffer<char> stage_dev_;
-  PinnedBuffer<char> stage_host_, fetch_host_;
+  PinnedBuffer<char> stage_host_;
   DeviceBuffer<k::Cand> cands_, best_local_, best_all_;
   DeviceBuffer<SplitInfo> results_dev_;
+  MappedBuffer host_block_;
+  char* host_block_dev_ = nullptr;
+  DeviceBuffer<unsigned> done_counter_;
+  unsigned round_seq_ = 0;
   DeviceBuffer<FeatureMeta> meta_dev_;
   DeviceBuffer<QuantScale> qs_dev_;
   std::vector<FeatureMeta> meta_host_;

@@ -128,51 +128,106 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
+// Task descriptors reach a kernel either through a staged device array (+ a chunk -> task table)
+// or, for small rounds, inline in the kernel arguments (no host->device copy at all).
+template <bool PART>
+__device__ __forceinline__ int find_task(const InlineTasks& inl, int wg) {
+  int ti = 0;
+#pragma unroll 1
+  for (int i = 0; i < inl.count; ++i) {
+    const int first = PART ? inl.t[i].first_pchunk : inl.t[i].first_hchunk;
+    if (wg >= first) ti = i;
+  }
+  return ti;
+}
+
+// Pass 1 of the partition: ballot masks + left counts per 2048-row chunk.  A task that fits ONE
+// chunk is finished right here (ranks from the masks in LDS, scatter, child ranges), so rounds made
+// of small leaves need no second launch.  The workgroups also clear the histogram slots of the round.
 __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
-    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, const NodeRange* __restrict__ nodes,
-    const int32_t* __restrict__ a0, const int32_t* __restrict__ a1, const uint8_t* __restrict__ bins_fm, int64_t N,
-    uint64_t* __restrict__ mask, int32_t* __restrict__ chunk_left, BagParams bag) {
-  __shared__ int wave_cnt[kPartThreads / kWave];
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl,
+    NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+    int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint8_t* __restrict__ bins_fm, int64_t N,
+    uint64_t* __restrict__ mask, int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, BagParams bag,
+    int64_t* __restrict__ zero_ptr, int64_t zero_words) {
+  constexpr int kWords = kPartChunk / kWave;
+  __shared__ unsigned long long smask[kWords];
+  __shared__ int word_prefix[kWords + 1];
   const int wg = blockIdx.x;
-  const SplitTask t = tasks[chunk_task[wg]];
+  for (int64_t i = (int64_t)wg * kPartThreads + threadIdx.x; i < zero_words; i += (int64_t)gridDim.x * kPartThreads)
+    zero_ptr[i] = 0;
+  const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
+  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   const int c = wg - t.first_pchunk;
   const NodeRange p = nodes[t.parent_node];
   const int32_t* src = (p.buf ? a1 : a0) + p.begin;
   const int base = c * kPartChunk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int cnt = 0;
+  int32_t myrow[kPartChunk / kPartThreads];
 #pragma unroll
   for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
-    int pos = base + kk * kPartThreads + threadIdx.x;
+    const int pos = base + kk * kPartThreads + threadIdx.x;
     bool left = false;
-    if (pos < p.count) left = goes_left(t, bins_fm, N, src[pos], bag);
-    unsigned long long m = __ballot(left);
-    if (lane == 0) {
-      mask[(int64_t)wg * (kPartChunk / kWave) + kk * (kPartThreads / kWave) + wave] = m;
-      cnt += __popcll(m);
+    myrow[kk] = 0;
+    if (pos < p.count) {
+      myrow[kk] = src[pos];
+      left = goes_left(t, bins_fm, N, myrow[kk], bag);
     }
+    const unsigned long long m = __ballot(left);
+    if (lane == 0) smask[kk * (kPartThreads / kWave) + wave] = m;
   }
-  if (lane == 0) wave_cnt[wave] = cnt;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
+  if (threadIdx.x < kWave) {
+    int pc = threadIdx.x < kWords ? __popcll(smask[threadIdx.x]) : 0;
+    int incl = pc;
 #pragma unroll
-    for (int w = 0; w < kPartThreads / kWave; ++w) s += wave_cnt[w];
-    chunk_left[wg] = s;
+    for (int d = 1; d < kWords; d <<= 1) {
+      int o = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += o;
+    }
+    if (threadIdx.x < kWords) word_prefix[threadIdx.x] = incl - pc;
+    if (threadIdx.x == kWords - 1) word_prefix[kWords] = incl;
+  }
+  __syncthreads();
+  const int lefts = word_prefix[kWords];
+  if (t.num_pchunk == 1) {
+    int32_t* dst = (p.buf ? a0_dst : a1_dst) + p.begin;
+#pragma unroll
+    for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
+      const int w = kk * (kPartThreads / kWave) + wave;
+      const int in_chunk = w * kWave + lane;
+      if (in_chunk < p.count) {
+        const unsigned long long m = smask[w];
+        const bool left = (m >> lane) & 1ull;
+        const int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
+        dst[left ? lrank : lefts + (in_chunk - lrank)] = myrow[kk];
+      }
+    }
+    if (threadIdx.x == 0) {
+      nodes[t.left_node] = NodeRange{p.begin, lefts, 1 - p.buf, 0};
+      nodes[t.right_node] = NodeRange{p.begin + lefts, p.count - lefts, 1 - p.buf, 0};
+      task_left[ti] = lefts;
+    }
+  } else {
+    if (threadIdx.x < kWords) mask[(int64_t)wg * kWords + threadIdx.x] = smask[threadIdx.x];
+    if (threadIdx.x == 0) chunk_left[wg] = lefts;
   }
 }
 
+// Pass 2 (tasks that span several chunks): each chunk adds up the left counts of the chunks before
+// it and scatters its rows - lefts to the front of the leaf's range, rights behind them, both in order.
 __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
-    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, NodeRange* __restrict__ nodes,
-    const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src, int32_t* __restrict__ a0_dst,
-    int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask, const int32_t* __restrict__ chunk_left,
-    int32_t* __restrict__ task_left) {
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl,
+    NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src,
+    int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask,
+    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left) {
   constexpr int kWords = kPartChunk / kWave;   // 32 mask words per chunk
   __shared__ int red_before[kPartThreads / kWave], red_all[kPartThreads / kWave];
   __shared__ int word_prefix[kWords];
   const int wg = blockIdx.x;
-  const int ti = chunk_task[wg];
-  const SplitTask t = tasks[ti];
+  const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
+  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
+  if (t.num_pchunk == 1) return;   // finished by pass 1
   const int c = wg - t.first_pchunk;
   const NodeRange p = nodes[t.parent_node];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,7 +288,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
 // histogram
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(
-    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, int rows_per_chunk,
+    const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl, int rows_per_chunk,
     const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, int64_t* __restrict__ pool,
     int64_t slot_words, int64_t plane, int F, int tile_first, int tile_step) {
@@ -241,7 +296,8 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   __shared__ long long red[3][kHistThreads / kWave];
   const int x = blockIdx.x;
   const int tile = tile_first + (int)blockIdx.y * tile_step;
-  const SplitTask t = tasks[chunk_task[x]];
+  const int ti = tasks ? chunk_task[x] : find_task<false>(inl, x);
+  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   const int c = x - t.first_hchunk;
   const int node = t.hist_child ? t.right_node : t.left_node;
   const NodeRange r = nodes[node];
@@ -308,6 +364,79 @@ __device__ __forceinline__ void take_better(double& g, uint64_t& key, int64_t& l
   if (cand_better(g2, k2, g, key)) { g = g2; key = k2; lg = lg2; lh = lh2; }
 }
 
+// Best split of ONE feature of one leaf, computed by one wave (4 bins per lane).  When `sib` is
+// given the leaf's histogram is first derived in place: self = self(parent) - sibling.
+// On return every lane holds the running best updated with this feature's winner.
+__device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __restrict__ self,
+                                                  const int64_t* __restrict__ sib, int64_t plane,
+                                                  const FeatureMeta m, const LeafScanCtx& ctx, const SplitParams& sp,
+                                                  double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+  const int64_t e = (int64_t)f * kMaxBins + lane * 4;
+  int64_t g[4], h[4];
+  {
+    const longlong2* gs = reinterpret_cast<const longlong2*>(self + e);
+    const longlong2* hs = reinterpret_cast<const longlong2*>(self + plane + e);
+    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+    g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
+    h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
+  }
+  if (sib) {
+    const longlong2* gs = reinterpret_cast<const longlong2*>(sib + e);
+    const longlong2* hs = reinterpret_cast<const longlong2*>(sib + plane + e);
+    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+    g[0] -= g01.x; g[1] -= g01.y; g[2] -= g23.x; g[3] -= g23.y;
+    h[0] -= h01.x; h[1] -= h01.y; h[2] -= h23.x; h[3] -= h23.y;
+    longlong2* go = reinterpret_cast<longlong2*>(self + e);
+    longlong2* ho = reinterpret_cast<longlong2*>(self + plane + e);
+    go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
+    ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
+  }
+  const int nb = m.num_bin, mb = m.missing_bin;
+  const int vb = mb >= 0 ? nb - 1 : nb;
+  // stats of the missing-value bin, broadcast from the lane that holds it
+  int64_t mg = 0, mh = 0;
+  if (mb >= 0) {
+    const int j = mb & 3;
+    int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
+    int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
+    mg = shfl_i64(og, mb >> 2);
+    mh = shfl_i64(oh, mb >> 2);
+  }
+  // inclusive prefix inside the lane, exclusive prefix across lanes
+  g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
+  h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
+  int64_t ig = g[3], ih = h[3];
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    int64_t og = shfl_up_i64(ig, d), oh = shfl_up_i64(ih, d);
+    if (lane >= d) { ig += og; ih += oh; }
+  }
+  const int64_t eg = ig - g[3], eh = ih - h[3];
+  const int last = mb >= 0 ? vb - 1 : vb - 2;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  double lbg = ninf;
+  uint64_t lkey = ~0ull;
+  int64_t llg = 0, llh = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int thr = lane * 4 + j;
+    if (thr <= last) {
+      const int64_t lg = eg + g[j], lh = eh + h[j];
+      take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp), cand_key(f, thr, 0), lg, lh);
+      if (mb >= 0 && thr <= vb - 2)
+        take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp), cand_key(f, thr, 1), lg + mg, lh + mh);
+    }
+  }
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    double g2 = shfl_xor_f64(lbg, msk);
+    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)lkey, msk);
+    int64_t lg2 = shfl_xor_i64(llg, msk), lh2 = shfl_xor_i64(llh, msk);
+    take_better(lbg, lkey, llg, llh, g2, k2, lg2, lh2);
+  }
+  take_better(bg, bkey, blg, blh, lbg, lkey, llg, llh);
+}
+
 __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict__ tasks,
                                                    const FeatureMeta* __restrict__ meta, int F, int f_first_tile,
                                                    int tile_step, int64_t* __restrict__ pool, int64_t slot_words,
@@ -338,78 +467,18 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
   Cand* out = cands + (int64_t)s * F + f;
   const FeatureMeta m = meta[f];
   const int my_tile = f / kTileFeatures;
-  const bool owned = tile_step <= 1 || ((my_tile - f_first_tile) % tile_step == 0 && my_tile >= f_first_tile);
+  const bool owned = tile_step <= 1 || (my_tile % tile_step) == f_first_tile;
   if (!m.enabled || !owned) {
     if (lane == 0) *out = Cand{ninf, ~0ull, 0, 0};
     return;
   }
-  // 4 consecutive bins per lane
-  const int64_t e = (int64_t)f * kMaxBins + lane * 4;
-  int64_t g[4], h[4];
-  {
-    const longlong2* gs = reinterpret_cast<const longlong2*>(self + e);
-    const longlong2* hs = reinterpret_cast<const longlong2*>(self + plane + e);
-    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
-    g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
-    h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
-  }
-  if (t.parent_slot >= 0) {
-    // self aliases the parent's storage: self = parent - sibling, cell by cell
-    const int64_t* sb = pool + (int64_t)t.sibling_slot * slot_words;
-    const longlong2* gs = reinterpret_cast<const longlong2*>(sb + e);
-    const longlong2* hs = reinterpret_cast<const longlong2*>(sb + plane + e);
-    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
-    g[0] -= g01.x; g[1] -= g01.y; g[2] -= g23.x; g[3] -= g23.y;
-    h[0] -= h01.x; h[1] -= h01.y; h[2] -= h23.x; h[3] -= h23.y;
-    longlong2* go = reinterpret_cast<longlong2*>(self + e);
-    longlong2* ho = reinterpret_cast<longlong2*>(self + plane + e);
-    go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
-    ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
-  }
-  const int nb = m.num_bin, mb = m.missing_bin;
-  const int vb = mb >= 0 ? nb - 1 : nb;
-  // stats of the missing-value bin, broadcast from the lane that holds it
-  int64_t mg = 0, mh = 0;
-  if (mb >= 0) {
-    const int j = mb & 3;
-    int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
-    int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
-    mg = shfl_i64(og, mb >> 2);
-    mh = shfl_i64(oh, mb >> 2);
-  }
-  // inclusive prefix inside the lane, exclusive prefix across lanes
-  g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
-  h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
-  int64_t ig = g[3], ih = h[3];
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    int64_t og = shfl_up_i64(ig, d), oh = shfl_up_i64(ih, d);
-    if (lane >= d) { ig += og; ih += oh; }
-  }
-  const int64_t eg = ig - g[3], eh = ih - h[3];
   const QuantScale q = *qs;
   const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp);
-  const int last = mb >= 0 ? vb - 1 : vb - 2;
+  const int64_t* sb = t.parent_slot >= 0 ? pool + (int64_t)t.sibling_slot * slot_words : nullptr;
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int thr = lane * 4 + j;
-    if (thr <= last) {
-      const int64_t lg = eg + g[j], lh = eh + h[j];
-      take_better(bg, bkey, blg, blh, split_gain(lg, lh, ctx, sp), cand_key(f, thr, 0), lg, lh);
-      if (mb >= 0 && thr <= vb - 2)
-        take_better(bg, bkey, blg, blh, split_gain(lg + mg, lh + mh, ctx, sp), cand_key(f, thr, 1), lg + mg, lh + mh);
-    }
-  }
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    double g2 = shfl_xor_f64(bg, msk);
-    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
-    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
-    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
-  }
+  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh);
   if (lane == 0) *out = Cand{bg, bkey, blg, blh};
 }
 
@@ -454,6 +523,69 @@ __global__ __launch_bounds__(64) void select_kernel(const ScanTaskDev* __restric
     const int64_t* nt = node_totals + (int64_t)tasks[s].node * 4;
     if (best_out) best_out[s] = Cand{bg, bkey, blg, blh};
     write_split(&out[s], bg, bkey, blg, blh, nt[0], nt[1], nt[2], *qs, sp);
+  }
+}
+
+// Fused scan + select for rounds handled without a host copy: one 16-wave workgroup per leaf walks
+// all features (wave w takes features w, w+16, ...), reduces the waves' winners through LDS and
+// writes the SplitInfo straight into host-mapped memory.  The workgroup that finishes last also
+// hands over the children's row counts and raises the round's completion flag, which the host polls.
+constexpr int kFusedWaves = 16;
+__global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
+    const SplitTask* __restrict__ tasks, InlineTasks inl, int n_scan, int n_tasks,
+    const FeatureMeta* __restrict__ meta, int F, int64_t* __restrict__ pool, int64_t slot_words, int64_t plane,
+    int64_t* __restrict__ node_totals, const QuantScale* __restrict__ qs, SplitParams sp,
+    const int32_t* __restrict__ task_left, char* __restrict__ host_out, unsigned* __restrict__ done_counter,
+    unsigned seq) {
+  __shared__ Cand wbest[kFusedWaves];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x;
+  const int ti = s >> 1, side = s & 1;
+  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
+  const bool direct = side == t.hist_child;
+  const int node = side == 0 ? t.left_node : t.right_node;
+  const int slot = direct ? t.new_slot : t.parent_slot;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  int64_t* self = pool + (int64_t)slot * slot_words;
+  const int64_t* sb = direct ? nullptr : pool + (int64_t)t.new_slot * slot_words;
+  int64_t tc, tg, th;
+  if (direct) {
+    const int64_t* hd = self + 2 * plane;
+    tc = hd[0]; tg = hd[1]; th = hd[2];
+  } else {
+    const int64_t* sh = sb + 2 * plane;
+    const int64_t* pt = node_totals + (int64_t)t.parent_node * 4;
+    tc = pt[0] - sh[0]; tg = pt[1] - sh[1]; th = pt[2] - sh[2];
+  }
+  const QuantScale q = *qs;
+  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp);
+  double bg = ninf;
+  uint64_t bkey = ~0ull;
+  int64_t blg = 0, blh = 0;
+  for (int f = wave; f < F; f += kFusedWaves) {
+    const FeatureMeta m = meta[f];
+    if (!m.enabled) continue;
+    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh);
+  }
+  if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kFusedWaves; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
+    int64_t* nt = node_totals + (int64_t)node * 4;
+    nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
+    SplitInfo* out = reinterpret_cast<SplitInfo*>(host_out + kHostDataOffset);
+    write_split(&out[s], bg, bkey, blg, blh, tc, tg, th, q, sp);
+    __threadfence_system();
+    const unsigned old = atomicAdd(done_counter, 1u);
+    if (old == (unsigned)(n_scan - 1)) {
+      int32_t* tl = reinterpret_cast<int32_t*>(host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
+      for (int i = 0; i < n_tasks; ++i) tl[i] = task_left[i];
+      QuantScale* qo = reinterpret_cast<QuantScale*>(tl + n_tasks);
+      *qo = q;
+      *done_counter = 0u;
+      __threadfence_system();
+      *reinterpret_cast<volatile unsigned*>(host_out) = seq;
+    }
   }
 }
 
@@ -620,27 +752,40 @@ void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, co
   LGA_LAUNCH_CHECK();
 }
 
-void partition(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, NodeRange* nodes,
-               const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint8_t* bins_fm,
-               int64_t N, uint64_t* mask, int32_t* chunk_left, int32_t* task_left, BagParams bag, hipStream_t s) {
+void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
+               bool any_multi_chunk, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst,
+               int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
+               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s) {
   if (total_chunks <= 0) return;
-  hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, nodes,
-                     a0_src, a1_src, bins_fm, N, mask, chunk_left, bag);
+  hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
+                     nodes, a0_src, a1_src, a0_dst, a1_dst, bins_fm, N, mask, chunk_left, task_left, bag, zero_ptr,
+                     zero_words);
   LGA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, nodes,
-                     a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left);
+  if (!any_multi_chunk) return;
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
+                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left);
   LGA_LAUNCH_CHECK();
 }
 
-void histogram(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, int rows_per_chunk,
-               const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
-               const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
-               int tile_step, int tile_count, hipStream_t s) {
+void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
+               int rows_per_chunk, const NodeRange* nodes, const int32_t* a0, const int32_t* a1,
+               const uint8_t* bins_rt, int64_t N, const int64_t* packed, int64_t* pool, int64_t slot_words,
+               int64_t plane, int F, int tile_first, int tile_step, int tile_count, hipStream_t s) {
   if (total_chunks <= 0 || tile_count <= 0) return;
   if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
-  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task,
+  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
                      rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, tile_first,
                      tile_step);
+  LGA_LAUNCH_CHECK();
+}
+
+void scan_fused(const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks, const FeatureMeta* meta, int F,
+                int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
+                const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned* done_counter, unsigned seq,
+                hipStream_t s) {
+  if (n_scan <= 0) return;
+  hipLaunchKernelGGL(scan_fused_kernel, dim3(n_scan), dim3(kFusedWaves * kWave), 0, s, tasks, inl, n_scan, n_tasks, meta,
+                     F, pool, slot_words, plane, node_totals, qs, sp, task_left, host_out, done_counter, seq);
   LGA_LAUNCH_CHECK();
 }
 

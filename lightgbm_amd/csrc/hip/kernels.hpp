@@ -12,6 +12,17 @@ constexpr int kPartChunk = 2048;    // rows per partition workgroup (256 threads
 constexpr int kPartThreads = 256;
 constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
 
+// Small rounds carry their task descriptors inside the kernel arguments.
+constexpr int kInlineTasks = 16;
+struct InlineTasks {
+  SplitTask t[kInlineTasks];
+  int32_t count;
+  int32_t pad[3];
+};
+// Host-mapped result block: [completion flag (64 B) | SplitInfo x n_scan | left counts x n_tasks | QuantScale].
+constexpr int kHostDataOffset = 64;
+constexpr int kFusedScanMaxFeatures = 512;
+
 // Best candidate of one (leaf, feature) pair.
 struct Cand {
   double gain;
@@ -52,11 +63,14 @@ void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, co
 
 // Partition (or bagging when task.feature < 0): a0/a1 are the two row-index buffers a node's `buf` selects.
 struct BagParams { uint64_t seed, iter, salt; float fraction; };
-void partition(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, NodeRange* nodes,
-               const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint8_t* bins_fm,
-               int64_t N, uint64_t* mask, int32_t* chunk_left, int32_t* task_left, BagParams bag, hipStream_t s);
+// tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.
+// zero_ptr/zero_words: int64 range the partition workgroups clear on the way (the round's new histogram slots).
+void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
+               bool any_multi_chunk, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst,
+               int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
+               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s);
 
-void histogram(const SplitTask* tasks, const int32_t* chunk_task, int total_chunks, int rows_per_chunk,
+void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks, int rows_per_chunk,
                const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
                const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
                int tile_step, int tile_count, hipStream_t s);
@@ -66,6 +80,11 @@ void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F,
           const SplitParams& sp, Cand* cands, hipStream_t s);
 void select(const ScanTaskDev* tasks, int n_tasks, int F, const Cand* cands, const int64_t* node_totals,
             const QuantScale* qs, const SplitParams& sp, SplitInfo* out, Cand* best_out, hipStream_t s);
+// Fused scan + select writing into host-mapped memory and raising the completion flag `seq`.
+void scan_fused(const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks, const FeatureMeta* meta, int F,
+                int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
+                const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned* done_counter, unsigned seq,
+                hipStream_t s);
 // Feature-parallel: merge P ranks' winners (gathered [rank][task]) into SplitInfo.
 void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskDev* tasks, const int64_t* node_totals,
                    const QuantScale* qs, const SplitParams& sp, SplitInfo* out, hipStream_t s);

@@ -37,7 +37,8 @@ int hip_run_op(const std::string& name, void** p, int nptr, const int64_t* a, in
     // ptrs: tasks, chunk_task, nodes, a0, a1, bins_rt, packed, pool
     // ints: total_chunks, rows_per_chunk, N, slot_words, plane, F, tile_first, tile_step, tile_count
     if (nptr < 8 || nint < 9) return -1;
-    k::histogram((const SplitTask*)p[0], (const int32_t*)p[1], (int)a[0], (int)a[1], (const NodeRange*)p[2],
+    k::InlineTasks none{};
+    k::histogram((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], (int)a[1], (const NodeRange*)p[2],
                  (const int32_t*)p[3], (const int32_t*)p[4], (const uint8_t*)p[5], a[2], (const int64_t*)p[6],
                  (int64_t*)p[7], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], s);
     return 0;
@@ -45,9 +46,10 @@ int hip_run_op(const std::string& name, void** p, int nptr, const int64_t* a, in
   if (name == "partition") {
     // ptrs: tasks, chunk_task, nodes, a0, a1, bins_fm, mask, chunk_left, task_left ; ints: total_chunks, N
     if (nptr < 9 || nint < 2) return -1;
-    k::partition((const SplitTask*)p[0], (const int32_t*)p[1], (int)a[0], (NodeRange*)p[2], (const int32_t*)p[3],
-                 (const int32_t*)p[4], (int32_t*)p[3], (int32_t*)p[4], (const uint8_t*)p[5], a[1], (uint64_t*)p[6],
-                 (int32_t*)p[7], (int32_t*)p[8], k::BagParams{0, 0, 0, 0.f}, s);
+    k::InlineTasks none{};
+    k::partition((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], a[0] > 1, (NodeRange*)p[2],
+                 (const int32_t*)p[3], (const int32_t*)p[4], (int32_t*)p[3], (int32_t*)p[4], (const uint8_t*)p[5], a[1],
+                 (uint64_t*)p[6], (int32_t*)p[7], (int32_t*)p[8], k::BagParams{0, 0, 0, 0.f}, nullptr, 0, s);
     return 0;
   }
   if (name == "scan") {
