@@ -149,13 +149,23 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
     NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint8_t* __restrict__ bins_fm, int64_t N,
     uint64_t* __restrict__ mask, int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, BagParams bag,
-    int64_t* __restrict__ zero_ptr, int64_t zero_words) {
+    int total_chunks, int64_t* __restrict__ zero_ptr, int64_t zero_words) {
   constexpr int kWords = kPartChunk / kWave;
   __shared__ unsigned long long smask[kWords];
   __shared__ int word_prefix[kWords + 1];
   const int wg = blockIdx.x;
-  for (int64_t i = (int64_t)wg * kPartThreads + threadIdx.x; i < zero_words; i += (int64_t)gridDim.x * kPartThreads)
-    zero_ptr[i] = 0;
+  if (wg >= total_chunks) {
+    // trailing workgroups only clear the round's new histogram slots (16 KiB each, 16-byte stores)
+    longlong2* z = reinterpret_cast<longlong2*>(zero_ptr);
+    const int64_t pairs = zero_words >> 1;
+    const int64_t base = (int64_t)(wg - total_chunks) * (kPartThreads * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t i = base + j * kPartThreads + threadIdx.x;
+      if (i < pairs) z[i] = make_longlong2(0, 0);
+    }
+    return;
+  }
   const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
   const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   const int c = wg - t.first_pchunk;
@@ -757,9 +767,11 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
                int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
                int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s) {
   if (total_chunks <= 0) return;
-  hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
-                     nodes, a0_src, a1_src, a0_dst, a1_dst, bins_fm, N, mask, chunk_left, task_left, bag, zero_ptr,
-                     zero_words);
+  // zero_words is even (slot sizes are); one trailing workgroup clears 1024 x 16 bytes
+  const int zero_blocks = (int)(((zero_words >> 1) + kPartThreads * 4 - 1) / (kPartThreads * 4));
+  hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks + zero_blocks), dim3(kPartThreads), 0, s, tasks,
+                     chunk_task, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, bins_fm, N, mask, chunk_left, task_left,
+                     bag, total_chunks, zero_ptr, zero_words);
   LGA_LAUNCH_CHECK();
   if (!any_multi_chunk) return;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,

@@ -1,0 +1,53 @@
+"""sklearn-style estimators and the key=value command line."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from lightgbm_amd.sklearn import LGBMClassifier, LGBMRandomForestRegressor, LGBMRegressor
+from lightgbm_amd.utils.datasets import make_curve_1d, make_regression
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_regressor_and_forest_follow_the_sklearn_protocol():
+    X, y = make_regression(3000, 6, seed=0)
+    m = LGBMRegressor(n_estimators=40, num_leaves=15, device_type="cpu").fit(X[:2400], y[:2400], eval_set=[(X[2400:], y[2400:])],
+                                                                          eval_metric="rmse", early_stopping_rounds=10)
+    assert m.score(X[2400:], y[2400:]) > 0.8 and m.feature_importances_.sum() > 0
+    assert "valid_0" in m.evals_result_ and m.get_params()["num_leaves"] == 15
+    xg, yg, xt, yt = make_curve_1d()
+    rf = LGBMRandomForestRegressor(n_estimators=100, num_leaves=20, min_child_samples=5, random_state=345,
+                                   device_type="cpu").fit(xt, yt)          # NBB:204
+    assert np.sqrt(np.mean((rf.predict(xg) - yg) ** 2)) < 0.08
+
+
+def test_classifier_probabilities_and_labels():
+    rng = np.random.RandomState(1)
+    X = rng.randn(2000, 5)
+    y = np.where(X[:, 0] + X[:, 1] > 0, "yes", "no")
+    c = LGBMClassifier(n_estimators=30, device_type="cpu").fit(X, y)
+    proba = c.predict_proba(X)
+    assert proba.shape == (2000, 2) and np.allclose(proba.sum(axis=1), 1)
+    assert set(c.predict(X)) <= {"yes", "no"} and np.mean(c.predict(X) == y) > 0.95
+
+
+def test_cli_train_predict_convert(tmp_path):
+    X, y = make_regression(1500, 4, seed=2)
+    data = str(tmp_path / "train.csv")
+    np.savetxt(data, np.column_stack([y, X]), delimiter=",")
+    model, pred, js = str(tmp_path / "m.txt"), str(tmp_path / "p.txt"), str(tmp_path / "m.json")
+    env = {**os.environ, "LGA_FORCE_HOST": "1", "PYTHONPATH": ROOT}
+    run = lambda *a: subprocess.run([sys.executable, "-m", "lightgbm_amd.cli", *a], cwd=ROOT, env=env, capture_output=True,
+                                    text=True, timeout=300)
+    r = run("task=train", f"data={data}", f"output_model={model}", "num_trees=20", "num_leaves=15", "verbose=-1",
+            "objective=regression")
+    assert r.returncode == 0, r.stderr
+    r = run("task=predict", f"data={data}", f"input_model={model}", f"output_result={pred}")
+    assert r.returncode == 0, r.stderr
+    p = np.loadtxt(pred)
+    assert np.corrcoef(p, y)[0, 1] > 0.9
+    r = run("task=convert_model", f"input_model={model}", f"convert_model={js}")
+    assert r.returncode == 0 and len(json.load(open(js))["tree_info"]) == 20
