@@ -79,6 +79,7 @@ const ParamDef kParams[] = {
     P(gpu_device_id, "", Int, kNone, kNone),
     P(max_batch_leaves, "", Int, 0, kNone),
     P(profile, "", Bool, kNone, kNone),
+    P(device_bin_find, "", Bool, kNone, kNone),
 };
 #pragma GCC diagnostic pop
 #undef P

@@ -70,6 +70,7 @@ struct Config {
   int gpu_device_id = 0;
   int max_batch_leaves = 0;   // 0: as many leaves per growth round as the budget allows
   bool profile = false;
+  bool device_bin_find = true;   // device-resident raw matrices: find bin boundaries on the GPU
 
   // Names of parameters that were explicitly set (after alias resolution).
   std::vector<std::string> explicit_keys;

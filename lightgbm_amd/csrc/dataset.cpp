@@ -101,6 +101,14 @@ std::shared_ptr<Dataset> Dataset::from_reference(const Dataset* ref, int64_t nro
   return ds;
 }
 
+std::shared_ptr<Dataset> Dataset::from_mappers(std::vector<BinMapper>&& mappers, int64_t nrow) {
+  auto ds = std::make_shared<Dataset>();
+  ds->root_rows_ = nrow;
+  ds->mappers_ = std::move(mappers);
+  ds->finish_mappers();
+  return ds;
+}
+
 void Dataset::bin_rows(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, uint8_t* rt, uint8_t* fm,
                        int64_t total_rows, int64_t row_offset) const {
   const Dataset* r = root();

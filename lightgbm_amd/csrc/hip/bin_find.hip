@@ -1,0 +1,244 @@
+// Quantile bin construction on the device (used when the raw matrix already
+// lives in HBM): per feature, sort the row sample, run-length encode it into
+// distinct values + counts, and cut it into <= max_bin bins.
+//
+//   1. sample_to_keys      sample [ns][F] -> order-preserving 64-bit keys [F][npad], NaN / padding = max key
+//   2. bitonic sort        blocks of 2048 keys are sorted in LDS; larger strides run as global
+//                          compare-exchange steps, every merge tail (stride <= 1024) again in LDS
+//   3. rle_and_cut         one workgroup per feature: head flags + block scan -> distinct[], counts[];
+//                          lane 0 then runs the SAME greedy routine as the host BinMapper
+//                          (binning_core.hpp), so host and device boundaries are bit-identical
+#include "hip_engine.hpp"
+#include "../binning_core.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace lga {
+
+namespace {
+
+constexpr int kSortBlock = 2048;     // keys per workgroup in the LDS phases
+constexpr int kSortThreads = 1024;
+
+__device__ __forceinline__ uint64_t key_of(double v) {
+  if (v != v) return ~0ull;
+  uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double value_of(uint64_t k) {
+  uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+// key(+inf); anything above is NaN or padding
+constexpr uint64_t kMaxValueKey = 0xfff0000000000000ull;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_to_keys_kernel(const T* __restrict__ sample, int64_t ns, int ncol,
+                                                             int f0, int nf, int64_t npad,
+                                                             uint64_t* __restrict__ keys) {
+  const int f = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t k = ~0ull;
+    if (i < ns) {
+      double v = (double)sample[i * ncol + f0 + f];
+      if (v == 0.0) v = 0.0;   // -0.0 and +0.0 are one value
+      k = key_of(v);
+    }
+    keys[(int64_t)f * npad + i] = k;
+  }
+  (void)nf;
+}
+
+__device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
+  if ((a > b) == up) { uint64_t t = a; a = b; b = t; }
+}
+
+// Sorts every 2048-key block completely (k = 2 .. 2048) in LDS.
+__global__ __launch_bounds__(kSortThreads) void bitonic_block_sort_kernel(uint64_t* __restrict__ keys, int64_t npad) {
+  __shared__ uint64_t s[kSortBlock];
+  uint64_t* base = keys + (int64_t)blockIdx.y * npad + (int64_t)blockIdx.x * kSortBlock;
+  const int t = threadIdx.x;
+  s[t] = base[t];
+  s[t + kSortThreads] = base[t + kSortThreads];
+  __syncthreads();
+  const int64_t g0 = (int64_t)blockIdx.x * kSortBlock;
+  for (int k = 2; k <= kSortBlock; k <<= 1) {
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      const int i = ((t / j) * 2 * j) + (t % j);      // lower index of the pair
+      const bool up = (((g0 + i) & k) == 0);
+      uint64_t a = s[i], b = s[i + j];
+      cmp_swap(a, b, up);
+      s[i] = a; s[i + j] = b;
+      __syncthreads();
+    }
+  }
+  base[t] = s[t];
+  base[t + kSortThreads] = s[t + kSortThreads];
+}
+
+// One global compare-exchange step of stage k with stride j (j >= 2048).
+__global__ __launch_bounds__(256) void bitonic_global_step_kernel(uint64_t* __restrict__ keys, int64_t npad, int64_t j,
+                                                                  int64_t k) {
+  uint64_t* base = keys + (int64_t)blockIdx.y * npad;
+  const int64_t half = npad >> 1;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = ((t / j) * 2 * j) + (t % j);
+    const bool up = ((i & k) == 0);
+    uint64_t a = base[i], b = base[i + j];
+    if ((a > b) == up) { base[i] = b; base[i + j] = a; }
+  }
+}
+
+// Tail of stage k: strides 1024 .. 1 inside each 2048-key block, in LDS.
+__global__ __launch_bounds__(kSortThreads) void bitonic_block_merge_kernel(uint64_t* __restrict__ keys, int64_t npad,
+                                                                           int64_t k) {
+  __shared__ uint64_t s[kSortBlock];
+  uint64_t* base = keys + (int64_t)blockIdx.y * npad + (int64_t)blockIdx.x * kSortBlock;
+  const int t = threadIdx.x;
+  s[t] = base[t];
+  s[t + kSortThreads] = base[t + kSortThreads];
+  __syncthreads();
+  const int64_t g0 = (int64_t)blockIdx.x * kSortBlock;
+  for (int j = kSortBlock >> 1; j >= 1; j >>= 1) {
+    const int i = ((t / j) * 2 * j) + (t % j);
+    const bool up = (((g0 + i) & k) == 0);
+    uint64_t a = s[i], b = s[i + j];
+    cmp_swap(a, b, up);
+    s[i] = a; s[i + j] = b;
+    __syncthreads();
+  }
+  base[t] = s[t];
+  base[t + kSortThreads] = s[t + kSortThreads];
+}
+
+struct FeatureBins {      // result record per feature
+  int32_t n_bounds;       // inclusive upper bounds written (last = +inf)
+  int32_t n_nan;          // NaN rows in the sample
+  int32_t n_distinct;
+  int32_t pad;
+  double min_val, max_val;
+};
+
+__global__ __launch_bounds__(256) void rle_and_cut_kernel(const uint64_t* __restrict__ keys, int64_t npad, int64_t ns,
+                                                          double* __restrict__ distinct, int32_t* __restrict__ counts,
+                                                          int max_bin, int min_data_in_bin, int use_missing,
+                                                          double* __restrict__ bounds, FeatureBins* __restrict__ out) {
+  __shared__ int s_cnt[256];
+  __shared__ int s_total;
+  const int f = blockIdx.x, t = threadIdx.x;
+  const uint64_t* k = keys + (int64_t)f * npad;
+  double* dv = distinct + (int64_t)f * ns;
+  int32_t* dc = counts + (int64_t)f * ns;
+  // valid (non-NaN) prefix length: keys are sorted, NaN / padding sit at the end
+  int local = 0;
+  for (int64_t i = t; i < ns; i += 256) local += (k[i] <= kMaxValueKey) ? 1 : 0;
+  s_cnt[t] = local;
+  __syncthreads();
+  if (t == 0) { int s = 0; for (int i = 0; i < 256; ++i) s += s_cnt[i]; s_total = s; }
+  __syncthreads();
+  const int64_t nv = s_total;
+  __syncthreads();
+  // heads per contiguous segment
+  const int64_t seg = (nv + 255) / 256;
+  const int64_t lo = (int64_t)t * seg, hi = lo + seg < nv ? lo + seg : nv;
+  int heads = 0;
+  for (int64_t i = lo; i < hi; ++i) heads += (i == 0 || k[i] != k[i - 1]) ? 1 : 0;
+  s_cnt[t] = heads;
+  __syncthreads();
+  if (t == 0) { int s = 0; for (int i = 0; i < 256; ++i) { int c = s_cnt[i]; s_cnt[i] = s; s += c; } s_total = s; }
+  __syncthreads();
+  int pos = s_cnt[t];
+  const int nd = s_total;
+  // distinct values + the index of each head (stored in counts[] for now)
+  for (int64_t i = lo; i < hi; ++i) {
+    if (i == 0 || k[i] != k[i - 1]) { dv[pos] = value_of(k[i]); dc[pos] = (int32_t)i; ++pos; }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // head positions -> run lengths (read the neighbour before anyone overwrites: two phases)
+  int32_t tmp[1];
+  (void)tmp;
+  for (int base = 0; base < nd; base += 256) {
+    const int d = base + t;
+    int32_t c = 0;
+    if (d < nd) c = (d + 1 < nd ? dc[d + 1] : (int32_t)nv) - dc[d];
+    __syncthreads();
+    if (d < nd) dc[d] = c;
+    __syncthreads();
+  }
+  if (t == 0) {
+    const int n_nan = (int)(ns - nv);
+    int value_bins = max_bin - ((use_missing && n_nan > 0) ? 1 : 0);
+    if (value_bins < 1) value_bins = 1;
+    FeatureBins r;
+    r.n_bounds = greedy_bounds_core(dv, dc, nd, value_bins, nv, min_data_in_bin, bounds + (int64_t)f * (kMaxBins + 1));
+    r.n_nan = n_nan;
+    r.n_distinct = nd;
+    r.pad = 0;
+    r.min_val = nd > 0 ? dv[0] : 0.0;
+    r.max_val = nd > 0 ? dv[nd - 1] : 0.0;
+    out[f] = r;
+  }
+}
+
+int64_t next_pow2(int64_t n) { int64_t p = kSortBlock; while (p < n) p <<= 1; return p; }
+
+}  // namespace
+
+// sample: device memory, row-major [ns][ncol]; returns one BinMapper per column.
+std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, int64_t ns, int ncol, const Config& cfg) {
+  hipStream_t s = current_stream();
+  std::vector<BinMapper> mappers((size_t)ncol);
+  if (ns <= 0) return mappers;
+  const int64_t npad = next_pow2(ns);
+  const int batch = std::max(1, std::min(ncol, (int)std::max<int64_t>(1, (int64_t)(1ll << 27) / npad)));   // <= 1 GiB of keys
+  DeviceBuffer<uint64_t> keys((size_t)batch * (size_t)npad);
+  DeviceBuffer<double> distinct((size_t)batch * (size_t)ns);
+  DeviceBuffer<int32_t> counts((size_t)batch * (size_t)ns);
+  DeviceBuffer<double> bounds((size_t)batch * (kMaxBins + 1));
+  DeviceBuffer<FeatureBins> res((size_t)batch);
+  std::vector<double> h_bounds((size_t)batch * (kMaxBins + 1));
+  std::vector<FeatureBins> h_res((size_t)batch);
+  for (int f0 = 0; f0 < ncol; f0 += batch) {
+    const int nf = std::min(batch, ncol - f0);
+    dim3 g1((unsigned)std::min<int64_t>((npad + 255) / 256, 1024), (unsigned)nf);
+    if (dtype == 0)
+      hipLaunchKernelGGL(sample_to_keys_kernel<float>, g1, dim3(256), 0, s, (const float*)dev_sample, ns, ncol, f0, nf, npad, keys.get());
+    else
+      hipLaunchKernelGGL(sample_to_keys_kernel<double>, g1, dim3(256), 0, s, (const double*)dev_sample, ns, ncol, f0, nf, npad, keys.get());
+    LGA_HIP_CHECK(hipGetLastError());
+    dim3 gb((unsigned)(npad / kSortBlock), (unsigned)nf);
+    hipLaunchKernelGGL(bitonic_block_sort_kernel, gb, dim3(kSortThreads), 0, s, keys.get(), npad);
+    LGA_HIP_CHECK(hipGetLastError());
+    for (int64_t k = (int64_t)kSortBlock * 2; k <= npad; k <<= 1) {
+      for (int64_t j = k >> 1; j >= kSortBlock; j >>= 1) {
+        dim3 gg((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 2048), (unsigned)nf);
+        hipLaunchKernelGGL(bitonic_global_step_kernel, gg, dim3(256), 0, s, keys.get(), npad, j, k);
+        LGA_HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(bitonic_block_merge_kernel, gb, dim3(kSortThreads), 0, s, keys.get(), npad, k);
+      LGA_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(rle_and_cut_kernel, dim3((unsigned)nf), dim3(256), 0, s, keys.get(), npad, ns, distinct.get(),
+                       counts.get(), cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing ? 1 : 0, bounds.get(), res.get());
+    LGA_HIP_CHECK(hipGetLastError());
+    LGA_HIP_CHECK(hipMemcpyAsync(h_bounds.data(), bounds.get(), sizeof(double) * (size_t)nf * (kMaxBins + 1), hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipMemcpyAsync(h_res.data(), res.get(), sizeof(FeatureBins) * (size_t)nf, hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < nf; ++i) {
+      const FeatureBins& r = h_res[(size_t)i];
+      BinMapper& m = mappers[(size_t)(f0 + i)];
+      m.upper.assign(h_bounds.begin() + (size_t)i * (kMaxBins + 1), h_bounds.begin() + (size_t)i * (kMaxBins + 1) + r.n_bounds);
+      int nv = (int)m.upper.size();
+      m.missing = (cfg.use_missing && r.n_nan > 0) ? MissingType::NaN : MissingType::None;
+      if (m.missing == MissingType::NaN) { m.missing_bin = nv; m.num_bin = nv + 1; }
+      else { m.missing_bin = -1; m.num_bin = nv; }
+      m.min_val = r.min_val;
+      m.max_val = r.max_val;
+      m.trivial = m.num_bin <= 1;
+    }
+  }
+  return mappers;
+}
+
+}  // namespace lga

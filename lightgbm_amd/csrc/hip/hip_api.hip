@@ -46,8 +46,8 @@ int lga_hip_device_info(int* cus, int64_t* mem_bytes, int* lds_bytes) {
   });
 }
 
-// Raw matrix already in device memory (row-major): sample on the device, find bins on the host,
-// bin on the device.
+// Raw matrix already in device memory (row-major): sample, find bin boundaries and bin on the device
+// (device_bin_find=false moves the boundary search to the host; both give the same boundaries).
 int lga_hip_dataset_from_device_mat(const void* dev_data, int dtype, int64_t nrow, int ncol, const char* params,
                                     LgaDataset reference, LgaDataset* out) {
   return hguard([&] {
@@ -72,7 +72,7 @@ int lga_hip_dataset_from_device_mat(const void* dev_data, int dtype, int64_t nro
       }
       int64_t ns = (int64_t)rows.size();
       const size_t esz = dtype == 0 ? 4 : 8;
-      std::vector<char> host_rows((size_t)ns * (size_t)ncol * esz);
+      std::vector<char> host_rows(cfg.device_bin_find ? 0 : (size_t)ns * (size_t)ncol * esz);
       // contiguous runs are rare in a random sample: copy row by row in batches through a strided 2-D copy
       // (hipMemcpy2D cannot gather), so gather on the device first
       DeviceBuffer<int64_t> d_idx((size_t)std::max<int64_t>(ns, 1));
@@ -81,12 +81,16 @@ int lga_hip_dataset_from_device_mat(const void* dev_data, int dtype, int64_t nro
       void* ptrs[3] = {(void*)dev_data, d_idx.get(), d_rows.get()};
       int64_t ints[3] = {ns, (int64_t)ncol * (int64_t)esz, 0};
       if (hip_run_op("gather_rows_bytes", ptrs, 3, ints, 3) != 0) throw std::runtime_error("gather_rows_bytes failed");
-      LGA_HIP_CHECK(hipMemcpyAsync(host_rows.data(), d_rows.get(), host_rows.size(), hipMemcpyDeviceToHost, s));
-      LGA_HIP_CHECK(hipStreamSynchronize(s));
-      std::vector<double> sample((size_t)ns * (size_t)ncol);
-      for (size_t i = 0; i < sample.size(); ++i)
-        sample[i] = dtype == 0 ? (double)((const float*)host_rows.data())[i] : ((const double*)host_rows.data())[i];
-      ds = Dataset::from_sample(sample.data(), ns, ncol, nrow, cfg);
+      if (cfg.device_bin_find) {
+        ds = Dataset::from_mappers(find_bins_on_device(d_rows.get(), dtype, ns, ncol, cfg), nrow);
+      } else {
+        LGA_HIP_CHECK(hipMemcpyAsync(host_rows.data(), d_rows.get(), host_rows.size(), hipMemcpyDeviceToHost, s));
+        LGA_HIP_CHECK(hipStreamSynchronize(s));
+        std::vector<double> sample((size_t)ns * (size_t)ncol);
+        for (size_t i = 0; i < sample.size(); ++i)
+          sample[i] = dtype == 0 ? (double)((const float*)host_rows.data())[i] : ((const double*)host_rows.data())[i];
+        ds = Dataset::from_sample(sample.data(), ns, ncol, nrow, cfg);
+      }
     }
     bin_device_matrix(ds.get(), dev_data, dtype, nrow, ncol);
     *out = new DatasetBox{ds};

@@ -16,6 +16,9 @@ DeviceMirror* ensure_device_mirror(const Dataset* root);
 void download_bins_to_host(Dataset* ds);
 // Bins a raw matrix that already lives in device memory (row-major) into `ds`' mirror.
 void bin_device_matrix(const Dataset* ds, const void* dev_data, int dtype, int64_t nrow, int ncol);
+// Bin boundaries of every column of a row-major DEVICE sample [ns][ncol] (bin_find.hip); equal to
+// BinMapper::find_bins on the same sample.
+std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, int64_t ns, int ncol, const Config& cfg);
 // Streams a host matrix through the device binning kernel into `ds`' mirror.
 void bin_host_matrix_on_device(const Dataset* ds, const void* data, int dtype, int64_t nrow, int ncol, bool row_major);
 

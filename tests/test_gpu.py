@@ -159,6 +159,36 @@ def test_device_binning_equals_host_binning():
     np.testing.assert_array_equal(dt.get_bins(), dc.get_bins())
 
 
+@pytest.mark.parametrize("n,sample,dtype", [(1500, 200000, np.float64), (50000, 200000, np.float32),
+                                            (120000, 30000, np.float64)])
+def test_device_bin_boundaries_equal_host_boundaries(n, sample, dtype):
+    """Device sort + run-length encode + greedy cut gives bit-identical bounds to the host BinMapper."""
+    import torch
+    rng = np.random.RandomState(n)
+    X = rng.randn(n, 11)
+    X[:, 1] = rng.randint(-3, 4, n)                    # few distinct values, negative and zero
+    X[:, 2] = np.round(rng.exponential(1.0, n), 1)     # heavy ties
+    X[::7, 3] = np.nan
+    X[:, 4] = -2.5                                     # constant
+    X[:, 5] = rng.randint(0, 2, n) * 1e30
+    X[:, 6] = np.where(rng.rand(n) < 0.9, 0.0, rng.randn(n))   # mostly one value
+    X[::5, 7] = np.nan
+    X[1::5, 7] = 3.0
+    X[:, 8] = rng.randint(0, 1000, n)                  # more distinct values than bins
+    X = X.astype(dtype)
+    t = torch.from_numpy(X).cuda()
+    base = {**GPU, "bin_construct_sample_cnt": sample, "max_bin": 255, "min_data_in_bin": 3}
+    dd = lgb.Dataset(t, label=np.zeros(n), params={**base, "device_bin_find": True}).construct()
+    dh = lgb.Dataset(t, label=np.zeros(n), params={**base, "device_bin_find": False}).construct()
+    for f in range(X.shape[1]):
+        a, b = dd.bin_info(f), dh.bin_info(f)
+        assert a["num_bin"] == b["num_bin"] and a["missing_bin"] == b["missing_bin"], f
+        np.testing.assert_array_equal(a["upper_bounds"], b["upper_bounds"])
+    np.testing.assert_array_equal(dd.get_bins(), dh.get_bins())
+    small = lgb.Dataset(t, label=np.zeros(n), params={**base, "max_bin": 16}).construct()
+    assert max(small.bin_info(f)["num_bin"] for f in range(X.shape[1])) <= 16
+
+
 # ----------------------------------------------------------------------------- engine parity
 @pytest.mark.parametrize("params", [
     {"num_leaves": 31},
