@@ -35,7 +35,7 @@ struct EntryLess {
 inline bool splittable(const SplitInfo& s) { return s.feature >= 0 && std::isfinite(s.gain); }
 }  // namespace
 
-Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<int32_t>* leaf_nodes) {
+Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces) {
   stats_ = GrowStats();
   const SplitParams sp = split_params();
   be.begin_tree(meta, sp);
@@ -81,20 +81,30 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
       push(n.right);
       continue;
     }
-    // Stall: materialise every frontier leaf that can still be reached.
-    int limit = budget;
+    // Stall: continue the replay VIRTUALLY over everything that is known - leaves that are already
+    // partitioned hand over their children - and split every leaf it reaches that is not
+    // partitioned yet, all in one backend round.
     int pool_room = capacity_splits - materialized - (budget - 1);
     if (pool_room < 1) throw std::runtime_error("tree grower ran out of node capacity");
-    int max_new = std::min(limit, pool_room);
+    int max_new = std::min(budget, pool_room);
     if (cfg_.max_batch_leaves > 0) max_new = std::min(max_new, cfg_.max_batch_leaves);
-    std::vector<Entry> popped;
+    auto virt = frontier;
+    int vseq = seq;
+    int vbudget = budget;
     tasks.clear();
-    while (!frontier.empty() && (int)popped.size() < limit && (int)tasks.size() < max_new) {
-      Entry e = frontier.top();
-      frontier.pop();
-      popped.push_back(e);
+    while (!virt.empty() && vbudget > 0 && (int)tasks.size() < max_new) {
+      Entry e = virt.top();
+      virt.pop();
+      --vbudget;
       Node& c = nodes[(size_t)e.node];
-      if (c.left >= 0) continue;   // materialised earlier, waiting for its turn
+      if (c.left >= 0) {
+        for (int child : {c.left, c.right}) {
+          const SplitInfo& s = nodes[(size_t)child].best;
+          if (splittable(s)) virt.push(Entry{s.gain, vseq, child});
+          ++vseq;
+        }
+        continue;
+      }
       SplitTask t{};
       t.parent_node = e.node;
       t.left_node = (int)nodes.size();
@@ -119,7 +129,6 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
       nodes.push_back(r);
       tasks.push_back(t);
     }
-    for (const Entry& e : popped) frontier.push(e);
     infos.assign(tasks.size() * 2, SplitInfo{});
     be.split_round(tasks, infos.data());
     ++stats_.rounds;
@@ -140,7 +149,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   tree.reset(cfg_.num_leaves);
   std::vector<int> leaf_of_node(nodes.size(), -1);
   leaf_of_node[0] = 0;
-  leaf_nodes->assign(1, 0);
+  std::vector<int32_t> leaf_nodes(1, 0);
   {
     const SplitInfo& r = nodes[0].best;
     double G = (double)r.total_g * gunit, H = (double)r.total_h * hunit;
@@ -167,8 +176,22 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
                                 lc, rc, lh, rh);
     leaf_of_node[(size_t)n.left] = leaf;
     leaf_of_node[(size_t)n.right] = right_leaf;
-    (*leaf_nodes)[(size_t)leaf] = n.left;
-    leaf_nodes->push_back(n.right);
+    leaf_nodes[(size_t)leaf] = n.left;
+    leaf_nodes.push_back(n.right);
+  }
+  // Rows of a final leaf: a leaf that was partitioned speculatively (its split never got its turn)
+  // has its rows in the ranges of its deepest partitioned descendants.
+  pieces->clear();
+  std::vector<int> stack;
+  for (size_t l = 0; l < leaf_nodes.size(); ++l) {
+    stack.assign(1, leaf_nodes[l]);
+    while (!stack.empty()) {
+      int id = stack.back();
+      stack.pop_back();
+      const Node& n = nodes[(size_t)id];
+      if (n.left < 0) pieces->push_back(LeafPiece{id, (int32_t)l});
+      else { stack.push_back(n.right); stack.push_back(n.left); }
+    }
   }
   return tree;
 }

@@ -5,13 +5,15 @@
 // Strict best-first growth is a chain of num_leaves-1 dependent steps.  Here
 // the chain is replayed on the host over split gains that are already known,
 // and it only stalls when the next leaf to split has not been partitioned /
-// histogrammed yet.  At a stall, every frontier leaf that could still be
-// reached with the remaining budget (the top-R by gain) is split in ONE
-// batched backend round.  A leaf is only ever materialised when its parent's
-// split is final, so speculation never corrupts row ranges, and the replay
-// keeps exactly the splits strict best-first would have made - the tree is
-// identical, the number of device round trips drops from num_leaves-1 to
-// roughly the tree depth.
+// histogrammed yet.  At a stall the replay is continued virtually over every
+// gain that is known - leaves that are already partitioned contribute their
+// children - and every leaf this virtual replay reaches within the remaining
+// budget is split in ONE batched backend round.  Speculation only decides
+// WHAT is computed early: the real replay keeps exactly the splits strict
+// best-first would have made, so the tree is identical, while the number of
+// device round trips drops from num_leaves-1 to roughly the tree depth.  A
+// leaf whose speculative split never gets its turn stays a leaf; its rows are
+// then found in the ranges of its partitioned descendants (LeafPiece).
 #pragma once
 #include "backend.hpp"
 #include "config.hpp"
@@ -20,6 +22,12 @@
 #include <vector>
 
 namespace lga {
+
+// Rows [range of `node`] belong to final leaf `leaf`.
+struct LeafPiece {
+  int32_t node;
+  int32_t leaf;
+};
 
 struct GrowStats {
   int rounds = 0;
@@ -30,9 +38,9 @@ struct GrowStats {
 class TreeGrower {
  public:
   TreeGrower(const Config& cfg, const Dataset* ds);
-  // Grows one tree (leaf values NOT yet shrunk).  leaf_nodes[l] = backend node
-  // id that holds the rows of leaf l.
-  Tree grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<int32_t>* leaf_nodes);
+  // Grows one tree (leaf values NOT yet shrunk).  `pieces` lists the backend
+  // nodes whose row ranges make up each leaf.
+  Tree grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces);
   const GrowStats& last_stats() const { return stats_; }
   SplitParams split_params() const;
 

@@ -53,6 +53,7 @@ struct PhaseProfile {
   double ms[kCount] = {0, 0, 0, 0, 0, 0};
   double host_ms = 0;
   int64_t rounds = 0, trees = 0, tasks = 0;
+  int64_t part_rows = 0, hist_rows = 0;   // rows partitioned / rows accumulated into histograms (without the roots)
   hipEvent_t ev[kCount + 1];
   bool created = false;
   void init() {
@@ -71,7 +72,8 @@ struct PhaseProfile {
   ~PhaseProfile() { if (created) for (auto& e : ev) (void)hipEventDestroy(e); }
   std::string json() const {
     std::ostringstream os;
-    os << "{\"rounds\":" << rounds << ",\"trees\":" << trees << ",\"split_tasks\":" << tasks << ",\"upload_ms\":" << ms[kUpload]
+    os << "{\"rounds\":" << rounds << ",\"trees\":" << trees << ",\"split_tasks\":" << tasks << ",\"partition_rows\":" << part_rows
+       << ",\"hist_rows\":" << hist_rows << ",\"upload_ms\":" << ms[kUpload]
        << ",\"partition_ms\":" << ms[kPartition] << ",\"hist_ms\":" << ms[kHist] << ",\"comm_ms\":" << ms[kComm]
        << ",\"scan_ms\":" << ms[kScan] << ",\"fetch_ms\":" << ms[kFetch] << "}";
     return os.str();
@@ -362,6 +364,8 @@ class HipBackend : public TreeBackend {
       for (int i = 0; i < B; ++i) {
         const SplitTask& t = tasks[(size_t)i];
         const NodeRange p = ranges_host_[(size_t)t.parent_node];
+        prof.part_rows += p.count;
+        prof.hist_rows += t.hist_child == 0 ? tl[i] : p.count - tl[i];
         ranges_host_[(size_t)t.left_node] = NodeRange{p.begin, tl[i], 1 - p.buf, 0};
         ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
       }
@@ -561,11 +565,11 @@ class HipEngine : public Engine {
   }
 
   void add_trained_tree_to_train_scores(const Tree& tree) override {
-    int L = tree.num_leaves;
+    int L = (int)leaf_nodes_.size();
     std::vector<k::LeafSpan> spans((size_t)L);
     for (int l = 0; l < L; ++l) {
-      const NodeRange& r = backend_->range(leaf_nodes_[(size_t)l]);
-      spans[(size_t)l] = k::LeafSpan{r.begin, r.begin + r.count, r.buf, 0, tree.leaf_value[(size_t)l]};
+      const NodeRange& r = backend_->range(leaf_nodes_[(size_t)l].node);
+      spans[(size_t)l] = k::LeafSpan{r.begin, r.begin + r.count, r.buf, 0, tree.leaf_value[(size_t)leaf_nodes_[(size_t)l].leaf]};
     }
     std::sort(spans.begin(), spans.end(), [](const k::LeafSpan& a, const k::LeafSpan& b) {
       if (a.begin != b.begin) return a.begin < b.begin;
@@ -729,7 +733,7 @@ class HipEngine : public Engine {
   hipEvent_t upload_ev_ = nullptr;
   bool upload_pending_ = false;
   bool has_init_ = false, have_max_ = false;
-  std::vector<int32_t> leaf_nodes_;
+  std::vector<LeafPiece> leaf_nodes_;
   std::vector<std::unique_ptr<Valid>> valid_;
 };
 

@@ -421,10 +421,10 @@ class HostEngine : public Engine {
   }
 
   void add_trained_tree_to_train_scores(const Tree& tree) override {
-    for (int l = 0; l < tree.num_leaves; ++l) {
-      const NodeRange& r = backend_.range(leaf_nodes_[(size_t)l]);
+    for (const LeafPiece& pc : leaf_nodes_) {
+      const NodeRange& r = backend_.range(pc.node);
       const int32_t* rows = backend_.arena(r.buf) + r.begin;
-      double v = tree.leaf_value[(size_t)l];
+      double v = tree.leaf_value[(size_t)pc.leaf];
       for (int32_t i = 0; i < r.count; ++i) scores_[(size_t)rows[i]] += v;
     }
     if (!oob_.empty()) traverse_add(train_->root(), oob_, scores_, tree, 1.0);
@@ -492,7 +492,7 @@ class HostEngine : public Engine {
   std::vector<double> scores_;
   std::vector<float> grad_, hess_;
   std::vector<int64_t> packed_;
-  std::vector<int32_t> leaf_nodes_;
+  std::vector<LeafPiece> leaf_nodes_;
   std::vector<int32_t> missing_bin_;
   std::vector<Valid> valid_;
 };
