@@ -6,6 +6,7 @@
 #include "../metric.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <sstream>
@@ -461,10 +462,8 @@ class HipEngine : public Engine {
     bag_ptr_ = base_rows_.get();
     bag_n_ = n_base_;
     oob_n_ = 0;
-    int F = train_->num_features();
-    std::vector<int32_t> mb((size_t)std::max(F, 1), -1);
-    for (int f = 0; f < F; ++f) mb[(size_t)f] = train_->inner_mapper(f).missing_bin;
-    missing_bin_dev_.upload(mb.data(), mb.size(), stream_);
+    if (const char* e = std::getenv("LGA_SCORE_UPDATE"))
+      score_update_ = std::string(e) == "leaf" ? 1 : (std::string(e) == "walk" ? 2 : 0);
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
 
@@ -509,22 +508,22 @@ class HipEngine : public Engine {
   }
 
   void reset_scores(double v) override {
-    k::init_scores(scores_.get(), has_init_ ? init_score_dev_.get() : nullptr, base_rows_.get(), n_base_, v, stream_);
+    k::init_scores(scores_.get(), has_init_ ? init_score_dev_.get() : nullptr, base_or_null(), n_base_, v, stream_);
     for (auto& vs : valid_)
       k::init_scores(score_ptr(*vs), (vs->has_init ? vs->init.get() : (vs->shared_scores && has_init_ ? init_score_dev_.get() : nullptr)),
                      vs->rows.get(), vs->n, v, stream_);
   }
   void scale_scores(int which, double f) override {
-    if (which < 0) k::scale_add(scores_.get(), base_rows_.get(), n_base_, f, 0.0, stream_);
+    if (which < 0) k::scale_add(scores_.get(), base_or_null(), n_base_, f, 0.0, stream_);
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, f, 0.0, stream_); }
   }
   void add_constant(int which, double c) override {
-    if (which < 0) k::scale_add(scores_.get(), base_rows_.get(), n_base_, 1.0, c, stream_);
+    if (which < 0) k::scale_add(scores_.get(), base_or_null(), n_base_, 1.0, c, stream_);
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, 1.0, c, stream_); }
   }
 
   void compute_gradients(const ObjectiveSpec& obj) override {
-    k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_rows_.get(), n_base_, grad_.get(),
+    k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_or_null(), n_base_, grad_.get(),
                  hess_.get(), maxbits_.get(), stream_);
     have_max_ = true;
   }
@@ -556,15 +555,24 @@ class HipEngine : public Engine {
   }
 
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
-    if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_rows_.get(), n_base_, maxbits_.get(), stream_);
+    if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
-    k::quantize(grad_.get(), hess_.get(), bag_ptr_, bag_n_, maxbits_.get(), backend_->qs_device(), packed_.get(), stream_);
+    k::quantize(grad_.get(), hess_.get(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
+                backend_->qs_device(), packed_.get(), stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
     backend_->set_packed(packed_.get());
     return grower_.grow(*backend_, meta, &leaf_nodes_);
   }
 
+  // The new tree's leaf values reach the training scores either through the leaf row ranges the grower
+  // left behind (a scattered read-modify-write per row) or by walking the tree over the binned rows in
+  // storage order (coalesced scores, ~depth one-byte bin reads per row).  Large row sets favour the walk.
   void add_trained_tree_to_train_scores(const Tree& tree) override {
+    const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
+    if (walk) {
+      traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, scores_.get());
+      return;
+    }
     int L = (int)leaf_nodes_.size();
     std::vector<k::LeafSpan> spans((size_t)L);
     for (int l = 0; l < L; ++l) {
@@ -582,21 +590,18 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
     mark_upload();
     k::leaf_add(span_dev_.get(), L, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(), stream_);
-    if (oob_n_ > 0) {
-      k::TreeDev td = upload_tree(tree);
-      k::traverse_add(td, mir_->bins_fm.get(), N_, missing_bin_dev_.get(), bag_ptr_ + bag_n_, oob_n_, 1.0, scores_.get(), stream_);
-    }
+    if (oob_n_ > 0) traverse(upload_tree(tree), mir_, N_, bag_ptr_ + bag_n_, oob_n_, 1.0, scores_.get());
   }
 
   void add_tree_by_traversal(int which, const Tree& tree, double sign) override {
     if (tree.num_leaves > 1 && (tree.split_feature_inner.empty() || tree.split_feature_inner[0] < 0))
       throw std::runtime_error("tree has no bin thresholds (loaded from a model file); cannot traverse binned data");
-    k::TreeDev td = upload_tree(tree);
+    const TreeOnDevice td = upload_tree(tree);
     if (which < 0) {
-      k::traverse_add(td, mir_->bins_fm.get(), N_, missing_bin_dev_.get(), base_rows_.get(), n_base_, sign, scores_.get(), stream_);
+      traverse(td, mir_, N_, base_or_null(), n_base_, sign, scores_.get());
     } else {
       auto& v = *valid_[(size_t)which];
-      k::traverse_add(td, v.mir->bins_fm.get(), v.N, missing_bin_dev_.get(), v.rows.get(), v.n, sign, score_ptr(v), stream_);
+      traverse(td, v.mir, v.N, v.ds->used_indices() ? v.rows.get() : nullptr, v.n, sign, score_ptr(v));
     }
   }
 
@@ -682,33 +687,50 @@ class HipEngine : public Engine {
     upload_pending_ = true;
   }
 
-  k::TreeDev upload_tree(const Tree& tree) {
-    int L = tree.num_leaves, ni = L - 1;
-    size_t ints = (size_t)std::max(ni, 1) * 5;
-    size_t bytes = ((ints * sizeof(int32_t) + 7) & ~(size_t)7) + sizeof(double) * (size_t)L;
-    wait_upload();
-    tree_host_.resize(bytes);
-    tree_dev_.resize(bytes);
-    int32_t* ip = reinterpret_cast<int32_t*>(tree_host_.get());
-    size_t stride = (size_t)std::max(ni, 1);
+  // Device copy of a tree for binned traversal: [TreeNodeDev x (L-1) | leaf values x L].  The same tree is
+  // usually applied to several score vectors in a row (out-of-bag rows, every validation set), so the
+  // upload is skipped when the packed bytes have not changed.
+  struct TreeOnDevice {
+    const k::TreeNodeDev* nodes;
+    const double* leaf_value;
+    int n_internal, num_leaves;
+  };
+  TreeOnDevice upload_tree(const Tree& tree) {
+    const int L = tree.num_leaves, ni = L - 1;
+    const size_t doff = sizeof(k::TreeNodeDev) * (size_t)std::max(ni, 1);
+    const size_t bytes = doff + sizeof(double) * (size_t)L;
+    tree_pack_.resize(bytes);
+    k::TreeNodeDev* np = reinterpret_cast<k::TreeNodeDev*>(tree_pack_.data());
     for (int i = 0; i < ni; ++i) {
-      ip[i] = tree.split_feature_inner[(size_t)i];
-      ip[stride + i] = tree.threshold_bin[(size_t)i];
-      ip[2 * stride + i] = (tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 1 : 0;
-      ip[3 * stride + i] = tree.left_child[(size_t)i];
-      ip[4 * stride + i] = tree.right_child[(size_t)i];
+      const int f = tree.split_feature_inner[(size_t)i];
+      const int mb = train_->inner_mapper(f).missing_bin;
+      np[i].feature = f;
+      np[i].meta = (tree.threshold_bin[(size_t)i] & 255) | ((tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 256 : 0) |
+                   ((mb + 1) << 16);
+      np[i].left = tree.left_child[(size_t)i];
+      np[i].right = tree.right_child[(size_t)i];
     }
-    size_t doff = (ints * sizeof(int32_t) + 7) & ~(size_t)7;
-    std::memcpy(tree_host_.get() + doff, tree.leaf_value.data(), sizeof(double) * (size_t)L);
-    LGA_HIP_CHECK(hipMemcpyAsync(tree_dev_.get(), tree_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
-    mark_upload();
-    const int32_t* dp = reinterpret_cast<const int32_t*>(tree_dev_.get());
-    k::TreeDev td;
-    td.feature = dp; td.threshold = dp + stride; td.default_left = dp + 2 * stride; td.left = dp + 3 * stride;
-    td.right = dp + 4 * stride;
+    std::memcpy(tree_pack_.data() + doff, tree.leaf_value.data(), sizeof(double) * (size_t)L);
+    if (tree_pack_ != tree_uploaded_) {
+      wait_upload();
+      tree_host_.resize(bytes);
+      tree_dev_.resize(bytes);
+      std::memcpy(tree_host_.get(), tree_pack_.data(), bytes);
+      LGA_HIP_CHECK(hipMemcpyAsync(tree_dev_.get(), tree_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
+      mark_upload();
+      tree_uploaded_ = tree_pack_;
+    }
+    TreeOnDevice td;
+    td.nodes = reinterpret_cast<const k::TreeNodeDev*>(tree_dev_.get());
     td.leaf_value = reinterpret_cast<const double*>(tree_dev_.get() + doff);
+    td.n_internal = ni;
     td.num_leaves = L;
     return td;
+  }
+  void traverse(const TreeOnDevice& td, const DeviceMirror* m, int64_t N, const int32_t* rows, int64_t n, double sign,
+                double* scores) {
+    k::traverse_add(td.nodes, td.n_internal, td.leaf_value, td.num_leaves, m->bins_fm.get(), N, rows, n, sign, scores,
+                    stream_);
   }
 
   std::shared_ptr<Dataset> train_;
@@ -719,8 +741,12 @@ class HipEngine : public Engine {
   DeviceMirror* mir_ = nullptr;
   std::unique_ptr<HipBackend> backend_;
   int64_t N_ = 0, n_base_ = 0, bag_n_ = 0, oob_n_ = 0;
+  // rows == nullptr lets an elementwise kernel index rows directly (the training set is the whole root)
+  const int32_t* base_or_null() const { return train_->used_indices() ? base_rows_.get() : nullptr; }
   const int32_t* bag_ptr_ = nullptr;
-  DeviceBuffer<int32_t> base_rows_, bag_rows_, missing_bin_dev_;
+  DeviceBuffer<int32_t> base_rows_, bag_rows_;
+  static constexpr int64_t kWalkMinRows = 1 << 20;
+  int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;
   DeviceBuffer<int64_t> packed_;
@@ -730,6 +756,7 @@ class HipEngine : public Engine {
   PinnedBuffer<double> red_host_;
   PinnedBuffer<k::LeafSpan> span_host_;
   PinnedBuffer<char> tree_host_;
+  std::vector<char> tree_pack_, tree_uploaded_;
   hipEvent_t upload_ev_ = nullptr;
   bool upload_pending_ = false;
   bool has_init_ = false, have_max_ = false;

@@ -55,6 +55,25 @@ __device__ __forceinline__ float wave_max_f32(float v) {
   return v;
 }
 
+// Same-address global atomics are serialised in the memory system (~10+ ns each), so reductions
+// first combine a whole workgroup and, for a maximum, skip the atomic when it cannot change anything.
+__device__ __forceinline__ void publish_max(uint32_t* target, float v) {
+  const uint32_t bits = __float_as_uint(v);   // non-negative floats order like their bit patterns
+  if (bits > __atomic_load_n(target, __ATOMIC_RELAXED)) atomicMax(target, bits);
+}
+template <int WAVES>
+__device__ __forceinline__ double block_sum_f64(double v, double* lds_scratch) {
+  v = wave_sum_f64(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) lds_scratch[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) t += lds_scratch[w];
+  return t;
+}
+
 inline int grid_for(int64_t n, int threads, int max_blocks = 2048) {
   int64_t b = (n + threads - 1) / threads;
   if (b < 1) b = 1;
@@ -65,27 +84,47 @@ inline int grid_for(int64_t n, int threads, int max_blocks = 2048) {
 // ---------------------------------------------------------------------------
 // gradients / quantisation
 // ---------------------------------------------------------------------------
+// Four independent rows per lane and trip: all loads of a trip are issued before the (fp64) math,
+// which keeps enough memory requests in flight at 8 waves per SIMD.
 __global__ __launch_bounds__(256) void gradients_kernel(ObjectiveSpec obj, const double* __restrict__ scores,
                                                         const float* __restrict__ label,
                                                         const float* __restrict__ weight,
                                                         const int32_t* __restrict__ rows, int64_t n,
                                                         float* __restrict__ g, float* __restrict__ h,
                                                         uint32_t* maxbits) {
+  constexpr int U = 4;
   float mg = 0.f, mh = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = rows ? rows[i] : i;
-    float gg, hh;
-    grad_hess(obj, scores[r], label[r], weight ? weight[r] : 1.0f, &gg, &hh);
-    g[r] = gg;
-    h[r] = hh;
-    mg = fmaxf(mg, fabsf(gg));
-    mh = fmaxf(mh, hh);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+    int64_t r[U];
+    double sc[U];
+    float lb[U], wt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      r[u] = i < n ? (rows ? (int64_t)rows[i] : i) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] >= 0) { sc[u] = scores[r[u]]; lb[u] = label[r[u]]; wt[u] = weight ? weight[r[u]] : 1.0f; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] >= 0) {
+        float gg, hh;
+        grad_hess(obj, sc[u], lb[u], wt[u], &gg, &hh);
+        g[r[u]] = gg;
+        h[r[u]] = hh;
+        mg = fmaxf(mg, fabsf(gg));
+        mh = fmaxf(mh, hh);
+      }
+    }
   }
   mg = wave_max_f32(mg);
   mh = wave_max_f32(mh);
   if ((threadIdx.x & 63) == 0) {
-    atomicMax(&maxbits[0], __float_as_uint(mg));   // non-negative floats order like their bit patterns
-    atomicMax(&maxbits[1], __float_as_uint(mh));
+    publish_max(&maxbits[0], mg);
+    publish_max(&maxbits[1], mh);
   }
 }
 
@@ -100,8 +139,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
   mg = wave_max_f32(mg);
   mh = wave_max_f32(mh);
   if ((threadIdx.x & 63) == 0) {
-    atomicMax(&maxbits[0], __float_as_uint(mg));
-    atomicMax(&maxbits[1], __float_as_uint(mh));
+    publish_max(&maxbits[0], mg);
+    publish_max(&maxbits[1], mh);
   }
 }
 
@@ -320,19 +359,39 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
   const int nf = min(kTileFeatures, F - tile * kTileFeatures);
   long long sg = 0, sh = 0;
-  for (int i = lo + threadIdx.x; i < hi; i += kHistThreads) {
-    const int row = rows[i];
-    const unsigned long long p = (unsigned long long)packed[row];
-    const uint4 ra = recs[(int64_t)row * 2];
-    const uint4 rb = recs[(int64_t)row * 2 + 1];
-    sg += (long long)(int32_t)(p >> 32);
-    sh += (long long)(p & 0xffffffffull);
-    const unsigned w[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+  // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
+  // SIMD keep ~U x 3 memory requests per lane in flight.
+  constexpr int U = 4;
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kHistThreads * U) {
+    int row[U];
+    unsigned long long p[U];
+    uint4 ra[U], rb[U];
 #pragma unroll
-    for (int k = 0; k < kTileFeatures; ++k) {
-      if (k < nf) {
-        unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-        atomicAdd(&lds[k * kMaxBins + bin], p);
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kHistThreads;
+      row[u] = i < hi ? rows[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (row[u] >= 0) {
+        p[u] = (unsigned long long)packed[row[u]];
+        ra[u] = recs[(int64_t)row[u] * 2];
+        rb[u] = recs[(int64_t)row[u] * 2 + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (row[u] >= 0) {
+        sg += (long long)(int32_t)(p[u] >> 32);
+        sh += (long long)(p[u] & 0xffffffffull);
+        const unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+        for (int k = 0; k < kTileFeatures; ++k) {
+          if (k < nf) {
+            unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+            atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+          }
+        }
       }
     }
   }
@@ -638,21 +697,39 @@ __global__ __launch_bounds__(256) void leaf_add_kernel(const LeafSpan* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void traverse_add_kernel(TreeDev tree, const uint8_t* __restrict__ bins_fm, int64_t N,
-                                                           const int32_t* __restrict__ missing_bin,
+// Adds a tree to the scores of `rows` by walking it over the binned data.  Nodes are 16-byte records
+// staged in LDS (one ds_read_b128 per step); rows are visited in storage order, so the one-byte bin
+// reads of neighbouring lanes share cache lines and the score update is a coalesced read-modify-write.
+template <bool IN_LDS>
+__global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __restrict__ nodes, int n_internal,
+                                                           const double* __restrict__ leaf_value, int num_leaves,
+                                                           const uint8_t* __restrict__ bins_fm, int64_t N,
                                                            const int32_t* __restrict__ rows, int64_t n, double sign,
                                                            double* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const TreeNodeDev* tn = nodes;
+  const double* lv = leaf_value;
+  if (IN_LDS) {
+    int4* sn = reinterpret_cast<int4*>(smem);
+    double* sv = reinterpret_cast<double*>(smem + (size_t)n_internal * sizeof(TreeNodeDev));
+    const int4* gn = reinterpret_cast<const int4*>(nodes);
+    for (int i = threadIdx.x; i < n_internal; i += blockDim.x) sn[i] = gn[i];
+    for (int i = threadIdx.x; i < num_leaves; i += blockDim.x) sv[i] = leaf_value[i];
+    __syncthreads();
+    tn = reinterpret_cast<const TreeNodeDev*>(smem);
+    lv = sv;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
-    int node = 0;
-    if (tree.num_leaves <= 1) node = ~0;
+    int node = num_leaves <= 1 ? ~0 : 0;
     while (node >= 0) {
-      const int f = tree.feature[node];
-      const int b = bins_fm[(int64_t)f * N + r];
-      const bool left = (b == missing_bin[f]) ? (tree.default_left[node] != 0) : (b <= tree.threshold[node]);
-      node = left ? tree.left[node] : tree.right[node];
+      const TreeNodeDev t = tn[node];
+      const int b = bins_fm[(int64_t)t.feature * N + r];
+      const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
+      const bool left = (b == mb) ? (dl != 0) : (b <= thr);
+      node = left ? t.left : t.right;
     }
-    scores[r] += sign * tree.leaf_value[~node];
+    scores[r] += sign * lv[~node];
   }
 }
 
@@ -689,9 +766,10 @@ __global__ __launch_bounds__(256) void metric_sum_kernel(int32_t metric, Objecti
     s += w * point_loss(metric, pred, raw, label[r], obj);
     sw += w;
   }
-  s = wave_sum_f64(s);
-  sw = wave_sum_f64(sw);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ double scratch[4];
+  s = block_sum_f64<4>(s, scratch);
+  sw = block_sum_f64<4>(sw, scratch);
+  if (threadIdx.x == 0) {
     atomicAdd(&out2[0], s);
     atomicAdd(&out2[1], sw);
   }
@@ -708,8 +786,11 @@ __global__ __launch_bounds__(256) void label_sums_kernel(const float* __restrict
     b += w;
     if (label[r] > 0.0f) c += w;
   }
-  a = wave_sum_f64(a); b = wave_sum_f64(b); c = wave_sum_f64(c);
-  if ((threadIdx.x & 63) == 0) {
+  __shared__ double scratch[4];
+  a = block_sum_f64<4>(a, scratch);
+  b = block_sum_f64<4>(b, scratch);
+  c = block_sum_f64<4>(c, scratch);
+  if (threadIdx.x == 0) {
     atomicAdd(&out3[0], a);
     atomicAdd(&out3[1], b);
     atomicAdd(&out3[2], c);
@@ -834,11 +915,17 @@ void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int
   LGA_LAUNCH_CHECK();
 }
 
-void traverse_add(const TreeDev& tree, const uint8_t* bins_fm, int64_t N, const int32_t* missing_bin,
-                  const int32_t* rows, int64_t n, double sign, double* scores, hipStream_t s) {
+void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
+                  const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
+                  hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(traverse_add_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, tree, bins_fm, N, missing_bin, rows,
-                     n, sign, scores);
+  const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)num_leaves * sizeof(double);
+  if (sm <= 48 * 1024)
+    hipLaunchKernelGGL(traverse_add_kernel<true>, dim3(grid_for(n, 256)), dim3(256), sm, s, nodes, n_internal,
+                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores);
+  else
+    hipLaunchKernelGGL(traverse_add_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, nodes, n_internal,
+                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores);
   LGA_LAUNCH_CHECK();
 }
 

@@ -40,14 +40,10 @@ struct ScanTaskDev {
   int32_t pad;
 };
 
-struct TreeDev {           // device arrays of one tree for binned traversal
-  const int32_t* feature;      // inner feature per internal node
-  const int32_t* threshold;    // bin threshold
-  const int32_t* default_left;
-  const int32_t* left;
-  const int32_t* right;
-  const double* leaf_value;
-  int32_t num_leaves;
+struct TreeNodeDev {       // internal node of a tree for binned traversal (16 bytes, one LDS read)
+  int32_t feature;         // inner feature
+  int32_t meta;            // threshold bin | default_left << 8 | (missing_bin + 1) << 16
+  int32_t left, right;     // >= 0 internal node, < 0: ~leaf
 };
 
 struct LeafSpan {          // final leaf of a grown tree
@@ -91,8 +87,9 @@ void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskD
 
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
-void traverse_add(const TreeDev& tree, const uint8_t* bins_fm, int64_t N, const int32_t* missing_bin,
-                  const int32_t* rows, int64_t n, double sign, double* scores, hipStream_t s);
+void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
+                  const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
+                  hipStream_t s);
 void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s);
 void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s);
 void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
