@@ -64,6 +64,8 @@ def main():
         "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 100.0, "verbose": -1, "device_type": "gpu",
         "tree_learner": "data" if distributed else "serial", "profile": bool(args.profile),
     }
+    if args.auc:
+        params["metric"] = ["auc", "binary_logloss"]   # evaluated once, after the timed steps
     t0 = time.time()
     if distributed:
         ds = distributed_dataset(X, y, params=params)

@@ -3,12 +3,12 @@
 // distinct values + counts, and cut it into <= max_bin bins.
 //
 //   1. sample_to_keys      sample [ns][F] -> order-preserving 64-bit keys [F][npad], NaN / padding = max key
-//   2. bitonic sort        blocks of 2048 keys are sorted in LDS; larger strides run as global
-//                          compare-exchange steps, every merge tail (stride <= 1024) again in LDS
+//   2. bitonic sort        (sort.hip)
 //   3. rle_and_cut         one workgroup per feature: head flags + block scan -> distinct[], counts[];
 //                          lane 0 then runs the SAME greedy routine as the host BinMapper
 //                          (binning_core.hpp), so host and device boundaries are bit-identical
 #include "hip_engine.hpp"
+#include "sort.hpp"
 #include "../binning_core.hpp"
 #include <algorithm>
 #include <cstring>
@@ -16,9 +16,6 @@
 namespace lga {
 
 namespace {
-
-constexpr int kSortBlock = 2048;     // keys per workgroup in the LDS phases
-constexpr int kSortThreads = 1024;
 
 __device__ __forceinline__ uint64_t key_of(double v) {
   if (v != v) return ~0ull;
@@ -47,68 +44,6 @@ __global__ __launch_bounds__(256) void sample_to_keys_kernel(const T* __restrict
     keys[(int64_t)f * npad + i] = k;
   }
   (void)nf;
-}
-
-__device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
-  if ((a > b) == up) { uint64_t t = a; a = b; b = t; }
-}
-
-// Sorts every 2048-key block completely (k = 2 .. 2048) in LDS.
-__global__ __launch_bounds__(kSortThreads) void bitonic_block_sort_kernel(uint64_t* __restrict__ keys, int64_t npad) {
-  __shared__ uint64_t s[kSortBlock];
-  uint64_t* base = keys + (int64_t)blockIdx.y * npad + (int64_t)blockIdx.x * kSortBlock;
-  const int t = threadIdx.x;
-  s[t] = base[t];
-  s[t + kSortThreads] = base[t + kSortThreads];
-  __syncthreads();
-  const int64_t g0 = (int64_t)blockIdx.x * kSortBlock;
-  for (int k = 2; k <= kSortBlock; k <<= 1) {
-    for (int j = k >> 1; j >= 1; j >>= 1) {
-      const int i = ((t / j) * 2 * j) + (t % j);      // lower index of the pair
-      const bool up = (((g0 + i) & k) == 0);
-      uint64_t a = s[i], b = s[i + j];
-      cmp_swap(a, b, up);
-      s[i] = a; s[i + j] = b;
-      __syncthreads();
-    }
-  }
-  base[t] = s[t];
-  base[t + kSortThreads] = s[t + kSortThreads];
-}
-
-// One global compare-exchange step of stage k with stride j (j >= 2048).
-__global__ __launch_bounds__(256) void bitonic_global_step_kernel(uint64_t* __restrict__ keys, int64_t npad, int64_t j,
-                                                                  int64_t k) {
-  uint64_t* base = keys + (int64_t)blockIdx.y * npad;
-  const int64_t half = npad >> 1;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < half; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = ((t / j) * 2 * j) + (t % j);
-    const bool up = ((i & k) == 0);
-    uint64_t a = base[i], b = base[i + j];
-    if ((a > b) == up) { base[i] = b; base[i + j] = a; }
-  }
-}
-
-// Tail of stage k: strides 1024 .. 1 inside each 2048-key block, in LDS.
-__global__ __launch_bounds__(kSortThreads) void bitonic_block_merge_kernel(uint64_t* __restrict__ keys, int64_t npad,
-                                                                           int64_t k) {
-  __shared__ uint64_t s[kSortBlock];
-  uint64_t* base = keys + (int64_t)blockIdx.y * npad + (int64_t)blockIdx.x * kSortBlock;
-  const int t = threadIdx.x;
-  s[t] = base[t];
-  s[t + kSortThreads] = base[t + kSortThreads];
-  __syncthreads();
-  const int64_t g0 = (int64_t)blockIdx.x * kSortBlock;
-  for (int j = kSortBlock >> 1; j >= 1; j >>= 1) {
-    const int i = ((t / j) * 2 * j) + (t % j);
-    const bool up = (((g0 + i) & k) == 0);
-    uint64_t a = s[i], b = s[i + j];
-    cmp_swap(a, b, up);
-    s[i] = a; s[i + j] = b;
-    __syncthreads();
-  }
-  base[t] = s[t];
-  base[t + kSortThreads] = s[t + kSortThreads];
 }
 
 struct FeatureBins {      // result record per feature
@@ -181,8 +116,6 @@ __global__ __launch_bounds__(256) void rle_and_cut_kernel(const uint64_t* __rest
   }
 }
 
-int64_t next_pow2(int64_t n) { int64_t p = kSortBlock; while (p < n) p <<= 1; return p; }
-
 }  // namespace
 
 // sample: device memory, row-major [ns][ncol]; returns one BinMapper per column.
@@ -190,7 +123,7 @@ std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, in
   hipStream_t s = current_stream();
   std::vector<BinMapper> mappers((size_t)ncol);
   if (ns <= 0) return mappers;
-  const int64_t npad = next_pow2(ns);
+  const int64_t npad = sort_padded_size(ns);
   const int batch = std::max(1, std::min(ncol, (int)std::max<int64_t>(1, (int64_t)(1ll << 27) / npad)));   // <= 1 GiB of keys
   DeviceBuffer<uint64_t> keys((size_t)batch * (size_t)npad);
   DeviceBuffer<double> distinct((size_t)batch * (size_t)ns);
@@ -207,18 +140,7 @@ std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, in
     else
       hipLaunchKernelGGL(sample_to_keys_kernel<double>, g1, dim3(256), 0, s, (const double*)dev_sample, ns, ncol, f0, nf, npad, keys.get());
     LGA_HIP_CHECK(hipGetLastError());
-    dim3 gb((unsigned)(npad / kSortBlock), (unsigned)nf);
-    hipLaunchKernelGGL(bitonic_block_sort_kernel, gb, dim3(kSortThreads), 0, s, keys.get(), npad);
-    LGA_HIP_CHECK(hipGetLastError());
-    for (int64_t k = (int64_t)kSortBlock * 2; k <= npad; k <<= 1) {
-      for (int64_t j = k >> 1; j >= kSortBlock; j >>= 1) {
-        dim3 gg((unsigned)std::min<int64_t>((npad / 2 + 255) / 256, 2048), (unsigned)nf);
-        hipLaunchKernelGGL(bitonic_global_step_kernel, gg, dim3(256), 0, s, keys.get(), npad, j, k);
-        LGA_HIP_CHECK(hipGetLastError());
-      }
-      hipLaunchKernelGGL(bitonic_block_merge_kernel, gb, dim3(kSortThreads), 0, s, keys.get(), npad, k);
-      LGA_HIP_CHECK(hipGetLastError());
-    }
+    bitonic_sort_u64(keys.get(), npad, nf, s);
     hipLaunchKernelGGL(rle_and_cut_kernel, dim3((unsigned)nf), dim3(256), 0, s, keys.get(), npad, ns, distinct.get(),
                        counts.get(), cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing ? 1 : 0, bounds.get(), res.get());
     LGA_HIP_CHECK(hipGetLastError());

@@ -614,8 +614,11 @@ class HipEngine : public Engine {
       EvalResult r;
       r.name = metric_name(mk);
       r.higher_better = metric_higher_better(mk);
-      if (mk == kMetAuc) {
-        // rank statistic: scores come back to the host, which sorts them
+      if (mk == kMetAuc && !dist() && !m->has_weight) {
+        // rank statistic, sorted and scanned on the device
+        r.value = auc_on_device(sc, m->label.get(), ds->used_indices() ? rows : nullptr, n, stream_);
+      } else if (mk == kMetAuc) {
+        // weighted or distributed: scores come back to the host (exact weighted sort / binned merge over ranks)
         std::vector<double> hs((size_t)n);
         tmp_f64_.resize((size_t)std::max<int64_t>(n, 1));
         k::gather_f64(sc, rows, n, tmp_f64_.get(), stream_);

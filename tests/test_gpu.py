@@ -220,6 +220,27 @@ def test_gpu_binary_matches_cpu_quality_and_first_tree():
     assert abs(ec["training"]["binary_logloss"][-1] - eg["training"]["binary_logloss"][-1]) < 1e-3
 
 
+@pytest.mark.parametrize("leaves,n", [(4, 5000), (31, 70000)])
+def test_device_auc_equals_host_auc(leaves, n):
+    """Sort + scan AUC on the device against the host's sorted formulation, heavy ties included.
+    A regression objective keeps CPU and GPU trees (hence scores) bit-identical."""
+    rng = np.random.RandomState(leaves)
+    X = rng.randn(n, 6)
+    y = (X[:, 0] + 0.5 * X[:, 1] * X[:, 2] + 0.7 * rng.randn(n) > 0).astype(np.float64)
+    p = {"objective": "regression", "num_leaves": leaves, "metric": ["auc"], "min_data_in_leaf": 5}
+    idx = np.sort(rng.choice(n, n // 3, replace=False))
+    out = {}
+    for name, dev in (("cpu", CPU), ("gpu", GPU)):
+        full = lgb.Dataset(X, label=y, params=dev)
+        ev = {}
+        lgb.train({**dev, **p}, full, 6, valid_sets=[full, full.subset(idx)], valid_names=["all", "part"],
+                  evals_result=ev)
+        out[name] = ev
+    for k in ("all", "part"):
+        assert out["cpu"][k]["auc"] == out["gpu"][k]["auc"], k
+    assert 0.6 < out["gpu"]["all"]["auc"][-1] < 1.0
+
+
 def test_gpu_predictor_matches_host_predictor():
     import torch
     X, y = make_regression(30000, 20, seed=5)
