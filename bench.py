@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--rows", type=int, default=N_ROWS)
     ap.add_argument("--leaves", type=int, default=255)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="report round/host-time counters (no device event timers)")
     ap.add_argument("--auc", action="store_true", help="also report train AUC after the timed steps")
     args = ap.parse_args()
 
@@ -118,7 +119,7 @@ def main():
     if args.auc:
         res = dict((m, v) for _, m, v, _ in booster._eval(-1, "training"))
         out["config"]["train_metric"] = res
-    if args.profile:
+    if args.profile or args.stats:
         out["config"]["profile"] = booster.profile()
         out["config"]["last_tree"] = booster.grow_stats()
     if rank == 0:

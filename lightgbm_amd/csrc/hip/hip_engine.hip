@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "../metric.hpp"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -19,7 +20,12 @@ namespace lga {
 namespace {
 DeviceAllocFn g_alloc = nullptr;
 DeviceFreeFn g_free = nullptr;
-hipStream_t g_stream = nullptr;
+// The stream is a per-thread setting (like torch's current stream): fold boosters of one CV run are
+// driven from their own host threads on their own streams.  Threads that never set one use the
+// stream the first caller installed.
+hipStream_t g_default_stream = nullptr;
+thread_local hipStream_t t_stream = nullptr;
+thread_local bool t_stream_set = false;
 }  // namespace
 
 void set_device_allocator(DeviceAllocFn a, DeviceFreeFn f) { g_alloc = a; g_free = f; }
@@ -38,8 +44,13 @@ void device_free(void* p) {
   if (!p) return;
   if (g_free) g_free(p); else (void)hipFree(p);
 }
-void set_current_stream(hipStream_t s) { g_stream = s; }
-hipStream_t current_stream() { return g_stream; }
+void set_current_stream(hipStream_t s) {
+  static bool have_default = false;
+  if (!have_default) { g_default_stream = s; have_default = true; }
+  t_stream = s;
+  t_stream_set = true;
+}
+hipStream_t current_stream() { return t_stream_set ? t_stream : g_default_stream; }
 
 namespace {
 
@@ -54,6 +65,9 @@ struct PhaseProfile {
   double ms[kCount] = {0, 0, 0, 0, 0, 0};
   double host_ms = 0;
   int64_t rounds = 0, trees = 0, tasks = 0;
+  // host wall clock (ms): enqueueing a round, waiting for its flag, and the time between rounds (replay)
+  double host_launch_ms = 0, host_wait_ms = 0, host_between_ms = 0;
+  std::chrono::steady_clock::time_point last_end{};
   int64_t part_rows = 0, hist_rows = 0;   // rows partitioned / rows accumulated into histograms (without the roots)
   hipEvent_t ev[kCount + 1];
   bool created = false;
@@ -76,7 +90,8 @@ struct PhaseProfile {
     os << "{\"rounds\":" << rounds << ",\"trees\":" << trees << ",\"split_tasks\":" << tasks << ",\"partition_rows\":" << part_rows
        << ",\"hist_rows\":" << hist_rows << ",\"upload_ms\":" << ms[kUpload]
        << ",\"partition_ms\":" << ms[kPartition] << ",\"hist_ms\":" << ms[kHist] << ",\"comm_ms\":" << ms[kComm]
-       << ",\"scan_ms\":" << ms[kScan] << ",\"fetch_ms\":" << ms[kFetch] << "}";
+       << ",\"scan_ms\":" << ms[kScan] << ",\"fetch_ms\":" << ms[kFetch] << ",\"host_launch_ms\":" << host_launch_ms
+       << ",\"host_wait_ms\":" << host_wait_ms << ",\"host_between_rounds_ms\":" << host_between_ms << "}";
     return os.str();
   }
 };
@@ -240,6 +255,8 @@ class HipBackend : public TreeBackend {
   void run_round(std::vector<SplitTask>& tasks, bool root, SplitInfo* infos) {
     const int B = (int)tasks.size();
     const int n_scan = root ? 1 : 2 * B;
+    const auto t_begin = std::chrono::steady_clock::now();
+    if (!root) prof.host_between_ms += std::chrono::duration<double, std::milli>(t_begin - prof.last_end).count();
     const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
     const bool inline_tasks = fused && B <= k::kInlineTasks;
     int64_t total_rows = 0;
@@ -326,7 +343,11 @@ class HipBackend : public TreeBackend {
                     stream_);
       prof.mark(PhaseProfile::kFetch, stream_);
       prof.mark(PhaseProfile::kCount, stream_);
+      const auto t_launched = std::chrono::steady_clock::now();
       wait_flag(seq);
+      const auto t_done = std::chrono::steady_clock::now();
+      prof.host_launch_ms += std::chrono::duration<double, std::milli>(t_launched - t_begin).count();
+      prof.host_wait_ms += std::chrono::duration<double, std::milli>(t_done - t_launched).count();
       if (prof.on) sync();
     } else {
       const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(stage_dev_.get() + off_scan_);
@@ -371,6 +392,7 @@ class HipBackend : public TreeBackend {
         ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
       }
     }
+    prof.last_end = std::chrono::steady_clock::now();
   }
 
   // Polls the completion flag the last scan workgroup writes into host-mapped memory.  The stream is
@@ -452,7 +474,7 @@ class HipEngine : public Engine {
     hess_.resize((size_t)N_);
     packed_.resize((size_t)N_);
     maxbits_.resize(2);
-    red_dev_.resize(8);
+    red_dev_.resize(k::kReduceDoubles);
     red_host_.resize(8);
     if (!train_->root_init_score().empty()) {
       init_score_dev_.upload(train_->root_init_score().data(), (size_t)N_, stream_);

@@ -752,49 +752,71 @@ __global__ __launch_bounds__(256) void init_scores_kernel(double* __restrict__ s
 // ---------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------
+// Sums are reduced in a fixed order so that a metric is bit-reproducible: every workgroup stores its
+// partial sums, and the workgroup that finishes last adds them up (lane-strided, then a fixed shuffle tree).
+// out: [3 results | arrival counter | 4 unused | 3 partials per workgroup ...].
+template <int NV>
+__device__ __forceinline__ void ordered_finish(const double (&v)[NV], double* out, double* lds_scratch) {
+  __shared__ bool last;
+  double t[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) t[j] = block_sum_f64<4>(v[j], lds_scratch);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) out[8 + (size_t)blockIdx.x * 3 + j] = t[j];
+    __threadfence();
+    const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(out + 3), 1u);
+    last = old == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last || threadIdx.x >= 64) return;
+  __threadfence();
+  double acc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+  for (unsigned b = threadIdx.x; b < gridDim.x; b += 64) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += __builtin_nontemporal_load(&out[8 + (size_t)b * 3 + j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) acc[j] = wave_sum_f64(acc[j]);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) out[j] = acc[j];
+  }
+}
+
 __global__ __launch_bounds__(256) void metric_sum_kernel(int32_t metric, ObjectiveSpec obj,
                                                          const double* __restrict__ scores,
                                                          const float* __restrict__ label,
                                                          const float* __restrict__ weight,
-                                                         const int32_t* __restrict__ rows, int64_t n, double* out2) {
-  double s = 0.0, sw = 0.0;
+                                                         const int32_t* __restrict__ rows, int64_t n, double* out) {
+  __shared__ double scratch[4];
+  double v[2] = {0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
     const double w = weight ? (double)weight[r] : 1.0;
     const double raw = scores[r];
     const double pred = transform_score(obj.kind, obj.sigmoid, raw);
-    s += w * point_loss(metric, pred, raw, label[r], obj);
-    sw += w;
+    v[0] += w * point_loss(metric, pred, raw, label[r], obj);
+    v[1] += w;
   }
-  __shared__ double scratch[4];
-  s = block_sum_f64<4>(s, scratch);
-  sw = block_sum_f64<4>(sw, scratch);
-  if (threadIdx.x == 0) {
-    atomicAdd(&out2[0], s);
-    atomicAdd(&out2[1], sw);
-  }
+  ordered_finish<2>(v, out, scratch);
 }
 
 __global__ __launch_bounds__(256) void label_sums_kernel(const float* __restrict__ label,
                                                          const float* __restrict__ weight,
-                                                         const int32_t* __restrict__ rows, int64_t n, double* out3) {
-  double a = 0.0, b = 0.0, c = 0.0;
+                                                         const int32_t* __restrict__ rows, int64_t n, double* out) {
+  __shared__ double scratch[4];
+  double v[3] = {0.0, 0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
     const double w = weight ? (double)weight[r] : 1.0;
-    a += w * (double)label[r];
-    b += w;
-    if (label[r] > 0.0f) c += w;
+    v[0] += w * (double)label[r];
+    v[1] += w;
+    if (label[r] > 0.0f) v[2] += w;
   }
-  __shared__ double scratch[4];
-  a = block_sum_f64<4>(a, scratch);
-  b = block_sum_f64<4>(b, scratch);
-  c = block_sum_f64<4>(c, scratch);
-  if (threadIdx.x == 0) {
-    atomicAdd(&out3[0], a);
-    atomicAdd(&out3[1], b);
-    atomicAdd(&out3[2], c);
-  }
+  ordered_finish<3>(v, out, scratch);
 }
 
 template <typename T>
@@ -943,7 +965,7 @@ void init_scores(double* scores, const double* init, const int32_t* rows, int64_
 
 void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
                 const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s) {
-  LGA_HIP_CHECK(hipMemsetAsync(out2, 0, 2 * sizeof(double), s));
+  LGA_HIP_CHECK(hipMemsetAsync(out2, 0, 4 * sizeof(double), s));
   if (n <= 0) return;
   hipLaunchKernelGGL(metric_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, metric, obj, scores, label,
                      weight, rows, n, out2);
@@ -951,7 +973,7 @@ void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, 
 }
 
 void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s) {
-  LGA_HIP_CHECK(hipMemsetAsync(out3, 0, 3 * sizeof(double), s));
+  LGA_HIP_CHECK(hipMemsetAsync(out3, 0, 4 * sizeof(double), s));
   if (n <= 0) return;
   hipLaunchKernelGGL(label_sums_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, label, weight, rows, n, out3);
   LGA_LAUNCH_CHECK();

@@ -92,6 +92,8 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
                   hipStream_t s);
 void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s);
 void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s);
+// Reduction outputs need kReduceDoubles doubles: results first, then per-workgroup partials.
+constexpr int kReduceDoubles = 8 + 3 * 1024;
 void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
                 const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s);
 void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s);

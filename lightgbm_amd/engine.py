@@ -212,6 +212,55 @@ def make_folds(n: int, nfold: int, label: Optional[np.ndarray] = None, stratifie
     return [(all_idx[fold_of != k], all_idx[fold_of == k]) for k in range(nfold)]
 
 
+class _FoldRunner:
+    """Runs the k fold boosters of a CV either one after the other or - HIP build, small data - concurrently:
+    fold i owns host thread i and HIP stream i, so the latency-bound growth rounds of small folds
+    (45 k rows in the reference, r/gridsearchCV.R:26-27) overlap on the GPU instead of queueing.
+    Results do not depend on the mode: every fold is an independent, deterministic computation."""
+
+    def __init__(self, k: int, concurrent: bool):
+        self.k = k
+        self.concurrent = concurrent and k > 1
+        if self.concurrent:
+            import torch
+            from concurrent.futures import ThreadPoolExecutor
+            torch.cuda.synchronize()           # the shared binned dataset is complete before side streams read it
+            self.streams = [torch.cuda.Stream() for _ in range(k)]
+            self.pools = [ThreadPoolExecutor(max_workers=1) for _ in range(k)]
+
+    def _enter(self, i):
+        import contextlib
+        if not self.concurrent:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.streams[i])
+
+    def construct(self, i, fn):
+        """Boosters are created from the calling thread (they share the root dataset), but on fold i's stream."""
+        with self._enter(i):
+            return fn()
+
+    def map(self, fns):
+        """fns[i]() for every fold; concurrently when enabled."""
+        if not self.concurrent:
+            return [fn() for fn in fns]
+
+        def run(i, fn):
+            from . import _device, _lib
+            with self._enter(i):
+                _device.sync_stream(_lib.load()[0])
+                return fn()
+        futures = [self.pools[i].submit(run, i, fn) for i, fn in enumerate(fns)]
+        return [f.result() for f in futures]
+
+    def close(self):
+        if self.concurrent:
+            for s in self.streams:
+                s.synchronize()
+            for p in self.pools:
+                p.shutdown(wait=True)
+
+
 def _agg_cv_result(raw_results: List[List[Tuple]], eval_train_metric: bool):
     """Mean / stdv over folds of every (data, metric) pair, in first-seen order."""
     cvmap: Dict[str, List[float]] = {}
@@ -233,8 +282,11 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
        fobj: Optional[Callable] = None, feval=None, init_model=None, early_stopping_rounds: Optional[int] = None,
        fpreproc=None, verbose_eval: Union[bool, int, None] = None, show_stdv: bool = True, seed: int = 0,
        callbacks: Optional[List[Callable]] = None, eval_train_metric: bool = False, return_cvbooster: bool = False,
-       **kwargs) -> Dict[str, Any]:
-    """k-fold cross-validation; returns ``{"<metric>-mean": [...], "<metric>-stdv": [...]}`` (+ ``"cvbooster"``)."""
+       concurrent_folds: Optional[bool] = None, **kwargs) -> Dict[str, Any]:
+    """k-fold cross-validation; returns ``{"<metric>-mean": [...], "<metric>-stdv": [...]}`` (+ ``"cvbooster"``).
+
+    ``concurrent_folds``: drive the fold boosters from k host threads on k HIP streams (default: on for the
+    HIP build when the data has at most 2 M rows and no Python-side objective / metric is used)."""
     if not isinstance(train_set, Dataset):
         raise TypeError("Training only accepts Dataset object")
     params = _prepare_params(params, kwargs)
@@ -272,18 +324,26 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
         label = train_set.get_label() if stratified else None
         folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)
 
+    from . import _lib
+    on_gpu = _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host")
+    if concurrent_folds is None:
+        concurrent_folds = on_gpu and n <= 2_000_000 and fobj is None and feval is None
+    runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu)
+
     cvbooster = CVBooster()
-    for tr_idx, te_idx in folds:
-        tr = train_set.subset(tr_idx)
-        te = train_set.subset(te_idx)
-        fold_params = params
-        if fpreproc is not None:
-            tr, te, fold_params = fpreproc(tr, te, dict(params))
-        b = Booster(fold_params, tr)
-        if eval_train_metric:
-            b._train_data_name = "train"
-        b.add_valid(te, "valid")
-        cvbooster.append(b)
+    for k, (tr_idx, te_idx) in enumerate(folds):
+        def build(tr_idx=tr_idx, te_idx=te_idx):
+            tr = train_set.subset(tr_idx)
+            te = train_set.subset(te_idx)
+            fold_params = params
+            if fpreproc is not None:
+                tr, te, fold_params = fpreproc(tr, te, dict(params))
+            b = Booster(fold_params, tr)
+            if eval_train_metric:
+                b._train_data_name = "train"
+            b.add_valid(te, "valid")
+            return b
+        cvbooster.append(runner.construct(k, build))
 
     callbacks = list(callbacks or [])
     if early_stopping_rounds is not None and early_stopping_rounds > 0:
@@ -295,32 +355,37 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     cb_before, cb_after = _split_callbacks(callbacks)
 
     results: Dict[str, List[float]] = {}
-    for i in range(num_boost_round):
-        for c in cb_before:
-            c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
-        finished = [b.update(fobj=fobj) for b in cvbooster.boosters]
-        cvbooster.iterations_run = i + 1
-        raw = []
-        for b in cvbooster.boosters:
-            one = []
-            if eval_train_metric:
-                one.extend(b.eval_train(feval))
-            one.extend(b.eval_valid(feval))
-            raw.append(one)
-        res = _agg_cv_result(raw, eval_train_metric)
-        for _, key, mean, _, std in res:
-            results.setdefault(f"{key}-mean", []).append(mean)
-            results.setdefault(f"{key}-stdv", []).append(std)
-        try:
-            for c in cb_after:
-                c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))
-        except cb.EarlyStopException as es:
-            cvbooster.best_iteration = es.best_iteration + 1
-            for k in results:
-                results[k] = results[k][: cvbooster.best_iteration]
-            break
-        if all(finished):
-            break
+    try:
+        for i in range(num_boost_round):
+            for c in cb_before:
+                c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
+            def step(b):
+                done = b.update(fobj=fobj)
+                one = []
+                if eval_train_metric:
+                    one.extend(b.eval_train(feval))
+                one.extend(b.eval_valid(feval))
+                return done, one
+            stepped = runner.map([(lambda b=b: step(b)) for b in cvbooster.boosters])
+            finished = [d for d, _ in stepped]
+            raw = [one for _, one in stepped]
+            cvbooster.iterations_run = i + 1
+            res = _agg_cv_result(raw, eval_train_metric)
+            for _, key, mean, _, std in res:
+                results.setdefault(f"{key}-mean", []).append(mean)
+                results.setdefault(f"{key}-stdv", []).append(std)
+            try:
+                for c in cb_after:
+                    c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))
+            except cb.EarlyStopException as es:
+                cvbooster.best_iteration = es.best_iteration + 1
+                for k in results:
+                    results[k] = results[k][: cvbooster.best_iteration]
+                break
+            if all(finished):
+                break
+    finally:
+        runner.close()
     out: Dict[str, Any] = dict(results)
     if return_cvbooster:
         out["cvbooster"] = cvbooster

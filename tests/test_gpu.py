@@ -271,6 +271,16 @@ def test_gpu_cv_and_rstyle_grid_row():
     assert g.best_iter == c.best_iter and abs(g.best_score - c.best_score) < 1e-9
 
 
+def test_concurrent_fold_streams_give_the_same_cv():
+    """Fold boosters on their own host threads / HIP streams: same numbers as one after the other."""
+    X, y = make_diamonds_like(20000, seed=4)
+    d = lgb.Dataset(X, label=y, params=GPU)
+    p = {**GPU, "objective": "regression", "metric": "rmse", "learning_rate": 0.2, "num_leaves": 31}
+    a = lgb.cv(p, d, 40, nfold=5, early_stopping_rounds=5, seed=3, concurrent_folds=False)
+    b = lgb.cv(p, d, 40, nfold=5, early_stopping_rounds=5, seed=3, concurrent_folds=True)
+    assert a["rmse-mean"] == b["rmse-mean"] and a["rmse-stdv"] == b["rmse-stdv"]
+
+
 def test_gpu_rf_and_rollback_and_custom_objective():
     X, y = make_regression(20000, 8, seed=6)
     p = {"boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1, "feature_fraction": 0.8, "num_leaves": 63}
