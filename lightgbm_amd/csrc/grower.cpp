@@ -1,6 +1,9 @@
 #include "grower.hpp"
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <queue>
 #include <stdexcept>
 
@@ -35,7 +38,29 @@ struct EntryLess {
 inline bool splittable(const SplitInfo& s) { return s.feature >= 0 && std::isfinite(s.gain); }
 }  // namespace
 
+namespace {
+// LGA_GROW_TRACE=1: host-side time of grow() outside the backend calls, printed every 100 trees.
+struct GrowTrace {
+  bool on = std::getenv("LGA_GROW_TRACE") != nullptr;
+  double total_us = 0, backend_us = 0, tail_us = 0;
+  int trees = 0;
+  using clock = std::chrono::steady_clock;
+  static double us(clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
+  void report() {
+    if (++trees % 100 == 0) {
+      std::fprintf(stderr, "[grow trace] per tree: total %.1f us, in backend %.1f us, host %.1f us (of which after the last round %.1f us)\n",
+                   total_us / 100, backend_us / 100, (total_us - backend_us) / 100, tail_us / 100);
+      total_us = backend_us = tail_us = 0;
+    }
+  }
+};
+GrowTrace g_trace;
+}  // namespace
+
 Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces) {
+  const auto t_enter = GrowTrace::clock::now();
+  auto t_last_backend = t_enter;
+  double backend_us = 0;
   stats_ = GrowStats();
   const SplitParams sp = split_params();
   be.begin_tree(meta, sp);
@@ -47,6 +72,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   nodes.reserve((size_t)be.node_capacity());
   nodes.emplace_back();
   be.root_round(&nodes[0].best);
+  if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_enter, t_last_backend); }
   stats_.rounds = 1;
   const QuantScale qs = be.quant_scale();
   const double gunit = unit_of(qs.kg), hunit = unit_of(qs.kh);
@@ -130,7 +156,9 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
       tasks.push_back(t);
     }
     infos.assign(tasks.size() * 2, SplitInfo{});
+    const auto t_call = GrowTrace::clock::now();
     be.split_round(tasks, infos.data());
+    if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_call, t_last_backend); }
     ++stats_.rounds;
     materialized += (int)tasks.size();
     for (size_t i = 0; i < tasks.size(); ++i) {
@@ -192,6 +220,13 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
       if (n.left < 0) pieces->push_back(LeafPiece{id, (int32_t)l});
       else { stack.push_back(n.right); stack.push_back(n.left); }
     }
+  }
+  if (g_trace.on) {
+    const auto t_exit = GrowTrace::clock::now();
+    g_trace.total_us += GrowTrace::us(t_enter, t_exit);
+    g_trace.backend_us += backend_us;
+    g_trace.tail_us += GrowTrace::us(t_last_backend, t_exit);
+    g_trace.report();
   }
   return tree;
 }

@@ -159,7 +159,12 @@ class HipBackend : public TreeBackend {
   }
 
   void set_bag(const int32_t* rows_dev, int64_t n) { bag_ = rows_dev; bag_n_ = n; }
-  void set_packed(const int64_t* packed_dev) { packed_ = packed_dev; }
+  // packed_dev == nullptr: `rows_src` are row lines that carry the gradients (kernels.hpp: build_row_lines)
+  void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) { packed_ = packed_dev; hist_src_ = rows_src; }
+  // Row lines only: the root pass quantises these float gradients itself (no separate quantisation kernel).
+  void set_root_quant(const float* g, const float* h, const uint32_t* maxbits) {
+    root_quant_ = k::FusedQuant{g, h, maxbits, qs_dev_.get()};
+  }
   QuantScale* qs_device() { return qs_dev_.get(); }
 
   int node_capacity() const override { return 2 * capacity_splits_ + 1; }
@@ -179,7 +184,6 @@ class HipBackend : public TreeBackend {
                                    hipMemcpyHostToDevice, stream_));
       // meta_host_ stays alive and unchanged until the copy has run (next sync is in root_round)
     }
-    LGA_HIP_CHECK(hipMemcpyAsync(arena_[0].get(), bag_, sizeof(int32_t) * (size_t)bag_n_, hipMemcpyDeviceToDevice, stream_));
     ranges_host_[0] = NodeRange{0, (int32_t)bag_n_, 0, 0};
     ++prof.trees;
   }
@@ -312,9 +316,12 @@ class HipBackend : public TreeBackend {
       dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
       dhc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_hch_);
     }
+    // The root's rows are the bag itself: node 0 (buffer 0) is read from there, so a tree starts without
+    // copying the row list.  Only the root round and the round that splits the root ever touch node 0.
+    const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
     prof.mark(PhaseProfile::kPartition, stream_);
     if (!root)
-      k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), arena_[0].get(), arena_[1].get(), arena_[0].get(),
+      k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, mask_.get(), chunk_left_.get(), task_left_.get(),
                    k::BagParams{0, 0, 0, 0.f}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
                    (int64_t)slot_words_ * B, stream_);
@@ -327,8 +334,9 @@ class HipBackend : public TreeBackend {
         if (owned > 0) { tile_first = r; tile_step = P; tile_count = owned; }
         else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
       }
-      k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), arena_[0].get(), arena_[1].get(), mir_->bins_rt.get(), N_,
-                   packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count, stream_);
+      k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_,
+                   packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count,
+                   root ? &root_quant_ : nullptr, stream_);
     }
     prof.mark(PhaseProfile::kComm, stream_);
     if (mode_ == ParallelMode::Data)
@@ -447,6 +455,8 @@ class HipBackend : public TreeBackend {
   const int32_t* bag_ = nullptr;
   int64_t bag_n_ = 0;
   const int64_t* packed_ = nullptr;
+  const uint8_t* hist_src_ = nullptr;
+  k::FusedQuant root_quant_{};
 };
 
 // ---------------------------------------------------------------------------
@@ -472,7 +482,6 @@ class HipEngine : public Engine {
     scores_.resize((size_t)N_);
     grad_.resize((size_t)N_);
     hess_.resize((size_t)N_);
-    packed_.resize((size_t)N_);
     maxbits_.resize(2);
     red_dev_.resize(k::kReduceDoubles);
     red_host_.resize(8);
@@ -484,6 +493,17 @@ class HipEngine : public Engine {
     bag_ptr_ = base_rows_.get();
     bag_n_ = n_base_;
     oob_n_ = 0;
+    // Large single-tile datasets get a private copy of the bin records interleaved with the packed
+    // gradients (one 128-byte line per three rows); everything else keeps the separate gradient array.
+    const bool lines_possible = train_->num_tiles() == 1 && backend_->mode() != ParallelMode::Feature;
+    use_lines_ = lines_possible && N_ >= kLinesMinRows;
+    if (const char* e = std::getenv("LGA_ROW_LINES")) use_lines_ = lines_possible && std::string(e) != "0";   // 0 / 1 override the size rule
+    if (use_lines_) {
+      lines_.resize((size_t)k::row_line_bytes(N_));
+      k::build_row_lines(mir_->bins_rt.get(), N_, lines_.get(), stream_);
+    } else {
+      packed_.resize((size_t)N_);
+    }
     if (const char* e = std::getenv("LGA_SCORE_UPDATE"))
       score_update_ = std::string(e) == "leaf" ? 1 : (std::string(e) == "walk" ? 2 : 0);
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -579,10 +599,15 @@ class HipEngine : public Engine {
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
-    k::quantize(grad_.get(), hess_.get(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
-                backend_->qs_device(), packed_.get(), stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
-    backend_->set_packed(packed_.get());
+    if (use_lines_) {
+      backend_->set_packed(nullptr, lines_.get());
+      backend_->set_root_quant(grad_.get(), hess_.get(), maxbits_.get());
+    } else {
+      k::quantize(grad_.get(), hess_.get(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
+                  backend_->qs_device(), packed_.get(), stream_);
+      backend_->set_packed(packed_.get(), mir_->bins_rt.get());
+    }
     return grower_.grow(*backend_, meta, &leaf_nodes_);
   }
 
@@ -771,6 +796,9 @@ class HipEngine : public Engine {
   const int32_t* bag_ptr_ = nullptr;
   DeviceBuffer<int32_t> base_rows_, bag_rows_;
   static constexpr int64_t kWalkMinRows = 1 << 20;
+  static constexpr int64_t kLinesMinRows = 1 << 18;
+  bool use_lines_ = false;
+  DeviceBuffer<uint8_t> lines_;
   int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;

@@ -171,13 +171,15 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
 // or, for small rounds, inline in the kernel arguments (no host->device copy at all).
 template <bool PART>
 __device__ __forceinline__ int find_task(const InlineTasks& inl, int wg) {
-  int ti = 0;
+  // last task whose first chunk is <= wg (first chunks increase strictly: every task owns >= 1 chunk)
+  int lo = 0, hi = inl.count - 1;
 #pragma unroll 1
-  for (int i = 0; i < inl.count; ++i) {
-    const int first = PART ? inl.t[i].first_pchunk : inl.t[i].first_hchunk;
-    if (wg >= first) ti = i;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    const int first = PART ? inl.t[mid].first_pchunk : inl.t[mid].first_hchunk;
+    if (wg >= first) lo = mid; else hi = mid - 1;
   }
-  return ti;
+  return lo;
 }
 
 // Pass 1 of the partition: ballot masks + left counts per 2048-row chunk.  A task that fits ONE
@@ -336,11 +338,27 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
 // ---------------------------------------------------------------------------
 // histogram
 // ---------------------------------------------------------------------------
+// LINES: the rows come from the engine's 128-byte row lines (three rows per line: 3 x 32 bin bytes, then
+// their 3 packed gradient words), so a sparse leaf pays ONE line per row instead of one for the bin
+// record and another for the gradient word.  Single-tile datasets only; bins_rt then points at the lines.
+__device__ __forceinline__ unsigned div3(unsigned r) { return (unsigned)(((unsigned long long)r * 0xAAAAAAABull) >> 33); }
+
+// QUANT (root pass over row lines): the gradients arrive as floats, are quantised here and written into
+// the rows' lines on the way - the lines are in flight anyway, so the separate quantisation pass (a
+// scattered 8-byte write per row) disappears.
+struct QuantSource {
+  const float* g;
+  const float* h;
+  const uint32_t* maxbits;
+  QuantScale* qs_out;
+};
+
+template <bool LINES, bool QUANT>
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl, int rows_per_chunk,
     const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, int64_t* __restrict__ pool,
-    int64_t slot_words, int64_t plane, int F, int tile_first, int tile_step) {
+    int64_t slot_words, int64_t plane, int F, int tile_first, int tile_step, QuantSource qsrc) {
   __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
   __shared__ long long red[3][kHistThreads / kWave];
   const int x = blockIdx.x;
@@ -359,6 +377,12 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
   const int nf = min(kTileFeatures, F - tile * kTileFeatures);
   long long sg = 0, sh = 0;
+  int kg = 0, kh = 0;
+  if (QUANT) {
+    kg = quant_exponent(__uint_as_float(qsrc.maxbits[0]));
+    kh = quant_exponent(__uint_as_float(qsrc.maxbits[1]));
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { qsrc.qs_out->kg = kg; qsrc.qs_out->kh = kh; }
+  }
   // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
   // SIMD keep ~U x 3 memory requests per lane in flight.
   constexpr int U = 4;
@@ -374,9 +398,22 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] >= 0) {
-        p[u] = (unsigned long long)packed[row[u]];
-        ra[u] = recs[(int64_t)row[u] * 2];
-        rb[u] = recs[(int64_t)row[u] * 2 + 1];
+        if (LINES) {
+          const unsigned line = div3((unsigned)row[u]), slot = (unsigned)row[u] - line * 3u;
+          const uint4* L = recs + (int64_t)line * 8;
+          ra[u] = L[slot * 2];
+          rb[u] = L[slot * 2 + 1];
+          if (QUANT) {
+            p[u] = (unsigned long long)pack_gh(lga::quantize(qsrc.g[row[u]], kg), lga::quantize(qsrc.h[row[u]], kh));
+            reinterpret_cast<unsigned long long*>(const_cast<uint4*>(L))[12 + slot] = p[u];
+          } else {
+            p[u] = reinterpret_cast<const unsigned long long*>(L)[12 + slot];
+          }
+        } else {
+          p[u] = (unsigned long long)packed[row[u]];
+          ra[u] = recs[(int64_t)row[u] * 2];
+          rb[u] = recs[(int64_t)row[u] * 2 + 1];
+        }
       }
     }
 #pragma unroll
@@ -385,11 +422,27 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
         sg += (long long)(int32_t)(p[u] >> 32);
         sh += (long long)(p[u] & 0xffffffffull);
         const unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+        if (LINES) {
+          // byte k of the row's record holds feature (k + row) mod 32: the lanes of a wave work on
+          // different features at any moment, so a feature with three distinct values no longer makes
+          // 64 lanes queue on three LDS words; the (bin + 8 f) rotation keeps equal bins of different
+          // features in different banks.
+          const unsigned rot = (unsigned)row[u];
 #pragma unroll
-        for (int k = 0; k < kTileFeatures; ++k) {
-          if (k < nf) {
-            unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-            atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+          for (int k = 0; k < kTileFeatures; ++k) {
+            const unsigned f = (k + rot) & 31u;
+            if (f < (unsigned)nf) {
+              const unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+              atomicAdd(&lds[f * kMaxBins + ((bin + 8u * f) & 255u)], p[u]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < kTileFeatures; ++k) {
+            if (k < nf) {
+              unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+              atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+            }
           }
         }
       }
@@ -400,7 +453,8 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   unsigned long long* gp = reinterpret_cast<unsigned long long*>(slot + (int64_t)tile * kTileFeatures * kMaxBins);
   unsigned long long* hp = reinterpret_cast<unsigned long long*>(slot + plane + (int64_t)tile * kTileFeatures * kMaxBins);
   for (int e = threadIdx.x; e < nf * kMaxBins; e += kHistThreads) {
-    unsigned long long v = lds[e];
+    const int fe = e >> 8;
+    unsigned long long v = LINES ? lds[(fe << 8) + ((e + 8 * fe) & 255)] : lds[e];
     if (v != 0ull) {
       atomicAdd(&gp[e], (unsigned long long)(long long)(int32_t)(v >> 32));
       atomicAdd(&hp[e], v & 0xffffffffull);
@@ -885,12 +939,58 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                int rows_per_chunk, const NodeRange* nodes, const int32_t* a0, const int32_t* a1,
                const uint8_t* bins_rt, int64_t N, const int64_t* packed, int64_t* pool, int64_t slot_words,
-               int64_t plane, int F, int tile_first, int tile_step, int tile_count, hipStream_t s) {
+               int64_t plane, int F, int tile_first, int tile_step, int tile_count, const FusedQuant* quant,
+               hipStream_t s) {
   if (total_chunks <= 0 || tile_count <= 0) return;
   if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
-  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
-                     rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, tile_first,
-                     tile_step);
+  const QuantSource none{nullptr, nullptr, nullptr, nullptr};
+  if (packed == nullptr) {
+    if (tile_count != 1 || tile_first != 0) throw std::runtime_error("row lines hold a single feature tile");
+    if (quant && quant->g)
+      hipLaunchKernelGGL((hist_kernel<true, true>), dim3(total_chunks, 1), dim3(kHistThreads), 0, s, tasks, chunk_task,
+                         inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, 0, 1,
+                         QuantSource{quant->g, quant->h, quant->maxbits, quant->qs_out});
+    else
+      hipLaunchKernelGGL((hist_kernel<true, false>), dim3(total_chunks, 1), dim3(kHistThreads), 0, s, tasks, chunk_task,
+                         inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, 0, 1, none);
+  } else {
+    if (quant && quant->g) throw std::runtime_error("fused quantisation needs the row-line layout");
+    hipLaunchKernelGGL((hist_kernel<false, false>), dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks,
+                       chunk_task, inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F,
+                       tile_first, tile_step, none);
+  }
+  LGA_LAUNCH_CHECK();
+}
+
+// Row r's 32 bin bytes are stored rotated by r: byte j of the line slot = feature (j + r) mod 32.
+__global__ __launch_bounds__(256) void build_lines_kernel(const unsigned* __restrict__ recs, int64_t N, unsigned* __restrict__ lines) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    unsigned src[8], dst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) src[i] = recs[r * 8 + i];
+    const unsigned rot = (unsigned)(r & 31);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const unsigned f = (j + rot) & 31u;                      // feature stored at byte j
+      unsigned b = 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) if ((f >> 2) == (unsigned)q) b = (src[q] >> ((f & 3u) * 8)) & 255u;
+      dst[j >> 2] |= b << ((j & 3) * 8);
+    }
+    const int64_t line = r / 3;
+    const int slot = (int)(r - line * 3);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lines[line * 32 + slot * 8 + i] = dst[i];
+  }
+}
+
+void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hipStream_t s) {
+  if (N <= 0) return;
+  LGA_HIP_CHECK(hipMemsetAsync(lines, 0, (size_t)row_line_bytes(N), s));
+  hipLaunchKernelGGL(build_lines_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, s,
+                     reinterpret_cast<const unsigned*>(bins_rt_tile0), N, reinterpret_cast<unsigned*>(lines));
   LGA_LAUNCH_CHECK();
 }
 

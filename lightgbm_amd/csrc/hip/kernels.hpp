@@ -13,7 +13,7 @@ constexpr int kPartThreads = 256;
 constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
 
 // Small rounds carry their task descriptors inside the kernel arguments.
-constexpr int kInlineTasks = 16;
+constexpr int kInlineTasks = 56;   // 56 x 64 B: the largest struct that still fits the 4 KiB kernel-argument block
 struct InlineTasks {
   SplitTask t[kInlineTasks];
   int32_t count;
@@ -56,6 +56,10 @@ void gradients(const ObjectiveSpec& obj, const double* scores, const float* labe
 void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s);
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
               int64_t* packed, hipStream_t s);
+// Row lines (single feature tile): line r/3 = [3 x 32 bin bytes | 3 x 8-byte packed gradients | 8 spare];
+// the 32 bin bytes of row r are rotated by r (byte j = feature (j + r) mod 32).
+inline int64_t row_line_bytes(int64_t N) { return ((N + 2) / 3) * 128; }
+void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hipStream_t s);
 
 // Partition (or bagging when task.feature < 0): a0/a1 are the two row-index buffers a node's `buf` selects.
 struct BagParams { uint64_t seed, iter, salt; float fraction; };
@@ -66,10 +70,18 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
                int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
                int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s);
 
+// packed == nullptr: bins_rt points at row lines (see build_row_lines) that carry the gradients themselves.
+// quant (row lines, root pass): quantise the float gradients inside the pass and store them in the lines.
+struct FusedQuant {
+  const float* g = nullptr;
+  const float* h = nullptr;
+  const uint32_t* maxbits = nullptr;
+  QuantScale* qs_out = nullptr;
+};
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks, int rows_per_chunk,
                const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
                const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
-               int tile_step, int tile_count, hipStream_t s);
+               int tile_step, int tile_count, const FusedQuant* quant, hipStream_t s);
 
 void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F, int f_first_tile, int tile_step,
           int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,

@@ -40,7 +40,7 @@ int hip_run_op(const std::string& name, void** p, int nptr, const int64_t* a, in
     k::InlineTasks none{};
     k::histogram((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], (int)a[1], (const NodeRange*)p[2],
                  (const int32_t*)p[3], (const int32_t*)p[4], (const uint8_t*)p[5], a[2], (const int64_t*)p[6],
-                 (int64_t*)p[7], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], s);
+                 (int64_t*)p[7], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], nullptr, s);
     return 0;
   }
   if (name == "partition") {

@@ -206,6 +206,18 @@ def test_gpu_regression_trees_equal_cpu_trees(params):
     assert trees_of(a) == trees_of(b)
 
 
+@pytest.mark.parametrize("lines", ["0", "1"])
+def test_row_line_layout_grows_the_same_trees(lines, monkeypatch):
+    """Bin records interleaved with the packed gradients (the large-data layout) vs the separate arrays."""
+    monkeypatch.setenv("LGA_ROW_LINES", lines)
+    X, y = make_regression(50001, 9, seed=11)     # row count not divisible by three
+    X[::17, 2] = np.nan
+    p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.7, "bagging_freq": 1}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 8)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 8)
+    assert trees_of(a) == trees_of(b)
+
+
 def test_gpu_binary_matches_cpu_quality_and_first_tree():
     X, y = make_higgs_like(60000, seed=2, device="numpy")
     p = {"objective": "binary", "num_leaves": 63, "metric": ["auc", "binary_logloss"], "min_sum_hessian_in_leaf": 10.0}
