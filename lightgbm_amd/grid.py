@@ -149,19 +149,21 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                    showsd: bool = False, stratified: bool = True, seed: int = 0, checkpoint: Optional[str] = None,
                    resume: bool = True, workers: Optional[Sequence[Any]] = None, compat_sentinel: bool = False,
                    dataset_params: Optional[Dict[str, Any]] = None, verbose: bool = False,
-                   inject_fail_after: Optional[int] = None, progress: Optional[Callable[[int, int], None]] = None):
+                   inject_fail_after: Optional[int] = None, progress: Optional[Callable[[int, int], None]] = None,
+                   base_params: Optional[Dict[str, Any]] = None):
     """Runs early-stopped k-fold CV for every row of ``param_grid`` and fills ``iteration`` / ``score``.
 
     ``workers``: None -> run in this process; otherwise a list of devices, one worker process each,
-    e.g. ``[0, 1, ..., 7]`` (GPU ids) or ``["cpu", "cpu"]``.  Returns the grid as a DataFrame (row
-    order unchanged; rank it with :func:`rank_grid`).
+    e.g. ``[0, 1, ..., 7]`` (GPU ids) or ``["cpu", "cpu"]``.  ``base_params`` are engine parameters every
+    row shares (a row's own columns win).  Returns the grid as a DataFrame (row order unchanged; rank it
+    with :func:`rank_grid`).
     """
     import pandas as pd
     grid = param_grid.copy() if hasattr(param_grid, "copy") and hasattr(param_grid, "columns") else pd.DataFrame(list(param_grid))
     for c in RESULT_COLUMNS:
         if c not in grid.columns:
             grid.insert(0 if c == "iteration" else 1, c, np.nan)
-    rows = [_row_params(r) for r in grid.to_dict(orient="records")]
+    rows = [{**(base_params or {}), **_row_params(r)} for r in grid.to_dict(orient="records")]
     cv_kwargs = dict(nrounds=nrounds, nfold=nfold, objective=objective, eval=eval, showsd=showsd,
                      early_stopping_rounds=early_stopping_rounds, verbose=0, stratified=stratified, seed=seed,
                      compat_sentinel=compat_sentinel)

@@ -105,11 +105,15 @@ def make_curve_1d(n: int = 1000, seed: int = 8657, noise: float = 0.05) -> Tuple
 
 
 def make_regression(n: int, f: int, seed: int = 0, informative: int | None = None, noise: float = 0.3,
-                    dtype=np.float64) -> Tuple[np.ndarray, np.ndarray]:
+                    dtype=np.float64, coef_seed: int | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Rows from ``seed``; the linear coefficients from ``coef_seed`` when given (so that shards / train and
+    test sets drawn with different seeds follow the same relationship), else from ``seed`` as well."""
     rng = np.random.RandomState(seed)
     X = rng.standard_normal((n, f)).astype(dtype)
     k = informative or max(3, f // 3)
     w = rng.standard_normal(k)
+    if coef_seed is not None:
+        w = np.random.RandomState(coef_seed).standard_normal(k)
     y = X[:, :k] @ w
     y = y + np.sin(2.0 * X[:, 0]) * 2.0 + X[:, 1] * X[:, 2] + (X[:, min(3, f - 1)] > 0.5) * 1.5
     y = y + noise * rng.standard_normal(n)

@@ -10,7 +10,7 @@ CPU = {"device_type": "cpu", "verbose": -1}
 
 
 def _data(n=4000, f=8, seed=0, nan=True):
-    X, y = make_regression(n, f, seed=seed)
+    X, y = make_regression(n, f, seed=seed, coef_seed=0)
     if nan:
         X[::11, 1] = np.nan
         X[::7, 3] = np.nan
