@@ -46,10 +46,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # LGA_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, agreed bin boundaries, RCCL
+    # communicator) even with one rank - a plumbing check for boxes that have a single GPU
+    distributed = world > 1 or os.environ.get("LGA_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import lightgbm_amd as lgb

@@ -103,6 +103,11 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
         callbacks.append(cb.record_evaluation(evals_result))
     cb_before, cb_after = _split_callbacks(callbacks)
 
+    # periodic snapshots (snapshot_freq / save_period): "<output_model>.snapshot_iter_<k>", written atomically, so a
+    # killed run can continue with train(init_model=<latest snapshot>)
+    snapshot_freq = int(get_param(params, "snapshot_freq", -1) or -1)
+    snapshot_base = str(get_param(params, "output_model", "LightGBM_model.txt"))
+
     need_eval = bool(booster.valid_sets) or is_valid_contain_train
     booster.best_iteration = 0
     evaluation_result_list: List[Tuple] = []
@@ -110,6 +115,8 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
         for c in cb_before:
             c(cb.CallbackEnv(booster, params, i, 0, num_boost_round, None))
         finished = booster.update(fobj=fobj)
+        if snapshot_freq > 0 and (i + 1) % snapshot_freq == 0:
+            booster.save_model(f"{snapshot_base}.snapshot_iter_{i + 1}")
         evaluation_result_list = []
         if need_eval:
             if is_valid_contain_train:

@@ -206,3 +206,27 @@ def test_pandas_and_names():
     b = lgb.train({**CPU, "num_leaves": 7}, lgb.Dataset(df, label=pd.Series(y)), 3)
     assert "feature_names=a b c_d e" in b.model_to_string()
     np.testing.assert_array_equal(b.predict(df), b.predict(X))
+
+
+def test_snapshots_allow_resuming_a_killed_run(tmp_path):
+    """snapshot_freq writes '<output_model>.snapshot_iter_k'; init_model continues from it to the same model."""
+    X, y = make_regression(3000, 6, seed=8)
+    out = str(tmp_path / "model.txt")
+    p = {**CPU, "num_leaves": 15, "snapshot_freq": 4, "output_model": out}
+    full = lgb.train(p, lgb.Dataset(X, label=y, params=CPU, free_raw_data=False), 10)
+    import os
+    assert os.path.exists(out + ".snapshot_iter_4") and os.path.exists(out + ".snapshot_iter_8")
+    assert not os.path.exists(out + ".snapshot_iter_10")
+    part = lgb.Booster(model_file=out + ".snapshot_iter_8")
+    assert part.num_trees() == 8
+    resumed = lgb.train({**CPU, "num_leaves": 15}, lgb.Dataset(X, label=y, params=CPU, free_raw_data=False), 2,
+                        init_model=out + ".snapshot_iter_8")
+    assert resumed.num_trees() == 10
+    np.testing.assert_allclose(resumed.predict(X), full.predict(X), rtol=1e-9, atol=1e-9)
+
+
+def test_unimplemented_parameters_are_refused():
+    X, y = make_regression(500, 4, seed=1)
+    for bad in ({"feature_fraction_bynode": 0.5}, {"zero_as_missing": True}):
+        with pytest.raises(lgb.LightGBMError):
+            lgb.train({**CPU, **bad}, lgb.Dataset(X, label=y, params=CPU), 2)
