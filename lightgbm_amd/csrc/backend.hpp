@@ -50,6 +50,34 @@ class TreeBackend {
   virtual QuantScale quant_scale() const = 0;
   // Local row count of a node (after the round that created it).
   virtual int64_t node_local_count(int node) const = 0;
+
+  // Asynchronous form: up to max_in_flight() rounds may be submitted before the first one is waited
+  // for, so one round's latency-bound tail (split scan, result hand-over, host replay) overlaps with
+  // another round's row-level work.  Rounds in flight never share a leaf; a round may depend on the
+  // results of any round that has been waited for.  The default runs every round at submission.
+  virtual int max_in_flight() const { return 1; }
+  virtual int submit_round(std::vector<SplitTask>& tasks) {
+    int ticket = 0;
+    while (ticket < (int)held_.size() && held_[(size_t)ticket].busy) ++ticket;
+    if (ticket == (int)held_.size()) held_.emplace_back();
+    Held& h = held_[(size_t)ticket];
+    h.busy = true;
+    h.infos.assign(tasks.size() * 2, SplitInfo{});
+    split_round(tasks, h.infos.data());
+    return ticket;
+  }
+  virtual void wait_round(int ticket, SplitInfo* infos) {
+    Held& h = held_[(size_t)ticket];
+    for (size_t i = 0; i < h.infos.size(); ++i) infos[i] = h.infos[i];
+    h.busy = false;
+  }
+
+ private:
+  struct Held {
+    bool busy = false;
+    std::vector<SplitInfo> infos;
+  };
+  std::vector<Held> held_;
 };
 
 }  // namespace lga

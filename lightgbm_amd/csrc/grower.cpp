@@ -9,7 +9,9 @@
 
 namespace lga {
 
-TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds) {}
+TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds) {
+  if (const char* e = std::getenv("LGA_SPEC_FLOOR")) spec_floor_ = std::atof(e);
+}
 
 SplitParams TreeGrower::split_params() const {
   SplitParams p;
@@ -43,14 +45,16 @@ namespace {
 struct GrowTrace {
   bool on = std::getenv("LGA_GROW_TRACE") != nullptr;
   double total_us = 0, backend_us = 0, tail_us = 0;
+  double rows_split = 0, rows_used = 0;   // rows of all partitioned leaves / of the leaves whose split was used
   int trees = 0;
   using clock = std::chrono::steady_clock;
   static double us(clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
   void report() {
     if (++trees % 100 == 0) {
-      std::fprintf(stderr, "[grow trace] per tree: total %.1f us, in backend %.1f us, host %.1f us (of which after the last round %.1f us)\n",
-                   total_us / 100, backend_us / 100, (total_us - backend_us) / 100, tail_us / 100);
-      total_us = backend_us = tail_us = 0;
+      std::fprintf(stderr, "[grow trace] per tree: total %.1f us, in backend %.1f us, host %.1f us (of which after the last round %.1f us); "
+                   "rows partitioned %.0f, of used splits %.0f\n",
+                   total_us / 100, backend_us / 100, (total_us - backend_us) / 100, tail_us / 100, rows_split / 100, rows_used / 100);
+      total_us = backend_us = tail_us = rows_split = rows_used = 0;
     }
   }
 };
@@ -92,85 +96,149 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   std::vector<int> chosen;   // node ids in strict best-first order
   int budget = budget_total;
   int materialized = 0;
-  std::vector<SplitTask> tasks;
+  const int max_flight = cfg_.max_batch_leaves > 0 ? 1 : std::max(1, be.max_in_flight());
+  struct Flight {
+    int ticket;
+    std::vector<SplitTask> tasks;
+  };
+  std::vector<Flight> flights;           // oldest first
   std::vector<SplitInfo> infos;
+  // Leaves whose gain is far below the smallest gain the previous tree still used are unlikely to get
+  // their turn: they wait until the real replay asks for them (the stalled leaf itself always goes).
+  const double floor_gain = spec_floor_ * prev_cutoff_;
 
-  while (budget > 0 && !frontier.empty()) {
-    Entry top = frontier.top();
-    Node& n = nodes[(size_t)top.node];
-    if (n.left >= 0) {
-      // already partitioned and scanned: the split is final
+  auto submit = [&](std::vector<SplitTask>&& tasks) {
+    Flight f;
+    f.tasks = std::move(tasks);
+    const auto t_call = GrowTrace::clock::now();
+    f.ticket = be.submit_round(f.tasks);
+    if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_call, t_last_backend); }
+    ++stats_.rounds;
+    flights.push_back(std::move(f));
+  };
+  auto wait_oldest = [&]() {
+    Flight f = std::move(flights.front());
+    flights.erase(flights.begin());
+    infos.assign(f.tasks.size() * 2, SplitInfo{});
+    const auto t_call = GrowTrace::clock::now();
+    be.wait_round(f.ticket, infos.data());
+    if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_call, t_last_backend); }
+    for (size_t i = 0; i < f.tasks.size(); ++i) {
+      for (int side = 0; side < 2; ++side) {
+        int id = side == 0 ? f.tasks[i].left_node : f.tasks[i].right_node;
+        nodes[(size_t)id].best = infos[i * 2 + (size_t)side];
+        if (depth_blocked(nodes[(size_t)id].depth)) nodes[(size_t)id].best.feature = -1;
+      }
+      nodes[(size_t)f.tasks[i].parent_node].ready = true;
+    }
+  };
+
+  while (true) {
+    // 1. the real replay: strict best-first over leaves whose children are known
+    bool stalled_on_flight = false;
+    while (budget > 0 && !frontier.empty()) {
+      const Entry top = frontier.top();
+      Node& n = nodes[(size_t)top.node];
+      if (n.left < 0) break;                              // not partitioned yet
+      if (!n.ready) { stalled_on_flight = true; break; }  // its round is still in flight
       frontier.pop();
       chosen.push_back(top.node);
       --budget;
       push(n.left);
       push(n.right);
+    }
+    if (budget == 0 || frontier.empty()) break;
+
+    // 2. the virtual replay: what would the replay reach with everything known so far?  Partitioned
+    //    leaves hand over their children; every leaf reached that is not partitioned yet becomes a task.
+    std::vector<SplitTask> tasks;
+    if ((int)flights.size() < max_flight) {
+      // Capacity rule: after any submission there must be one free split per remaining unit of budget
+      // (every remaining pick may need a fresh partition).  A round that contains the stalled leaf gets
+      // that leaf picked as soon as it is back, so it may use the last free split; a purely speculative
+      // round may not.
+      const int pool_room = capacity_splits - materialized - (budget - 1);
+      const bool top_needs_task = nodes[(size_t)frontier.top().node].left < 0;
+      int max_new = std::min(budget, top_needs_task ? pool_room : pool_room - 1);
+      if (max_new < 1 && flights.empty()) throw std::runtime_error("tree grower ran out of node capacity");
+      if (cfg_.max_batch_leaves > 0) max_new = std::min(max_new, cfg_.max_batch_leaves);
+      auto virt = frontier;
+      int vseq = seq;
+      int vbudget = budget;
+      while (!virt.empty() && vbudget > 0 && (int)tasks.size() < max_new) {
+        Entry e = virt.top();
+        virt.pop();
+        --vbudget;
+        Node& c = nodes[(size_t)e.node];
+        if (c.left >= 0) {
+          if (!c.ready) continue;                         // in flight: children unknown
+          for (int child : {c.left, c.right}) {
+            const SplitInfo& s = nodes[(size_t)child].best;
+            if (splittable(s)) virt.push(Entry{s.gain, vseq, child});
+            ++vseq;
+          }
+          continue;
+        }
+        const bool is_stall_leaf = e.node == frontier.top().node;
+        if (!is_stall_leaf && e.gain < floor_gain) continue;
+        SplitTask t{};
+        t.parent_node = e.node;
+        t.left_node = (int)nodes.size();
+        t.right_node = (int)nodes.size() + 1;
+        t.feature = c.best.feature;
+        t.threshold = c.best.threshold;
+        t.default_left = c.best.default_left;
+        t.missing_bin = meta[(size_t)c.best.feature].missing_bin;
+        int64_t lc = c.best.left_cnt, rc = c.best.total_cnt - c.best.left_cnt;
+        t.hist_child = lc <= rc ? 0 : 1;
+        t.parent_slot = c.slot;
+        t.new_slot = 1 + materialized + (int)tasks.size();
+        t.depth = c.depth + 1;
+        Node l, r;
+        l.parent = r.parent = e.node;
+        l.depth = r.depth = c.depth + 1;
+        l.slot = t.hist_child == 0 ? t.new_slot : t.parent_slot;
+        r.slot = t.hist_child == 1 ? t.new_slot : t.parent_slot;
+        c.left = t.left_node;
+        c.right = t.right_node;
+        nodes.push_back(l);
+        nodes.push_back(r);
+        tasks.push_back(t);
+      }
+    }
+    if (!tasks.empty()) {
+      materialized += (int)tasks.size();
+      // Nothing else in flight and room for two rounds: halve the batch, so that from here on one half's
+      // scan / hand-over / replay overlaps with the other half's partition and histogram work.
+      if (flights.empty() && max_flight >= 2 && tasks.size() >= 2) {
+        const size_t half = (tasks.size() + 1) / 2;
+        std::vector<SplitTask> second(tasks.begin() + (std::ptrdiff_t)half, tasks.end());
+        tasks.resize(half);
+        submit(std::move(tasks));
+        submit(std::move(second));
+      } else {
+        submit(std::move(tasks));
+      }
       continue;
     }
-    // Stall: continue the replay VIRTUALLY over everything that is known - leaves that are already
-    // partitioned hand over their children - and split every leaf it reaches that is not
-    // partitioned yet, all in one backend round.
-    int pool_room = capacity_splits - materialized - (budget - 1);
-    if (pool_room < 1) throw std::runtime_error("tree grower ran out of node capacity");
-    int max_new = std::min(budget, pool_room);
-    if (cfg_.max_batch_leaves > 0) max_new = std::min(max_new, cfg_.max_batch_leaves);
-    auto virt = frontier;
-    int vseq = seq;
-    int vbudget = budget;
-    tasks.clear();
-    while (!virt.empty() && vbudget > 0 && (int)tasks.size() < max_new) {
-      Entry e = virt.top();
-      virt.pop();
-      --vbudget;
-      Node& c = nodes[(size_t)e.node];
-      if (c.left >= 0) {
-        for (int child : {c.left, c.right}) {
-          const SplitInfo& s = nodes[(size_t)child].best;
-          if (splittable(s)) virt.push(Entry{s.gain, vseq, child});
-          ++vseq;
-        }
-        continue;
-      }
-      SplitTask t{};
-      t.parent_node = e.node;
-      t.left_node = (int)nodes.size();
-      t.right_node = (int)nodes.size() + 1;
-      t.feature = c.best.feature;
-      t.threshold = c.best.threshold;
-      t.default_left = c.best.default_left;
-      t.missing_bin = meta[(size_t)c.best.feature].missing_bin;
-      int64_t lc = c.best.left_cnt, rc = c.best.total_cnt - c.best.left_cnt;
-      t.hist_child = lc <= rc ? 0 : 1;
-      t.parent_slot = c.slot;
-      t.new_slot = 1 + materialized + (int)tasks.size();
-      t.depth = c.depth + 1;
-      Node l, r;
-      l.parent = r.parent = e.node;
-      l.depth = r.depth = c.depth + 1;
-      l.slot = t.hist_child == 0 ? t.new_slot : t.parent_slot;
-      r.slot = t.hist_child == 1 ? t.new_slot : t.parent_slot;
-      c.left = t.left_node;
-      c.right = t.right_node;
-      nodes.push_back(l);
-      nodes.push_back(r);
-      tasks.push_back(t);
+    // 3. nothing new to start: a round must finish first
+    if (flights.empty()) {
+      if (stalled_on_flight) throw std::runtime_error("tree grower: waiting for a round that was never submitted");
+      throw std::runtime_error("tree grower stalled without work");
     }
-    infos.assign(tasks.size() * 2, SplitInfo{});
-    const auto t_call = GrowTrace::clock::now();
-    be.split_round(tasks, infos.data());
-    if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_call, t_last_backend); }
-    ++stats_.rounds;
-    materialized += (int)tasks.size();
-    for (size_t i = 0; i < tasks.size(); ++i) {
-      for (int side = 0; side < 2; ++side) {
-        int id = side == 0 ? tasks[i].left_node : tasks[i].right_node;
-        nodes[(size_t)id].best = infos[i * 2 + (size_t)side];
-        if (depth_blocked(nodes[(size_t)id].depth)) nodes[(size_t)id].best.feature = -1;
-      }
-    }
+    wait_oldest();
   }
+  // rounds still in flight only carried speculation: their results are not needed, the device work is
+  while (!flights.empty()) wait_oldest();
   stats_.materialized_splits = materialized;
   stats_.used_splits = (int)chosen.size();
+  // smallest gain that made it into this tree (0 when the tree ran out of splittable leaves first)
+  prev_cutoff_ = 0.0;
+  if ((int)chosen.size() == budget_total && !chosen.empty()) {
+    double m = nodes[(size_t)chosen[0]].best.gain;
+    for (int id : chosen) m = std::min(m, nodes[(size_t)id].best.gain);
+    prev_cutoff_ = m;
+  }
 
   // Assemble the tree in LightGBM numbering by replaying the final order.
   Tree tree;
@@ -222,6 +290,8 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     }
   }
   if (g_trace.on) {
+    for (const Node& n : nodes) if (n.left >= 0) g_trace.rows_split += (double)n.best.total_cnt;
+    for (int id : chosen) g_trace.rows_used += (double)nodes[(size_t)id].best.total_cnt;
     const auto t_exit = GrowTrace::clock::now();
     g_trace.total_us += GrowTrace::us(t_enter, t_exit);
     g_trace.backend_us += backend_us;

@@ -49,12 +49,15 @@ class TreeGrower {
     int parent = -1;
     int depth = 0;
     int slot = 0;
-    int left = -1, right = -1;   // children node ids once materialised
+    int left = -1, right = -1;   // children node ids once the leaf's split has been submitted
+    bool ready = false;          // ... and once that round's results are in
     SplitInfo best;
   };
   const Config cfg_;
   const Dataset* ds_;
   GrowStats stats_;
+  double prev_cutoff_ = 0.0;   // smallest used gain of the previous tree
+  double spec_floor_ = 0.5;    // speculate only on gains >= spec_floor_ * prev_cutoff_
 };
 
 }  // namespace lga

@@ -127,35 +127,51 @@ class HipBackend : public TreeBackend {
     arena_[1].resize((size_t)std::max<int64_t>(max_rows, 1));
     max_pchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), k::kPartChunk) + max_batch_ + 1;
     max_hchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), 1024) + max_batch_ + 1;
-    mask_.resize((size_t)max_pchunks_ * (k::kPartChunk / 64));
-    chunk_left_.resize((size_t)max_pchunks_);
-    task_left_.resize((size_t)max_batch_ + 1);
-    // one staging block: [tasks | scan tasks | pchunk table | hchunk table]
+    // one staging block per round context: [tasks | scan tasks | pchunk table | hchunk table]
     off_tasks_ = 64;   // the first 64 bytes stage one NodeRange
     off_scan_ = off_tasks_ + sizeof(SplitTask) * (size_t)(max_batch_ + 1);
     off_pch_ = off_scan_ + sizeof(k::ScanTaskDev) * (size_t)(2 * max_batch_ + 2);
     off_hch_ = off_pch_ + sizeof(int32_t) * (size_t)max_pchunks_;
     stage_bytes_ = off_hch_ + sizeof(int32_t) * (size_t)max_hchunks_;
     stage_bytes_ = (stage_bytes_ + 255) & ~(size_t)255;
-    stage_host_.resize(stage_bytes_);
-    stage_dev_.resize(stage_bytes_);
     cands_.resize((size_t)(2 * max_batch_ + 2) * (size_t)std::max(F_, 1));
     results_dev_.resize((size_t)(2 * max_batch_ + 2));
-    // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
-    host_block_.resize(k::kHostDataOffset + sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) +
-                       sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
-    std::memset(host_block_.get(), 0, host_block_.size());
-    host_block_dev_ = host_block_.device_ptr();
-    done_counter_.resize(4);
-    done_counter_.zero(stream_);
+    // Two rounds may be in flight when results travel through the mapped block (fused scan) and no
+    // per-phase event timing is requested; the second context owns a stream of its own.
+    prof.on = cfg.profile;
+    const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
+    // Small data gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on
+    // their own streams) already fill the hardware queues.
+    n_ctx_ = (fused && !prof.on && max_rows >= (int64_t)1 << 19) ? 2 : 1;
+    if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = (fused && !prof.on) ? std::max(1, std::min(2, std::atoi(e))) : 1;
+    for (int c = 0; c < n_ctx_; ++c) {
+      RoundCtx& x = ctx_[c];
+      if (c == 0) x.stream = stream_;
+      else { LGA_HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking)); x.owns_stream = true; }
+      x.mask.resize((size_t)max_pchunks_ * (k::kPartChunk / 64));
+      x.chunk_left.resize((size_t)max_pchunks_);
+      x.task_left.resize((size_t)max_batch_ + 1);
+      x.stage_host.resize(stage_bytes_);
+      x.stage_dev.resize(stage_bytes_);
+      // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
+      x.host_block.resize(k::kHostDataOffset + sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) +
+                          sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+      std::memset(x.host_block.get(), 0, x.host_block.size());
+      x.done_counter.resize(4);
+      x.done_counter.zero(stream_);
+    }
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     meta_dev_.resize((size_t)std::max(F_, 1));
     qs_dev_.resize(1);
     if (mode_ == ParallelMode::Feature) {
       best_local_.resize((size_t)(2 * max_batch_ + 2));
       best_all_.resize((size_t)(2 * max_batch_ + 2) * (size_t)comm_->size());
     }
-    prof.on = cfg.profile;
     prof.init();
+  }
+  ~HipBackend() override {
+    for (int c = 0; c < n_ctx_; ++c)
+      if (ctx_[c].owns_stream) { (void)hipStreamSynchronize(ctx_[c].stream); (void)hipStreamDestroy(ctx_[c].stream); }
   }
 
   void set_bag(const int32_t* rows_dev, int64_t n) { bag_ = rows_dev; bag_n_ = n; }
@@ -195,17 +211,29 @@ class HipBackend : public TreeBackend {
     t.parent_node = -1; t.left_node = 0; t.right_node = 0; t.feature = 0; t.hist_child = 0;
     t.parent_slot = 0; t.new_slot = 0;
     // the root's row range goes to the device through the staging block's first bytes
-    std::memcpy(stage_host_.get(), &ranges_host_[0], sizeof(NodeRange));
-    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), stage_host_.get(), sizeof(NodeRange), hipMemcpyHostToDevice, stream_));
+    RoundCtx& x = ctx_[0];
+    std::memcpy(x.stage_host.get(), &ranges_host_[0], sizeof(NodeRange));
+    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), x.stage_host.get(), sizeof(NodeRange), hipMemcpyHostToDevice, stream_));
     LGA_HIP_CHECK(hipMemsetAsync(pool_.get(), 0, sizeof(int64_t) * (size_t)slot_words_, stream_));
-    run_round(tasks, true, out);
+    launch_round(x, tasks, true);
+    finish_round(x, out);
   }
 
   void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) override {
     if (tasks.empty()) return;
-    if ((int)tasks.size() > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
-    run_round(tasks, false, infos);
+    launch_round(ctx_[0], tasks, false);
+    finish_round(ctx_[0], infos);
   }
+
+  int max_in_flight() const override { return n_ctx_; }
+  int submit_round(std::vector<SplitTask>& tasks) override {
+    int c = 0;
+    while (c < n_ctx_ && ctx_[c].busy) ++c;
+    if (c == n_ctx_) throw std::runtime_error("more rounds submitted than the backend keeps in flight");
+    launch_round(ctx_[c], tasks, false);
+    return c;
+  }
+  void wait_round(int ticket, SplitInfo* infos) override { finish_round(ctx_[ticket], infos); }
 
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
   int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
@@ -216,22 +244,23 @@ class HipBackend : public TreeBackend {
     t.parent_node = node_id; t.left_node = node_id; t.right_node = node_id;
     t.feature = -1; t.first_pchunk = 0; t.num_pchunk = ceil_div(n, k::kPartChunk);
     if (t.num_pchunk > max_pchunks_) throw std::runtime_error("bagging chunk table overflow");
-    char* st = stage_host_.get();
+    RoundCtx& x = ctx_[0];
+    char* st = x.stage_host.get();
     std::memcpy(st + off_tasks_, &t, sizeof(t));
     int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
     for (int c = 0; c < t.num_pchunk; ++c) pc[c] = 0;
     NodeRange r{0, (int32_t)n, 0, 0};
     std::memcpy(st, &r, sizeof(NodeRange));
-    upload_stage(off_pch_ + sizeof(int32_t) * (size_t)t.num_pchunk);
-    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get() + node_id, stage_dev_.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
-    const SplitTask* dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
-    const int32_t* dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
+    upload_stage(x, off_pch_ + sizeof(int32_t) * (size_t)t.num_pchunk);
+    LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get() + node_id, x.stage_dev.get(), sizeof(NodeRange), hipMemcpyDeviceToDevice, stream_));
+    const SplitTask* dt = reinterpret_cast<const SplitTask*>(x.stage_dev.get() + off_tasks_);
+    const int32_t* dpc = reinterpret_cast<const int32_t*>(x.stage_dev.get() + off_pch_);
     k::InlineTasks none{};
     k::partition(dt, dpc, none, t.num_pchunk, t.num_pchunk > 1, nodes_.get(), base_rows, nullptr, nullptr, out, nullptr,
-                 N_, mask_.get(), chunk_left_.get(), task_left_.get(), k::BagParams{seed, iter, salt, (float)fraction},
+                 N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(), k::BagParams{seed, iter, salt, (float)fraction},
                  nullptr, 0, stream_);
     int32_t nl = 0;
-    LGA_HIP_CHECK(hipMemcpyAsync(&nl, task_left_.get(), sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipMemcpyAsync(&nl, x.task_left.get(), sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     sync();
     return nl;
   }
@@ -249,24 +278,45 @@ class HipBackend : public TreeBackend {
     return (int)c;
   }
 
-  void upload_stage(size_t bytes) {
-    LGA_HIP_CHECK(hipMemcpyAsync(stage_dev_.get(), stage_host_.get(), bytes, hipMemcpyHostToDevice, stream_));
+  // Everything one round in flight owns: its stream, scratch for the partition, the staging block for
+  // large task lists, and the host-mapped block its results and completion flag arrive in.
+  struct RoundCtx {
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    DeviceBuffer<uint64_t> mask;
+    DeviceBuffer<int32_t> chunk_left, task_left;
+    DeviceBuffer<char> stage_dev;
+    PinnedBuffer<char> stage_host;
+    MappedBuffer host_block;
+    DeviceBuffer<unsigned> done_counter;
+    unsigned seq = 0;
+    // the round in flight
+    bool busy = false, root = false, fused = false;
+    std::vector<SplitTask> tasks;
+    std::chrono::steady_clock::time_point t_begin, t_launched;
+  };
+
+  void upload_stage(RoundCtx& x, size_t bytes) {
+    LGA_HIP_CHECK(hipMemcpyAsync(x.stage_dev.get(), x.stage_host.get(), bytes, hipMemcpyHostToDevice, x.stream));
   }
 
-  // One growth round.  root: no partition, a single scan task.  Small rounds (<= kInlineTasks leaves) carry
-  // their descriptors in the kernel arguments; results come back through host-mapped memory and a
-  // completion flag the host polls, so such a round costs 3-4 kernel launches and no copy or stream sync.
-  void run_round(std::vector<SplitTask>& tasks, bool root, SplitInfo* infos) {
+  // Enqueues one growth round on the context's stream.  root: no partition, a single scan task.  Rounds
+  // of <= kInlineTasks leaves carry their descriptors in the kernel arguments; results come back through
+  // host-mapped memory and a completion flag, so such a round costs 4 kernel launches and no copy.
+  void launch_round(RoundCtx& x, std::vector<SplitTask>& tasks, bool root) {
+    if (x.busy) throw std::runtime_error("round context is still in flight");
     const int B = (int)tasks.size();
+    if (B > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
     const int n_scan = root ? 1 : 2 * B;
-    const auto t_begin = std::chrono::steady_clock::now();
-    if (!root) prof.host_between_ms += std::chrono::duration<double, std::milli>(t_begin - prof.last_end).count();
+    hipStream_t st_ = x.stream;
+    x.t_begin = std::chrono::steady_clock::now();
+    if (!root) prof.host_between_ms += std::chrono::duration<double, std::milli>(x.t_begin - prof.last_end).count();
     const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
     const bool inline_tasks = fused && B <= k::kInlineTasks;
     int64_t total_rows = 0;
     for (const auto& t : tasks) total_rows += root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
     const int hch = pick_hist_chunk(total_rows);
-    char* st = stage_host_.get();
+    char* st = x.stage_host.get();
     int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
     int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
     int np = 0, nh = 0;
@@ -292,7 +342,7 @@ class HipBackend : public TreeBackend {
     const SplitTask* dt = nullptr;
     const int32_t* dpc = nullptr;
     const int32_t* dhc = nullptr;
-    prof.mark(PhaseProfile::kUpload, stream_);
+    prof.mark(PhaseProfile::kUpload, st_);
     if (inline_tasks) {
       inl.count = B;
       std::memcpy(inl.t, tasks.data(), sizeof(SplitTask) * (size_t)B);
@@ -311,21 +361,21 @@ class HipBackend : public TreeBackend {
           else { sdt.slot = t.parent_slot; sdt.parent_slot = t.parent_slot; sdt.sibling_slot = t.new_slot; }
         }
       }
-      upload_stage(off_hch_ + sizeof(int32_t) * (size_t)nh);
-      dt = reinterpret_cast<const SplitTask*>(stage_dev_.get() + off_tasks_);
-      dpc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_pch_);
-      dhc = reinterpret_cast<const int32_t*>(stage_dev_.get() + off_hch_);
+      upload_stage(x, off_hch_ + sizeof(int32_t) * (size_t)nh);
+      dt = reinterpret_cast<const SplitTask*>(x.stage_dev.get() + off_tasks_);
+      dpc = reinterpret_cast<const int32_t*>(x.stage_dev.get() + off_pch_);
+      dhc = reinterpret_cast<const int32_t*>(x.stage_dev.get() + off_hch_);
     }
     // The root's rows are the bag itself: node 0 (buffer 0) is read from there, so a tree starts without
     // copying the row list.  Only the root round and the round that splits the root ever touch node 0.
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
-    prof.mark(PhaseProfile::kPartition, stream_);
+    prof.mark(PhaseProfile::kPartition, st_);
     if (!root)
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
-                   arena_[1].get(), mir_->bins_fm.get(), N_, mask_.get(), chunk_left_.get(), task_left_.get(),
+                   arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
                    k::BagParams{0, 0, 0, 0.f}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
-                   (int64_t)slot_words_ * B, stream_);
-    prof.mark(PhaseProfile::kHist, stream_);
+                   (int64_t)slot_words_ * B, st_);
+    prof.mark(PhaseProfile::kHist, st_);
     {
       int tile_first = 0, tile_step = 1, tile_count = T_;
       if (mode_ == ParallelMode::Feature) {
@@ -336,63 +386,79 @@ class HipBackend : public TreeBackend {
       }
       k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_,
                    packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count,
-                   root ? &root_quant_ : nullptr, stream_);
+                   root ? &root_quant_ : nullptr, st_);
     }
-    prof.mark(PhaseProfile::kComm, stream_);
+    prof.mark(PhaseProfile::kComm, st_);
     if (mode_ == ParallelMode::Data)
       comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true,
-                               stream_);
-    prof.mark(PhaseProfile::kScan, stream_);
-    char* hres = host_block_.get() + k::kHostDataOffset;
+                               st_);
+    prof.mark(PhaseProfile::kScan, st_);
+    char* hres = x.host_block.get() + k::kHostDataOffset;
     if (fused) {
-      const unsigned seq = ++round_seq_ ? round_seq_ : ++round_seq_;   // never 0
+      if (++x.seq == 0) ++x.seq;   // never 0
       k::scan_fused(dt, inl, n_scan, root ? 0 : B, meta_dev_.get(), F_, pool_.get(), slot_words_, plane_,
-                    node_totals_.get(), qs_dev_.get(), sp_, task_left_.get(), host_block_dev_, done_counter_.get(), seq,
-                    stream_);
-      prof.mark(PhaseProfile::kFetch, stream_);
-      prof.mark(PhaseProfile::kCount, stream_);
-      const auto t_launched = std::chrono::steady_clock::now();
-      wait_flag(seq);
-      const auto t_done = std::chrono::steady_clock::now();
-      prof.host_launch_ms += std::chrono::duration<double, std::milli>(t_launched - t_begin).count();
-      prof.host_wait_ms += std::chrono::duration<double, std::milli>(t_done - t_launched).count();
-      if (prof.on) sync();
+                    node_totals_.get(), qs_dev_.get(), sp_, x.task_left.get(), x.host_block.device_ptr(),
+                    x.done_counter.get(), x.seq, st_);
+      prof.mark(PhaseProfile::kFetch, st_);
+      prof.mark(PhaseProfile::kCount, st_);
     } else {
-      const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(stage_dev_.get() + off_scan_);
+      const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(x.stage_dev.get() + off_scan_);
       int first = 0, step = 1;
       if (mode_ == ParallelMode::Feature) { first = comm_->rank(); step = comm_->size(); }
       k::scan(ds, n_scan, meta_dev_.get(), F_, first, step, pool_.get(), slot_words_, plane_, node_totals_.get(),
-              qs_dev_.get(), sp_, cands_.get(), stream_);
+              qs_dev_.get(), sp_, cands_.get(), st_);
       if (mode_ == ParallelMode::Feature) {
         k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(),
-                  best_local_.get(), stream_);
-        comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, stream_);
+                  best_local_.get(), st_);
+        comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, st_);
         k::merge_winners(best_all_.get(), comm_->size(), n_scan, ds, node_totals_.get(), qs_dev_.get(), sp_,
-                         results_dev_.get(), stream_);
+                         results_dev_.get(), st_);
       } else {
         k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(), nullptr,
-                  stream_);
+                  st_);
       }
-      prof.mark(PhaseProfile::kFetch, stream_);
+      prof.mark(PhaseProfile::kFetch, st_);
       size_t off = sizeof(SplitInfo) * (size_t)n_scan;
-      LGA_HIP_CHECK(hipMemcpyAsync(hres, results_dev_.get(), off, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(hres, results_dev_.get(), off, hipMemcpyDeviceToHost, st_));
       if (!root)
-        LGA_HIP_CHECK(hipMemcpyAsync(hres + off, task_left_.get(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, stream_));
+        LGA_HIP_CHECK(hipMemcpyAsync(hres + off, x.task_left.get(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, st_));
       LGA_HIP_CHECK(hipMemcpyAsync(hres + off + sizeof(int32_t) * (size_t)(root ? 0 : B), qs_dev_.get(),
-                                   sizeof(QuantScale), hipMemcpyDeviceToHost, stream_));
-      prof.mark(PhaseProfile::kCount, stream_);
-      sync();
+                                   sizeof(QuantScale), hipMemcpyDeviceToHost, st_));
+      prof.mark(PhaseProfile::kCount, st_);
     }
+    x.busy = true;
+    x.root = root;
+    x.fused = fused;
+    x.tasks = tasks;
+    x.t_launched = std::chrono::steady_clock::now();
+    prof.host_launch_ms += std::chrono::duration<double, std::milli>(x.t_launched - x.t_begin).count();
+  }
+
+  // Waits for the round of this context and hands its results over.
+  void finish_round(RoundCtx& x, SplitInfo* infos) {
+    if (!x.busy) throw std::runtime_error("no round in flight on this context");
+    const auto t_wait = std::chrono::steady_clock::now();
+    if (x.fused) {
+      wait_flag(x);
+      if (prof.on) LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
+    } else {
+      LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
+    }
+    prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
     prof.collect(PhaseProfile::kCount);
     ++prof.rounds;
+    const bool root = x.root;
+    const int B = (int)x.tasks.size();
+    const int n_scan = root ? 1 : 2 * B;
     if (!root) prof.tasks += B;
+    const char* hres = x.host_block.get() + k::kHostDataOffset;
     std::memcpy(infos, hres, sizeof(SplitInfo) * (size_t)n_scan);
     const int32_t* tl = reinterpret_cast<const int32_t*>(hres + sizeof(SplitInfo) * (size_t)n_scan);
     if (root) {
       std::memcpy(&qs_host_, tl, sizeof(QuantScale));
     } else {
       for (int i = 0; i < B; ++i) {
-        const SplitTask& t = tasks[(size_t)i];
+        const SplitTask& t = x.tasks[(size_t)i];
         const NodeRange p = ranges_host_[(size_t)t.parent_node];
         prof.part_rows += p.count;
         prof.hist_rows += t.hist_child == 0 ? tl[i] : p.count - tl[i];
@@ -400,17 +466,19 @@ class HipBackend : public TreeBackend {
         ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
       }
     }
+    x.busy = false;
     prof.last_end = std::chrono::steady_clock::now();
   }
 
   // Polls the completion flag the last scan workgroup writes into host-mapped memory.  The stream is
   // queried now and then so that a failed launch surfaces as an error instead of an endless wait.
-  void wait_flag(unsigned seq) {
-    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(host_block_.get());
+  void wait_flag(RoundCtx& x) {
+    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(x.host_block.get());
+    const unsigned seq = x.seq;
     unsigned spins = 0;
     while (*flag != seq) {
       if ((++spins & 4095u) == 0) {
-        hipError_t q = hipStreamQuery(stream_);
+        hipError_t q = hipStreamQuery(x.stream);
         if (q == hipSuccess) {
           if (*flag == seq) break;
           throw std::runtime_error("growth round finished without raising its completion flag");
@@ -435,16 +503,10 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<NodeRange> nodes_;
   DeviceBuffer<int64_t> node_totals_;
   DeviceBuffer<int32_t> arena_[2];
-  DeviceBuffer<uint64_t> mask_;
-  DeviceBuffer<int32_t> chunk_left_, task_left_;
-  DeviceBuffer<char> stage_dev_;
-  PinnedBuffer<char> stage_host_;
+  RoundCtx ctx_[2];
+  int n_ctx_ = 1;
   DeviceBuffer<k::Cand> cands_, best_local_, best_all_;
   DeviceBuffer<SplitInfo> results_dev_;
-  MappedBuffer host_block_;
-  char* host_block_dev_ = nullptr;
-  DeviceBuffer<unsigned> done_counter_;
-  unsigned round_seq_ = 0;
   DeviceBuffer<FeatureMeta> meta_dev_;
   DeviceBuffer<QuantScale> qs_dev_;
   std::vector<FeatureMeta> meta_host_;

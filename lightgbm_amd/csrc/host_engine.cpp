@@ -62,6 +62,12 @@ class HostBackend : public TreeBackend {
   int node_capacity() const override { return 2 * capacity_splits_ + 1; }
   QuantScale quant_scale() const override { return qs_; }
   int64_t node_local_count(int node) const override { return ranges_[(size_t)node].count; }
+  // Rounds run at submission here; LGA_HOST_IN_FLIGHT=2 lets the tests drive the grower's
+  // several-rounds-in-flight logic through this backend.
+  int max_in_flight() const override {
+    const char* e = std::getenv("LGA_HOST_IN_FLIGHT");
+    return e ? std::max(1, std::atoi(e)) : 1;
+  }
   const NodeRange& range(int node) const { return ranges_[(size_t)node]; }
   const int32_t* arena(int buf) const { return arena_[buf].data(); }
 
@@ -88,6 +94,7 @@ class HostBackend : public TreeBackend {
     // 1. partition
     int64_t batch_rows = 0;
     for (size_t i = 0; i < B; ++i) batch_rows += ranges_[(size_t)tasks[i].parent_node].count;
+    (void)batch_rows;   // only read by the OpenMP clause below
 #pragma omp parallel for schedule(dynamic) if (B > 1 && batch_rows > 200000)
     for (size_t i = 0; i < B; ++i) partition(tasks[i]);
     double t1 = now_s();

@@ -206,10 +206,12 @@ def test_gpu_regression_trees_equal_cpu_trees(params):
     assert trees_of(a) == trees_of(b)
 
 
-@pytest.mark.parametrize("lines", ["0", "1"])
-def test_row_line_layout_grows_the_same_trees(lines, monkeypatch):
-    """Bin records interleaved with the packed gradients (the large-data layout) vs the separate arrays."""
+@pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2")])
+def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
+    """The large-data paths - bin records interleaved with the packed gradients, two growth rounds in
+    flight on two streams - against the CPU oracle (both are size-gated, so they are forced here)."""
     monkeypatch.setenv("LGA_ROW_LINES", lines)
+    monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)
     X, y = make_regression(50001, 9, seed=11)     # row count not divisible by three
     X[::17, 2] = np.nan
     p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.7, "bagging_freq": 1}
@@ -336,8 +338,9 @@ def _run_ranks(P, fn):
     return out
 
 
-@pytest.mark.parametrize("P", [2, 4])
-def test_gpu_data_parallel_equals_serial(P):
+@pytest.mark.parametrize("P,flight", [(2, "1"), (4, "1"), (2, "2"), (4, "2")])
+def test_gpu_data_parallel_equals_serial(P, flight, monkeypatch):
+    monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)   # "2": the overlapped rounds large shards use
     X, y = make_regression(40000, 10, seed=8)
     params = {**GPU, "num_leaves": 63}
     serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X[:20000], params=GPU), 10)
