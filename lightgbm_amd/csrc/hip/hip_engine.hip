@@ -142,7 +142,9 @@ class HipBackend : public TreeBackend {
     const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
     // Small data gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on
     // their own streams) already fill the hardware queues.
-    n_ctx_ = (fused && !prof.on && max_rows >= (int64_t)1 << 19) ? 2 : 1;
+    // Distributed learners keep one round in flight unless asked otherwise: two would put collectives of
+    // one communicator on two streams.
+    n_ctx_ = (fused && !prof.on && mode_ == ParallelMode::Serial && max_rows >= (int64_t)1 << 19) ? 2 : 1;
     if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = (fused && !prof.on) ? std::max(1, std::min(2, std::atoi(e))) : 1;
     for (int c = 0; c < n_ctx_; ++c) {
       RoundCtx& x = ctx_[c];
