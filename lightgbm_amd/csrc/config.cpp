@@ -80,6 +80,7 @@ const ParamDef kParams[] = {
     P(max_batch_leaves, "", Int, 0, kNone),
     P(profile, "", Bool, kNone, kNone),
     P(device_bin_find, "", Bool, kNone, kNone),
+    P(iteration_offset, "", Int, 0, kNone),
 };
 #pragma GCC diagnostic pop
 #undef P

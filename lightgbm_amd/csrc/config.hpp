@@ -70,6 +70,8 @@ struct Config {
   int gpu_device_id = 0;
   int max_batch_leaves = 0;   // 0: as many leaves per growth round as the budget allows
   bool profile = false;
+  int iteration_offset = 0;       // number the iterations from here: the random streams (bagging, feature
+                                  // sampling) of iteration k are the same wherever that iteration is trained
   bool device_bin_find = true;   // device-resident raw matrices: find bin boundaries on the GPU
 
   // Names of parameters that were explicitly set (after alias resolution).

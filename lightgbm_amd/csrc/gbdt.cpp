@@ -14,6 +14,7 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
   if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
   is_rf_ = cfg_.boosting == "rf";
   average_output_ = is_rf_;
+  iter_ = cfg_.iteration_offset;
   setup_objective();
   for (const auto& m : cfg_.resolved_metrics()) metrics_.push_back(metric_kind_from_name(m));
   engine_ = factory(train_, cfg_);
@@ -134,9 +135,18 @@ bool Booster::update_one_iter() {
   ensure_scores();
   if (!is_rf_) engine_->compute_gradients(obj_);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
-  if (bagging && (iter_ % cfg_.bagging_freq == 0)) engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
+  if (bagging) draw_bag();
   Tree tree = engine_->train_tree(sample_features());
   return finish_iteration(std::move(tree));
+}
+
+// The bag of iteration k is drawn at the last multiple of bagging_freq <= k, also when training starts
+// in the middle of such a period (iteration_offset).
+void Booster::draw_bag() {
+  const int period_start = iter_ - iter_ % cfg_.bagging_freq;
+  if (bag_drawn_ && period_start != iter_) return;
+  engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)period_start);
+  bag_drawn_ = true;
 }
 
 bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64_t n) {
@@ -150,7 +160,7 @@ bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64
   }
   engine_->set_gradients(grad, hess, n);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
-  if (bagging && (iter_ % cfg_.bagging_freq == 0)) engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
+  if (bagging) draw_bag();
   Tree tree = engine_->train_tree(sample_features());
   return finish_iteration(std::move(tree));
 }

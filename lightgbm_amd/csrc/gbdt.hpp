@@ -86,6 +86,8 @@ class Booster {
   bool scores_initialised_ = false;
   double init_score_ = 0.0;
   int iter_ = 0;                 // iterations attempted (drives bagging / feature sampling streams)
+  bool bag_drawn_ = false;
+  void draw_bag();
   std::vector<Tree> trees_;
   // model meta
   int max_feature_idx_ = -1;

@@ -78,3 +78,18 @@ def test_random_forest_family_averages_and_stages():
     base = float(np.std(yt))
     assert float(np.sqrt(np.mean((gb.predict(Xt) - yt) ** 2))) < 0.6 * base
     assert err[-1] < 0.8 * base
+
+
+def test_tree_sizes_header_gives_the_byte_length_of_every_tree_block():
+    """Upstream's loader cuts the tree section by `tree_sizes`; the blocks must have exactly these lengths."""
+    X, y = _data(2000, 5, seed=9, nan=False)
+    b = lgb.train({**CPU, "num_leaves": 7}, lgb.Dataset(X, label=y, params=CPU), 5)
+    text = b.model_to_string()
+    sizes = [int(v) for v in text.split("tree_sizes=", 1)[1].splitlines()[0].split()]
+    body = text[text.index("Tree=0"):text.index("end of trees")]
+    assert sum(sizes) == len(body.encode())
+    pos = 0
+    for i, sz in enumerate(sizes):
+        block = body[pos:pos + sz]
+        assert block.startswith(f"Tree={i}\n") and block.endswith("\n\n")
+        pos += sz

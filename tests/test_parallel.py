@@ -46,7 +46,7 @@ def run_ranks(P, fn):
     return out
 
 
-@pytest.mark.parametrize("P", [2, 3, 4])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
 def test_data_parallel_equals_serial_regression(P):
     X, y = make_regression(6000, 9, seed=0)
     params = {**CPU, "num_leaves": 31, "min_data_in_leaf": 20}

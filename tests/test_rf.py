@@ -1,5 +1,6 @@
 """Random-forest / bagging mode vs boosting (bagging_boosting.ipynb)."""
 import numpy as np
+import pytest
 
 import lightgbm_amd as lgb
 from lightgbm_amd.utils.datasets import make_curve_1d, make_regression
@@ -50,3 +51,21 @@ def test_bagging_vs_boosting_on_the_toy_curve():
     assert rf_err[100] < rf_err[1] and rf_err[100] < 0.08
     # one boosted tree at eta 0.02 is still far from the curve; one deep bagged tree is already close
     assert rf_err[1] < err[0]
+
+
+@pytest.mark.parametrize("freq", [1, 3])
+def test_forest_grown_in_parts_equals_the_forest_grown_in_one_go(freq):
+    """Tree-parallel rf: iteration k draws the same bag / feature subset wherever it is trained."""
+    from lightgbm_amd.parallel import merge_forests, train_forest_part, tree_share
+    X, y = make_regression(3000, 8, seed=12)
+    p = {**CPU, "boosting": "rf", "num_leaves": 31, "bagging_fraction": 0.63, "bagging_freq": freq,
+         "feature_fraction": 0.8, "min_data_in_leaf": 5}
+    ds = lgb.Dataset(X, label=y, params=CPU)
+    whole = lgb.train(p, ds, 14)
+    parts = [train_forest_part(p, ds, tree_share(14, 3, r)) for r in range(3)]
+    assert [b.num_trees() for b in parts] == [4, 5, 5]
+    merged = merge_forests([b.model_to_string() for b in parts])
+    assert merged.num_trees() == 14
+    a, b = whole.model_to_string(), merged.model_to_string()
+    assert a[a.index("Tree=0"):a.index("end of trees")] == b[b.index("Tree=0"):b.index("end of trees")]
+    np.testing.assert_allclose(merged.predict(X), whole.predict(X), rtol=1e-12, atol=1e-12)
