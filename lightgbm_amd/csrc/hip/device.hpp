@@ -116,6 +116,18 @@ class MappedBuffer {
   size_t n_ = 0;
 };
 
+// Named ranges for rocprofv3 --marker-trace (roctx).  The library is bound at run time and only when
+// profiling was asked for (profile=true or LGA_ROCTX=1); otherwise a range costs one branch.
+void trace_enable(bool on);
+void trace_push(const char* name);
+void trace_pop();
+struct TraceRange {
+  explicit TraceRange(const char* name) { trace_push(name); }
+  ~TraceRange() { trace_pop(); }
+  TraceRange(const TraceRange&) = delete;
+  TraceRange& operator=(const TraceRange&) = delete;
+};
+
 // Device copy of a root dataset's bin matrices.
 struct DeviceMirror {
   int64_t rows = 0;

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "../metric.hpp"
 #include <algorithm>
+#include <dlfcn.h>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -51,6 +52,31 @@ void set_current_stream(hipStream_t s) {
   t_stream_set = true;
 }
 hipStream_t current_stream() { return t_stream_set ? t_stream : g_default_stream; }
+
+namespace {
+struct RoctxApi {
+  bool tried = false, on = false;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+RoctxApi g_roctx;
+}  // namespace
+
+void trace_enable(bool on) {
+  if (on && !g_roctx.tried) {
+    g_roctx.tried = true;
+    for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+      g_roctx.pop = (int (*)())dlsym(h, "roctxRangePop");
+      if (g_roctx.push && g_roctx.pop) break;
+    }
+  }
+  g_roctx.on = on && g_roctx.push && g_roctx.pop;
+}
+void trace_push(const char* name) { if (g_roctx.on) (void)g_roctx.push(name); }
+void trace_pop() { if (g_roctx.on) (void)g_roctx.pop(); }
 
 namespace {
 
@@ -139,6 +165,7 @@ class HipBackend : public TreeBackend {
     // Two rounds may be in flight when results travel through the mapped block (fused scan) and no
     // per-phase event timing is requested; the second context owns a stream of its own.
     prof.on = cfg.profile;
+    if (cfg.profile || std::getenv("LGA_ROCTX")) trace_enable(true);
     const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
     // Small data gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on
     // their own streams) already fill the hardware queues.
@@ -372,6 +399,7 @@ class HipBackend : public TreeBackend {
     // copying the row list.  Only the root round and the round that splits the root ever touch node 0.
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
     prof.mark(PhaseProfile::kPartition, st_);
+    trace_push(root ? "lga.root_round" : "lga.split_round");
     if (!root)
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
@@ -428,6 +456,7 @@ class HipBackend : public TreeBackend {
                                    sizeof(QuantScale), hipMemcpyDeviceToHost, st_));
       prof.mark(PhaseProfile::kCount, st_);
     }
+    trace_pop();
     x.busy = true;
     x.root = root;
     x.fused = fused;
@@ -440,6 +469,7 @@ class HipBackend : public TreeBackend {
   void finish_round(RoundCtx& x, SplitInfo* infos) {
     if (!x.busy) throw std::runtime_error("no round in flight on this context");
     const auto t_wait = std::chrono::steady_clock::now();
+    TraceRange wait_range("lga.wait_round");
     if (x.fused) {
       wait_flag(x);
       if (prof.on) LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
@@ -629,6 +659,7 @@ class HipEngine : public Engine {
   }
 
   void compute_gradients(const ObjectiveSpec& obj) override {
+    TraceRange range("lga.gradients");
     k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_or_null(), n_base_, grad_.get(),
                  hess_.get(), maxbits_.get(), stream_);
     have_max_ = true;
@@ -661,6 +692,7 @@ class HipEngine : public Engine {
   }
 
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
+    TraceRange range("lga.train_tree");
     if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
@@ -679,6 +711,7 @@ class HipEngine : public Engine {
   // left behind (a scattered read-modify-write per row) or by walking the tree over the binned rows in
   // storage order (coalesced scores, ~depth one-byte bin reads per row).  Large row sets favour the walk.
   void add_trained_tree_to_train_scores(const Tree& tree) override {
+    TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
     if (walk) {
       traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, scores_.get());
@@ -717,6 +750,7 @@ class HipEngine : public Engine {
   }
 
   std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
+    TraceRange range("lga.eval");
     const double* sc; const DeviceMirror* m; const int32_t* rows; int64_t n; const Dataset* ds;
     if (which < 0) { sc = scores_.get(); m = mir_; rows = base_rows_.get(); n = n_base_; ds = train_.get(); }
     else { auto& v = *valid_[(size_t)which]; sc = score_ptr(v); m = v.mir; rows = v.rows.get(); n = v.n; ds = v.ds.get(); }
