@@ -47,6 +47,8 @@ def _declare(lib, hip: bool):
         "lga_alias_table_json": (c_char_p, []),
         "lga_resolve_alias": (c_int, [c_char_p, c_char_p, c_int]),
         "lga_dataset_from_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_char_p, c_void_p, c_int, P(c_void_p)]),
+        "lga_dataset_save_binary": (c_int, [c_void_p, c_char_p]),
+        "lga_dataset_load_binary": (c_int, [c_char_p, P(c_void_p)]),
         "lga_dataset_from_sample": (c_int, [c_void_p, c_int64, c_int, c_int64, c_char_p, P(c_void_p)]),
         "lga_dataset_bin_matrix": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
         "lga_dataset_from_reference": (c_int, [c_void_p, c_int64, P(c_void_p)]),

@@ -217,6 +217,13 @@ class Dataset:
             return self
         if self.data is None:
             raise LightGBMError("Cannot construct a Dataset whose raw data was freed")
+        if isinstance(self.data, (str, os.PathLike)):
+            # a binary cache written by save_binary(): boundaries, bins and fields come from the file
+            h = ctypes.c_void_p()
+            check(lib.lga_dataset_load_binary(c_str(os.fspath(self.data)), ctypes.byref(h)))
+            self._handle = h
+            self._set_fields()
+            return self
         mat, names = _to_matrix(self.data)
         params = _with_device(self.params)
         if self.reference is not None:
@@ -276,6 +283,14 @@ class Dataset:
         self._set_fields()
         if self.free_raw_data:
             self.data = None
+        return self
+
+    def save_binary(self, filename: str) -> "Dataset":
+        """Writes the binned dataset (bin boundaries, bins, label / weight / init_score) to ``filename``;
+        ``Dataset(filename)`` loads it back without touching the raw data again."""
+        self.construct()
+        lib, _ = _lib.load()
+        check(lib.lga_dataset_save_binary(self._root_handle(), c_str(os.fspath(filename))))
         return self
 
     def _root_handle(self):

@@ -199,6 +199,17 @@ int lga_dataset_get_bins(LgaDataset ds, uint8_t* fm_out, uint8_t* rt_out) {
   });
 }
 
+int lga_dataset_save_binary(LgaDataset ds, const char* path) {
+  return guard([&] {
+    Dataset* d = D(ds);
+    engine_ensure_host_bins(d);
+    d->root()->save_binary(path);
+  });
+}
+int lga_dataset_load_binary(const char* path, LgaDataset* out) {
+  return guard([&] { *out = new DatasetBox{Dataset::load_binary(path)}; });
+}
+
 int lga_dataset_free(LgaDataset ds) { return guard([&] { delete (DatasetBox*)ds; }); }
 
 int lga_comm_create_callback(int rank, int size, lga_allreduce_fn ar, lga_allgather_fn ag, LgaComm* out) {

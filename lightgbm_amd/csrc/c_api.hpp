@@ -34,6 +34,8 @@ int lga_dataset_get_feature_names(LgaDataset ds, char* out, int64_t cap, int64_t
 int lga_dataset_bin_info(LgaDataset ds, int real_feature, int* num_bin, int* missing_bin, double* upper, int cap,
                          int* n_upper);
 int lga_dataset_get_bins(LgaDataset ds, uint8_t* fm_out, uint8_t* rt_out);
+int lga_dataset_save_binary(LgaDataset ds, const char* path);
+int lga_dataset_load_binary(const char* path, LgaDataset* out);
 int lga_dataset_free(LgaDataset ds);
 
 // ---- communicator (callbacks implemented by the caller, e.g. torch.distributed/gloo) ----

@@ -2,6 +2,7 @@
 #include "binning_core.hpp"
 #include <algorithm>
 #include <stdexcept>
+#include <cstdio>
 #include <cstring>
 #ifdef _OPENMP
 #include <omp.h>
@@ -204,6 +205,112 @@ std::vector<float> Dataset::local_weight() const {
   std::vector<float> out(used_indices_->size());
   for (size_t i = 0; i < out.size(); ++i) out[i] = l[(size_t)(*used_indices_)[i]];
   return out;
+}
+
+namespace {
+constexpr char kBinaryMagic[8] = {'L', 'G', 'A', 'B', 'I', 'N', '0', '1'};
+struct Writer {
+  FILE* f;
+  void raw(const void* p, size_t n) { if (n && std::fwrite(p, 1, n, f) != n) throw std::runtime_error("dataset cache: write failed"); }
+  template <typename T> void pod(const T& v) { raw(&v, sizeof(T)); }
+  template <typename T> void vec(const std::vector<T>& v) { pod<uint64_t>(v.size()); raw(v.data(), v.size() * sizeof(T)); }
+  void str(const std::string& s) { pod<uint64_t>(s.size()); raw(s.data(), s.size()); }
+};
+struct Reader {
+  FILE* f;
+  void raw(void* p, size_t n) { if (n && std::fread(p, 1, n, f) != n) throw std::runtime_error("dataset cache: file is truncated"); }
+  template <typename T> T pod() { T v; raw(&v, sizeof(T)); return v; }
+  template <typename T> void vec(std::vector<T>& v, uint64_t limit) {
+    uint64_t n = pod<uint64_t>();
+    if (n > limit) throw std::runtime_error("dataset cache: implausible array length");
+    v.resize((size_t)n);
+    raw(v.data(), (size_t)n * sizeof(T));
+  }
+  std::string str() {
+    uint64_t n = pod<uint64_t>();
+    if (n > (1u << 20)) throw std::runtime_error("dataset cache: implausible string length");
+    std::string s((size_t)n, '\0');
+    raw(&s[0], (size_t)n);
+    return s;
+  }
+};
+struct FileCloser { FILE* f; ~FileCloser() { if (f) std::fclose(f); } };
+}  // namespace
+
+void Dataset::save_binary(const std::string& path) const {
+  if (parent_) throw std::runtime_error("save_binary: save the root dataset, not a subset");
+  if (!has_host_bins()) throw std::runtime_error("save_binary: the dataset has no host copy of its bins");
+  const std::string tmp = path + ".tmp";
+  {
+    FileCloser fc{std::fopen(tmp.c_str(), "wb")};
+    if (!fc.f) throw std::runtime_error("save_binary: cannot open " + tmp);
+    Writer w{fc.f};
+    w.raw(kBinaryMagic, sizeof(kBinaryMagic));
+    w.pod<int64_t>(root_rows_);
+    w.pod<int32_t>((int32_t)mappers_.size());
+    for (size_t i = 0; i < mappers_.size(); ++i) {
+      const BinMapper& m = mappers_[i];
+      w.vec(m.upper);
+      w.pod<int32_t>(m.num_bin);
+      w.pod<int32_t>((int32_t)m.missing);
+      w.pod<int32_t>(m.missing_bin);
+      w.pod<double>(m.min_val);
+      w.pod<double>(m.max_val);
+      w.pod<int32_t>(m.trivial ? 1 : 0);
+      w.str(feature_names[i]);
+    }
+    w.vec(bins_fm_);
+    w.vec(label_);
+    w.vec(weight_);
+    w.vec(init_score_);
+    if (std::fflush(fc.f) != 0) throw std::runtime_error("save_binary: flush failed");
+  }
+  if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("save_binary: cannot move the file into place");
+}
+
+std::shared_ptr<Dataset> Dataset::load_binary(const std::string& path) {
+  FileCloser fc{std::fopen(path.c_str(), "rb")};
+  if (!fc.f) throw std::runtime_error("load_binary: cannot open " + path);
+  Reader r{fc.f};
+  char magic[8];
+  r.raw(magic, sizeof(magic));
+  if (std::memcmp(magic, kBinaryMagic, sizeof(magic)) != 0) throw std::runtime_error("load_binary: not a dataset cache file");
+  auto ds = std::make_shared<Dataset>();
+  ds->root_rows_ = r.pod<int64_t>();
+  if (ds->root_rows_ <= 0 || ds->root_rows_ > 2147483000LL) throw std::runtime_error("load_binary: bad row count");
+  int32_t nf = r.pod<int32_t>();
+  if (nf <= 0 || nf > (1 << 24)) throw std::runtime_error("load_binary: bad feature count");
+  ds->mappers_.resize((size_t)nf);
+  ds->feature_names.resize((size_t)nf);
+  for (int32_t i = 0; i < nf; ++i) {
+    BinMapper& m = ds->mappers_[(size_t)i];
+    r.vec(m.upper, kMaxBins + 1);
+    m.num_bin = r.pod<int32_t>();
+    m.missing = (MissingType)r.pod<int32_t>();
+    m.missing_bin = r.pod<int32_t>();
+    m.min_val = r.pod<double>();
+    m.max_val = r.pod<double>();
+    m.trivial = r.pod<int32_t>() != 0;
+    if (m.num_bin < 1 || m.num_bin > kMaxBins || m.upper.empty()) throw std::runtime_error("load_binary: bad bin mapper");
+    ds->feature_names[(size_t)i] = r.str();
+  }
+  ds->finish_mappers();
+  const uint64_t n = (uint64_t)ds->root_rows_;
+  const int F = (int)ds->used_feature_.size();
+  r.vec(ds->bins_fm_, (uint64_t)F * n);
+  if (ds->bins_fm_.size() != (size_t)F * n) throw std::runtime_error("load_binary: bin matrix has the wrong size");
+  r.vec(ds->label_, n);
+  r.vec(ds->weight_, n);
+  r.vec(ds->init_score_, n);
+  // the row-tile-major copy is derived
+  const int T = ds->num_tiles();
+  ds->bins_rt_.assign((size_t)T * n * kTileFeatures, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t row = 0; row < (int64_t)n; ++row)
+    for (int f = 0; f < F; ++f)
+      ds->bins_rt_[((size_t)(f / kTileFeatures) * n + (size_t)row) * kTileFeatures + (size_t)(f % kTileFeatures)] =
+          ds->bins_fm_[(size_t)f * n + (size_t)row];
+  return ds;
 }
 
 void Dataset::set_feature_names(const std::vector<std::string>& names) {

@@ -34,6 +34,10 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   // Mapper-only dataset from bin boundaries found elsewhere (the device bin finder).
   static std::shared_ptr<Dataset> from_mappers(std::vector<BinMapper>&& mappers, int64_t nrow);
   std::shared_ptr<Dataset> subset(const int32_t* indices, int64_t n) const;
+  // Binary cache of a ROOT dataset: bin boundaries, feature names, the feature-major bin matrix and the
+  // label / weight / init-score vectors.  Loading skips sampling, bin finding and binning.
+  void save_binary(const std::string& path) const;
+  static std::shared_ptr<Dataset> load_binary(const std::string& path);
 
   // ---- shape ----
   int64_t num_data() const { return used_indices_ ? (int64_t)used_indices_->size() : root_rows_; }

@@ -1,7 +1,10 @@
-"""Bin construction and value->bin mapping (SURVEY Appendix B.4)."""
+"""Bin construction and value->bin mapping."""
 import numpy as np
+import pytest
 
 import lightgbm_amd as lgb
+
+CPU = {"device_type": "cpu", "verbose": -1}
 
 
 def _ds(X, **params):
@@ -73,3 +76,32 @@ def test_bin_sample_controls_boundaries():
     b = lgb.Dataset(X[2000:], label=np.zeros(2000), bin_sample=X, params={"device_type": "cpu"}).construct()
     for f in range(3):
         np.testing.assert_array_equal(a.bin_info(f)["upper_bounds"], b.bin_info(f)["upper_bounds"])
+
+
+def test_binary_cache_round_trip(tmp_path):
+    """save_binary / Dataset(path): same bins, same fields, same model - without the raw matrix."""
+    rng = np.random.RandomState(3)
+    X = rng.randn(3000, 40)
+    X[::6, 2] = np.nan
+    X[:, 9] = 7.0
+    y = X[:, 0] - 2 * X[:, 1] + rng.randn(3000) * 0.1
+    w = rng.rand(3000) + 0.5
+    d = lgb.Dataset(X, label=y, weight=w, params=CPU, feature_name=[f"f{i}" for i in range(40)])
+    path = tmp_path / "train.bin"
+    d.save_binary(str(path))
+    e = lgb.Dataset(str(path), params=CPU).construct()
+    assert e.num_data() == 3000 and e.num_feature() == 40
+    np.testing.assert_array_equal(e.get_bins(), d.get_bins())
+    np.testing.assert_array_equal(e.get_label(), d.get_label())
+    np.testing.assert_array_equal(e.get_weight(), d.get_weight())
+    assert e.get_feature_name() == d.get_feature_name()
+    for f in (0, 2, 9):
+        a, b = d.bin_info(f), e.bin_info(f)
+        assert a["num_bin"] == b["num_bin"] and a["missing_bin"] == b["missing_bin"]
+        np.testing.assert_array_equal(a["upper_bounds"], b["upper_bounds"])
+    p = {**CPU, "num_leaves": 15}
+    assert lgb.train(p, d, 5).model_to_string() == lgb.train(p, e, 5).model_to_string()
+    with open(path, "r+b") as fh:      # a damaged file is refused, not half-loaded
+        fh.truncate(1000)
+    with pytest.raises(lgb.LightGBMError):
+        lgb.Dataset(str(path), params=CPU).construct()

@@ -1,4 +1,4 @@
-"""Parameter registry: aliases, defaults, validation, merging (SURVEY 4B unit tier)."""
+"""Parameter registry: aliases, defaults, validation, merging."""
 import numpy as np
 import pytest
 

@@ -159,6 +159,19 @@ def test_device_binning_equals_host_binning():
     np.testing.assert_array_equal(dt.get_bins(), dc.get_bins())
 
 
+def test_binary_cache_of_a_device_dataset(tmp_path):
+    """Bins that only exist in HBM are fetched for the cache file; the loaded dataset trains the same model."""
+    import torch
+    X, y = make_regression(20000, 12, seed=21)
+    d = lgb.Dataset(torch.from_numpy(X).cuda(), label=y, params=GPU)
+    path = str(tmp_path / "d.bin")
+    d.save_binary(path)
+    e = lgb.Dataset(path, params=GPU)
+    p = {**GPU, "num_leaves": 31}
+    assert trees_of(lgb.train(p, d, 6)) == trees_of(lgb.train(p, e, 6))
+    assert trees_of(lgb.train({**CPU, "num_leaves": 31}, lgb.Dataset(path, params=CPU), 6)) == trees_of(lgb.train(p, e, 6))
+
+
 @pytest.mark.parametrize("n,sample,dtype", [(1500, 200000, np.float64), (50000, 200000, np.float32),
                                             (120000, 30000, np.float64)])
 def test_device_bin_boundaries_equal_host_boundaries(n, sample, dtype):

@@ -1,4 +1,4 @@
-"""Grid search plumbing of r/gridsearchCV.R on a small synthetic regression (BASELINE config 1, CPU)."""
+"""Grid search plumbing of r/gridsearchCV.R on a small synthetic regression, on the CPU engine."""
 import json
 import os
 import subprocess

@@ -1,4 +1,4 @@
-"""LightGBM text model format: writer / parser round trip, golden string, decision rule (SURVEY Appendix C)."""
+"""LightGBM text model format: writer / parser round trip, golden string, decision rule."""
 import numpy as np
 import pytest
 

@@ -18,7 +18,7 @@ def trees_of(b):
 
 
 def test_regression_quality_matches_sklearn_histgb():
-    # SURVEY 7.2 step 1 exit criterion: diamonds-like regression within 2 % of sklearn's histogram GBDT
+    # diamonds-like regression must land within 2 % of sklearn's histogram GBDT
     from sklearn.ensemble import HistGradientBoostingRegressor
     X, y = make_diamonds_like(20000, seed=3)
     tr, te = slice(0, 16000), slice(16000, None)
