@@ -293,7 +293,8 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     """k-fold cross-validation; returns ``{"<metric>-mean": [...], "<metric>-stdv": [...]}`` (+ ``"cvbooster"``).
 
     ``concurrent_folds``: drive the fold boosters from k host threads on k HIP streams (default: on for the
-    HIP build when the data has at most 2 M rows and no Python-side objective / metric is used)."""
+    HIP build when the data has at most 500 k rows - larger folds fill the GPU on their own - and no
+    Python-side objective / metric is used)."""
     if not isinstance(train_set, Dataset):
         raise TypeError("Training only accepts Dataset object")
     params = _prepare_params(params, kwargs)
@@ -334,7 +335,7 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     from . import _lib
     on_gpu = _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host")
     if concurrent_folds is None:
-        concurrent_folds = on_gpu and n <= 2_000_000 and fobj is None and feval is None
+        concurrent_folds = on_gpu and n <= 500_000 and fobj is None and feval is None
     runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu)
 
     cvbooster = CVBooster()

@@ -351,9 +351,10 @@ def _run_ranks(P, fn):
     return out
 
 
-@pytest.mark.parametrize("P,flight", [(2, "1"), (4, "1"), (2, "2"), (4, "2")])
-def test_gpu_data_parallel_equals_serial(P, flight, monkeypatch):
-    monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)   # "2": the overlapped rounds large shards use
+@pytest.mark.parametrize("P,flight,lines", [(2, "1", "0"), (4, "1", "1"), (2, "2", "1"), (4, "2", "0")])
+def test_gpu_data_parallel_equals_serial(P, flight, lines, monkeypatch):
+    monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)   # "2": overlapped rounds
+    monkeypatch.setenv("LGA_ROW_LINES", lines)           # "1": the row-line layout large shards use
     X, y = make_regression(40000, 10, seed=8)
     params = {**GPU, "num_leaves": 63}
     serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X[:20000], params=GPU), 10)
