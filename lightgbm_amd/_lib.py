@@ -95,6 +95,7 @@ def _declare(lib, hip: bool):
             "lga_hip_set_allocator": (c_int, [ALLOC_FN, FREE_FN]),
             "lga_hip_set_stream": (c_int, [c_void_p]),
             "lga_hip_device_info": (c_int, [P(c_int), P(c_int64), P(c_int)]),
+            "lga_hip_dataset_from_host_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_char_p, P(c_void_p)]),
             "lga_hip_dataset_from_device_mat": (c_int, [c_void_p, c_int, c_int64, c_int, c_char_p, c_void_p, P(c_void_p)]),
             "lga_hip_dataset_upload_raw": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int]),
             "lga_hip_dataset_bin_device": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int]),

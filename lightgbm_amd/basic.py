@@ -252,6 +252,11 @@ class Dataset:
             check(lib.lga_hip_dataset_from_device_mat(ctypes.c_void_p(mat.data_ptr()), dtype, nrow, ncol, c_str(pstr),
                                                       None, ctypes.byref(h)))
             mat_binned = True
+        elif on_gpu and bool(get_param(params, "device_bin_find", True)):
+            # host matrix, device dataset: boundaries are found and bins are built on the GPU
+            ptr, dtype, _, _, rm = _mat_args(mat)
+            check(lib.lga_hip_dataset_from_host_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), ctypes.byref(h)))
+            mat_binned = True
         else:
             ptr, dtype, _, _, rm = _mat_args(mat)
             check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), None, 0 if on_gpu else 1,

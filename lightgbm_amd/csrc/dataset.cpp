@@ -47,6 +47,21 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
   return ds;
 }
 
+std::vector<int64_t> Dataset::sample_rows(int64_t nrow, const Config& cfg) {
+  int64_t want = cfg.bin_construct_sample_cnt;
+  std::vector<int64_t> rows;
+  if (nrow <= want) {
+    rows.resize((size_t)nrow);
+    for (int64_t i = 0; i < nrow; ++i) rows[(size_t)i] = i;
+  } else {
+    float p = (float)((double)want / (double)nrow);
+    rows.reserve((size_t)(want + want / 8));
+    for (int64_t i = 0; i < nrow; ++i)
+      if (rng_uniform((uint64_t)cfg.data_random_seed, 0x5a17u, (uint64_t)i) < p) rows.push_back(i);
+  }
+  return rows;
+}
+
 std::shared_ptr<Dataset> Dataset::from_matrix(const void* data, int dtype, int64_t nrow, int ncol, bool row_major,
                                               const Config& cfg, const Dataset* reference, bool bin_on_host) {
   if (nrow <= 0 || ncol <= 0) throw std::runtime_error("Dataset: empty matrix");
@@ -63,17 +78,7 @@ std::shared_ptr<Dataset> Dataset::from_matrix(const void* data, int dtype, int64
     ds->finish_mappers();
   } else {
     // row sample for bin finding
-    int64_t want = cfg.bin_construct_sample_cnt;
-    std::vector<int64_t> rows;
-    if (nrow <= want) {
-      rows.resize((size_t)nrow);
-      for (int64_t i = 0; i < nrow; ++i) rows[(size_t)i] = i;
-    } else {
-      float p = (float)((double)want / (double)nrow);
-      rows.reserve((size_t)(want + want / 8));
-      for (int64_t i = 0; i < nrow; ++i)
-        if (rng_uniform((uint64_t)cfg.data_random_seed, 0x5a17u, (uint64_t)i) < p) rows.push_back(i);
-    }
+    std::vector<int64_t> rows = sample_rows(nrow, cfg);
     int64_t ns = (int64_t)rows.size();
     std::vector<double> sample((size_t)ns * ncol);
 #pragma omp parallel for schedule(static)

@@ -31,6 +31,9 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
                                               const Config& cfg);
   // Mapper-only dataset with `nrow` rows that shares `ref`'s bin boundaries (bins are filled later).
   static std::shared_ptr<Dataset> from_reference(const Dataset* ref, int64_t nrow);
+  // Rows whose values the bin boundaries are derived from: all rows up to bin_construct_sample_cnt,
+  // otherwise a seeded Bernoulli sample of about that many (ascending).
+  static std::vector<int64_t> sample_rows(int64_t nrow, const Config& cfg);
   // Mapper-only dataset from bin boundaries found elsewhere (the device bin finder).
   static std::shared_ptr<Dataset> from_mappers(std::vector<BinMapper>&& mappers, int64_t nrow);
   std::shared_ptr<Dataset> subset(const int32_t* indices, int64_t n) const;

@@ -61,15 +61,7 @@ int lga_hip_dataset_from_device_mat(const void* dev_data, int dtype, int64_t nro
       if (ref->num_total_features() != ncol) throw std::runtime_error("reference has a different number of features");
       ds = Dataset::from_reference(ref, nrow);
     } else {
-      // sampled rows -> host
-      int64_t want = cfg.bin_construct_sample_cnt;
-      std::vector<int64_t> rows;
-      if (nrow <= want) { rows.resize((size_t)nrow); for (int64_t i = 0; i < nrow; ++i) rows[(size_t)i] = i; }
-      else {
-        float p = (float)((double)want / (double)nrow);
-        for (int64_t i = 0; i < nrow; ++i)
-          if (rng_uniform((uint64_t)cfg.data_random_seed, 0x5a17u, (uint64_t)i) < p) rows.push_back(i);
-      }
+      std::vector<int64_t> rows = Dataset::sample_rows(nrow, cfg);
       int64_t ns = (int64_t)rows.size();
       const size_t esz = dtype == 0 ? 4 : 8;
       std::vector<char> host_rows(cfg.device_bin_find ? 0 : (size_t)ns * (size_t)ncol * esz);
@@ -93,6 +85,41 @@ int lga_hip_dataset_from_device_mat(const void* dev_data, int dtype, int64_t nro
       }
     }
     bin_device_matrix(ds.get(), dev_data, dtype, nrow, ncol);
+    *out = new DatasetBox{ds};
+  });
+}
+
+// Raw matrix in host memory, dataset on the device: the sampled rows go up first and the bin boundaries are
+// found there (sort + run-length + cut per feature), then the matrix streams through the binning kernel.
+int lga_hip_dataset_from_host_mat(const void* data, int dtype, int64_t nrow, int ncol, int row_major, const char* params,
+                                  LgaDataset* out) {
+  return hguard([&] {
+    if (nrow <= 0 || ncol <= 0) throw std::runtime_error("Dataset: empty matrix");
+    if (nrow > 2147483000LL) throw std::runtime_error("Dataset: more than 2^31 rows per device is not supported");
+    Config cfg;
+    cfg.set(std::string(params ? params : ""));
+    hipStream_t s = current_stream();
+    std::vector<int64_t> rows = Dataset::sample_rows(nrow, cfg);
+    const int64_t ns = (int64_t)rows.size();
+    const size_t esz = dtype == 0 ? 4 : 8;
+    std::vector<char> sample((size_t)ns * (size_t)ncol * esz);
+    const char* src = (const char*)data;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < ns; ++i) {
+      const int64_t r = rows[(size_t)i];
+      if (row_major) {
+        std::memcpy(&sample[(size_t)i * (size_t)ncol * esz], src + (size_t)r * (size_t)ncol * esz, (size_t)ncol * esz);
+      } else {
+        for (int c = 0; c < ncol; ++c)
+          std::memcpy(&sample[((size_t)i * (size_t)ncol + (size_t)c) * esz], src + ((size_t)c * (size_t)nrow + (size_t)r) * esz, esz);
+      }
+    }
+    DeviceBuffer<char> d_sample(sample.size());
+    LGA_HIP_CHECK(hipMemcpyAsync(d_sample.get(), sample.data(), sample.size(), hipMemcpyHostToDevice, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    std::shared_ptr<Dataset> ds = Dataset::from_mappers(find_bins_on_device(d_sample.get(), dtype, ns, ncol, cfg), nrow);
+    d_sample.release();
+    bin_host_matrix_on_device(ds.get(), data, dtype, nrow, ncol, row_major != 0);
     *out = new DatasetBox{ds};
   });
 }
