@@ -4,9 +4,10 @@
 //
 //   1. sample_to_keys      sample [ns][F] -> order-preserving 64-bit keys [F][npad], NaN / padding = max key
 //   2. bitonic sort        (sort.hip)
-//   3. rle_and_cut         one workgroup per feature: head flags + block scan -> distinct[], counts[];
-//                          lane 0 then runs the SAME greedy routine as the host BinMapper
-//                          (binning_core.hpp), so host and device boundaries are bit-identical
+//   3. rle_and_cut         one workgroup per feature: head flags + block scan -> distinct[], counts[], then
+//                          prefix sums; lane 0 runs the cut-to-cut form of the host BinMapper's greedy routine
+//                          (binning_core.hpp: greedy_bounds_jump, checked equal to the value-by-value form),
+//                          so host and device boundaries are bit-identical
 #include "hip_engine.hpp"
 #include "sort.hpp"
 #include "../binning_core.hpp"
@@ -56,10 +57,14 @@ struct FeatureBins {      // result record per feature
 
 __global__ __launch_bounds__(256) void rle_and_cut_kernel(const uint64_t* __restrict__ keys, int64_t npad, int64_t ns,
                                                           double* __restrict__ distinct, int32_t* __restrict__ counts,
+                                                          int64_t* __restrict__ prefix, int64_t* __restrict__ small_pref,
+                                                          int32_t* __restrict__ next_big,
                                                           int max_bin, int min_data_in_bin, int use_missing,
                                                           double* __restrict__ bounds, FeatureBins* __restrict__ out) {
   __shared__ int s_cnt[256];
   __shared__ int s_total;
+  __shared__ long long s_sum[256], s_small[256];
+  __shared__ int s_first_big[256];
   const int f = blockIdx.x, t = threadIdx.x;
   const uint64_t* k = keys + (int64_t)f * npad;
   double* dv = distinct + (int64_t)f * ns;
@@ -101,12 +106,56 @@ __global__ __launch_bounds__(256) void rle_and_cut_kernel(const uint64_t* __rest
     if (d < nd) dc[d] = c;
     __syncthreads();
   }
+  const int n_nan = (int)(ns - nv);
+  int value_bins = max_bin - ((use_missing && n_nan > 0) ? 1 : 0);
+  if (value_bins < 1) value_bins = 1;
+  int64_t* pf = prefix + (int64_t)f * (ns + 1);
+  int64_t* sp = small_pref + (int64_t)f * (ns + 1);
+  int32_t* nbg = next_big + (int64_t)f * (ns + 1);
+  if (nd > value_bins) {
+    // prefix sums of the counts (all values / the values below the mean bin size) and, for every
+    // position, the next value that fills a bin on its own: inputs of the cut-to-cut search
+    double mean = (double)nv / (double)value_bins;
+    if (mean < (double)min_data_in_bin) mean = (double)min_data_in_bin;
+    const int seg2 = (nd + 255) / 256;
+    const int lo2 = min(t * seg2, nd), hi2 = min(lo2 + seg2, nd);
+    long long sum = 0, sum_small = 0;
+    int first_big = nd;
+    for (int i = hi2 - 1; i >= lo2; --i) {
+      const int c = dc[i];
+      sum += c;
+      if ((double)c >= mean) first_big = i; else sum_small += c;
+    }
+    s_sum[t] = sum; s_small[t] = sum_small; s_first_big[t] = first_big;
+    __syncthreads();
+    if (t == 0) {
+      long long a = 0, b = 0;
+      for (int i = 0; i < 256; ++i) { long long x = s_sum[i], y = s_small[i]; s_sum[i] = a; s_small[i] = b; a += x; b += y; }
+      int nxt = nd;
+      for (int i = 255; i >= 0; --i) { int x = s_first_big[i]; s_first_big[i] = nxt; if (x < nd) nxt = x; }
+      pf[0] = 0; sp[0] = 0; nbg[nd] = nd;
+    }
+    __syncthreads();
+    long long a = s_sum[t], b = s_small[t];
+    for (int i = lo2; i < hi2; ++i) {
+      const int c = dc[i];
+      a += c;
+      if (!((double)c >= mean)) b += c;
+      pf[i + 1] = a;
+      sp[i + 1] = b;
+    }
+    int nxt = s_first_big[t];   // first big value in the segments after this one
+    for (int i = hi2 - 1; i >= lo2; --i) {
+      if ((double)dc[i] >= mean) nxt = i;
+      nbg[i] = nxt;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   if (t == 0) {
-    const int n_nan = (int)(ns - nv);
-    int value_bins = max_bin - ((use_missing && n_nan > 0) ? 1 : 0);
-    if (value_bins < 1) value_bins = 1;
     FeatureBins r;
-    r.n_bounds = greedy_bounds_core(dv, dc, nd, value_bins, nv, min_data_in_bin, bounds + (int64_t)f * (kMaxBins + 1));
+    r.n_bounds = greedy_bounds_jump(dv, dc, pf, sp, nbg, nd, value_bins, nv, min_data_in_bin,
+                                    bounds + (int64_t)f * (kMaxBins + 1));
     r.n_nan = n_nan;
     r.n_distinct = nd;
     r.pad = 0;
@@ -128,6 +177,8 @@ std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, in
   DeviceBuffer<uint64_t> keys((size_t)batch * (size_t)npad);
   DeviceBuffer<double> distinct((size_t)batch * (size_t)ns);
   DeviceBuffer<int32_t> counts((size_t)batch * (size_t)ns);
+  DeviceBuffer<int64_t> prefix((size_t)batch * (size_t)(ns + 1)), small_pref((size_t)batch * (size_t)(ns + 1));
+  DeviceBuffer<int32_t> next_big((size_t)batch * (size_t)(ns + 1));
   DeviceBuffer<double> bounds((size_t)batch * (kMaxBins + 1));
   DeviceBuffer<FeatureBins> res((size_t)batch);
   std::vector<double> h_bounds((size_t)batch * (kMaxBins + 1));
@@ -142,7 +193,7 @@ std::vector<BinMapper> find_bins_on_device(const void* dev_sample, int dtype, in
     LGA_HIP_CHECK(hipGetLastError());
     bitonic_sort_u64(keys.get(), npad, nf, s);
     hipLaunchKernelGGL(rle_and_cut_kernel, dim3((unsigned)nf), dim3(256), 0, s, keys.get(), npad, ns, distinct.get(),
-                       counts.get(), cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing ? 1 : 0, bounds.get(), res.get());
+                       counts.get(), prefix.get(), small_pref.get(), next_big.get(), cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing ? 1 : 0, bounds.get(), res.get());
     LGA_HIP_CHECK(hipGetLastError());
     LGA_HIP_CHECK(hipMemcpyAsync(h_bounds.data(), bounds.get(), sizeof(double) * (size_t)nf * (kMaxBins + 1), hipMemcpyDeviceToHost, s));
     LGA_HIP_CHECK(hipMemcpyAsync(h_res.data(), res.get(), sizeof(FeatureBins) * (size_t)nf, hipMemcpyDeviceToHost, s));

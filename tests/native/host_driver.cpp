@@ -4,6 +4,7 @@
 // custom gradients, rollback, model text round trip, prediction, and a two-rank data-parallel run over
 // an in-process communicator.  Exit code 0 = every check held and the sanitizers stayed silent.
 #include "c_api.hpp"
+#include "binning_core.hpp"
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
@@ -78,7 +79,48 @@ static std::string trees_of(const std::string& m) {
   return m.substr(a, b - a);
 }
 
+// The cut-to-cut form of the bin-boundary search must reproduce the value-by-value form exactly.
+static void check_jump_cut() {
+  for (int trial = 0; trial < 3000; ++trial) {
+    const int n = 1 + (int)(uni() * (trial % 3 == 0 ? 40 : 3000));
+    const int max_bin = 2 + (int)(uni() * 254);
+    const int min_data = 1 + (int)(uni() * (trial % 5 == 0 ? 200 : 6));
+    const int style = trial % 4;
+    std::vector<double> distinct((size_t)n);
+    std::vector<int> counts((size_t)n);
+    double v = -5.0;
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+      v += 1e-3 + uni();
+      distinct[(size_t)i] = v;
+      int c = 1;
+      if (style == 0) c = 1 + (int)(uni() * 3);
+      else if (style == 1) c = uni() < 0.02 ? 1 + (int)(uni() * 5000) : 1 + (int)(uni() * 4);
+      else if (style == 2) c = 1 + (int)(uni() * uni() * 400);
+      else c = (i % 50 == 7) ? 3000 : 1;
+      counts[(size_t)i] = c;
+      total += c;
+    }
+    double mean = (double)total / (double)max_bin;
+    if (mean < (double)min_data) mean = (double)min_data;
+    std::vector<int64_t> prefix((size_t)n + 1, 0), small((size_t)n + 1, 0);
+    std::vector<int> next_big((size_t)n + 1, n);
+    for (int i = 0; i < n; ++i) {
+      prefix[(size_t)i + 1] = prefix[(size_t)i] + counts[(size_t)i];
+      small[(size_t)i + 1] = small[(size_t)i] + ((double)counts[(size_t)i] >= mean ? 0 : counts[(size_t)i]);
+    }
+    for (int i = n - 1; i >= 0; --i) next_big[(size_t)i] = (double)counts[(size_t)i] >= mean ? i : next_big[(size_t)i + 1];
+    std::vector<double> a((size_t)max_bin + 2), b((size_t)max_bin + 2);
+    const int na = lga::greedy_bounds_core(distinct.data(), counts.data(), n, max_bin, total, min_data, a.data());
+    const int nb = lga::greedy_bounds_jump(distinct.data(), counts.data(), prefix.data(), small.data(), next_big.data(), n,
+                                           max_bin, total, min_data, b.data());
+    REQUIRE(na == nb);
+    for (int i = 0; i < na; ++i) REQUIRE(a[(size_t)i] == b[(size_t)i]);
+  }
+}
+
 int main() {
+  check_jump_cut();
   const int64_t n = 6000;
   const int f = 37;   // two feature tiles
   std::vector<double> X((size_t)n * f);
