@@ -42,6 +42,8 @@ struct SplitParams {
   double max_delta_step;
   int32_t min_data_in_leaf;
   int32_t max_depth;  // <=0: unlimited
+  double bynode_fraction;   // feature_fraction_bynode (>= 1: every enabled feature at every node)
+  uint64_t bynode_seed;     // differs per tree
 };
 
 // Power-of-two scales of the current boosting iteration: real = q * 2^-k.
@@ -81,7 +83,7 @@ struct SplitTask {
   int32_t first_hchunk;  // first histogram chunk
   int32_t num_hchunk;
   int32_t depth;         // depth of the children
-  int32_t pad;
+  int32_t parent_key;    // position key of the parent (uint32 bits; see node_feature_on)
 };
 
 // Row range of a node inside the two ping-pong row-index arenas.
@@ -99,7 +101,7 @@ struct ScanTask {
   int32_t parent_slot; // -1: histogram already in `slot`; else slot = parent - sibling
   int32_t sibling_slot;
   int32_t depth;
-  int32_t pad;
+  uint32_t key;        // position key of the node (node_feature_on)
 };
 
 struct FeatureMeta {
@@ -224,6 +226,20 @@ LGA_HD uint64_t rng_u64(uint64_t seed, uint64_t stream, uint64_t index) {
 // Uniform in [0,1) with 24 random bits (exactly representable in float).
 LGA_HD float rng_uniform(uint64_t seed, uint64_t stream, uint64_t index) {
   return (float)(rng_u64(seed, stream, index) >> 40) * (1.0f / 16777216.0f);
+}
+
+// Per-node feature sampling (feature_fraction_bynode).  A node is named by its POSITION in the tree - a key
+// derived from its parent's key and its side - so the subset does not depend on the order in which leaves
+// happen to be partitioned.  Every feature is kept with probability `bynode_fraction`, one (hashed from the
+// key) always.
+constexpr uint32_t kRootNodeKey = 1u;
+LGA_HD uint32_t child_node_key(uint32_t parent_key, int side) {
+  return (uint32_t)mix64(((uint64_t)parent_key << 1) | (uint64_t)(side & 1)) | 1u;
+}
+LGA_HD bool node_feature_on(const SplitParams& sp, uint32_t key, int f, int num_features) {
+  if (!(sp.bynode_fraction < 1.0)) return true;
+  if ((int)(mix64(sp.bynode_seed ^ ((uint64_t)key << 24)) % (uint64_t)(num_features > 0 ? num_features : 1)) == f) return true;
+  return rng_uniform(sp.bynode_seed, (uint64_t)key, (uint64_t)f) < (float)sp.bynode_fraction;
 }
 
 LGA_HD double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }

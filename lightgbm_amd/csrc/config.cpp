@@ -317,12 +317,10 @@ void Config::check() {
   else if (d == "gpu" || d == "hip" || d == "cuda" || d == "rocm") device_type = "gpu";
   else throw std::runtime_error("unknown device_type \"" + device_type + "\"");
   // accepted names whose behaviour is not implemented: refuse instead of training something else silently
-  if (feature_fraction_bynode < 1.0)
-    throw std::runtime_error("feature_fraction_bynode < 1 is not supported (use feature_fraction: one feature subset per tree)");
   if (zero_as_missing) throw std::runtime_error("zero_as_missing=true is not supported (NaN is the missing value)");
   if (boosting == "rf") {
     bool row_sub = bagging_freq > 0 && bagging_fraction < 1.0;
-    bool col_sub = feature_fraction < 1.0;
+    bool col_sub = feature_fraction < 1.0 || feature_fraction_bynode < 1.0;
     if (!row_sub && !col_sub)
       throw std::runtime_error(
           "boosting=rf needs row sub-sampling (bagging_freq > 0 and bagging_fraction < 1) "

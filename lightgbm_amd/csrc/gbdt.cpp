@@ -136,6 +136,7 @@ bool Booster::update_one_iter() {
   if (!is_rf_) engine_->compute_gradients(obj_);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
   if (bagging) draw_bag();
+  engine_->set_tree_index(iter_);
   Tree tree = engine_->train_tree(sample_features());
   return finish_iteration(std::move(tree));
 }
@@ -161,6 +162,7 @@ bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64
   engine_->set_gradients(grad, hess, n);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
   if (bagging) draw_bag();
+  engine_->set_tree_index(iter_);
   Tree tree = engine_->train_tree(sample_features());
   return finish_iteration(std::move(tree));
 }

@@ -22,6 +22,8 @@ SplitParams TreeGrower::split_params() const {
   p.max_delta_step = cfg_.max_delta_step;
   p.min_data_in_leaf = cfg_.min_data_in_leaf;
   p.max_depth = cfg_.max_depth;
+  p.bynode_fraction = cfg_.feature_fraction_bynode;
+  p.bynode_seed = mix64((uint64_t)cfg_.feature_fraction_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x51ed27ull);
   return p;
 }
 
@@ -194,7 +196,10 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
         t.parent_slot = c.slot;
         t.new_slot = 1 + materialized + (int)tasks.size();
         t.depth = c.depth + 1;
+        t.parent_key = (int32_t)c.key;
         Node l, r;
+        l.key = child_node_key(c.key, 0);
+        r.key = child_node_key(c.key, 1);
         l.parent = r.parent = e.node;
         l.depth = r.depth = c.depth + 1;
         l.slot = t.hist_child == 0 ? t.new_slot : t.parent_slot;

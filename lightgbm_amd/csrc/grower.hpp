@@ -42,6 +42,8 @@ class TreeGrower {
   // nodes whose row ranges make up each leaf.
   Tree grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces);
   const GrowStats& last_stats() const { return stats_; }
+  // Index of the tree about to be grown: seeds its per-node feature sampling.
+  void set_tree_index(int64_t i) { tree_index_ = i; }
   SplitParams split_params() const;
 
  private:
@@ -51,11 +53,13 @@ class TreeGrower {
     int slot = 0;
     int left = -1, right = -1;   // children node ids once the leaf's split has been submitted
     bool ready = false;          // ... and once that round's results are in
+    uint32_t key = kRootNodeKey; // position key (per-node feature sampling)
     SplitInfo best;
   };
   const Config cfg_;
   const Dataset* ds_;
   GrowStats stats_;
+  int64_t tree_index_ = 0;
   double prev_cutoff_ = 0.0;   // smallest used gain of the previous tree
   double spec_floor_ = 0.5;    // speculate only on gains >= spec_floor_ * prev_cutoff_
 };

@@ -385,7 +385,7 @@ class HipBackend : public TreeBackend {
           k::ScanTaskDev& sdt = sd[i];
           sdt.node = side == 0 ? t.left_node : t.right_node;
           sdt.parent_node = t.parent_node;
-          sdt.pad = 0;
+          sdt.key = root ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
           if (side == t.hist_child) { sdt.slot = t.new_slot; sdt.parent_slot = -1; sdt.sibling_slot = -1; }
           else { sdt.slot = t.parent_slot; sdt.parent_slot = t.parent_slot; sdt.sibling_slot = t.new_slot; }
         }
@@ -691,6 +691,7 @@ class HipEngine : public Engine {
     oob_n_ = n_base_ - bag_n_;
   }
 
+  void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     TraceRange range("lga.train_tree");
     if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_or_null(), n_base_, maxbits_.get(), stream_);

@@ -493,7 +493,8 @@ __device__ __forceinline__ void take_better(double& g, uint64_t& key, int64_t& l
 __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __restrict__ self,
                                                   const int64_t* __restrict__ sib, int64_t plane,
                                                   const FeatureMeta m, const LeafScanCtx& ctx, const SplitParams& sp,
-                                                  double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+                                                  double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh,
+                                                  bool evaluate = true) {
   const int64_t e = (int64_t)f * kMaxBins + lane * 4;
   int64_t g[4], h[4];
   {
@@ -514,6 +515,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
     go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
     ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
   }
+  if (!evaluate) return;   // feature not offered at this node: only its histogram had to be derived
   const int nb = m.num_bin, mb = m.missing_bin;
   const int vb = mb >= 0 ? nb - 1 : nb;
   // stats of the missing-value bin, broadcast from the lane that holds it
@@ -601,7 +603,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh);
+  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F));
   if (lane == 0) *out = Cand{bg, bkey, blg, blh};
 }
 
@@ -667,6 +669,7 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
   const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   const bool direct = side == t.hist_child;
   const int node = side == 0 ? t.left_node : t.right_node;
+  const uint32_t key = t.parent_node < 0 ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
   const int slot = direct ? t.new_slot : t.parent_slot;
   const double ninf = -std::numeric_limits<double>::infinity();
   int64_t* self = pool + (int64_t)slot * slot_words;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
   for (int f = wave; f < F; f += kFusedWaves) {
     const FeatureMeta m = meta[f];
     if (!m.enabled) continue;
-    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh);
+    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F));
   }
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();

@@ -37,7 +37,7 @@ struct ScanTaskDev {
   int32_t parent_slot;    // -1: histogram already in `slot`
   int32_t sibling_slot;
   int32_t parent_node;
-  int32_t pad;
+  uint32_t key;           // position key of the node (per-node feature sampling)
 };
 
 struct TreeNodeDev {       // internal node of a tree for binned traversal (16 bytes, one LDS read)

@@ -83,7 +83,7 @@ class HostBackend : public TreeBackend {
   void root_round(SplitInfo* out) override {
     build_hist(0, 0);
     reduce_slots(0, 1);
-    ScanTask st{0, 0, -1, -1, 0, 0};
+    ScanTask st{0, 0, -1, -1, 0, kRootNodeKey};
     scan_nodes(&st, 1, out);
   }
 
@@ -115,6 +115,7 @@ class HostBackend : public TreeBackend {
         ScanTask& s = st[i * 2 + (size_t)side];
         s.node = side == 0 ? t.left_node : t.right_node;
         s.depth = t.depth;
+        s.key = child_node_key((uint32_t)t.parent_key, side);
         if (side == t.hist_child) { s.slot = t.new_slot; s.parent_slot = -1; s.sibling_slot = -1; }
         else { s.slot = t.parent_slot; s.parent_slot = t.parent_slot; s.sibling_slot = t.new_slot; }
       }
@@ -238,7 +239,7 @@ class HostBackend : public TreeBackend {
       LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_);
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
-        if (!meta_[(size_t)f].enabled || !owns_feature(f)) continue;
+        if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_)) continue;
         scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, &best);
       }
       local[(size_t)i] = best;
@@ -412,6 +413,7 @@ class HostEngine : public Engine {
     }
   }
 
+  void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     // quantisation scale from the largest |g| and h of the training rows
     float mx[2] = {0.f, 0.f};

@@ -209,6 +209,7 @@ def test_device_bin_boundaries_equal_host_boundaries(n, sample, dtype):
     {"num_leaves": 63, "max_depth": 5, "feature_fraction": 0.7},
     {"num_leaves": 31, "bagging_fraction": 0.6, "bagging_freq": 2},
     {"num_leaves": 15, "max_bin": 63, "lambda_l1": 0.1, "min_gain_to_split": 0.05},
+    {"num_leaves": 63, "feature_fraction_bynode": 0.5, "min_data_in_leaf": 5},
 ])
 def test_gpu_regression_trees_equal_cpu_trees(params):
     X, y = make_regression(40000, 12, seed=3)

@@ -227,6 +227,31 @@ def test_snapshots_allow_resuming_a_killed_run(tmp_path):
 
 def test_unimplemented_parameters_are_refused():
     X, y = make_regression(500, 4, seed=1)
-    for bad in ({"feature_fraction_bynode": 0.5}, {"zero_as_missing": True}):
+    for bad in ({"zero_as_missing": True},):
         with pytest.raises(lgb.LightGBMError):
             lgb.train({**CPU, **bad}, lgb.Dataset(X, label=y, params=CPU), 2)
+
+
+def _internal_nodes(node):
+    if "split_feature" in node:
+        yield node
+        yield from _internal_nodes(node["left_child"])
+        yield from _internal_nodes(node["right_child"])
+
+
+def test_feature_fraction_bynode_samples_per_node_and_is_order_independent():
+    """Per-node feature subsets: named by tree position, so batched / speculative growth and the textbook
+    one-leaf-at-a-time growth pick the same splits; the model differs from the unsampled one and still learns."""
+    X, y = make_regression(6000, 12, seed=14)
+    ds = lgb.Dataset(X, label=y, params=CPU)
+    p = {**CPU, "num_leaves": 31, "feature_fraction_bynode": 0.4, "min_data_in_leaf": 10}
+    a = lgb.train(p, ds, 12)
+    b = lgb.train({**p, "max_batch_leaves": 1}, ds, 12)
+    assert trees_of(a) == trees_of(b)
+    full = lgb.train({**CPU, "num_leaves": 31, "min_data_in_leaf": 10}, ds, 12)
+    assert trees_of(a) != trees_of(full)
+    rmse = lambda m: float(np.sqrt(np.mean((m.predict(X) - y) ** 2)))
+    assert rmse(a) < 0.5 * float(np.std(y))
+    # different trees draw different subsets
+    used = [set(t["split_feature"] for t in _internal_nodes(tr["tree_structure"])) for tr in a.dump_model()["tree_info"][:4]]
+    assert len({frozenset(u) for u in used}) > 1
