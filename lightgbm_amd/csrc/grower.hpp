@@ -61,7 +61,7 @@ class TreeGrower {
   GrowStats stats_;
   int64_t tree_index_ = 0;
   double prev_cutoff_ = 0.0;   // smallest used gain of the previous tree
-  double spec_floor_ = 0.5;    // speculate only on gains >= spec_floor_ * prev_cutoff_
+  double spec_floor_ = 0.75;   // speculate only on gains >= spec_floor_ * prev_cutoff_
 };
 
 }  // namespace lga

@@ -146,7 +146,7 @@ class HipBackend : public TreeBackend {
     stream_ = current_stream();
     pool_.resize((size_t)(capacity_splits_ + 1) * slot_words_);
     int n_nodes = 2 * capacity_splits_ + 2;
-    nodes_.resize((size_t)n_nodes);
+    nodes_.resize((size_t)n_nodes + 2);   // + the bagging partition's scratch entries
     node_totals_.resize((size_t)n_nodes * 4);
     ranges_host_.resize((size_t)n_nodes);
     arena_[0].resize((size_t)std::max<int64_t>(max_rows, 1));
@@ -269,8 +269,10 @@ class HipBackend : public TreeBackend {
                         uint64_t iter, uint64_t salt) {
     if (n == 0) return 0;
     SplitTask t{};
-    const int node_id = 2 * capacity_splits_ + 1;   // scratch node entry beyond the grower's range
-    t.parent_node = node_id; t.left_node = node_id; t.right_node = node_id;
+    // Scratch node entries beyond the grower's range.  The children must not alias the parent: the first
+    // chunk's workgroup writes the child ranges while the other chunks still read the parent's.
+    const int node_id = 2 * capacity_splits_ + 1;
+    t.parent_node = node_id; t.left_node = node_id + 1; t.right_node = node_id + 2;
     t.feature = -1; t.first_pchunk = 0; t.num_pchunk = ceil_div(n, k::kPartChunk);
     if (t.num_pchunk > max_pchunks_) throw std::runtime_error("bagging chunk table overflow");
     RoundCtx& x = ctx_[0];

@@ -309,6 +309,30 @@ def test_concurrent_fold_streams_give_the_same_cv():
     assert a["rmse-mean"] == b["rmse-mean"] and a["rmse-stdv"] == b["rmse-stdv"]
 
 
+def test_bagging_over_many_partition_chunks():
+    """The bagging partition spans hundreds of 2048-row chunks: later chunks must still see the parent range
+    after the first one has published the bag / out-of-bag ranges."""
+    X, y = make_regression(1_500_000, 4, seed=12)
+    # no boost-from-average: the label mean of 1.5 M rows depends on the summation order in its last bits
+    p = {"num_leaves": 15, "bagging_fraction": 0.5, "bagging_freq": 1, "min_data_in_leaf": 50,
+         "boost_from_average": False}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 3)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 3)
+    assert trees_of(a) == trees_of(b)
+
+
+def test_concurrent_folds_with_bagging_and_feature_fraction():
+    """A grid-search row of the reference (r/gridsearchCV.R:11-18): bagging + feature sampling, five fold
+    boosters on their own streams."""
+    X, y = make_diamonds_like(43000, seed=5)
+    d = lgb.Dataset(X, label=y, params=GPU)
+    p = {**GPU, "objective": "regression", "metric": "rmse", "learning_rate": 0.1, "num_leaves": 31,
+         "min_data_in_leaf": 20, "feature_fraction": 0.8, "bagging_fraction": 0.6, "bagging_freq": 4}
+    a = lgb.cv(p, d, 60, nfold=5, early_stopping_rounds=5, seed=3, concurrent_folds=False)
+    b = lgb.cv(p, d, 60, nfold=5, early_stopping_rounds=5, seed=3, concurrent_folds=True)
+    assert a["rmse-mean"] == b["rmse-mean"] and a["rmse-stdv"] == b["rmse-stdv"]
+
+
 def test_gpu_rf_and_rollback_and_custom_objective():
     X, y = make_regression(20000, 8, seed=6)
     p = {"boosting": "rf", "bagging_fraction": 0.63, "bagging_freq": 1, "feature_fraction": 0.8, "num_leaves": 63}
