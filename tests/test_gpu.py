@@ -220,6 +220,18 @@ def test_gpu_regression_trees_equal_cpu_trees(params):
     assert trees_of(a) == trees_of(b)
 
 
+@pytest.mark.parametrize("first", [0, 10, 20, 30])
+def test_randomised_parity_sweep(first):
+    """Random shapes (across the row-line, two-rounds-in-flight and tree-walk size gates), missing values,
+    weights, subsets and parameter sets: the device engine grows the CPU oracle's trees, bit for bit."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import parity_sweep
+    for seed in range(first, first + 10):
+        same, case = parity_sweep.run_case(seed, 1_200_000)
+        assert same, f"seed {seed}: {case}"
+
+
 @pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2")])
 def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     """The large-data paths - bin records interleaved with the packed gradients, two growth rounds in
