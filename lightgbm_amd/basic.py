@@ -624,8 +624,11 @@ class Booster:
 
     # -- prediction --
     def predict(self, data, start_iteration: int = 0, num_iteration: Optional[int] = None, raw_score: bool = False,
-                pred_leaf: bool = False, device: Optional[str] = None, **kwargs) -> np.ndarray:
-        """Predicts a dense matrix.  ``num_iteration=k`` uses the first k trees (staged prediction)."""
+                pred_leaf: bool = False, pred_contrib: bool = False, device: Optional[str] = None,
+                **kwargs) -> np.ndarray:
+        """Predicts a dense matrix.  ``num_iteration=k`` uses the first k trees (staged prediction).
+        ``pred_leaf``: leaf index per (row, tree).  ``pred_contrib``: SHAP values, ``[n, n_features + 1]`` in
+        raw-score units; the last column is the expected value and every row sums to the raw prediction."""
         lib, hip = _lib.load()
         if isinstance(data, Dataset):
             raise TypeError("Cannot predict a Dataset; pass the raw matrix")
@@ -634,23 +637,26 @@ class Booster:
         if num_iteration is None or num_iteration <= 0:
             num_iteration = -1
         mat, _ = _to_matrix(data)
-        ptype = 2 if pred_leaf else (1 if raw_score else 0)
+        ptype = 3 if pred_contrib else (2 if pred_leaf else (1 if raw_score else 0))
         used = ctypes.c_int()
         check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
         nrow = mat.shape[0]
-        use_gpu = hip and not pred_leaf and (device == "gpu" or _is_torch(mat) or
+        use_gpu = hip and not pred_leaf and not pred_contrib and (device == "gpu" or _is_torch(mat) or
                                              (device is None and nrow * max(used.value, 1) >= 2_000_000))
         if use_gpu:
             from . import _device
             return _device.predict(lib, self._handle, mat, start_iteration, num_iteration, ptype)
         if _is_torch(mat):
             mat = mat.cpu().numpy()
-        out = np.empty(nrow * (used.value if pred_leaf else 1), dtype=np.float64)
+        width = (mat.shape[1] + 1) if pred_contrib else (used.value if pred_leaf else 1)
+        out = np.empty(nrow * width, dtype=np.float64)
         ptr, dtype, nr, nc, rm = _mat_args(mat)
         check(lib.lga_booster_predict(self._handle, ptr, dtype, nr, nc, rm, start_iteration, num_iteration, ptype,
                                       out.ctypes.data_as(ctypes.c_void_p)))
         if pred_leaf:
             return out.reshape(nrow, used.value).astype(np.int32)
+        if pred_contrib:
+            return out.reshape(nrow, width)
         return out
 
     # -- model IO --
@@ -709,6 +715,99 @@ class Booster:
         o, a, s = ctypes.c_char_p(), ctypes.c_int(), ctypes.c_double()
         check(lib.lga_booster_info(self._handle, ctypes.byref(o), ctypes.byref(a), ctypes.byref(s)))
         return {"objective": o.value.decode(), "average_output": bool(a.value), "sigmoid": s.value}
+
+    def num_model_per_iteration(self) -> int:
+        return 1
+
+    def get_leaf_output(self, tree_id: int, leaf_id: int) -> float:
+        return float(self._tree_arrays()[tree_id]["leaf_value"][leaf_id])
+
+    def lower_bound(self) -> float:
+        """Smallest raw score the model can produce (sum of the per-tree minimum leaf values)."""
+        mins = [float(np.min(t["leaf_value"])) for t in self._tree_arrays()]
+        return self._combine_bounds(mins)
+
+    def upper_bound(self) -> float:
+        maxs = [float(np.max(t["leaf_value"])) for t in self._tree_arrays()]
+        return self._combine_bounds(maxs)
+
+    def _combine_bounds(self, per_tree: List[float]) -> float:
+        if not per_tree:
+            return 0.0
+        total = float(np.sum(per_tree))
+        return total / len(per_tree) if self.objective_info()["average_output"] else total
+
+    def _tree_arrays(self) -> List[Dict[str, np.ndarray]]:
+        from .models.ensemble import TreeEnsemble
+        ens = TreeEnsemble.from_string(self.model_to_string(num_iteration=-1))
+        return [{"leaf_value": t.leaf_value} for t in ens.trees]
+
+    def trees_to_dataframe(self):
+        """One row per node of every tree (pandas), with the python-package's column set: ``tree_index,
+        node_depth, node_index, left_child, right_child, parent_index, split_feature, split_gain, threshold,
+        decision_type, missing_direction, missing_type, value, weight, count``."""
+        import pandas as pd
+        model = self.dump_model(num_iteration=-1)
+        names = model["feature_names"]
+        rows: List[Dict[str, Any]] = []
+
+        def node_name(tree_index, node):
+            if "split_index" in node:
+                return f"{tree_index}-S{node['split_index']}"
+            return f"{tree_index}-L{node.get('leaf_index', 0)}"
+
+        def walk(tree_index, node, depth, parent):
+            is_split = "split_index" in node
+            row = {"tree_index": tree_index, "node_depth": depth, "node_index": node_name(tree_index, node),
+                   "left_child": None, "right_child": None, "parent_index": parent, "split_feature": None,
+                   "split_gain": None, "threshold": None, "decision_type": None, "missing_direction": None,
+                   "missing_type": None}
+            if is_split:
+                row.update(left_child=node_name(tree_index, node["left_child"]),
+                           right_child=node_name(tree_index, node["right_child"]),
+                           split_feature=names[node["split_feature"]], split_gain=node["split_gain"],
+                           threshold=node["threshold"], decision_type=node["decision_type"],
+                           missing_direction="left" if node["default_left"] else "right",
+                           missing_type=node["missing_type"], value=node["internal_value"],
+                           weight=node["internal_weight"], count=node["internal_count"])
+            else:
+                row.update(value=node["leaf_value"], weight=node.get("leaf_weight"), count=node.get("leaf_count"))
+            rows.append(row)
+            if is_split:
+                walk(tree_index, node["left_child"], depth + 1, row["node_index"])
+                walk(tree_index, node["right_child"], depth + 1, row["node_index"])
+
+        for t in model["tree_info"]:
+            walk(t["tree_index"], t["tree_structure"], 1, None)
+        return pd.DataFrame(rows)
+
+    def eval(self, data: Dataset, name: str, feval=None):
+        """Evaluates the metrics on ``data`` (added as a validation set on first use)."""
+        if data is self.train_set:
+            return self._eval(-1, name, feval)
+        for i, d in enumerate(self.valid_sets):
+            if d is data:
+                return self._eval(i, name, feval)
+        self.add_valid(data, name)
+        return self._eval(len(self.valid_sets) - 1, name, feval)
+
+    # pickling / copying go through the text model (training state is not kept)
+    def __getstate__(self):
+        return {"model": self.model_to_string(num_iteration=-1), "best_iteration": self.best_iteration,
+                "best_score": getattr(self, "best_score", {}), "params": dict(self.params)}
+
+    def __setstate__(self, state):
+        self.__init__(params=state.get("params"), model_str=state["model"])
+        self.best_iteration = state.get("best_iteration", 0)
+        self.best_score = state.get("best_score", {})
+
+    def __copy__(self):
+        return self.__deepcopy__(None)
+
+    def __deepcopy__(self, memo):
+        b = Booster(params=dict(self.params), model_str=self.model_to_string(num_iteration=-1))
+        b.best_iteration = self.best_iteration
+        return b
 
     def _prepend(self, first: "Booster"):
         lib, _ = _lib.load()

@@ -276,6 +276,13 @@ void Booster::predict(const void* data, int dtype, int64_t nrow, int ncol, bool 
       if (type == kPredictLeaf) {
         for (int t = 0; t < n_it; ++t)
           out[i * (int64_t)n_it + t] = (double)trees_[(size_t)(start_iter + t)].predict_leaf(row.data());
+      } else if (type == kPredictContrib) {
+        // [ncol contributions | expected value] per row, in raw-score units
+        double* phi = out + i * (int64_t)(ncol + 1);
+        for (int c = 0; c <= ncol; ++c) phi[c] = 0.0;
+        for (int t = 0; t < n_it; ++t) trees_[(size_t)(start_iter + t)].add_contributions(row.data(), ncol, phi);
+        if (average_output_ && n_it > 0)
+          for (int c = 0; c <= ncol; ++c) phi[c] /= (double)n_it;
       } else {
         double s = 0.0;
         for (int t = 0; t < n_it; ++t) s += trees_[(size_t)(start_iter + t)].predict(row.data());

@@ -16,7 +16,7 @@ namespace lga {
 
 using EngineFactory = std::function<std::unique_ptr<Engine>(std::shared_ptr<Dataset>, const Config&)>;
 
-enum PredictType : int { kPredictNormal = 0, kPredictRaw = 1, kPredictLeaf = 2 };
+enum PredictType : int { kPredictNormal = 0, kPredictRaw = 1, kPredictLeaf = 2, kPredictContrib = 3 };
 
 class Booster {
  public:

@@ -80,6 +80,117 @@ int Tree::predict_leaf(const double* row) const {
   return ~node;
 }
 
+// ---------------------------------------------------------------------------
+// Path-dependent SHAP values (Lundberg, Erion & Lee 2018, "Consistent individualized feature attribution
+// for tree ensembles", algorithm 2).  A path keeps, for every distinct feature met on the way down, the
+// fraction of "feature unknown" paths (by training row counts) and of "feature known" paths (1 on the
+// branch the row takes, 0 on the other) that flow through it, plus the permutation weights per subset size.
+// ---------------------------------------------------------------------------
+namespace {
+struct PathStep {
+  int feature;
+  double zero, one, weight;
+};
+
+void path_extend(std::vector<PathStep>& p, int d, double zero, double one, int feature) {
+  p[(size_t)d] = PathStep{feature, zero, one, d == 0 ? 1.0 : 0.0};
+  for (int i = d - 1; i >= 0; --i) {
+    p[(size_t)i + 1].weight += one * p[(size_t)i].weight * (double)(i + 1) / (double)(d + 1);
+    p[(size_t)i].weight = zero * p[(size_t)i].weight * (double)(d - i) / (double)(d + 1);
+  }
+}
+
+void path_unwind(std::vector<PathStep>& p, int d, int k) {
+  const double one = p[(size_t)k].one, zero = p[(size_t)k].zero;
+  double next = p[(size_t)d].weight;
+  for (int i = d - 1; i >= 0; --i) {
+    if (one != 0.0) {
+      const double keep = p[(size_t)i].weight;
+      p[(size_t)i].weight = next * (double)(d + 1) / ((double)(i + 1) * one);
+      next = keep - p[(size_t)i].weight * zero * (double)(d - i) / (double)(d + 1);
+    } else {
+      p[(size_t)i].weight = p[(size_t)i].weight * (double)(d + 1) / (zero * (double)(d - i));
+    }
+  }
+  for (int i = k; i < d; ++i) {
+    p[(size_t)i].feature = p[(size_t)i + 1].feature;
+    p[(size_t)i].zero = p[(size_t)i + 1].zero;
+    p[(size_t)i].one = p[(size_t)i + 1].one;
+  }
+}
+
+double path_unwound_sum(const std::vector<PathStep>& p, int d, int k) {
+  const double one = p[(size_t)k].one, zero = p[(size_t)k].zero;
+  double next = p[(size_t)d].weight, total = 0.0;
+  for (int i = d - 1; i >= 0; --i) {
+    if (one != 0.0) {
+      const double w = next * (double)(d + 1) / ((double)(i + 1) * one);
+      total += w;
+      next = p[(size_t)i].weight - w * zero * (double)(d - i) / (double)(d + 1);
+    } else {
+      total += p[(size_t)i].weight * (double)(d + 1) / (zero * (double)(d - i));
+    }
+  }
+  return total;
+}
+
+struct ShapWalk {
+  const Tree& t;
+  const double* row;
+  double* phi;
+  double count_of(int child) const {
+    return (double)(child < 0 ? t.leaf_count[(size_t)~child] : t.internal_count[(size_t)child]);
+  }
+  // `parent` holds d steps (indices 0..d-1); this node adds step d.
+  void visit(int node, const std::vector<PathStep>& parent, int d, double zero, double one, int feature) const {
+    std::vector<PathStep> p(parent.begin(), parent.begin() + d);
+    p.resize((size_t)d + 2);
+    path_extend(p, d, zero, one, feature);
+    if (node < 0) {
+      const double v = t.leaf_value[(size_t)~node];
+      for (int i = 1; i <= d; ++i)
+        phi[p[(size_t)i].feature] += path_unwound_sum(p, d, i) * (p[(size_t)i].one - p[(size_t)i].zero) * v;
+      return;
+    }
+    const int f = t.split_feature[(size_t)node];
+    const bool left = Tree::go_left(row[f], t.threshold[(size_t)node], t.decision_type[(size_t)node]);
+    const int hot = left ? t.left_child[(size_t)node] : t.right_child[(size_t)node];
+    const int cold = left ? t.right_child[(size_t)node] : t.left_child[(size_t)node];
+    const double w = (double)t.internal_count[(size_t)node];
+    const double hot_zero = w > 0 ? count_of(hot) / w : 0.5, cold_zero = w > 0 ? count_of(cold) / w : 0.5;
+    double in_zero = 1.0, in_one = 1.0;
+    int k = 1;
+    for (; k <= d; ++k) if (p[(size_t)k].feature == f) break;
+    if (k <= d) {   // the feature was split on above: fold that step into this one
+      in_zero = p[(size_t)k].zero;
+      in_one = p[(size_t)k].one;
+      path_unwind(p, d, k);
+      d -= 1;
+    }
+    visit(hot, p, d + 1, hot_zero * in_zero, in_one, f);
+    visit(cold, p, d + 1, cold_zero * in_zero, 0.0, f);
+  }
+};
+}  // namespace
+
+double Tree::expected_value() const {
+  if (num_leaves <= 1) return leaf_value[0];
+  double s = 0.0, n = 0.0;
+  for (int l = 0; l < num_leaves; ++l) {
+    s += (double)leaf_count[(size_t)l] * leaf_value[(size_t)l];
+    n += (double)leaf_count[(size_t)l];
+  }
+  return n > 0 ? s / n : 0.0;
+}
+
+void Tree::add_contributions(const double* row, int n_features, double* phi) const {
+  phi[n_features] += expected_value();
+  if (num_leaves <= 1) return;
+  ShapWalk walk{*this, row, phi};
+  std::vector<PathStep> empty;
+  walk.visit(0, empty, 0, 1.0, 1.0, -1);
+}
+
 int Tree::max_depth() const {
   int d = 0;
   for (int v : leaf_depth) d = std::max(d, v);

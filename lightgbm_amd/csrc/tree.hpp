@@ -55,6 +55,11 @@ struct Tree {
   }
   int predict_leaf(const double* row) const;
   double predict(const double* row) const { return leaf_value[(size_t)predict_leaf(row)]; }
+  // Adds this tree's per-feature contributions (path-dependent SHAP values weighted by the training row
+  // counts of the nodes) for one row to phi[0 .. n_features); phi[n_features] receives the tree's expected
+  // value.  The entries of one row sum to predict(row).
+  void add_contributions(const double* row, int n_features, double* phi) const;
+  double expected_value() const;
   // Traversal over binned features: bins(inner_feature) -> bin of this row.
   template <typename BinGetter>
   int predict_leaf_binned(BinGetter bins, const int32_t* missing_bin_of_inner) const {

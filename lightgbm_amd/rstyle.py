@@ -36,7 +36,10 @@ from .basic import Booster, Dataset
 from .engine import cv as _cv
 from .engine import train as _train
 
-__all__ = ["lgb_Dataset", "lgb_train", "lgb_cv", "RCVBooster", "as_list", "predict"]
+__all__ = ["lgb_Dataset", "lgb_train", "lgb_cv", "RCVBooster", "as_list", "predict", "lgb_Dataset_create_valid",
+           "lgb_Dataset_construct", "lgb_Dataset_save", "getinfo", "setinfo", "dim", "slice_rows", "lgb_save",
+           "lgb_load", "lgb_dump", "lgb_importance", "lgb_interprete", "lgb_model_dt_tree", "lgb_get_eval_result",
+           "saveRDS_lgb_Booster", "readRDS_lgb_Booster"]
 
 
 def lgb_Dataset(data, label=None, weight=None, **kwargs) -> Dataset:
@@ -167,7 +170,135 @@ def lgb_cv(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3,
     return out
 
 
-def predict(booster: Booster, data, num_iteration: Optional[int] = None, rawscore: bool = False, **kwargs) -> np.ndarray:
+def predict(booster: Booster, data, num_iteration: Optional[int] = None, rawscore: bool = False,
+            predleaf: bool = False, predcontrib: bool = False, **kwargs) -> np.ndarray:
     """``predict(fit, X)`` on a dense matrix (all iterations unless ``num_iteration`` is given)."""
     return booster.predict(data, num_iteration=num_iteration if num_iteration is not None else -1,
-                           raw_score=rawscore, **kwargs)
+                           raw_score=rawscore, pred_leaf=predleaf, pred_contrib=predcontrib, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The rest of the R binding's everyday surface (not called by the reference scripts, but what a user of
+# ``library(lightgbm)`` reaches for next): dataset helpers, model files, importance / interpretation tables.
+# ---------------------------------------------------------------------------------------------------------
+def lgb_Dataset_create_valid(dataset: Dataset, data, label=None, **kwargs) -> Dataset:
+    """``lgb.Dataset.create.valid``: a validation set binned with the training set's boundaries."""
+    return dataset.create_valid(data, label=label, **kwargs)
+
+
+def lgb_Dataset_construct(dataset: Dataset) -> Dataset:
+    return dataset.construct()
+
+
+def lgb_Dataset_save(dataset: Dataset, fname: str) -> Dataset:
+    """``lgb.Dataset.save``: binary cache of the binned dataset (reload with ``lgb_Dataset(fname)``)."""
+    return dataset.save_binary(fname)
+
+
+def getinfo(dataset: Dataset, name: str):
+    getter = {"label": dataset.get_label, "weight": dataset.get_weight, "init_score": dataset.get_init_score}
+    if name not in getter:
+        raise ValueError("getinfo: name must be one of label, weight, init_score")
+    return getter[name]()
+
+
+def setinfo(dataset: Dataset, name: str, info) -> Dataset:
+    setter = {"label": dataset.set_label, "weight": dataset.set_weight, "init_score": dataset.set_init_score}
+    if name not in setter:
+        raise ValueError("setinfo: name must be one of label, weight, init_score")
+    return setter[name](info)
+
+
+def dim(dataset: Dataset):
+    dataset.construct()
+    return (dataset.num_data(), dataset.num_feature())
+
+
+def slice_rows(dataset: Dataset, idxset) -> Dataset:
+    """``slice(dataset, idxset)`` with R's 1-based row numbers."""
+    idx = np.asarray(list(idxset), dtype=np.int64) - 1
+    return dataset.construct().subset(idx)
+
+
+def lgb_save(booster: Booster, filename: str, num_iteration: Optional[int] = None) -> Booster:
+    return booster.save_model(filename, num_iteration=num_iteration)
+
+
+def lgb_load(filename: Optional[str] = None, model_str: Optional[str] = None) -> Booster:
+    if filename is None and model_str is None:
+        raise ValueError("lgb_load: need filename or model_str")
+    return Booster(model_file=filename) if filename is not None else Booster(model_str=model_str)
+
+
+def lgb_dump(booster: Booster, num_iteration: Optional[int] = None) -> str:
+    """``lgb.dump``: the model as a JSON string."""
+    import json
+    return json.dumps(booster.dump_model(num_iteration=num_iteration))
+
+
+def saveRDS_lgb_Booster(booster: Booster, file: str) -> None:
+    """``saveRDS.lgb.Booster``: serialise the booster object (the raw model text travels inside)."""
+    import pickle
+    with open(file, "wb") as f:
+        pickle.dump(booster, f)
+
+
+def readRDS_lgb_Booster(file: str) -> Booster:
+    import pickle
+    with open(file, "rb") as f:
+        return pickle.load(f)
+
+
+def lgb_importance(booster: Booster, percentage: bool = True):
+    """``lgb.importance``: data frame ``Feature, Gain, Cover, Frequency`` sorted by gain (``Cover`` = rows that
+    pass through the feature's splits)."""
+    import pandas as pd
+    df = booster.trees_to_dataframe()
+    splits = df[df["split_feature"].notna()]
+    agg = splits.groupby("split_feature").agg(Gain=("split_gain", "sum"), Cover=("count", "sum"),
+                                              Frequency=("split_gain", "size")).reset_index()
+    agg = agg.rename(columns={"split_feature": "Feature"})
+    for c in ("Gain", "Cover", "Frequency"):
+        agg[c] = agg[c].astype(float)
+        if percentage and agg[c].sum() > 0:
+            agg[c] = agg[c] / agg[c].sum()
+    return agg.sort_values("Gain", ascending=False).reset_index(drop=True)
+
+
+def lgb_interprete(booster: Booster, data, idxset, num_iteration: Optional[int] = None):
+    """``lgb.interprete``: per requested row (1-based) a data frame ``Feature, Contribution`` sorted by absolute
+    contribution; the contributions are SHAP values in raw-score units."""
+    import pandas as pd
+    X = np.asarray(data)
+    idx = np.asarray(list(idxset), dtype=np.int64) - 1
+    phi = booster.predict(X[idx], pred_contrib=True, num_iteration=num_iteration if num_iteration else -1)
+    names = booster.feature_name()
+    out = []
+    for r in range(len(idx)):
+        df = pd.DataFrame({"Feature": names, "Contribution": phi[r, : len(names)]})
+        out.append(df.reindex(df["Contribution"].abs().sort_values(ascending=False).index).reset_index(drop=True))
+    return out
+
+
+def lgb_model_dt_tree(booster: Booster, num_iteration: Optional[int] = None):
+    """``lgb.model.dt.tree``: one row per node, R's column names."""
+    df = booster.trees_to_dataframe()
+    if num_iteration is not None and num_iteration > 0:
+        df = df[df["tree_index"] < num_iteration]
+    return df.rename(columns={"node_depth": "depth", "parent_index": "node_parent"})
+
+
+def lgb_get_eval_result(booster, data_name: str, eval_name: str, iters=None, is_err: bool = False):
+    """``lgb.get.eval.result``: recorded metric values of a ``lgb_train`` / ``lgb_cv`` result."""
+    rec = getattr(booster, "record_evals", None) or {}
+    if data_name not in rec:
+        raise KeyError(f"data_name {data_name!r} not in record_evals ({sorted(rec)})")
+    if eval_name not in rec[data_name]:
+        raise KeyError(f"eval_name {eval_name!r} not in record_evals[{data_name!r}] ({sorted(rec[data_name])})")
+    series = rec[data_name][eval_name]
+    if isinstance(series, dict):
+        series = series["eval_err" if is_err else "eval"]
+    vals = np.asarray(series, dtype=np.float64)
+    if iters is not None:
+        vals = vals[np.asarray(list(iters), dtype=np.int64) - 1]
+    return vals

@@ -93,3 +93,81 @@ def test_tree_sizes_header_gives_the_byte_length_of_every_tree_block():
         block = body[pos:pos + sz]
         assert block.startswith(f"Tree={i}\n") and block.endswith("\n\n")
         pos += sz
+
+
+# ----------------------------------------------------------------------------- interpretation / R helpers
+def test_shap_contributions_equal_brute_force_shapley():
+    """pred_contrib against the definition: Shapley values of the path-dependent conditional expectation
+    (unknown features average the children by their training row counts), all 2^F subsets enumerated."""
+    import itertools, math
+    X, y = make_regression(3000, 4, seed=1)
+    X[::11, 2] = np.nan
+    b = lgb.train({**CPU, "num_leaves": 12, "min_data_in_leaf": 5}, lgb.Dataset(X, label=y, params=CPU), 6)
+    phi = b.predict(X[:12], pred_contrib=True)
+    np.testing.assert_allclose(phi.sum(axis=1), b.predict(X[:12], raw_score=True), atol=1e-12)
+    trees = b.dump_model()["tree_info"]
+    F = 4
+
+    def count(n):
+        return n["internal_count"] if "split_index" in n else n["leaf_count"]
+
+    def expect(n, x, known):
+        if "split_index" not in n:
+            return n["leaf_value"]
+        f = n["split_feature"]
+        if f in known:
+            v = x[f]
+            left = n["default_left"] if np.isnan(v) else v <= n["threshold"]
+            return expect(n["left_child"] if left else n["right_child"], x, known)
+        l, r = n["left_child"], n["right_child"]
+        return (count(l) * expect(l, x, known) + count(r) * expect(r, x, known)) / (count(l) + count(r))
+
+    for i in range(6):
+        want = np.zeros(F + 1)
+        for t in trees:
+            root = t["tree_structure"]
+            want[F] += expect(root, X[i], set())
+            for f in range(F):
+                others = [j for j in range(F) if j != f]
+                for k in range(F):
+                    w = math.factorial(k) * math.factorial(F - k - 1) / math.factorial(F)
+                    for S in itertools.combinations(others, k):
+                        want[f] += w * (expect(root, X[i], set(S) | {f}) - expect(root, X[i], set(S)))
+        np.testing.assert_allclose(phi[i], want, atol=1e-12)
+
+
+def test_r_style_helper_surface(tmp_path):
+    import pickle
+    from lightgbm_amd import rstyle as R
+    X, y = make_regression(2000, 5, seed=2)
+    d = R.lgb_Dataset(X[:1500], label=y[:1500], params=CPU)
+    v = R.lgb_Dataset_create_valid(d, X[1500:], label=y[1500:])
+    assert R.dim(d) == (1500, 5) and R.dim(R.slice_rows(d, range(1, 101))) == (100, 5)
+    np.testing.assert_allclose(R.getinfo(d, "label"), y[:1500].astype(np.float32))
+    fit = R.lgb_train({"learning_rate": 0.1, **CPU}, d, 15, valids={"test": v}, objective="regression", eval="rmse",
+                      verbose=0)
+    curve = R.lgb_get_eval_result(fit, "test", "rmse")
+    assert len(curve) == 15 and curve[-1] < curve[0]
+    assert R.lgb_get_eval_result(fit, "test", "rmse", iters=[1, 15]).tolist() == [curve[0], curve[-1]]
+    imp = R.lgb_importance(fit)
+    assert list(imp.columns) == ["Feature", "Gain", "Cover", "Frequency"] and abs(imp["Gain"].sum() - 1) < 1e-12
+    assert imp["Gain"].is_monotonic_decreasing
+    tab = R.lgb_model_dt_tree(fit)
+    assert {"tree_index", "depth", "node_parent", "split_feature", "threshold", "value", "count"} <= set(tab.columns)
+    assert tab["tree_index"].nunique() == 15
+    assert (tab[tab["split_feature"].isna()].groupby("tree_index")["count"].sum() == 1500).all()
+    inter = R.lgb_interprete(fit, X, [1, 2, 3])
+    assert len(inter) == 3 and list(inter[0].columns) == ["Feature", "Contribution"]
+    assert inter[0]["Contribution"].abs().is_monotonic_decreasing
+    # model files, JSON dump, object serialisation
+    R.lgb_save(fit, str(tmp_path / "m.txt"))
+    again = R.lgb_load(str(tmp_path / "m.txt"))
+    np.testing.assert_array_equal(R.predict(again, X[1500:]), R.predict(fit, X[1500:]))
+    assert '"tree_info"' in R.lgb_dump(fit)
+    R.saveRDS_lgb_Booster(fit, str(tmp_path / "m.rds"))
+    np.testing.assert_array_equal(R.predict(R.readRDS_lgb_Booster(str(tmp_path / "m.rds")), X[:50]), R.predict(fit, X[:50]))
+    clone = pickle.loads(pickle.dumps(fit))
+    assert clone.model_to_string() == fit.model_to_string()
+    assert fit.lower_bound() <= R.predict(fit, X).min() and R.predict(fit, X).max() <= fit.upper_bound()
+    leaf = R.predict(fit, X[:5], predleaf=True)
+    assert leaf.shape == (5, 15) and fit.get_leaf_output(0, int(leaf[0, 0])) == fit._tree_arrays()[0]["leaf_value"][leaf[0, 0]]
