@@ -70,6 +70,7 @@ const ParamDef kParams[] = {
     P(alpha, "", Double, 1e-300, kNone),
     P(fair_c, "", Double, 1e-300, kNone),
     P(poisson_max_delta_step, "", Double, 1e-300, kNone),
+    P(tweedie_variance_power, "", Double, 1.0, 1.999999999),
     P(metric_freq, "output_freq", Int, 1, kNone),
     P(is_provide_training_metric, "training_metric,is_training_metric,train_metric", Bool, kNone, kNone),
     P(snapshot_freq, "save_period", Int, kNone, kNone),
@@ -251,6 +252,8 @@ std::string Config::canonical_objective(const std::string& name0) {
       {"regression_l1", "regression_l1"}, {"l1", "regression_l1"}, {"mean_absolute_error", "regression_l1"},
       {"mae", "regression_l1"},
       {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
+      {"quantile", "quantile"}, {"mape", "mape"}, {"mean_absolute_percentage_error", "mape"},
+      {"gamma", "gamma"}, {"tweedie", "tweedie"},
       {"binary", "binary"}, {"binary_logloss", "binary"}, {"binary:logistic", "binary"},
       {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
       {"custom", "custom"}, {"none", "custom"}, {"null", "custom"}, {"na", "custom"},
@@ -267,6 +270,8 @@ std::string Config::canonical_metric(const std::string& name0) {
       {"rmse", "rmse"}, {"root_mean_squared_error", "rmse"}, {"l2_root", "rmse"},
       {"l1", "l1"}, {"mean_absolute_error", "l1"}, {"mae", "l1"}, {"regression_l1", "l1"},
       {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
+      {"quantile", "quantile"}, {"mape", "mape"}, {"mean_absolute_percentage_error", "mape"},
+      {"gamma", "gamma"}, {"gamma_deviance", "gamma_deviance"}, {"tweedie", "tweedie"},
       {"binary_logloss", "binary_logloss"}, {"binary", "binary_logloss"}, {"logloss", "binary_logloss"},
       {"binary_error", "binary_error"}, {"error", "binary_error"},
       {"auc", "auc"},
@@ -287,6 +292,7 @@ std::vector<std::string> Config::resolved_metrics() const {
     else if (o == "huber") out.push_back("huber");
     else if (o == "fair") out.push_back("fair");
     else if (o == "poisson") out.push_back("poisson");
+    else if (o == "quantile" || o == "mape" || o == "gamma" || o == "tweedie") out.push_back(o);
     else if (o == "binary") out.push_back("binary_logloss");
     else if (o == "cross_entropy") out.push_back("cross_entropy");
     return out;

@@ -56,6 +56,7 @@ struct Config {
   double alpha = 0.9;          // huber / quantile
   double fair_c = 1.0;
   double poisson_max_delta_step = 0.7;
+  double tweedie_variance_power = 1.5;
   // metric
   std::vector<std::string> metric;   // empty: derived from the objective
   int metric_freq = 1;

@@ -50,6 +50,12 @@ class Engine {
   // Add `tree` (final leaf values) to the training scores, using the row
   // ranges of the tree just grown for in-bag rows and traversal for the rest.
   virtual void add_trained_tree_to_train_scores(const Tree& tree) = 0;
+  // Objectives with percentile leaf outputs (percentile.hpp): for every leaf of the tree just grown, the
+  // alpha-percentile of label - score over the leaf's in-bag rows, weighted by the row weights (times
+  // 1 / max(1, |label|) with mape_scale).  values arrives holding the tree's current leaf values, which
+  // leaves without rows keep.
+  virtual void leaf_residual_percentiles(const Tree& tree, double alpha, bool mape_scale,
+                                         std::vector<double>* values) = 0;
   // Add (sign=+1) or remove (sign=-1) a tree's output by traversal of the binned rows.
   virtual void add_tree_by_traversal(int which, const Tree& tree, double sign) = 0;
 

@@ -35,11 +35,16 @@ void Booster::setup_objective() {
   obj_.alpha = cfg_.alpha;
   obj_.fair_c = cfg_.fair_c;
   obj_.poisson_max_delta = cfg_.poisson_max_delta_step;
+  obj_.tweedie_rho = cfg_.tweedie_variance_power;
   if (o == "regression") { obj_.kind = kObjRegression; objective_str_ = "regression"; }
   else if (o == "regression_l1") { obj_.kind = kObjRegressionL1; objective_str_ = "regression_l1"; }
   else if (o == "huber") { obj_.kind = kObjHuber; objective_str_ = "huber"; }
   else if (o == "fair") { obj_.kind = kObjFair; objective_str_ = "fair"; }
   else if (o == "poisson") { obj_.kind = kObjPoisson; objective_str_ = "poisson"; }
+  else if (o == "quantile") { obj_.kind = kObjQuantile; objective_str_ = "quantile"; }
+  else if (o == "mape") { obj_.kind = kObjMape; objective_str_ = "mape"; }
+  else if (o == "gamma") { obj_.kind = kObjGamma; objective_str_ = "gamma"; }
+  else if (o == "tweedie") { obj_.kind = kObjTweedie; objective_str_ = "tweedie"; }
   else if (o == "binary") {
     obj_.kind = kObjBinary;
     std::ostringstream os;
@@ -68,7 +73,11 @@ double Booster::boost_from_average() {
     case kObjHuber:
     case kObjFair:
     case kObjRegressionL1:   // mean instead of the median: a constant start either way
+    case kObjQuantile:
+    case kObjMape:
       return swy / sw;
+    case kObjGamma:
+    case kObjTweedie:
     case kObjPoisson: {
       double m = swy / sw;
       return std::log(m > 1e-10 ? m : 1e-10);
@@ -138,7 +147,25 @@ bool Booster::update_one_iter() {
   if (bagging) draw_bag();
   engine_->set_tree_index(iter_);
   Tree tree = engine_->train_tree(sample_features());
+  renew_leaf_outputs(tree);
   return finish_iteration(std::move(tree));
+}
+
+// regression_l1, quantile and mape take a sign step per row, whose Newton leaf value is bounded by one; the
+// loss-minimising constant of a leaf is a percentile of its residuals, which replaces it (percentile.hpp).
+void Booster::renew_leaf_outputs(Tree& tree) {
+  if (tree.num_leaves <= 1) return;
+  double alpha;
+  bool mape = false;
+  switch (obj_.kind) {
+    case kObjRegressionL1: alpha = 0.5; break;
+    case kObjQuantile: alpha = obj_.alpha; break;
+    case kObjMape: alpha = 0.5; mape = true; break;
+    default: return;
+  }
+  std::vector<double> values(tree.leaf_value.begin(), tree.leaf_value.begin() + tree.num_leaves);
+  engine_->leaf_residual_percentiles(tree, alpha, mape, &values);
+  for (int l = 0; l < tree.num_leaves; ++l) tree.set_leaf_value(l, values[(size_t)l]);
 }
 
 // The bag of iteration k is drawn at the last multiple of bagging_freq <= k, also when training starts

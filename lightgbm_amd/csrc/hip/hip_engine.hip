@@ -4,6 +4,8 @@
 #include "hip_engine.hpp"
 #include "kernels.hpp"
 #include "../metric.hpp"
+#include "../percentile.hpp"
+#include "sort.hpp"
 #include <algorithm>
 #include <dlfcn.h>
 #include <chrono>
@@ -720,24 +722,63 @@ class HipEngine : public Engine {
       traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, scores_.get());
       return;
     }
-    int L = (int)leaf_nodes_.size();
-    std::vector<k::LeafSpan> spans((size_t)L);
-    for (int l = 0; l < L; ++l) {
-      const NodeRange& r = backend_->range(leaf_nodes_[(size_t)l].node);
-      spans[(size_t)l] = k::LeafSpan{r.begin, r.begin + r.count, r.buf, 0, tree.leaf_value[(size_t)leaf_nodes_[(size_t)l].leaf]};
-    }
-    std::sort(spans.begin(), spans.end(), [](const k::LeafSpan& a, const k::LeafSpan& b) {
-      if (a.begin != b.begin) return a.begin < b.begin;
-      return a.end < b.end;   // empty leaves first so the last entry with begin <= p is the non-empty one
-    });
-    wait_upload();
-    span_host_.resize((size_t)L);
-    std::memcpy(span_host_.get(), spans.data(), sizeof(k::LeafSpan) * (size_t)L);
-    span_dev_.resize((size_t)L);
-    LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
-    mark_upload();
+    const int L = upload_spans(&tree);
     k::leaf_add(span_dev_.get(), L, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(), stream_);
     if (oob_n_ > 0) traverse(upload_tree(tree), mir_, N_, bag_ptr_ + bag_n_, oob_n_, 1.0, scores_.get());
+  }
+
+  // Unweighted: the residuals are ranked on the device (one sort of (leaf, residual) keys, then one thread
+  // per leaf reads its percentile off the sorted segment).  Weighted (row weights or MAPE's label scale): the
+  // (leaf, residual, weight) triples go to the host, which ranks them like the host engine does.
+  void leaf_residual_percentiles(const Tree& tree, double alpha, bool mape_scale,
+                                 std::vector<double>* values) override {
+    TraceRange range("lga.leaf_percentiles");
+    const int L = tree.num_leaves;
+    const std::vector<double> keep = *values;
+    std::vector<int> has((size_t)L, 0);
+    const int n_spans = upload_spans(nullptr);
+    const bool weighted = mape_scale || mir_->has_weight;
+    if (bag_n_ > 0 && !weighted) {
+      const int64_t npad = sort_padded_size(bag_n_);
+      sort_keys_.resize((size_t)npad);
+      pct_values_.resize((size_t)L);
+      pct_counts_.resize((size_t)L);
+      k::residual_keys(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(),
+                       mir_->label.get(), sort_keys_.get(), npad, stream_);
+      bitonic_sort_u64(sort_keys_.get(), npad, 1, stream_);
+      k::leaf_percentiles(sort_keys_.get(), bag_n_, L, alpha, pct_values_.get(), pct_counts_.get(), stream_);
+      std::vector<int32_t> counts((size_t)L);
+      LGA_HIP_CHECK(hipMemcpyAsync(values->data(), pct_values_.get(), sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(counts.data(), pct_counts_.get(), sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+      for (int l = 0; l < L; ++l) has[(size_t)l] = counts[(size_t)l] > 0;
+    } else if (bag_n_ > 0) {
+      const size_t n = (size_t)bag_n_;
+      item_leaf_.resize(n);
+      tmp_f32_.resize(2 * n);
+      k::residual_items(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(),
+                        mir_->label.get(), weight_ptr(mir_), mape_scale ? 1 : 0, item_leaf_.get(), tmp_f32_.get(),
+                        tmp_f32_.get() + n, stream_);
+      std::vector<int32_t> leaf(n);
+      std::vector<float> val(n), wt(n);
+      LGA_HIP_CHECK(hipMemcpyAsync(leaf.data(), item_leaf_.get(), sizeof(int32_t) * n, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(val.data(), tmp_f32_.get(), sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(wt.data(), tmp_f32_.get() + n, sizeof(float) * n, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+      std::vector<std::vector<WeightedResidual>> items((size_t)L);
+      for (size_t i = 0; i < n; ++i) items[(size_t)leaf[i]].push_back(WeightedResidual{val[i], wt[i]});
+#pragma omp parallel for schedule(dynamic)
+      for (int l = 0; l < L; ++l) {
+        auto& v = items[(size_t)l];
+        if (v.empty()) continue;
+        has[(size_t)l] = 1;
+        std::sort(v.begin(), v.end(), [](const WeightedResidual& a, const WeightedResidual& b) {
+          return a.value != b.value ? a.value < b.value : a.weight < b.weight;
+        });
+        (*values)[(size_t)l] = percentile_weighted(v.data(), (int64_t)v.size(), alpha);
+      }
+    }
+    merge_leaf_percentiles(comm_, *values, has, keep);
   }
 
   void add_tree_by_traversal(int which, const Tree& tree, double sign) override {
@@ -831,6 +872,29 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
 
+  // Row ranges of the last grown tree's leaves -> span_dev_, sorted by begin (empty ranges first, so the last
+  // entry with begin <= p is the one that owns position p).  Returns the number of spans.
+  int upload_spans(const Tree* tree) {
+    const int L = (int)leaf_nodes_.size();
+    std::vector<k::LeafSpan> spans((size_t)L);
+    for (int l = 0; l < L; ++l) {
+      const NodeRange& r = backend_->range(leaf_nodes_[(size_t)l].node);
+      const int leaf = leaf_nodes_[(size_t)l].leaf;
+      spans[(size_t)l] = k::LeafSpan{r.begin, r.begin + r.count, r.buf, leaf, tree ? tree->leaf_value[(size_t)leaf] : 0.0};
+    }
+    std::sort(spans.begin(), spans.end(), [](const k::LeafSpan& a, const k::LeafSpan& b) {
+      if (a.begin != b.begin) return a.begin < b.begin;
+      return a.end < b.end;
+    });
+    wait_upload();
+    span_host_.resize((size_t)L);
+    std::memcpy(span_host_.get(), spans.data(), sizeof(k::LeafSpan) * (size_t)L);
+    span_dev_.resize((size_t)L);
+    LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
+    mark_upload();
+    return L;
+  }
+
   void wait_upload() { if (upload_pending_) { LGA_HIP_CHECK(hipEventSynchronize(upload_ev_)); upload_pending_ = false; } }
   void mark_upload() {
     if (!upload_ev_) LGA_HIP_CHECK(hipEventCreateWithFlags(&upload_ev_, hipEventDisableTiming));
@@ -906,6 +970,9 @@ class HipEngine : public Engine {
   DeviceBuffer<int64_t> packed_;
   DeviceBuffer<uint32_t> maxbits_;
   DeviceBuffer<k::LeafSpan> span_dev_;
+  DeviceBuffer<uint64_t> sort_keys_;
+  DeviceBuffer<double> pct_values_;
+  DeviceBuffer<int32_t> pct_counts_, item_leaf_;
   DeviceBuffer<char> tree_dev_;
   PinnedBuffer<double> red_host_;
   PinnedBuffer<k::LeafSpan> span_host_;

@@ -13,6 +13,7 @@
 //    place (parent - smaller child) on the way in.
 #include "kernels.hpp"
 #include "device.hpp"
+#include "../percentile.hpp"
 
 namespace lga {
 namespace k {
@@ -754,6 +755,96 @@ __global__ __launch_bounds__(256) void leaf_add_kernel(const LeafSpan* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// percentile leaf outputs
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int span_of(const int32_t* begins, int n_spans, int32_t p) {
+  int lo = 0, hi = n_spans - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (begins[mid] <= p) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__device__ __forceinline__ float residual_of(const double* scores, const float* label, int32_t row) {
+  float r = (float)((double)label[row] - scores[row]);
+  return r == 0.0f ? 0.0f : r;   // one zero
+}
+__device__ __forceinline__ uint32_t float_order_bits(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_bits(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(256) void residual_keys_kernel(const LeafSpan* __restrict__ spans, int n_spans,
+                                                            const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                            int64_t n_rows, const double* __restrict__ scores,
+                                                            const float* __restrict__ label, uint64_t* __restrict__ keys,
+                                                            int64_t npad) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* begins = reinterpret_cast<int32_t*>(smem);
+  for (int i = threadIdx.x; i < n_spans; i += blockDim.x) begins[i] = spans[i].begin;
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npad; p += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t key = ~0ull;
+    if (p < n_rows) {
+      const LeafSpan sp = spans[span_of(begins, n_spans, (int32_t)p)];
+      const int32_t row = (sp.buf ? a1 : a0)[p];
+      key = ((uint64_t)(uint32_t)sp.leaf << 32) | float_order_bits(residual_of(scores, label, row));
+    }
+    keys[p] = key;
+  }
+}
+
+__global__ __launch_bounds__(256) void residual_items_kernel(const LeafSpan* __restrict__ spans, int n_spans,
+                                                             const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                             int64_t n_rows, const double* __restrict__ scores,
+                                                             const float* __restrict__ label, const float* __restrict__ weight,
+                                                             int mape_scale, int32_t* __restrict__ leaf_out,
+                                                             float* __restrict__ value_out, float* __restrict__ weight_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* begins = reinterpret_cast<int32_t*>(smem);
+  for (int i = threadIdx.x; i < n_spans; i += blockDim.x) begins[i] = spans[i].begin;
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_rows; p += (int64_t)gridDim.x * blockDim.x) {
+    const LeafSpan sp = spans[span_of(begins, n_spans, (int32_t)p)];
+    const int32_t row = (sp.buf ? a1 : a0)[p];
+    float wt = weight ? weight[row] : 1.0f;
+    if (mape_scale) wt = (float)((double)wt / fmax(1.0, fabs((double)label[row])));
+    leaf_out[p] = sp.leaf;
+    value_out[p] = residual_of(scores, label, row);
+    weight_out[p] = wt;
+  }
+}
+
+struct SortedKeyValues {
+  const uint64_t* keys;
+  __device__ double operator()(int64_t i) const { return (double)float_from_order_bits((uint32_t)keys[i]); }
+};
+
+__global__ __launch_bounds__(256) void leaf_percentiles_kernel(const uint64_t* __restrict__ keys, int64_t n_rows,
+                                                               int n_leaves, double alpha, double* __restrict__ values,
+                                                               int32_t* __restrict__ counts) {
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < n_leaves; l += gridDim.x * blockDim.x) {
+    // [first key of leaf l, first key of leaf l + 1)
+    int64_t bound[2];
+    for (int e = 0; e < 2; ++e) {
+      const uint64_t want = (uint64_t)(uint32_t)(l + e) << 32;
+      int64_t lo = 0, hi = n_rows;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < want) lo = mid + 1; else hi = mid;
+      }
+      bound[e] = lo;
+    }
+    const int64_t n = bound[1] - bound[0];
+    counts[l] = (int32_t)n;
+    values[l] = n > 0 ? percentile_unweighted(SortedKeyValues{keys + bound[0]}, n, alpha) : 0.0;
+  }
+}
+
 // Adds a tree to the scores of `rows` by walking it over the binned data.  Nodes are 16-byte records
 // staged in LDS (one ds_read_b128 per step); rows are visited in storage order, so the one-byte bin
 // reads of neighbouring lanes share cache lines and the score update is a coalesced read-modify-write.
@@ -1037,6 +1128,33 @@ void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int
   size_t sm = ((size_t)n_leaves * sizeof(int32_t) + 15) & ~(size_t)15;
   hipLaunchKernelGGL(leaf_add_kernel, dim3(grid_for(n_rows, 256)), dim3(256), sm, s, leaves, n_leaves, a0, a1, n_rows,
                      scores);
+  LGA_LAUNCH_CHECK();
+}
+
+void residual_keys(const LeafSpan* spans, int n_spans, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+                   const double* scores, const float* label, uint64_t* keys, int64_t npad, hipStream_t s) {
+  if (npad <= 0 || n_spans <= 0) return;
+  size_t sm = ((size_t)n_spans * sizeof(int32_t) + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(residual_keys_kernel, dim3(grid_for(npad, 256)), dim3(256), sm, s, spans, n_spans, a0, a1, n_rows,
+                     scores, label, keys, npad);
+  LGA_LAUNCH_CHECK();
+}
+
+void residual_items(const LeafSpan* spans, int n_spans, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+                    const double* scores, const float* label, const float* weight, int mape_scale,
+                    int32_t* leaf_out, float* value_out, float* weight_out, hipStream_t s) {
+  if (n_rows <= 0 || n_spans <= 0) return;
+  size_t sm = ((size_t)n_spans * sizeof(int32_t) + 15) & ~(size_t)15;
+  hipLaunchKernelGGL(residual_items_kernel, dim3(grid_for(n_rows, 256)), dim3(256), sm, s, spans, n_spans, a0, a1,
+                     n_rows, scores, label, weight, mape_scale, leaf_out, value_out, weight_out);
+  LGA_LAUNCH_CHECK();
+}
+
+void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double alpha, double* values,
+                      int32_t* counts, hipStream_t s) {
+  if (n_leaves <= 0) return;
+  hipLaunchKernelGGL(leaf_percentiles_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, s, keys, n_rows, n_leaves,
+                     alpha, values, counts);
   LGA_LAUNCH_CHECK();
 }
 

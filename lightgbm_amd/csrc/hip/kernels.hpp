@@ -46,8 +46,8 @@ struct TreeNodeDev {       // internal node of a tree for binned traversal (16 b
   int32_t left, right;     // >= 0 internal node, < 0: ~leaf
 };
 
-struct LeafSpan {          // final leaf of a grown tree
-  int32_t begin, end, buf, pad;
+struct LeafSpan {          // rows [begin, end) of arena buffer `buf` belong to final leaf `leaf`
+  int32_t begin, end, buf, leaf;
   double value;
 };
 
@@ -99,6 +99,17 @@ void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskD
 
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
+// Percentile leaf outputs (../percentile.hpp).  residual_keys: per in-bag row one sortable 64-bit key
+// (leaf id << 32 | order-preserving bits of float(label - score)), padding = ~0; leaf_percentiles: per leaf
+// the alpha-percentile of its (sorted) key segment and the segment length.  residual_items: the unsorted
+// (leaf, residual, weight) triples for the weighted case, which the host ranks.
+void residual_keys(const LeafSpan* spans, int n_spans, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+                   const double* scores, const float* label, uint64_t* keys, int64_t npad, hipStream_t s);
+void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double alpha, double* values,
+                      int32_t* counts, hipStream_t s);
+void residual_items(const LeafSpan* spans, int n_spans, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+                    const double* scores, const float* label, const float* weight, int mape_scale,
+                    int32_t* leaf_out, float* value_out, float* weight_out, hipStream_t s);
 void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
                   const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
                   hipStream_t s);

@@ -1,5 +1,6 @@
 #include "host_engine.hpp"
 #include "metric.hpp"
+#include "percentile.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -437,6 +438,42 @@ class HostEngine : public Engine {
       for (int32_t i = 0; i < r.count; ++i) scores_[(size_t)rows[i]] += v;
     }
     if (!oob_.empty()) traverse_add(train_->root(), oob_, scores_, tree, 1.0);
+  }
+
+  void leaf_residual_percentiles(const Tree& tree, double alpha, bool mape_scale,
+                                 std::vector<double>* values) override {
+    const int L = tree.num_leaves;
+    const std::vector<double> keep = *values;
+    const auto& label = train_->root_label();
+    const auto& w = train_->root_weight();
+    const bool weighted = mape_scale || !w.empty();
+    std::vector<std::vector<WeightedResidual>> items((size_t)L);
+    for (const LeafPiece& pc : leaf_nodes_) {
+      const NodeRange& r = backend_.range(pc.node);
+      const int32_t* rows = backend_.arena(r.buf) + r.begin;
+      auto& v = items[(size_t)pc.leaf];
+      for (int32_t i = 0; i < r.count; ++i) {
+        const int32_t row = rows[i];
+        float wt = w.empty() ? 1.0f : w[(size_t)row];
+        if (mape_scale) wt = (float)((double)wt / std::max(1.0, std::fabs((double)label[(size_t)row])));
+        v.push_back(WeightedResidual{(float)((double)label[(size_t)row] - scores_[(size_t)row]), wt});
+      }
+    }
+    std::vector<int> has((size_t)L, 0);
+#pragma omp parallel for schedule(dynamic)
+    for (int l = 0; l < L; ++l) {
+      auto& v = items[(size_t)l];
+      if (v.empty()) continue;
+      has[(size_t)l] = 1;
+      // equal residuals: order by weight as well, so the result does not depend on the row order
+      std::sort(v.begin(), v.end(), [](const WeightedResidual& a, const WeightedResidual& b) {
+        return a.value != b.value ? a.value < b.value : a.weight < b.weight;
+      });
+      if (weighted) (*values)[(size_t)l] = percentile_weighted(v.data(), (int64_t)v.size(), alpha);
+      else (*values)[(size_t)l] = percentile_unweighted([&](int64_t i) { return (double)v[(size_t)i].value; },
+                                                        (int64_t)v.size(), alpha);
+    }
+    merge_leaf_percentiles(comm_, *values, has, keep);
   }
 
   void add_tree_by_traversal(int which, const Tree& tree, double sign) override {

@@ -16,6 +16,11 @@ int32_t metric_kind_from_name(const std::string& n) {
   if (n == "binary_error") return kMetBinaryError;
   if (n == "auc") return kMetAuc;
   if (n == "cross_entropy") return kMetCrossEntropy;
+  if (n == "quantile") return kMetQuantile;
+  if (n == "mape") return kMetMape;
+  if (n == "gamma") return kMetGamma;
+  if (n == "gamma_deviance") return kMetGammaDeviance;
+  if (n == "tweedie") return kMetTweedie;
   throw std::runtime_error("unknown metric " + n);
 }
 
@@ -31,6 +36,11 @@ const char* metric_name(int32_t k) {
     case kMetBinaryError: return "binary_error";
     case kMetAuc: return "auc";
     case kMetCrossEntropy: return "cross_entropy";
+    case kMetQuantile: return "quantile";
+    case kMetMape: return "mape";
+    case kMetGamma: return "gamma";
+    case kMetGammaDeviance: return "gamma_deviance";
+    case kMetTweedie: return "tweedie";
   }
   return "?";
 }

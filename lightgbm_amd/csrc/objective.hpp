@@ -16,6 +16,10 @@ enum ObjectiveKind : int32_t {
   kObjBinary = 5,
   kObjCrossEntropy = 6,
   kObjCustom = 7,
+  kObjQuantile = 8,
+  kObjMape = 9,
+  kObjGamma = 10,
+  kObjTweedie = 11,
 };
 
 enum MetricKind : int32_t {
@@ -29,6 +33,11 @@ enum MetricKind : int32_t {
   kMetBinaryError = 7,
   kMetAuc = 8,
   kMetCrossEntropy = 9,
+  kMetQuantile = 10,
+  kMetMape = 11,
+  kMetGamma = 12,
+  kMetGammaDeviance = 13,
+  kMetTweedie = 14,
 };
 
 struct ObjectiveSpec {
@@ -37,9 +46,10 @@ struct ObjectiveSpec {
   double sigmoid;            // binary
   double pos_weight;         // binary: weight multiplier of positive rows
   double neg_weight;
-  double alpha;              // huber delta
+  double alpha;              // huber delta / quantile level
   double fair_c;
   double poisson_max_delta;  // poisson safety term
+  double tweedie_rho;        // tweedie variance power, in [1, 2)
 };
 
 // label is the raw label; for binary any label > 0 is positive.
@@ -81,6 +91,25 @@ LGA_HD void grad_hess(const ObjectiveSpec& o, double score, float label, float w
       double p = 1.0 / (1.0 + exp(-score));
       gg = p - (double)label; hh = p * (1.0 - p); break;
     }
+    case kObjQuantile: {
+      double d = score - (double)label;
+      gg = d >= 0.0 ? 1.0 - o.alpha : -o.alpha; hh = 1.0; break;
+    }
+    case kObjMape: {
+      // absolute percentage error: the L1 gradient scaled by 1 / max(1, |label|)
+      double d = score - (double)label;
+      double lw = 1.0 / fmax(1.0, fabs((double)label));
+      gg = (d > 0.0 ? 1.0 : (d < 0.0 ? -1.0 : 0.0)) * lw; hh = 1.0; break;
+    }
+    case kObjGamma: {
+      double e = exp(-score);
+      gg = 1.0 - (double)label * e; hh = (double)label * e; break;
+    }
+    case kObjTweedie: {
+      double a = exp((1.0 - o.tweedie_rho) * score), b = exp((2.0 - o.tweedie_rho) * score);
+      gg = -(double)label * a + b;
+      hh = -(double)label * (1.0 - o.tweedie_rho) * a + (2.0 - o.tweedie_rho) * b; break;
+    }
     default: gg = 0.0; hh = 1.0; break;
   }
   *g = (float)(gg * (double)weight);
@@ -92,7 +121,9 @@ LGA_HD double transform_score(int32_t obj_kind, double sigmoid, double score) {
   switch (obj_kind) {
     case kObjBinary: return 1.0 / (1.0 + exp(-sigmoid * score));
     case kObjCrossEntropy: return 1.0 / (1.0 + exp(-score));
-    case kObjPoisson: return exp(score);
+    case kObjPoisson:
+    case kObjGamma:
+    case kObjTweedie: return exp(score);
     default: return score;
   }
 }
@@ -130,6 +161,25 @@ LGA_HD double point_loss(int32_t metric, double pred, double raw, float label, c
       double p = pred, y = (double)label;
       double a = p > eps ? p : eps, b = 1.0 - p > eps ? 1.0 - p : eps;
       return -(y * log(a) + (1.0 - y) * log(b));
+    }
+    case kMetQuantile: {
+      double d = (double)label - pred;
+      return d >= 0.0 ? o.alpha * d : (o.alpha - 1.0) * d;
+    }
+    case kMetMape: return fabs((double)label - pred) / fmax(1.0, fabs((double)label));
+    case kMetGamma: {
+      // negative log-likelihood of a gamma distribution with unit shape: y / mu + log(mu)
+      double p = pred < 1e-10 ? 1e-10 : pred;
+      return (double)label / p + log(p);
+    }
+    case kMetGammaDeviance: {
+      // 2 * (y / mu - log(y / mu) - 1), the factor applied here
+      double t = (double)label / (pred + 1e-9);
+      return 2.0 * (t - log(t) - 1.0);
+    }
+    case kMetTweedie: {
+      double p = pred < 1e-10 ? 1e-10 : pred, rho = o.tweedie_rho;
+      return -(double)label * exp((1.0 - rho) * log(p)) / (1.0 - rho) + exp((2.0 - rho) * log(p)) / (2.0 - rho);
     }
     default: (void)raw; return 0.0;
   }

@@ -223,6 +223,6 @@ class TreeEnsemble:
             return 1.0 / (1.0 + np.exp(-sigmoid * out))
         if obj in ("cross_entropy", "xentropy"):
             return 1.0 / (1.0 + np.exp(-out))
-        if obj == "poisson":
+        if obj in ("poisson", "gamma", "tweedie"):
             return np.exp(out)
         return out

@@ -68,6 +68,45 @@ def test_data_parallel_equals_serial_regression(P):
     assert all(abs(m - global_l2) < 1e-6 for _, m in res)
 
 
+def test_data_parallel_l1_leaf_values_are_the_mean_of_the_local_medians():
+    """Percentile leaf outputs under row sharding: same split structure as serial, every rank ends with the
+    same model, and a leaf's value is the mean of the ranks' local residual medians."""
+    X, y = make_regression(4000, 5, seed=4)
+    params = {**CPU, "objective": "regression_l1", "num_leaves": 7, "learning_rate": 1.0, "boost_from_average": False}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X), 1)
+    half = len(y) // 2
+
+    def rank(r, comm):
+        sl = slice(0, half) if r == 0 else slice(half, None)
+        b = lgb.train({**params, "tree_learner": "data"}, lgb.Dataset(X[sl], label=y[sl], bin_sample=X), 1, comm=comm)
+        return b.model_to_string()
+    a, b = run_ranks(2, rank)
+    assert a == b
+    dp = lgb.Booster(model_str=a)
+    ts, td = serial.dump_model()["tree_info"][0], dp.dump_model()["tree_info"][0]
+
+    def shape(n):
+        return (n["split_feature"], n["threshold"], shape(n["left_child"]), shape(n["right_child"])) \
+            if "split_index" in n else None
+    assert shape(ts["tree_structure"]) == shape(td["tree_structure"])
+    leaf = dp.predict(X, pred_leaf=True)[:, 0]
+    y32 = y.astype(np.float32)
+
+    def median_rule(v):       # percentile.hpp: (1 - 0.5) * n values down from the top, interpolated
+        v = np.sort(v)
+        n = len(v)
+        if n <= 1:
+            return float(v[0])
+        pos = int(0.5 * n)
+        bias = 0.5 * n - pos
+        v1, v2 = float(v[n - pos]), float(v[n - 1 - pos])
+        return v1 - (v1 - v2) * bias
+    for l in np.unique(leaf):
+        parts = [y32[:half][leaf[:half] == l], y32[half:][leaf[half:] == l]]
+        want = np.mean([median_rule(p) for p in parts if len(p)])
+        assert abs(dp.get_leaf_output(0, int(l)) - want) < 1e-12
+
+
 def test_data_parallel_equals_serial_binary_first_trees_and_auc():
     X, y = make_higgs_like(8000, seed=1, device="numpy")
     params = {**CPU, "objective": "binary", "num_leaves": 15, "min_sum_hessian_in_leaf": 5.0, "metric": "auc"}

@@ -187,6 +187,70 @@ def test_other_objectives_train():
     assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
 
 
+def test_l1_and_quantile_leaves_are_residual_percentiles():
+    """One tree, learning rate 1, scores start at 0: a leaf's value is the percentile of the labels it holds."""
+    X, y = make_regression(5000, 4, seed=8)
+    y32 = y.astype(np.float32)
+    for obj, alpha in (("regression_l1", 0.5), ("quantile", 0.8)):
+        b = lgb.train({**CPU, "objective": obj, "alpha": alpha, "num_leaves": 8, "learning_rate": 1.0,
+                       "boost_from_average": False}, lgb.Dataset(X, label=y, params=CPU), 1)
+        leaf = b.predict(X, pred_leaf=True)[:, 0]
+        for l in np.unique(leaf):
+            v = np.sort(y32[leaf == l])
+            n = len(v)
+            pos = int((1 - alpha) * n)
+            bias = (1 - alpha) * n - pos
+            want = float(v[n - pos]) - (float(v[n - pos]) - float(v[n - 1 - pos])) * bias
+            assert abs(b.get_leaf_output(0, int(l)) - want) < 1e-12
+    # weighted: the weighted median splits the leaf's weight in half
+    w = np.where(X[:, 1] > 0, 3.0, 1.0)
+    b = lgb.train({**CPU, "objective": "regression_l1", "num_leaves": 6, "learning_rate": 1.0, "boost_from_average": False},
+                  lgb.Dataset(X, label=y, weight=w, params=CPU), 1)
+    leaf = b.predict(X, pred_leaf=True)[:, 0]
+    for l in np.unique(leaf):
+        m = leaf == l
+        v = b.get_leaf_output(0, int(l))
+        below = w[m][y32[m] < v].sum() / w[m].sum()
+        assert 0.45 < below < 0.55
+
+
+def test_quantile_mape_gamma_tweedie_objectives():
+    """Quantile regression hits its coverage level; the log-link families (gamma, tweedie) fit a positive
+    target; every objective's default metric is its own loss and it falls during training."""
+    rng = np.random.RandomState(21)
+    X = rng.randn(6000, 4)
+    y = 2.0 + X[:, 0] + (0.5 + 0.5 * (X[:, 1] > 0)) * rng.randn(6000)
+    d = lgb.Dataset(X, label=y, params=CPU)
+    for alpha in (0.1, 0.9):
+        ev = {}
+        b = lgb.train({**CPU, "objective": "quantile", "alpha": alpha, "num_leaves": 15, "learning_rate": 0.2}, d, 80,
+                      valid_sets=[d], evals_result=ev)
+        assert abs(np.mean(y <= b.predict(X)) - alpha) < 0.04
+        curve = ev["training"]["quantile"]
+        assert curve[-1] < curve[0]
+        u = y - b.predict(X)
+        assert abs(curve[-1] - np.mean(np.where(u >= 0, alpha * u, (alpha - 1) * u))) < 1e-9
+    ypos = np.exp(0.3 * X[:, 0] - 0.2 * X[:, 2]) * rng.gamma(4.0, 0.25, size=6000)
+    dpos = lgb.Dataset(X, label=ypos, params=CPU)
+    for obj, metric in (("gamma", "gamma"), ("tweedie", "tweedie"), ("mape", "mape")):
+        ev = {}
+        b = lgb.train({**CPU, "objective": obj, "num_leaves": 15}, dpos, 60, valid_sets=[dpos], evals_result=ev)
+        assert list(ev["training"]) == [metric]
+        assert ev["training"][metric][-1] < ev["training"][metric][0]
+        p = b.predict(X)
+        assert np.corrcoef(p, np.exp(0.3 * X[:, 0] - 0.2 * X[:, 2]))[0, 1] > 0.9, obj
+        if obj != "mape":
+            assert p.min() > 0 and np.allclose(p, np.exp(b.predict(X, raw_score=True)))
+            # the model file names the objective, so a reloaded booster applies the log link as well
+            np.testing.assert_array_equal(lgb.Booster(model_str=b.model_to_string()).predict(X), p)
+    ev = {}
+    lgb.train({**CPU, "objective": "gamma", "metric": ["gamma_deviance", "mape"]}, dpos, 20, valid_sets=[dpos],
+              evals_result=ev)
+    assert ev["training"]["gamma_deviance"][-1] < ev["training"]["gamma_deviance"][0]
+    with pytest.raises(Exception):
+        lgb.train({**CPU, "objective": "tweedie", "tweedie_variance_power": 2.5}, dpos, 2)
+
+
 def test_feature_fraction_and_bagging_change_trees_but_stay_deterministic():
     X, y = make_regression(4000, 10, seed=13)
     p = {**CPU, "feature_fraction": 0.6, "bagging_fraction": 0.7, "bagging_freq": 2}

@@ -4,7 +4,8 @@ Every seed draws a dataset shape (crossing the engine's size gates: row lines at
 in flight at 2^19, tree-walk score update at 2^20), a feature count (one or two 32-feature tiles),
 missing values, weights and a parameter set, trains a few iterations on both engines and compares the
 model text.  Regression objectives only: their gradients involve no transcendental function, so the
-integer histograms - and with them the trees - are bit-identical.
+integer histograms - and with them the trees - are bit-identical.  The percentile-output objectives
+(regression_l1, quantile, mape) also cover the device ranking of leaf residuals.
 
     python tools/parity_sweep.py [first_seed] [n_seeds] [max_rows]
 """
@@ -28,7 +29,7 @@ def draw_case(seed: int, max_rows: int):
         "min_data_in_leaf": int([1, 5, 20, 100][rng.randint(4)]),
         "max_bin": int([7, 63, 255][rng.randint(3)]),
         "boost_from_average": False,
-        "objective": ["regression", "huber", "fair"][rng.randint(3)],
+        "objective": ["regression", "huber", "fair", "regression_l1", "quantile", "mape"][rng.randint(6)],
         "learning_rate": float([0.3, 0.1][rng.randint(2)]),
     }
     if rng.rand() < 0.3:
