@@ -74,6 +74,7 @@ def _declare(lib, hip: bool):
         "lga_booster_rollback": (c_int, [c_void_p]),
         "lga_booster_num_trees": (c_int, [c_void_p, P(c_int)]),
         "lga_booster_num_feature": (c_int, [c_void_p, P(c_int)]),
+        "lga_booster_num_class": (c_int, [c_void_p, P(c_int)]),
         "lga_booster_eval_names": (c_int, [c_void_p, c_char_p, c_int]),
         "lga_booster_eval": (c_int, [c_void_p, c_int, c_void_p, c_int, P(c_int)]),
         "lga_booster_inner_nrows": (c_int, [c_void_p, c_int, P(c_int64)]),

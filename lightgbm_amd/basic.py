@@ -522,8 +522,12 @@ class Booster:
 
     def __boost(self, grad, hess) -> bool:
         lib, _ = _lib.load()
-        g = _to_1d(grad, np.float32)
-        h = _to_1d(hess, np.float32)
+        K = self.num_model_per_iteration()
+        if K > 1 and np.ndim(grad) == 2:
+            # [row][class] (the shape predictions are handed out in) -> the core's [class][row]
+            grad, hess = np.asarray(grad).T, np.asarray(hess).T
+        g = _to_1d(np.ascontiguousarray(grad).reshape(-1), np.float32)
+        h = _to_1d(np.ascontiguousarray(hess).reshape(-1), np.float32)
         if len(g) != len(h):
             raise ValueError("grad and hess have different lengths")
         fin = ctypes.c_int()
@@ -546,7 +550,7 @@ class Booster:
         return self
 
     def current_iteration(self) -> int:
-        return self.num_trees()
+        return self.num_trees() // self.num_model_per_iteration()
 
     def num_trees(self) -> int:
         lib, _ = _lib.load()
@@ -587,9 +591,11 @@ class Booster:
         lib, _ = _lib.load()
         n = ctypes.c_int64()
         check(lib.lga_booster_inner_nrows(self._handle, which, ctypes.byref(n)))
-        out = np.empty(n.value, dtype=np.float64)
+        K = self.num_model_per_iteration()
+        out = np.empty(n.value * K, dtype=np.float64)
         check(lib.lga_booster_inner_predict(self._handle, which, 1 if raw else 0, out.ctypes.data_as(ctypes.c_void_p)))
-        return out
+        # multiclass: the core's [class][row] layout becomes one row of num_class values per data row
+        return out if K == 1 else np.ascontiguousarray(out.reshape(K, n.value).T)
 
     def _eval(self, which: int, name: str, feval=None) -> List[Tuple[str, str, float, bool]]:
         lib, _ = _lib.load()
@@ -641,21 +647,22 @@ class Booster:
         used = ctypes.c_int()
         check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
         nrow = mat.shape[0]
-        use_gpu = hip and not pred_leaf and not pred_contrib and (device == "gpu" or _is_torch(mat) or
+        K = self.num_model_per_iteration()
+        use_gpu = hip and K == 1 and not pred_leaf and not pred_contrib and (device == "gpu" or _is_torch(mat) or
                                              (device is None and nrow * max(used.value, 1) >= 2_000_000))
         if use_gpu:
             from . import _device
             return _device.predict(lib, self._handle, mat, start_iteration, num_iteration, ptype)
         if _is_torch(mat):
             mat = mat.cpu().numpy()
-        width = (mat.shape[1] + 1) if pred_contrib else (used.value if pred_leaf else 1)
+        width = K * ((mat.shape[1] + 1) if pred_contrib else (used.value if pred_leaf else 1))
         out = np.empty(nrow * width, dtype=np.float64)
         ptr, dtype, nr, nc, rm = _mat_args(mat)
         check(lib.lga_booster_predict(self._handle, ptr, dtype, nr, nc, rm, start_iteration, num_iteration, ptype,
                                       out.ctypes.data_as(ctypes.c_void_p)))
         if pred_leaf:
-            return out.reshape(nrow, used.value).astype(np.int32)
-        if pred_contrib:
+            return out.reshape(nrow, width).astype(np.int32)
+        if pred_contrib or K > 1:
             return out.reshape(nrow, width)
         return out
 
@@ -717,7 +724,11 @@ class Booster:
         return {"objective": o.value.decode(), "average_output": bool(a.value), "sigmoid": s.value}
 
     def num_model_per_iteration(self) -> int:
-        return 1
+        """Trees per boosting iteration (``num_class`` for multiclass objectives, else 1)."""
+        lib, _ = _lib.load()
+        n = ctypes.c_int()
+        check(lib.lga_booster_num_class(self._handle, ctypes.byref(n)))
+        return n.value
 
     def get_leaf_output(self, tree_id: int, leaf_id: int) -> float:
         return float(self._tree_arrays()[tree_id]["leaf_value"][leaf_id])

@@ -247,6 +247,7 @@ int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess
 }
 int lga_booster_rollback(LgaBooster b) { return guard([&] { B(b)->rollback_one_iter(); }); }
 int lga_booster_num_trees(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_trees(); }); }
+int lga_booster_num_class(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_class(); }); }
 int lga_booster_num_feature(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_features(); }); }
 
 int lga_booster_eval_names(LgaBooster b, char* out, int cap) {

@@ -56,6 +56,7 @@ int lga_booster_num_trees(LgaBooster b, int* out);
 int lga_booster_num_feature(LgaBooster b, int* out);
 int lga_booster_eval_names(LgaBooster b, char* out, int cap);    // "l2:0,auc:1" (name:higher_better)
 int lga_booster_eval(LgaBooster b, int which, double* out, int cap, int* n);
+int lga_booster_num_class(LgaBooster b, int* out);   // trees per iteration
 int lga_booster_inner_nrows(LgaBooster b, int which, int64_t* out);
 int lga_booster_inner_predict(LgaBooster b, int which, int raw, double* out);
 int lga_booster_get_gradients(LgaBooster b, float* g, float* h);

@@ -65,6 +65,7 @@ const ParamDef kParams[] = {
     P(feature_pre_filter, "", Bool, kNone, kNone),
     P(boost_from_average, "", Bool, kNone, kNone),
     P(sigmoid, "", Double, 1e-300, kNone),
+    P(num_class, "num_classes", Int, 1, kNone),
     P(is_unbalance, "unbalance,unbalanced_sets", Bool, kNone, kNone),
     P(scale_pos_weight, "", Double, 1e-300, kNone),
     P(alpha, "", Double, 1e-300, kNone),
@@ -254,6 +255,9 @@ std::string Config::canonical_objective(const std::string& name0) {
       {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
       {"quantile", "quantile"}, {"mape", "mape"}, {"mean_absolute_percentage_error", "mape"},
       {"gamma", "gamma"}, {"tweedie", "tweedie"},
+      {"multiclass", "multiclass"}, {"softmax", "multiclass"}, {"multi:softprob", "multiclass"},
+      {"multiclassova", "multiclassova"}, {"multiclass_ova", "multiclassova"}, {"ova", "multiclassova"},
+      {"ovr", "multiclassova"},
       {"binary", "binary"}, {"binary_logloss", "binary"}, {"binary:logistic", "binary"},
       {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
       {"custom", "custom"}, {"none", "custom"}, {"null", "custom"}, {"na", "custom"},
@@ -272,6 +276,9 @@ std::string Config::canonical_metric(const std::string& name0) {
       {"huber", "huber"}, {"fair", "fair"}, {"poisson", "poisson"},
       {"quantile", "quantile"}, {"mape", "mape"}, {"mean_absolute_percentage_error", "mape"},
       {"gamma", "gamma"}, {"gamma_deviance", "gamma_deviance"}, {"tweedie", "tweedie"},
+      {"multi_logloss", "multi_logloss"}, {"multiclass", "multi_logloss"}, {"softmax", "multi_logloss"},
+      {"multiclassova", "multi_logloss"}, {"multiclass_ova", "multi_logloss"}, {"ova", "multi_logloss"},
+      {"ovr", "multi_logloss"}, {"multi_error", "multi_error"},
       {"binary_logloss", "binary_logloss"}, {"binary", "binary_logloss"}, {"logloss", "binary_logloss"},
       {"binary_error", "binary_error"}, {"error", "binary_error"},
       {"auc", "auc"},
@@ -293,6 +300,7 @@ std::vector<std::string> Config::resolved_metrics() const {
     else if (o == "fair") out.push_back("fair");
     else if (o == "poisson") out.push_back("poisson");
     else if (o == "quantile" || o == "mape" || o == "gamma" || o == "tweedie") out.push_back(o);
+    else if (o == "multiclass" || o == "multiclassova") out.push_back("multi_logloss");
     else if (o == "binary") out.push_back("binary_logloss");
     else if (o == "cross_entropy") out.push_back("cross_entropy");
     return out;
@@ -310,7 +318,13 @@ void Config::check() {
   if (b == "gbrt" || b == "gbdt") boosting = "gbdt";
   else if (b == "rf" || b == "random_forest") boosting = "rf";
   else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf)");
-  (void)canonical_objective(objective);
+  {
+    const std::string o = canonical_objective(objective);
+    const bool multi = o == "multiclass" || o == "multiclassova";
+    if (multi && num_class < 2) throw std::runtime_error("objective=" + o + " needs num_class >= 2");
+    if (!multi && o != "custom" && num_class != 1)
+      throw std::runtime_error("num_class must be 1 for objective=" + o);
+  }
   for (const auto& m : metric) (void)canonical_metric(m);
   std::string t = lower(tree_learner);
   if (t == "serial") tree_learner = "serial";

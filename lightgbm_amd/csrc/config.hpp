@@ -51,6 +51,7 @@ struct Config {
   // objective
   bool boost_from_average = true;
   double sigmoid = 1.0;
+  int num_class = 1;
   bool is_unbalance = false;
   double scale_pos_weight = 1.0;
   double alpha = 0.9;          // huber / quantile

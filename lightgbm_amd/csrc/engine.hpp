@@ -37,7 +37,14 @@ class Engine {
   virtual void scale_scores(int which, double factor) = 0;
   virtual void add_constant(int which, double v) = 0;
 
+  // Multiclass: the engine keeps num_class (Config::num_class) score and gradient vectors per dataset.
+  // select_class(k) makes class k's vectors the ones reset_scores / scale_scores / add_constant /
+  // set_gradients / train_tree / add_* operate on; compute_gradients fills all classes at once, eval and
+  // get_scores ([class][row]) see all of them.
+  virtual void select_class(int k) = 0;
   virtual void compute_gradients(const ObjectiveSpec& obj) = 0;
+  // Weighted number of training rows per class label (summed over ranks).
+  virtual void class_weights(int num_class, std::vector<double>* out) = 0;
   // Gradients supplied by the caller, ordered like the training dataset's rows.
   virtual void set_gradients(const float* g, const float* h, int64_t n) = 0;
   // Draw a new bag (every row when fraction >= 1).

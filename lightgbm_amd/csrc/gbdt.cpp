@@ -16,6 +16,8 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
   average_output_ = is_rf_;
   iter_ = cfg_.iteration_offset;
   setup_objective();
+  num_class_ = obj_.num_class;
+  init_scores_.assign((size_t)num_class_, 0.0);
   for (const auto& m : cfg_.resolved_metrics()) metrics_.push_back(metric_kind_from_name(m));
   engine_ = factory(train_, cfg_);
   max_feature_idx_ = train_->num_total_features() - 1;
@@ -29,6 +31,7 @@ Booster::Booster(const std::string& model_text) { load_model_from_string(model_t
 void Booster::setup_objective() {
   std::string o = Config::canonical_objective(cfg_.objective);
   obj_ = ObjectiveSpec{};
+  obj_.num_class = 1;
   obj_.sigmoid = cfg_.sigmoid;
   obj_.pos_weight = 1.0;
   obj_.neg_weight = 1.0;
@@ -51,7 +54,18 @@ void Booster::setup_objective() {
     os << "binary sigmoid:" << cfg_.sigmoid;
     objective_str_ = os.str();
   } else if (o == "cross_entropy") { obj_.kind = kObjCrossEntropy; objective_str_ = "cross_entropy"; }
-  else { obj_.kind = kObjCustom; objective_str_ = "custom"; }
+  else if (o == "multiclass" || o == "multiclassova") {
+    obj_.kind = o == "multiclass" ? kObjMulticlass : kObjMulticlassOva;
+    obj_.num_class = cfg_.num_class;
+    std::ostringstream os;
+    os << o << " num_class:" << cfg_.num_class;
+    if (o == "multiclassova") os << " sigmoid:" << cfg_.sigmoid;
+    objective_str_ = os.str();
+  } else {
+    obj_.kind = kObjCustom;
+    obj_.num_class = std::max(1, cfg_.num_class);   // caller-supplied gradients may be multiclass
+    objective_str_ = "custom";
+  }
 }
 
 void Booster::add_valid(std::shared_ptr<Dataset> ds, const std::string& name) {
@@ -96,7 +110,7 @@ double Booster::boost_from_average() {
   }
 }
 
-std::vector<FeatureMeta> Booster::sample_features() {
+std::vector<FeatureMeta> Booster::sample_features(int cls) {
   std::vector<FeatureMeta> meta = train_->feature_meta();
   int F = (int)meta.size();
   double ff = cfg_.feature_fraction;
@@ -105,7 +119,8 @@ std::vector<FeatureMeta> Booster::sample_features() {
   std::vector<int> perm((size_t)F);
   std::iota(perm.begin(), perm.end(), 0);
   for (int j = 0; j < k; ++j) {
-    uint64_t r = rng_u64((uint64_t)cfg_.feature_fraction_seed, (uint64_t)iter_, (uint64_t)j);
+    uint64_t r = rng_u64((uint64_t)cfg_.feature_fraction_seed, (uint64_t)iter_ * (uint64_t)num_class_ + (uint64_t)cls,
+                         (uint64_t)j);
     int pick = j + (int)(r % (uint64_t)(F - j));
     std::swap(perm[(size_t)j], perm[(size_t)pick]);
   }
@@ -116,12 +131,9 @@ std::vector<FeatureMeta> Booster::sample_features() {
 
 void Booster::ensure_scores() {
   if (scores_initialised_) return;
-  if (obj_.kind == kObjCustom) {
-    init_score_ = 0.0;
-    engine_->reset_scores(0.0);
-    scores_initialised_ = true;
-    return;
-  }
+  scores_initialised_ = true;
+  const int K = num_class_;
+  init_scores_.assign((size_t)K, 0.0);
   if (obj_.kind == kObjBinary) {
     double swy, sw, swp;
     engine_->label_stats(&swy, &sw, &swp);
@@ -132,9 +144,26 @@ void Booster::ensure_scores() {
     }
     obj_.pos_weight *= cfg_.scale_pos_weight;
   }
-  init_score_ = boost_from_average();
-  engine_->reset_scores(init_score_);
-  scores_initialised_ = true;
+  if (is_multiclass(obj_.kind)) {
+    // class priors: log p_k for softmax, logit(p_k) / sigmoid for one-vs-all; also validates the labels
+    std::vector<double> cw;
+    engine_->class_weights(K, &cw);
+    double total = 0.0;
+    for (double c : cw) total += c;
+    if (cfg_.boost_from_average && train_->root_init_score().empty() && total > 0.0) {
+      for (int k = 0; k < K; ++k) {
+        double p = std::min(std::max(cw[(size_t)k] / total, 1e-15), 1.0 - 1e-15);
+        init_scores_[(size_t)k] = obj_.kind == kObjMulticlass ? std::log(p) : std::log(p / (1.0 - p)) / obj_.sigmoid;
+      }
+    }
+  } else if (obj_.kind != kObjCustom) {
+    init_scores_[0] = boost_from_average();
+  }
+  for (int k = 0; k < K; ++k) {
+    engine_->select_class(k);
+    engine_->reset_scores(init_scores_[(size_t)k]);
+  }
+  engine_->select_class(0);
   if (is_rf_) engine_->compute_gradients(obj_);
 }
 
@@ -145,10 +174,16 @@ bool Booster::update_one_iter() {
   if (!is_rf_) engine_->compute_gradients(obj_);
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
   if (bagging) draw_bag();
-  engine_->set_tree_index(iter_);
-  Tree tree = engine_->train_tree(sample_features());
-  renew_leaf_outputs(tree);
-  return finish_iteration(std::move(tree));
+  bool all_stumps = true;
+  for (int k = 0; k < num_class_; ++k) {
+    engine_->select_class(k);
+    engine_->set_tree_index((int64_t)iter_ * num_class_ + k);
+    Tree tree = engine_->train_tree(sample_features(k));
+    renew_leaf_outputs(tree);
+    all_stumps = finish_tree(std::move(tree), k) && all_stumps;
+  }
+  engine_->select_class(0);
+  return finish_iteration(all_stumps);
 }
 
 // regression_l1, quantile and mape take a sign step per row, whose Newton leaf value is bounded by one; the
@@ -177,42 +212,66 @@ void Booster::draw_bag() {
   bag_drawn_ = true;
 }
 
+// grad / hess: [class][row] in the training dataset's row order (num_class * num_rows values).
 bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64_t n) {
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (is_rf_) throw std::runtime_error("custom gradients are not supported with boosting=rf");
+  const int64_t rows = engine_->num_rows(-1);
+  if (n != rows * num_class_) throw std::runtime_error("custom gradients: expected num_class * num_rows values");
   if (!scores_initialised_) {
     // gradients come from the caller: no boost-from-average, scores start at the data's init_score (or 0)
-    init_score_ = 0.0;
-    engine_->reset_scores(0.0);
+    init_scores_.assign((size_t)num_class_, 0.0);
+    for (int k = 0; k < num_class_; ++k) { engine_->select_class(k); engine_->reset_scores(0.0); }
     scores_initialised_ = true;
   }
-  engine_->set_gradients(grad, hess, n);
+  for (int k = 0; k < num_class_; ++k) {
+    engine_->select_class(k);
+    engine_->set_gradients(grad + (int64_t)k * rows, hess + (int64_t)k * rows, rows);
+  }
   bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
   if (bagging) draw_bag();
-  engine_->set_tree_index(iter_);
-  Tree tree = engine_->train_tree(sample_features());
-  return finish_iteration(std::move(tree));
+  bool all_stumps = true;
+  for (int k = 0; k < num_class_; ++k) {
+    engine_->select_class(k);
+    engine_->set_tree_index((int64_t)iter_ * num_class_ + k);
+    Tree tree = engine_->train_tree(sample_features(k));
+    all_stumps = finish_tree(std::move(tree), k) && all_stumps;
+  }
+  engine_->select_class(0);
+  return finish_iteration(all_stumps);
 }
 
-bool Booster::finish_iteration(Tree&& tree) {
-  ++iter_;
+// Adds class `cls`'s tree of the running iteration to the scores and to the model; returns true for a tree
+// without a split (kept as a zero tree so that every iteration holds num_class trees).
+bool Booster::finish_tree(Tree&& tree, int cls) {
+  const bool first_iteration = (int)trees_.size() < num_class_;
+  const double init = init_scores_[(size_t)cls];
+  int nv = engine_->num_valid();
   if (tree.num_leaves <= 1) {
-    if (!trees_.empty()) return true;   // nothing learnable any more: drop this iteration
     tree.leaf_value[0] = 0.0;
-    tree.add_bias(init_score_);
+    if (is_rf_) {
+      // a forest member that predicts the initial score everywhere
+      const double t = (double)((int)trees_.size() / num_class_);
+      tree.add_bias(init);
+      for (int w = -1; w < nv; ++w) {
+        engine_->scale_scores(w, t / (t + 1.0));
+        engine_->add_constant(w, init / (t + 1.0));
+      }
+    } else if (first_iteration) {
+      tree.add_bias(init);
+    }
     trees_.push_back(std::move(tree));
     return true;
   }
-  int nv = engine_->num_valid();
   if (!is_rf_) {
     tree.apply_shrinkage(cfg_.learning_rate);
     engine_->add_trained_tree_to_train_scores(tree);
     for (int v = 0; v < nv; ++v) engine_->add_tree_by_traversal(v, tree, 1.0);
-    if (trees_.empty() && init_score_ != 0.0) tree.add_bias(init_score_);
+    if (first_iteration && init != 0.0) tree.add_bias(init);
   } else {
     // running average of (init + tree) over the forest
-    double t = (double)trees_.size();
-    tree.add_bias(init_score_);
+    double t = (double)((int)trees_.size() / num_class_);
+    tree.add_bias(init);
     Tree scaled = tree;
     for (auto& v : scaled.leaf_value) v /= (t + 1.0);
     engine_->scale_scores(-1, t / (t + 1.0));
@@ -226,25 +285,40 @@ bool Booster::finish_iteration(Tree&& tree) {
   return false;
 }
 
+// Ends an iteration.  When no class found a split there is nothing learnable any more: the iteration is
+// dropped (except the very first one, whose zero trees carry the initial scores) and true is returned.
+bool Booster::finish_iteration(bool all_stumps) {
+  ++iter_;
+  if (!all_stumps) return false;
+  if (!is_rf_ && (int)trees_.size() > num_class_) trees_.resize(trees_.size() - (size_t)num_class_);
+  return true;
+}
+
 void Booster::rollback_one_iter() {
-  if (!engine_ || trees_.empty()) return;
-  Tree last = trees_.back();
-  int nv = engine_->num_valid();
-  if (!is_rf_) {
-    if (trees_.size() == 1 && init_score_ != 0.0) last.add_bias(-init_score_);
-    for (int w = -1; w < nv; ++w) engine_->add_tree_by_traversal(w, last, -1.0);
-  } else {
-    double t = (double)trees_.size();
-    if (trees_.size() == 1) {
-      engine_->reset_scores(init_score_);
+  if (!engine_ || (int)trees_.size() < num_class_) return;
+  const int K = num_class_;
+  const int nv = engine_->num_valid();
+  const bool only_iteration = (int)trees_.size() == K;
+  for (int k = 0; k < K; ++k) {
+    Tree last = trees_[trees_.size() - (size_t)K + (size_t)k];
+    engine_->select_class(k);
+    if (!is_rf_) {
+      if (only_iteration && init_scores_[(size_t)k] != 0.0) last.add_bias(-init_scores_[(size_t)k]);
+      for (int w = -1; w < nv; ++w) engine_->add_tree_by_traversal(w, last, -1.0);
     } else {
-      for (int w = -1; w < nv; ++w) {
-        engine_->add_tree_by_traversal(w, last, -1.0 / t);
-        engine_->scale_scores(w, t / (t - 1.0));
+      double t = (double)((int)trees_.size() / K);
+      if (only_iteration) {
+        engine_->reset_scores(init_scores_[(size_t)k]);
+      } else {
+        for (int w = -1; w < nv; ++w) {
+          engine_->add_tree_by_traversal(w, last, -1.0 / t);
+          engine_->scale_scores(w, t / (t - 1.0));
+        }
       }
     }
   }
-  trees_.pop_back();
+  engine_->select_class(0);
+  trees_.resize(trees_.size() - (size_t)K);
   --iter_;
 }
 
@@ -267,17 +341,43 @@ std::vector<EvalResult> Booster::eval(int which) {
   return engine_->eval(which, metrics_, obj_);
 }
 
+// Link function over one row's num_class raw scores (in place).
+void Booster::transform_row(double* v) const {
+  const int K = num_class_;
+  if (obj_.kind == kObjMulticlass) {
+    double mx = v[0];
+    for (int k = 1; k < K; ++k) mx = std::max(mx, v[k]);
+    double sum = 0.0;
+    for (int k = 0; k < K; ++k) { v[k] = std::exp(v[k] - mx); sum += v[k]; }
+    for (int k = 0; k < K; ++k) v[k] /= sum;
+  } else if (obj_.kind == kObjMulticlassOva) {
+    for (int k = 0; k < K; ++k) v[k] = 1.0 / (1.0 + std::exp(-obj_.sigmoid * v[k]));
+  } else {
+    for (int k = 0; k < K; ++k) v[k] = transform_score(obj_.kind, obj_.sigmoid, v[k]);
+  }
+}
+
+// out: [class][row]
 void Booster::inner_predict(int which, bool raw, double* out) {
   ensure_scores();
   engine_->get_scores(which, out);
-  if (!raw) {
-    int64_t n = engine_->num_rows(which);
+  if (raw) return;
+  const int64_t n = engine_->num_rows(which);
+  const int K = num_class_;
+  if (K == 1) {
     for (int64_t i = 0; i < n; ++i) out[i] = transform_score(obj_.kind, obj_.sigmoid, out[i]);
+    return;
+  }
+  std::vector<double> row((size_t)K);
+  for (int64_t i = 0; i < n; ++i) {
+    for (int k = 0; k < K; ++k) row[(size_t)k] = out[(int64_t)k * n + i];
+    transform_row(row.data());
+    for (int k = 0; k < K; ++k) out[(int64_t)k * n + i] = row[(size_t)k];
   }
 }
 
 int Booster::used_iterations(int start_iter, int num_iter) const {
-  int total = (int)trees_.size();
+  int total = current_iteration();
   start_iter = std::max(0, std::min(start_iter, total));
   int n = num_iter > 0 ? std::min(num_iter, total - start_iter) : total - start_iter;
   return n;
@@ -288,9 +388,11 @@ void Booster::predict(const void* data, int dtype, int64_t nrow, int ncol, bool 
   if (ncol <= max_feature_idx_)
     throw std::runtime_error("predict: the data has " + std::to_string(ncol) + " features, the model needs " +
                              std::to_string(max_feature_idx_ + 1));
-  int total = (int)trees_.size();
+  const int K = num_class_;
+  int total = current_iteration();
   start_iter = std::max(0, std::min(start_iter, total));
   int n_it = used_iterations(start_iter, num_iter);
+  auto tree_at = [&](int it, int k) -> const Tree& { return trees_[(size_t)(start_iter + it) * (size_t)K + (size_t)k]; };
 #pragma omp parallel
   {
     std::vector<double> row((size_t)ncol);
@@ -302,19 +404,26 @@ void Booster::predict(const void* data, int dtype, int64_t nrow, int ncol, bool 
       }
       if (type == kPredictLeaf) {
         for (int t = 0; t < n_it; ++t)
-          out[i * (int64_t)n_it + t] = (double)trees_[(size_t)(start_iter + t)].predict_leaf(row.data());
+          for (int k = 0; k < K; ++k)
+            out[(i * (int64_t)n_it + t) * K + k] = (double)tree_at(t, k).predict_leaf(row.data());
       } else if (type == kPredictContrib) {
-        // [ncol contributions | expected value] per row, in raw-score units
-        double* phi = out + i * (int64_t)(ncol + 1);
-        for (int c = 0; c <= ncol; ++c) phi[c] = 0.0;
-        for (int t = 0; t < n_it; ++t) trees_[(size_t)(start_iter + t)].add_contributions(row.data(), ncol, phi);
-        if (average_output_ && n_it > 0)
-          for (int c = 0; c <= ncol; ++c) phi[c] /= (double)n_it;
+        // per class [ncol contributions | expected value], in raw-score units
+        for (int k = 0; k < K; ++k) {
+          double* phi = out + (i * (int64_t)K + k) * (int64_t)(ncol + 1);
+          for (int c = 0; c <= ncol; ++c) phi[c] = 0.0;
+          for (int t = 0; t < n_it; ++t) tree_at(t, k).add_contributions(row.data(), ncol, phi);
+          if (average_output_ && n_it > 0)
+            for (int c = 0; c <= ncol; ++c) phi[c] /= (double)n_it;
+        }
       } else {
-        double s = 0.0;
-        for (int t = 0; t < n_it; ++t) s += trees_[(size_t)(start_iter + t)].predict(row.data());
-        if (average_output_ && n_it > 0) s /= (double)n_it;
-        out[i] = type == kPredictRaw ? s : transform_score(obj_.kind, obj_.sigmoid, s);
+        double* o = out + i * (int64_t)K;
+        for (int k = 0; k < K; ++k) {
+          double s = 0.0;
+          for (int t = 0; t < n_it; ++t) s += tree_at(t, k).predict(row.data());
+          if (average_output_ && n_it > 0) s /= (double)n_it;
+          o[k] = s;
+        }
+        if (type != kPredictRaw) transform_row(o);
       }
     }
   }
@@ -322,7 +431,7 @@ void Booster::predict(const void* data, int dtype, int64_t nrow, int ncol, bool 
 
 std::vector<double> Booster::feature_importance(int num_iter, int importance_type) const {
   std::vector<double> imp((size_t)(max_feature_idx_ + 1), 0.0);
-  int n = num_iter > 0 ? std::min(num_iter, (int)trees_.size()) : (int)trees_.size();
+  int n = (num_iter > 0 ? std::min(num_iter, current_iteration()) : current_iteration()) * num_class_;
   for (int t = 0; t < n; ++t) {
     const Tree& tr = trees_[(size_t)t];
     for (int i = 0; i + 1 < tr.num_leaves; ++i) {

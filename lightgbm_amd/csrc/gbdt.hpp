@@ -9,6 +9,7 @@
 #include "tree.hpp"
 #include <functional>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -33,9 +34,14 @@ class Booster {
   void rollback_one_iter();
   void reset_parameter(const std::string& params);
   // Put `first`'s trees in front of this booster's (continued training from init_model).
-  void prepend_trees(const Booster& first) { trees_.insert(trees_.begin(), first.trees_.begin(), first.trees_.end()); }
+  void prepend_trees(const Booster& first) {
+    if (first.num_class_ != num_class_) throw std::runtime_error("init_model has a different number of classes");
+    trees_.insert(trees_.begin(), first.trees_.begin(), first.trees_.end());
+  }
 
-  int current_iteration() const { return (int)trees_.size(); }
+  // A multiclass iteration holds num_class trees: tree t belongs to iteration t / K and class t % K.
+  int num_class() const { return num_class_; }
+  int current_iteration() const { return (int)trees_.size() / num_class_; }
   int num_trees() const { return (int)trees_.size(); }
   int num_features() const { return max_feature_idx_ + 1; }
   int num_valid() const { return engine_ ? engine_->num_valid() : 0; }
@@ -46,7 +52,8 @@ class Booster {
   int64_t inner_num_rows(int which) const { return engine_->num_rows(which); }
   void get_gradients(float* g, float* h) { engine_->get_gradients(g, h); }
 
-  // Dense prediction on the host.  out: nrow doubles (or nrow * used_trees ints-as-doubles for leaf indices).
+  // Dense prediction on the host.  out per row: num_class values (normal / raw), used_iterations * num_class
+  // leaf indices as doubles (leaf), or num_class * (ncol + 1) contributions.
   void predict(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, int start_iter, int num_iter,
                int type, double* out) const;
   int used_iterations(int start_iter, int num_iter) const;
@@ -63,14 +70,16 @@ class Booster {
   std::string last_profile() const { return engine_ ? engine_->profile_json() : "{}"; }
   GrowStats last_grow_stats() const { return engine_ ? engine_->grow_stats() : GrowStats(); }
   Engine* engine() { return engine_.get(); }
-  double init_score_value() const { return init_score_; }
+  double init_score_value() const { return init_scores_[0]; }
 
  private:
   void setup_objective();
   void ensure_scores();
   double boost_from_average();
-  std::vector<FeatureMeta> sample_features();
-  bool finish_iteration(Tree&& tree);
+  std::vector<FeatureMeta> sample_features(int cls);
+  bool finish_tree(Tree&& tree, int cls);
+  bool finish_iteration(bool all_stumps);
+  void transform_row(double* v) const;
   void load_model_from_string(const std::string& text);
 
   Config cfg_;
@@ -84,7 +93,8 @@ class Booster {
   bool is_rf_ = false;
   bool average_output_ = false;
   bool scores_initialised_ = false;
-  double init_score_ = 0.0;
+  std::vector<double> init_scores_ = {0.0};   // per class
+  int num_class_ = 1;
   int iter_ = 0;                 // iterations attempted (drives bagging / feature sampling streams)
   bool bag_drawn_ = false;
   void draw_bag();

@@ -577,9 +577,10 @@ class HipEngine : public Engine {
     else
       k::iota(base_rows_.get(), n_base_, stream_);
     bag_rows_.resize((size_t)std::max<int64_t>(n_base_, 1));
-    scores_.resize((size_t)N_);
-    grad_.resize((size_t)N_);
-    hess_.resize((size_t)N_);
+    K_ = std::max(1, cfg.num_class);
+    scores_.resize((size_t)N_ * (size_t)K_);
+    grad_.resize((size_t)N_ * (size_t)K_);
+    hess_.resize((size_t)N_ * (size_t)K_);
     maxbits_.resize(2);
     red_dev_.resize(k::kReduceDoubles);
     red_host_.resize(8);
@@ -626,7 +627,7 @@ class HipEngine : public Engine {
     else
       k::iota(v->rows.get(), v->n, stream_);
     v->shared_scores = false;
-    if (!v->shared_scores) v->scores.resize((size_t)v->N);
+    if (!v->shared_scores) v->scores.resize((size_t)v->N * (size_t)K_);
     if (!ds->root_init_score().empty() && !v->shared_scores) {
       v->init.upload(ds->root_init_score().data(), (size_t)v->N, stream_);
       v->has_init = true;
@@ -648,22 +649,49 @@ class HipEngine : public Engine {
   }
 
   void reset_scores(double v) override {
-    k::init_scores(scores_.get(), has_init_ ? init_score_dev_.get() : nullptr, base_or_null(), n_base_, v, stream_);
+    k::init_scores(sc(), has_init_ ? init_score_dev_.get() : nullptr, base_or_null(), n_base_, v, stream_);
     for (auto& vs : valid_)
       k::init_scores(score_ptr(*vs), (vs->has_init ? vs->init.get() : (vs->shared_scores && has_init_ ? init_score_dev_.get() : nullptr)),
                      vs->rows.get(), vs->n, v, stream_);
   }
   void scale_scores(int which, double f) override {
-    if (which < 0) k::scale_add(scores_.get(), base_or_null(), n_base_, f, 0.0, stream_);
+    if (which < 0) k::scale_add(sc(), base_or_null(), n_base_, f, 0.0, stream_);
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, f, 0.0, stream_); }
   }
   void add_constant(int which, double c) override {
-    if (which < 0) k::scale_add(scores_.get(), base_or_null(), n_base_, 1.0, c, stream_);
+    if (which < 0) k::scale_add(sc(), base_or_null(), n_base_, 1.0, c, stream_);
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, 1.0, c, stream_); }
+  }
+
+  void select_class(int k) override {
+    if (k < 0 || k >= K_) throw std::runtime_error("select_class: class out of range");
+    cls_ = k;
+  }
+  // Labels are kept on the host as well; counted there, once per training run.
+  void class_weights(int num_class, std::vector<double>* out) override {
+    const auto& y = train_->root_label();
+    const auto& w = train_->root_weight();
+    const std::vector<int32_t>* idx = train_->used_indices();
+    out->assign((size_t)num_class, 0.0);
+    for (int64_t i = 0; i < n_base_; ++i) {
+      const size_t r = idx ? (size_t)(*idx)[(size_t)i] : (size_t)i;
+      const int c = (int)y[r];
+      if (c < 0 || c >= num_class || (float)c != y[r])
+        throw std::runtime_error("multiclass labels must be integers in [0, num_class)");
+      (*out)[(size_t)c] += w.empty() ? 1.0 : (double)w[r];
+    }
+    if (dist()) comm_->allreduce_sum_f64(out->data(), out->size(), false, stream_);
   }
 
   void compute_gradients(const ObjectiveSpec& obj) override {
     TraceRange range("lga.gradients");
+    if (is_multiclass(obj.kind)) {
+      // all classes in one pass; the per-class maxima are taken when each class's tree is grown
+      k::multiclass_gradients(obj, scores_.get(), N_, mir_->label.get(), weight_ptr(mir_), base_or_null(), n_base_,
+                              grad_.get(), hess_.get(), stream_);
+      have_max_ = false;
+      return;
+    }
     k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_or_null(), n_base_, grad_.get(),
                  hess_.get(), maxbits_.get(), stream_);
     have_max_ = true;
@@ -673,18 +701,20 @@ class HipEngine : public Engine {
     tmp_f32_.resize((size_t)n * 2);
     LGA_HIP_CHECK(hipMemcpyAsync(tmp_f32_.get(), g, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream_));
     LGA_HIP_CHECK(hipMemcpyAsync(tmp_f32_.get() + n, h, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, stream_));
-    k::scatter_f32(tmp_f32_.get(), base_rows_.get(), n, grad_.get(), stream_);
-    k::scatter_f32(tmp_f32_.get() + n, base_rows_.get(), n, hess_.get(), stream_);
+    k::scatter_f32(tmp_f32_.get(), base_rows_.get(), n, gr(), stream_);
+    k::scatter_f32(tmp_f32_.get() + n, base_rows_.get(), n, he(), stream_);
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));   // g/h are caller memory
     have_max_ = false;
   }
   void get_gradients(float* g, float* h) override {
     tmp_f32_.resize((size_t)n_base_ * 2);
-    k::gather_f32(grad_.get(), base_rows_.get(), n_base_, tmp_f32_.get(), stream_);
-    k::gather_f32(hess_.get(), base_rows_.get(), n_base_, tmp_f32_.get() + n_base_, stream_);
-    LGA_HIP_CHECK(hipMemcpyAsync(g, tmp_f32_.get(), sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
-    LGA_HIP_CHECK(hipMemcpyAsync(h, tmp_f32_.get() + n_base_, sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
-    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    for (int k = 0; k < K_; ++k) {
+      k::gather_f32(grad_.get() + (size_t)k * (size_t)N_, base_rows_.get(), n_base_, tmp_f32_.get(), stream_);
+      k::gather_f32(hess_.get() + (size_t)k * (size_t)N_, base_rows_.get(), n_base_, tmp_f32_.get() + n_base_, stream_);
+      LGA_HIP_CHECK(hipMemcpyAsync(g + (size_t)k * (size_t)n_base_, tmp_f32_.get(), sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipMemcpyAsync(h + (size_t)k * (size_t)n_base_, tmp_f32_.get() + n_base_, sizeof(float) * (size_t)n_base_, hipMemcpyDeviceToHost, stream_));
+      LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    }
   }
 
   void resample(double fraction, uint64_t seed, uint64_t iter) override {
@@ -698,14 +728,14 @@ class HipEngine : public Engine {
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     TraceRange range("lga.train_tree");
-    if (!have_max_) k::absmax(grad_.get(), hess_.get(), base_or_null(), n_base_, maxbits_.get(), stream_);
+    if (!have_max_) k::absmax(gr(), he(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
     if (use_lines_) {
       backend_->set_packed(nullptr, lines_.get());
-      backend_->set_root_quant(grad_.get(), hess_.get(), maxbits_.get());
+      backend_->set_root_quant(gr(), he(), maxbits_.get());
     } else {
-      k::quantize(grad_.get(), hess_.get(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
+      k::quantize(gr(), he(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
                   backend_->qs_device(), packed_.get(), stream_);
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
@@ -719,12 +749,12 @@ class HipEngine : public Engine {
     TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
     if (walk) {
-      traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, scores_.get());
+      traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, sc());
       return;
     }
     const int L = upload_spans(&tree);
-    k::leaf_add(span_dev_.get(), L, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(), stream_);
-    if (oob_n_ > 0) traverse(upload_tree(tree), mir_, N_, bag_ptr_ + bag_n_, oob_n_, 1.0, scores_.get());
+    k::leaf_add(span_dev_.get(), L, backend_->arena(0), backend_->arena(1), bag_n_, sc(), stream_);
+    if (oob_n_ > 0) traverse(upload_tree(tree), mir_, N_, bag_ptr_ + bag_n_, oob_n_, 1.0, sc());
   }
 
   // Unweighted: the residuals are ranked on the device (one sort of (leaf, residual) keys, then one thread
@@ -743,7 +773,7 @@ class HipEngine : public Engine {
       sort_keys_.resize((size_t)npad);
       pct_values_.resize((size_t)L);
       pct_counts_.resize((size_t)L);
-      k::residual_keys(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(),
+      k::residual_keys(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, sc(),
                        mir_->label.get(), sort_keys_.get(), npad, stream_);
       bitonic_sort_u64(sort_keys_.get(), npad, 1, stream_);
       k::leaf_percentiles(sort_keys_.get(), bag_n_, L, alpha, pct_values_.get(), pct_counts_.get(), stream_);
@@ -756,7 +786,7 @@ class HipEngine : public Engine {
       const size_t n = (size_t)bag_n_;
       item_leaf_.resize(n);
       tmp_f32_.resize(2 * n);
-      k::residual_items(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, scores_.get(),
+      k::residual_items(span_dev_.get(), n_spans, backend_->arena(0), backend_->arena(1), bag_n_, sc(),
                         mir_->label.get(), weight_ptr(mir_), mape_scale ? 1 : 0, item_leaf_.get(), tmp_f32_.get(),
                         tmp_f32_.get() + n, stream_);
       std::vector<int32_t> leaf(n);
@@ -786,7 +816,7 @@ class HipEngine : public Engine {
       throw std::runtime_error("tree has no bin thresholds (loaded from a model file); cannot traverse binned data");
     const TreeOnDevice td = upload_tree(tree);
     if (which < 0) {
-      traverse(td, mir_, N_, base_or_null(), n_base_, sign, scores_.get());
+      traverse(td, mir_, N_, base_or_null(), n_base_, sign, sc());
     } else {
       auto& v = *valid_[(size_t)which];
       traverse(td, v.mir, v.N, v.ds->used_indices() ? v.rows.get() : nullptr, v.n, sign, score_ptr(v));
@@ -795,9 +825,10 @@ class HipEngine : public Engine {
 
   std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
     TraceRange range("lga.eval");
-    const double* sc; const DeviceMirror* m; const int32_t* rows; int64_t n; const Dataset* ds;
-    if (which < 0) { sc = scores_.get(); m = mir_; rows = base_rows_.get(); n = n_base_; ds = train_.get(); }
-    else { auto& v = *valid_[(size_t)which]; sc = score_ptr(v); m = v.mir; rows = v.rows.get(); n = v.n; ds = v.ds.get(); }
+    // class 0's vector; class k's follows at k * stride
+    const double* sc; const DeviceMirror* m; const int32_t* rows; int64_t n; const Dataset* ds; int64_t stride;
+    if (which < 0) { sc = scores_.get(); m = mir_; rows = base_rows_.get(); n = n_base_; ds = train_.get(); stride = N_; }
+    else { auto& v = *valid_[(size_t)which]; sc = all_scores(v); m = v.mir; rows = v.rows.get(); n = v.n; ds = v.ds.get(); stride = v.N; }
     std::vector<EvalResult> out;
     for (int32_t mk : metrics) {
       EvalResult r;
@@ -819,7 +850,10 @@ class HipEngine : public Engine {
         auto rr = eval_metrics_host(hs.data(), lab.data(), w.empty() ? nullptr : w.data(), nullptr, n, met, obj, comm_);
         r.value = rr[0].value;
       } else {
-        k::metric_sum(mk, obj, sc, m->label.get(), weight_ptr(m), rows, n, red_dev_.get(), stream_);
+        if (mk == kMetMultiLogloss || mk == kMetMultiError)
+          k::multi_metric_sum(mk, obj, sc, stride, m->label.get(), weight_ptr(m), rows, n, red_dev_.get(), stream_);
+        else
+          k::metric_sum(mk, obj, sc, m->label.get(), weight_ptr(m), rows, n, red_dev_.get(), stream_);
         red_dev_.download(red_host_.get(), 2, stream_);
         LGA_HIP_CHECK(hipStreamSynchronize(stream_));
         double b[2] = {red_host_[0], red_host_[1]};
@@ -834,12 +868,13 @@ class HipEngine : public Engine {
   }
 
   void get_scores(int which, double* out) override {
-    const double* sc; const int32_t* rows; int64_t n;
-    if (which < 0) { sc = scores_.get(); rows = base_rows_.get(); n = n_base_; }
-    else { auto& v = *valid_[(size_t)which]; sc = score_ptr(v); rows = v.rows.get(); n = v.n; }
-    tmp_f64_.resize((size_t)std::max<int64_t>(n, 1));
-    k::gather_f64(sc, rows, n, tmp_f64_.get(), stream_);
-    LGA_HIP_CHECK(hipMemcpyAsync(out, tmp_f64_.get(), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream_));
+    const double* sc; const int32_t* rows; int64_t n, stride;
+    if (which < 0) { sc = scores_.get(); rows = base_rows_.get(); n = n_base_; stride = N_; }
+    else { auto& v = *valid_[(size_t)which]; sc = all_scores(v); rows = v.rows.get(); n = v.n; stride = v.N; }
+    tmp_f64_.resize((size_t)std::max<int64_t>(n, 1) * (size_t)K_);
+    for (int k = 0; k < K_; ++k)
+      k::gather_f64(sc + (size_t)k * (size_t)stride, rows, n, tmp_f64_.get() + (size_t)k * (size_t)n, stream_);
+    LGA_HIP_CHECK(hipMemcpyAsync(out, tmp_f64_.get(), sizeof(double) * (size_t)n * (size_t)K_, hipMemcpyDeviceToHost, stream_));
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
 
@@ -860,7 +895,12 @@ class HipEngine : public Engine {
     bool shared_scores = false, has_init = false;
   };
   bool dist() const { return comm_ && comm_->size() > 1; }
-  double* score_ptr(Valid& v) { return v.shared_scores ? scores_.get() : v.scores.get(); }
+  // the selected class's vectors
+  double* sc() { return scores_.get() + (size_t)cls_ * (size_t)N_; }
+  float* gr() { return grad_.get() + (size_t)cls_ * (size_t)N_; }
+  float* he() { return hess_.get() + (size_t)cls_ * (size_t)N_; }
+  double* all_scores(Valid& v) { return v.shared_scores ? scores_.get() : v.scores.get(); }
+  double* score_ptr(Valid& v) { return all_scores(v) + (size_t)cls_ * (size_t)v.N; }
   static const float* weight_ptr(const DeviceMirror* m) { return m->has_weight ? m->weight.get() : nullptr; }
 
   void upload_meta(const Dataset* root, DeviceMirror* m) {
@@ -956,6 +996,7 @@ class HipEngine : public Engine {
   DeviceMirror* mir_ = nullptr;
   std::unique_ptr<HipBackend> backend_;
   int64_t N_ = 0, n_base_ = 0, bag_n_ = 0, oob_n_ = 0;
+  int K_ = 1, cls_ = 0;
   // rows == nullptr lets an elementwise kernel index rows directly (the training set is the whole root)
   const int32_t* base_or_null() const { return train_->used_indices() ? base_rows_.get() : nullptr; }
   const int32_t* bag_ptr_ = nullptr;

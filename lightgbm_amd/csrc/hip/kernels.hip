@@ -129,6 +129,17 @@ __global__ __launch_bounds__(256) void gradients_kernel(ObjectiveSpec obj, const
   }
 }
 
+__global__ __launch_bounds__(256) void multiclass_gradients_kernel(ObjectiveSpec obj, const double* __restrict__ scores,
+                                                                   int64_t stride, const float* __restrict__ label,
+                                                                   const float* __restrict__ weight,
+                                                                   const int32_t* __restrict__ rows, int64_t n,
+                                                                   float* __restrict__ g, float* __restrict__ h) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    multiclass_grad_hess(obj, scores, stride, r, label[r], weight ? weight[r] : 1.0f, g, h);
+  }
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, const float* __restrict__ h,
                                                      const int32_t* __restrict__ rows, int64_t n, uint32_t* maxbits) {
   float mg = 0.f, mh = 0.f;
@@ -952,6 +963,22 @@ __global__ __launch_bounds__(256) void metric_sum_kernel(int32_t metric, Objecti
   ordered_finish<2>(v, out, scratch);
 }
 
+__global__ __launch_bounds__(256) void multi_metric_sum_kernel(int32_t metric, ObjectiveSpec obj,
+                                                               const double* __restrict__ scores, int64_t stride,
+                                                               const float* __restrict__ label,
+                                                               const float* __restrict__ weight,
+                                                               const int32_t* __restrict__ rows, int64_t n, double* out) {
+  __shared__ double scratch[4];
+  double v[2] = {0.0, 0.0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    const double w = weight ? (double)weight[r] : 1.0;
+    v[0] += w * multi_point_loss(metric, obj, scores, stride, r, label[r]);
+    v[1] += w;
+  }
+  ordered_finish<2>(v, out, scratch);
+}
+
 __global__ __launch_bounds__(256) void label_sums_kernel(const float* __restrict__ label,
                                                          const float* __restrict__ weight,
                                                          const int32_t* __restrict__ rows, int64_t n, double* out) {
@@ -1190,6 +1217,23 @@ void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, 
   if (n <= 0) return;
   hipLaunchKernelGGL(metric_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, metric, obj, scores, label,
                      weight, rows, n, out2);
+  LGA_LAUNCH_CHECK();
+}
+
+void multi_metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, int64_t stride, const float* label,
+                      const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(out2, 0, 4 * sizeof(double), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(multi_metric_sum_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, metric, obj, scores, stride,
+                     label, weight, rows, n, out2);
+  LGA_LAUNCH_CHECK();
+}
+
+void multiclass_gradients(const ObjectiveSpec& obj, const double* scores, int64_t stride, const float* label,
+                          const float* weight, const int32_t* rows, int64_t n, float* g, float* h, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(multiclass_gradients_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, obj, scores, stride, label,
+                     weight, rows, n, g, h);
   LGA_LAUNCH_CHECK();
 }
 

@@ -53,6 +53,11 @@ struct LeafSpan {          // rows [begin, end) of arena buffer `buf` belong to 
 
 void gradients(const ObjectiveSpec& obj, const double* scores, const float* label, const float* weight,
                const int32_t* rows, int64_t n, float* g, float* h, uint32_t* maxbits, hipStream_t s);
+// Multiclass: class k's scores / gradients of row r live at [k * stride + r]; fills every class.
+void multiclass_gradients(const ObjectiveSpec& obj, const double* scores, int64_t stride, const float* label,
+                          const float* weight, const int32_t* rows, int64_t n, float* g, float* h, hipStream_t s);
+void multi_metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, int64_t stride, const float* label,
+                      const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s);
 void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s);
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
               int64_t* packed, hipStream_t s);

@@ -102,6 +102,7 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
                              std::to_string(b.num_features()));
   if (type == kPredictLeaf) throw std::runtime_error("device prediction does not produce leaf indices");
   hipStream_t s = current_stream();
+  if (b.num_class() != 1) throw std::runtime_error("the device predictor serves single-output models; multiclass models predict on the host");
   const auto& trees = b.trees();
   int total = (int)trees.size();
   start_iter = std::max(0, std::min(start_iter, total));

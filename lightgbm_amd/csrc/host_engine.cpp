@@ -314,9 +314,10 @@ class HostEngine : public Engine {
     if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
     N_ = train_->root_rows();
     base_ = base_rows_of(*train_);
-    scores_.assign((size_t)N_, 0.0);
-    grad_.assign((size_t)N_, 0.f);
-    hess_.assign((size_t)N_, 0.f);
+    K_ = std::max(1, cfg.num_class);
+    scores_.assign((size_t)N_ * (size_t)K_, 0.0);
+    grad_.assign((size_t)N_ * (size_t)K_, 0.f);
+    hess_.assign((size_t)N_ * (size_t)K_, 0.f);
     packed_.assign((size_t)N_, 0);
     bag_ = base_;
     int F = train_->num_features();
@@ -337,7 +338,8 @@ class HostEngine : public Engine {
     Valid v;
     v.ds = ds;
     v.rows = base_rows_of(*ds);
-    v.scores.assign((size_t)ds->root_rows(), 0.0);
+    v.stride = ds->root_rows();
+    v.scores.assign((size_t)ds->root_rows() * (size_t)K_, 0.0);
     valid_.push_back(std::move(v));
     return (int)valid_.size() - 1;
   }
@@ -366,25 +368,53 @@ class HostEngine : public Engine {
 
   void reset_scores(double v) override {
     const auto& is = train_->root_init_score();
-    for (int32_t r : base_) scores_[(size_t)r] = v + (is.empty() ? 0.0 : is[(size_t)r]);
+    double* s = sc();
+    for (int32_t r : base_) s[r] = v + (is.empty() ? 0.0 : is[(size_t)r]);
     for (auto& vs : valid_) {
       const auto& vis = vs.ds->root_init_score();
-      for (int32_t r : vs.rows) vs.scores[(size_t)r] = v + (vis.empty() ? 0.0 : vis[(size_t)r]);
+      double* t = vsc(vs);
+      for (int32_t r : vs.rows) t[r] = v + (vis.empty() ? 0.0 : vis[(size_t)r]);
     }
   }
   void scale_scores(int which, double f) override {
-    if (which < 0) { for (int32_t r : base_) scores_[(size_t)r] *= f; }
-    else { auto& v = valid_[(size_t)which]; for (int32_t r : v.rows) v.scores[(size_t)r] *= f; }
+    if (which < 0) { double* s = sc(); for (int32_t r : base_) s[r] *= f; }
+    else { auto& v = valid_[(size_t)which]; double* t = vsc(v); for (int32_t r : v.rows) t[r] *= f; }
   }
   void add_constant(int which, double c) override {
-    if (which < 0) { for (int32_t r : base_) scores_[(size_t)r] += c; }
-    else { auto& v = valid_[(size_t)which]; for (int32_t r : v.rows) v.scores[(size_t)r] += c; }
+    if (which < 0) { double* s = sc(); for (int32_t r : base_) s[r] += c; }
+    else { auto& v = valid_[(size_t)which]; double* t = vsc(v); for (int32_t r : v.rows) t[r] += c; }
+  }
+
+  void select_class(int k) override {
+    if (k < 0 || k >= K_) throw std::runtime_error("select_class: class out of range");
+    cls_ = k;
+  }
+  void class_weights(int num_class, std::vector<double>* out) override {
+    const auto& y = train_->root_label();
+    const auto& w = train_->root_weight();
+    out->assign((size_t)num_class, 0.0);
+    for (int32_t r : base_) {
+      const int c = (int)y[(size_t)r];
+      if (c < 0 || c >= num_class || (float)c != y[(size_t)r])
+        throw std::runtime_error("multiclass labels must be integers in [0, num_class)");
+      (*out)[(size_t)c] += w.empty() ? 1.0 : (double)w[(size_t)r];
+    }
+    if (dist()) comm_->allreduce_sum_f64(out->data(), out->size(), false, nullptr);
   }
 
   void compute_gradients(const ObjectiveSpec& obj) override {
     const auto& y = train_->root_label();
     const auto& w = train_->root_weight();
     int64_t n = (int64_t)base_.size();
+    if (is_multiclass(obj.kind)) {
+#pragma omp parallel for schedule(static) if (n > 16384)
+      for (int64_t i = 0; i < n; ++i) {
+        int32_t r = base_[(size_t)i];
+        multiclass_grad_hess(obj, scores_.data(), N_, r, y[(size_t)r], w.empty() ? 1.0f : w[(size_t)r], grad_.data(),
+                             hess_.data());
+      }
+      return;
+    }
 #pragma omp parallel for schedule(static) if (n > 16384)
     for (int64_t i = 0; i < n; ++i) {
       int32_t r = base_[(size_t)i];
@@ -394,14 +424,21 @@ class HostEngine : public Engine {
   }
   void set_gradients(const float* g, const float* h, int64_t n) override {
     if (n != (int64_t)base_.size()) throw std::runtime_error("custom gradients: wrong length");
+    float* gc = gr();
+    float* hc = he();
     for (int64_t i = 0; i < n; ++i) {
       int32_t r = base_[(size_t)i];
-      grad_[(size_t)r] = g[i];
-      hess_[(size_t)r] = h[i];
+      gc[r] = g[i];
+      hc[r] = h[i];
     }
   }
   void get_gradients(float* g, float* h) override {
-    for (size_t i = 0; i < base_.size(); ++i) { g[i] = grad_[(size_t)base_[i]]; h[i] = hess_[(size_t)base_[i]]; }
+    const size_t n = base_.size();
+    for (int k = 0; k < K_; ++k)
+      for (size_t i = 0; i < n; ++i) {
+        g[(size_t)k * n + i] = grad_[(size_t)k * (size_t)N_ + (size_t)base_[i]];
+        h[(size_t)k * n + i] = hess_[(size_t)k * (size_t)N_ + (size_t)base_[i]];
+      }
   }
 
   void resample(double fraction, uint64_t seed, uint64_t iter) override {
@@ -418,13 +455,15 @@ class HostEngine : public Engine {
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     // quantisation scale from the largest |g| and h of the training rows
     float mx[2] = {0.f, 0.f};
+    const float* gc = gr();
+    const float* hc = he();
     for (int32_t r : base_) {
-      mx[0] = std::max(mx[0], std::fabs(grad_[(size_t)r]));
-      mx[1] = std::max(mx[1], hess_[(size_t)r]);
+      mx[0] = std::max(mx[0], std::fabs(gc[r]));
+      mx[1] = std::max(mx[1], hc[r]);
     }
     if (dist()) comm_->allreduce_max_f32(mx, 2, false, nullptr);
     QuantScale qs{quant_exponent(mx[0]), quant_exponent(mx[1])};
-    quantize_rows_host(grad_.data(), hess_.data(), bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
+    quantize_rows_host(gc, hc, bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
     backend_.set_bag(bag_.data(), (int64_t)bag_.size());
     backend_.set_gradients(packed_.data(), qs);
     return grower_.grow(backend_, meta, &leaf_nodes_);
@@ -435,9 +474,10 @@ class HostEngine : public Engine {
       const NodeRange& r = backend_.range(pc.node);
       const int32_t* rows = backend_.arena(r.buf) + r.begin;
       double v = tree.leaf_value[(size_t)pc.leaf];
-      for (int32_t i = 0; i < r.count; ++i) scores_[(size_t)rows[i]] += v;
+      double* s = sc();
+      for (int32_t i = 0; i < r.count; ++i) s[rows[i]] += v;
     }
-    if (!oob_.empty()) traverse_add(train_->root(), oob_, scores_, tree, 1.0);
+    if (!oob_.empty()) traverse_add(train_->root(), oob_, sc(), tree, 1.0);
   }
 
   void leaf_residual_percentiles(const Tree& tree, double alpha, bool mape_scale,
@@ -456,7 +496,7 @@ class HostEngine : public Engine {
         const int32_t row = rows[i];
         float wt = w.empty() ? 1.0f : w[(size_t)row];
         if (mape_scale) wt = (float)((double)wt / std::max(1.0, std::fabs((double)label[(size_t)row])));
-        v.push_back(WeightedResidual{(float)((double)label[(size_t)row] - scores_[(size_t)row]), wt});
+        v.push_back(WeightedResidual{(float)((double)label[(size_t)row] - sc()[row]), wt});
       }
     }
     std::vector<int> has((size_t)L, 0);
@@ -477,25 +517,33 @@ class HostEngine : public Engine {
   }
 
   void add_tree_by_traversal(int which, const Tree& tree, double sign) override {
-    if (which < 0) traverse_add(train_->root(), base_, scores_, tree, sign);
-    else { auto& v = valid_[(size_t)which]; traverse_add(v.ds->root(), v.rows, v.scores, tree, sign); }
+    if (which < 0) traverse_add(train_->root(), base_, sc(), tree, sign);
+    else { auto& v = valid_[(size_t)which]; traverse_add(v.ds->root(), v.rows, vsc(v), tree, sign); }
   }
 
   std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
     if (which < 0) {
       const auto& w = train_->root_weight();
       return eval_metrics_host(scores_.data(), train_->root_label().data(), w.empty() ? nullptr : w.data(),
-                               base_.data(), (int64_t)base_.size(), metrics, obj, comm_);
+                               base_.data(), (int64_t)base_.size(), metrics, obj, comm_, N_);
     }
     auto& v = valid_[(size_t)which];
     const auto& w = v.ds->root_weight();
     return eval_metrics_host(v.scores.data(), v.ds->root_label().data(), w.empty() ? nullptr : w.data(),
-                             v.rows.data(), (int64_t)v.rows.size(), metrics, obj, comm_);
+                             v.rows.data(), (int64_t)v.rows.size(), metrics, obj, comm_, v.stride);
   }
 
   void get_scores(int which, double* out) override {
-    if (which < 0) { for (size_t i = 0; i < base_.size(); ++i) out[i] = scores_[(size_t)base_[i]]; }
-    else { auto& v = valid_[(size_t)which]; for (size_t i = 0; i < v.rows.size(); ++i) out[i] = v.scores[(size_t)v.rows[i]]; }
+    for (int k = 0; k < K_; ++k) {
+      if (which < 0) {
+        const size_t n = base_.size();
+        for (size_t i = 0; i < n; ++i) out[(size_t)k * n + i] = scores_[(size_t)k * (size_t)N_ + (size_t)base_[i]];
+      } else {
+        auto& v = valid_[(size_t)which];
+        const size_t n = v.rows.size();
+        for (size_t i = 0; i < n; ++i) out[(size_t)k * n + i] = v.scores[(size_t)k * (size_t)v.stride + (size_t)v.rows[i]];
+      }
+    }
   }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
 
@@ -503,15 +551,21 @@ class HostEngine : public Engine {
   struct Valid {
     std::shared_ptr<Dataset> ds;
     std::vector<int32_t> rows;
-    std::vector<double> scores;
+    std::vector<double> scores;   // [class][root row]
+    int64_t stride = 0;
   };
+  // the selected class's vectors
+  double* sc() { return scores_.data() + (size_t)cls_ * (size_t)N_; }
+  float* gr() { return grad_.data() + (size_t)cls_ * (size_t)N_; }
+  float* he() { return hess_.data() + (size_t)cls_ * (size_t)N_; }
+  double* vsc(Valid& v) { return v.scores.data() + (size_t)cls_ * (size_t)v.stride; }
   bool dist() const { return comm_ && comm_->size() > 1; }
 
-  void traverse_add(const Dataset* root, const std::vector<int32_t>& rows, std::vector<double>& scores,
-                    const Tree& tree, double sign) {
+  void traverse_add(const Dataset* root, const std::vector<int32_t>& rows, double* scores, const Tree& tree,
+                    double sign) {
     if (tree.num_leaves <= 1) {
       double v = tree.leaf_value[0] * sign;
-      for (int32_t r : rows) scores[(size_t)r] += v;
+      for (int32_t r : rows) scores[r] += v;
       return;
     }
     if (tree.split_feature_inner.empty() || tree.split_feature_inner[0] < 0)
@@ -524,7 +578,7 @@ class HostEngine : public Engine {
       int32_t r = rows[(size_t)i];
       int leaf = tree.predict_leaf_binned([&](int f) { return (int)fm[(size_t)f * (size_t)NR + (size_t)r]; },
                                           missing_bin_.data());
-      scores[(size_t)r] += sign * tree.leaf_value[(size_t)leaf];
+      scores[r] += sign * tree.leaf_value[(size_t)leaf];
     }
   }
 
@@ -534,6 +588,7 @@ class HostEngine : public Engine {
   HostBackend backend_;
   TreeGrower grower_;
   int64_t N_ = 0;
+  int K_ = 1, cls_ = 0;
   std::vector<int32_t> base_, bag_, oob_;
   std::vector<double> scores_;
   std::vector<float> grad_, hess_;

@@ -21,6 +21,8 @@ int32_t metric_kind_from_name(const std::string& n) {
   if (n == "gamma") return kMetGamma;
   if (n == "gamma_deviance") return kMetGammaDeviance;
   if (n == "tweedie") return kMetTweedie;
+  if (n == "multi_logloss") return kMetMultiLogloss;
+  if (n == "multi_error") return kMetMultiError;
   throw std::runtime_error("unknown metric " + n);
 }
 
@@ -41,6 +43,8 @@ const char* metric_name(int32_t k) {
     case kMetGamma: return "gamma";
     case kMetGammaDeviance: return "gamma_deviance";
     case kMetTweedie: return "tweedie";
+    case kMetMultiLogloss: return "multi_logloss";
+    case kMetMultiError: return "multi_error";
   }
   return "?";
 }
@@ -107,7 +111,7 @@ double auc_binned(const double* scores, const float* label, const float* weight,
 
 std::vector<EvalResult> eval_metrics_host(const double* scores, const float* label, const float* weight,
                                           const int32_t* rows, int64_t n, const std::vector<int32_t>& metrics,
-                                          const ObjectiveSpec& obj, Comm* comm) {
+                                          const ObjectiveSpec& obj, Comm* comm, int64_t class_stride) {
   std::vector<EvalResult> out;
   bool dist = comm && comm->size() > 1;
   for (int32_t m : metrics) {
@@ -131,9 +135,13 @@ std::vector<EvalResult> eval_metrics_host(const double* scores, const float* lab
       for (int64_t i = 0; i < n; ++i) {
         int64_t row = rows ? rows[i] : i;
         double w = weight ? weight[row] : 1.0;
-        double raw = scores[row];
-        double pred = transform_score(obj.kind, obj.sigmoid, raw);
-        sum += w * point_loss(m, pred, raw, label[row], obj);
+        if (m == kMetMultiLogloss || m == kMetMultiError) {
+          sum += w * multi_point_loss(m, obj, scores, class_stride, row, label[row]);
+        } else {
+          double raw = scores[row];
+          double pred = transform_score(obj.kind, obj.sigmoid, raw);
+          sum += w * point_loss(m, pred, raw, label[row], obj);
+        }
         sw += w;
       }
       if (dist) {

@@ -20,7 +20,8 @@ bool metric_higher_better(int32_t kind);
 // not attempted; each rank's rank-sum is combined through a global score grid).
 std::vector<EvalResult> eval_metrics_host(const double* scores, const float* label, const float* weight,
                                           const int32_t* rows, int64_t n, const std::vector<int32_t>& metrics,
-                                          const ObjectiveSpec& obj, Comm* comm);
+                                          const ObjectiveSpec& obj, Comm* comm, int64_t class_stride = 0);
+// class_stride: multiclass metrics read class k's score of a row at scores[k * class_stride + row].
 
 // Weighted AUC of (score, label>0) pairs, ties counted half.
 double auc_host(std::vector<std::pair<double, std::pair<float, float>>>& items);

@@ -23,14 +23,16 @@ std::vector<std::string> split_ws(const std::string& s) {
 }  // namespace
 
 std::string Booster::save_model_to_string(int start_iter, int num_iter, int importance_type) const {
-  int total = (int)trees_.size();
+  const int K = num_class_;
+  int total = current_iteration();
   start_iter = std::max(0, std::min(start_iter, total));
-  int n_it = used_iterations(start_iter, num_iter);
+  const int first_tree = start_iter * K;
+  const int n_it = used_iterations(start_iter, num_iter) * K;   // trees written
   std::ostringstream os;
   os << "tree\n";
   os << "version=v4\n";
-  os << "num_class=1\n";
-  os << "num_tree_per_iteration=1\n";
+  os << "num_class=" << K << "\n";
+  os << "num_tree_per_iteration=" << K << "\n";
   os << "label_index=" << label_index_ << "\n";
   os << "max_feature_idx=" << max_feature_idx_ << "\n";
   os << "objective=" << objective_str_ << "\n";
@@ -43,7 +45,7 @@ std::string Booster::save_model_to_string(int start_iter, int num_iter, int impo
   os << "\n";
   std::vector<std::string> blocks;
   blocks.reserve((size_t)n_it);
-  for (int t = 0; t < n_it; ++t) blocks.push_back(trees_[(size_t)(start_iter + t)].to_string(t));
+  for (int t = 0; t < n_it; ++t) blocks.push_back(trees_[(size_t)(first_tree + t)].to_string(t));
   os << "tree_sizes=";
   for (size_t i = 0; i < blocks.size(); ++i) os << (i ? " " : "") << blocks[i].size();
   os << "\n\n";
@@ -52,7 +54,7 @@ std::string Booster::save_model_to_string(int start_iter, int num_iter, int impo
   // importances: descending, zero entries omitted
   std::vector<double> imp((size_t)(max_feature_idx_ + 1), 0.0);
   for (int t = 0; t < n_it; ++t) {
-    const Tree& tr = trees_[(size_t)(start_iter + t)];
+    const Tree& tr = trees_[(size_t)(first_tree + t)];
     for (int i = 0; i + 1 < tr.num_leaves; ++i)
       imp[(size_t)tr.split_feature[(size_t)i]] += importance_type == 0 ? 1.0 : tr.split_gain[(size_t)i];
   }
@@ -105,8 +107,11 @@ void Booster::load_model_from_string(const std::string& text) {
     }
     return it->second;
   };
-  if (std::atoi(get("num_class", "1").c_str()) != 1) throw std::runtime_error("model parse: multiclass models are not supported");
-  if (std::atoi(get("num_tree_per_iteration", "1").c_str()) != 1) throw std::runtime_error("model parse: num_tree_per_iteration != 1");
+  num_class_ = std::atoi(get("num_tree_per_iteration", "1").c_str());
+  if (num_class_ < 1) throw std::runtime_error("model parse: num_tree_per_iteration < 1");
+  if (std::atoi(get("num_class", "1").c_str()) != num_class_)
+    throw std::runtime_error("model parse: num_class and num_tree_per_iteration differ");
+  init_scores_.assign((size_t)num_class_, 0.0);
   label_index_ = std::atoi(get("label_index", "0").c_str());
   max_feature_idx_ = std::atoi(get("max_feature_idx", nullptr).c_str());
   objective_str_ = get("objective", "regression");
@@ -122,8 +127,16 @@ void Booster::load_model_from_string(const std::string& text) {
     auto tok = split_ws(objective_str_);
     std::string name = tok.empty() ? "regression" : tok[0];
     cfg_.objective = Config::canonical_objective(name) == "custom" ? "regression" : name;
-    for (size_t k = 1; k < tok.size(); ++k)
+    for (size_t k = 1; k < tok.size(); ++k) {
       if (tok[k].rfind("sigmoid:", 0) == 0) cfg_.sigmoid = std::strtod(tok[k].c_str() + 8, nullptr);
+      if (tok[k].rfind("num_class:", 0) == 0) cfg_.num_class = std::atoi(tok[k].c_str() + 10);
+    }
+    const std::string canon = Config::canonical_objective(name);
+    if (canon == "multiclass" || canon == "multiclassova") {
+      if (cfg_.num_class != num_class_) throw std::runtime_error("model parse: objective num_class differs from the header");
+    } else {
+      cfg_.num_class = num_class_;
+    }
     std::string keep = objective_str_;
     setup_objective();
     objective_str_ = keep;
@@ -157,6 +170,8 @@ void Booster::load_model_from_string(const std::string& text) {
       throw std::runtime_error("model parse: tree_sizes lists " + std::to_string(declared) + " trees, found " +
                                std::to_string(trees_.size()));
   }
+  if (trees_.size() % (size_t)num_class_ != 0)
+    throw std::runtime_error("model parse: the number of trees is not a multiple of num_tree_per_iteration");
   // parameters block (kept verbatim for re-saving)
   loaded_parameters_.clear();
   bool in_params = false;
@@ -182,11 +197,14 @@ void Booster::load_model_from_string(const std::string& text) {
 }
 
 std::string Booster::dump_json(int start_iter, int num_iter) const {
-  int total = (int)trees_.size();
+  const int K = num_class_;
+  int total = current_iteration();
   start_iter = std::max(0, std::min(start_iter, total));
-  int n_it = used_iterations(start_iter, num_iter);
+  const int n_it = used_iterations(start_iter, num_iter) * K;   // trees written
+  start_iter *= K;                                              // first tree
   std::ostringstream os;
-  os << "{\"name\":\"tree\",\"version\":\"v4\",\"num_class\":1,\"num_tree_per_iteration\":1,\"label_index\":" << label_index_
+  os << "{\"name\":\"tree\",\"version\":\"v4\",\"num_class\":" << K << ",\"num_tree_per_iteration\":" << K
+     << ",\"label_index\":" << label_index_
      << ",\"max_feature_idx\":" << max_feature_idx_ << ",\"objective\":\"" << objective_str_ << "\",\"average_output\":"
      << (average_output_ ? "true" : "false") << ",\"feature_names\":[";
   for (size_t i = 0; i < feature_names_.size(); ++i) os << (i ? "," : "") << "\"" << feature_names_[i] << "\"";

@@ -20,6 +20,8 @@ enum ObjectiveKind : int32_t {
   kObjMape = 9,
   kObjGamma = 10,
   kObjTweedie = 11,
+  kObjMulticlass = 12,      // softmax over num_class score vectors
+  kObjMulticlassOva = 13,   // one binary (sigmoid) model per class
 };
 
 enum MetricKind : int32_t {
@@ -38,11 +40,13 @@ enum MetricKind : int32_t {
   kMetGamma = 12,
   kMetGammaDeviance = 13,
   kMetTweedie = 14,
+  kMetMultiLogloss = 15,
+  kMetMultiError = 16,
 };
 
 struct ObjectiveSpec {
   int32_t kind;
-  int32_t pad;
+  int32_t num_class;         // 1 unless multiclass
   double sigmoid;            // binary
   double pos_weight;         // binary: weight multiplier of positive rows
   double neg_weight;
@@ -114,6 +118,60 @@ LGA_HD void grad_hess(const ObjectiveSpec& o, double score, float label, float w
   }
   *g = (float)(gg * (double)weight);
   *h = (float)(hh * (double)weight);
+}
+
+LGA_HD bool is_multiclass(int32_t obj_kind) { return obj_kind == kObjMulticlass || obj_kind == kObjMulticlassOva; }
+
+// Multiclass: class k's score of row r is scores[k * stride + r]; gradients are laid out the same way.
+// Softmax: p = softmax(scores), g = p - [y == k], h = K / (K - 1) * p (1 - p).  One-vs-all: the binary
+// formula per class with label [y == k].
+LGA_HD void multiclass_grad_hess(const ObjectiveSpec& o, const double* scores, int64_t stride, int64_t r, float label,
+                                 float weight, float* g, float* h) {
+  const int K = o.num_class, y = (int)label;
+  if (o.kind == kObjMulticlassOva) {
+    for (int k = 0; k < K; ++k) {
+      const double t = k == y ? 1.0 : -1.0;
+      const double resp = -t * o.sigmoid / (1.0 + exp(t * o.sigmoid * scores[(int64_t)k * stride + r]));
+      const double ar = fabs(resp);
+      g[(int64_t)k * stride + r] = (float)(resp * (double)weight);
+      h[(int64_t)k * stride + r] = (float)(ar * (o.sigmoid - ar) * (double)weight);
+    }
+    return;
+  }
+  double mx = scores[r];
+  for (int k = 1; k < K; ++k) mx = fmax(mx, scores[(int64_t)k * stride + r]);
+  double sum = 0.0;
+  for (int k = 0; k < K; ++k) sum += exp(scores[(int64_t)k * stride + r] - mx);
+  const double factor = (double)K / (double)(K - 1);
+  for (int k = 0; k < K; ++k) {
+    const double p = exp(scores[(int64_t)k * stride + r] - mx) / sum;
+    g[(int64_t)k * stride + r] = (float)((p - (k == y ? 1.0 : 0.0)) * (double)weight);
+    h[(int64_t)k * stride + r] = (float)(factor * p * (1.0 - p) * (double)weight);
+  }
+}
+
+// multi_logloss: -log of the true class's probability (softmax, or that class's own sigmoid under
+// one-vs-all); multi_error: 1 when another class scores at least as high as the true one.
+LGA_HD double multi_point_loss(int32_t metric, const ObjectiveSpec& o, const double* scores, int64_t stride, int64_t r,
+                               float label) {
+  const int K = o.num_class, y = (int)label;
+  const double sy = scores[(int64_t)y * stride + r];
+  if (metric == kMetMultiError) {
+    int at_least = 0;
+    for (int k = 0; k < K; ++k) at_least += scores[(int64_t)k * stride + r] >= sy ? 1 : 0;
+    return at_least > 1 ? 1.0 : 0.0;
+  }
+  double p;
+  if (o.kind == kObjMulticlassOva) {
+    p = 1.0 / (1.0 + exp(-o.sigmoid * sy));
+  } else {
+    double mx = sy;
+    for (int k = 0; k < K; ++k) mx = fmax(mx, scores[(int64_t)k * stride + r]);
+    double sum = 0.0;
+    for (int k = 0; k < K; ++k) sum += exp(scores[(int64_t)k * stride + r] - mx);
+    p = exp(sy - mx) / sum;
+  }
+  return -log(p > 1e-15 ? p : 1e-15);
 }
 
 // score -> prediction (link function)

@@ -66,6 +66,8 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
         predictor = Booster(model_file=init_model)
     elif isinstance(init_model, Booster):
         predictor = init_model
+    if predictor is not None and predictor.num_model_per_iteration() > 1:
+        raise LightGBMError("continued training (init_model) of a multiclass model is not supported")
     if predictor is not None:
         # continue training: the old model's raw predictions become the data's initial scores
         raw = train_set.data
@@ -137,7 +139,7 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
     if predictor is not None:
         booster._prepend(predictor)
         if booster.best_iteration > 0:
-            booster.best_iteration += predictor.num_trees()
+            booster.best_iteration += predictor.current_iteration()
     if not keep_training_booster:
         booster = _carry(booster)
     return booster
@@ -321,7 +323,8 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     train_set.construct()
     n = train_set.num_data()
     objective = str(get_param(params, "objective", "regression"))
-    classification = objective in ("binary", "binary_logloss", "binary:logistic")
+    classification = objective in ("binary", "binary_logloss", "binary:logistic", "multiclass", "softmax",
+                                   "multiclassova", "multiclass_ova", "ova", "ovr")
     if folds is not None:
         if hasattr(folds, "split"):
             y = train_set.get_label()

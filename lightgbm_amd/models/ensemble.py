@@ -103,6 +103,10 @@ class TreeEnsemble:
         self.objective = header.get("objective", "regression")
         self.feature_names = header.get("feature_names", "").split()
         self.max_feature_idx = int(header.get("max_feature_idx", len(self.feature_names) - 1))
+        # trees per iteration: tree t belongs to iteration t // K and class t % K
+        self.num_class = int(header.get("num_tree_per_iteration", header.get("num_class", "1")))
+        if self.num_class < 1 or len(trees) % self.num_class:
+            raise ValueError("model parse: the number of trees is not a multiple of num_tree_per_iteration")
 
     # -- construction -------------------------------------------------------
     @classmethod
@@ -203,23 +207,33 @@ class TreeEnsemble:
         X = np.asarray(X, dtype=np.float64)
         if X.ndim != 2 or X.shape[1] <= self.max_feature_idx:
             raise ValueError(f"data has {X.shape[1] if X.ndim == 2 else '?'} columns, the model needs {self.max_feature_idx + 1}")
-        end = self.num_trees if num_iteration is None or num_iteration <= 0 else min(self.num_trees, start_iteration + num_iteration)
-        use = self.trees[start_iteration:end]
+        K = self.num_class
+        n_iter = self.num_trees // K
+        end = n_iter if num_iteration is None or num_iteration <= 0 else min(n_iter, start_iteration + num_iteration)
+        use = self.trees[start_iteration * K:end * K]
         if pred_leaf:
             return np.stack([t.predict_leaf(X) for t in use], axis=1) if use else np.zeros((X.shape[0], 0), dtype=np.int64)
-        out = np.zeros(X.shape[0], dtype=np.float64)
-        for t in use:
-            out += t.leaf_value[t.predict_leaf(X)]
+        out = np.zeros((X.shape[0], K), dtype=np.float64)
+        for i, t in enumerate(use):
+            out[:, i % K] += t.leaf_value[t.predict_leaf(X)]
         if self.average_output and use:
-            out /= len(use)
+            out /= len(use) // K
+        obj = self.objective.split()[0]
+        sigmoid = 1.0
+        for tok in self.objective.split()[1:]:
+            if tok.startswith("sigmoid:"):
+                sigmoid = float(tok.split(":", 1)[1])
+        if K > 1:
+            if raw_score:
+                return out
+            if obj == "multiclassova":
+                return 1.0 / (1.0 + np.exp(-sigmoid * out))
+            e = np.exp(out - out.max(axis=1, keepdims=True))
+            return e / e.sum(axis=1, keepdims=True)
+        out = out[:, 0]
         if raw_score:
             return out
-        obj = self.objective.split()[0]
         if obj == "binary":
-            sigmoid = 1.0
-            for tok in self.objective.split()[1:]:
-                if tok.startswith("sigmoid:"):
-                    sigmoid = float(tok.split(":", 1)[1])
             return 1.0 / (1.0 + np.exp(-sigmoid * out))
         if obj in ("cross_entropy", "xentropy"):
             return 1.0 / (1.0 + np.exp(-out))

@@ -138,29 +138,41 @@ class LGBMRandomForestRegressor(RegressorMixin, LGBMModel):
 
 
 class LGBMClassifier(ClassifierMixin, LGBMModel):
-    """Binary classifier."""
+    """Classifier: ``binary`` for two classes, ``multiclass`` (softmax, one tree per class and iteration)
+    for more.  Labels of any type are mapped to 0 .. n_classes-1 in sorted order (``classes_``)."""
 
     def _default_objective(self) -> str:
-        return "binary"
+        return "binary" if getattr(self, "n_classes_", 2) <= 2 else "multiclass"
+
+    def _params(self) -> Dict[str, Any]:
+        p = super()._params()
+        if getattr(self, "n_classes_", 2) > 2:
+            if p["objective"] in ("binary",):
+                p["objective"] = "multiclass"
+            p["num_class"] = int(self.n_classes_)
+        return p
 
     def _encode_label(self, y):
         y = np.asarray(y)
-        if not hasattr(self, "classes_") or self.classes_ is None:
-            self.classes_ = np.unique(y)
-            if len(self.classes_) != 2:
-                raise ValueError("LGBMClassifier supports exactly two classes")
-        return (y == self.classes_[1]).astype(np.float64)
+        if self.n_classes_ <= 2:
+            return (y == self.classes_[1]).astype(np.float64)
+        return np.searchsorted(self.classes_, y).astype(np.float64)
 
     def fit(self, X, y, **kwargs):
-        self.classes_ = None
+        self.classes_ = np.unique(np.asarray(y))
+        self.n_classes_ = len(self.classes_)
+        if self.n_classes_ < 2:
+            raise ValueError("LGBMClassifier needs at least two classes")
         return super().fit(X, y, **kwargs)
 
     def predict_proba(self, X, **kw) -> np.ndarray:
         p = self.booster_.predict(X, **kw)
-        return np.column_stack([1.0 - p, p])
+        return p if p.ndim == 2 else np.column_stack([1.0 - p, p])
 
     def predict(self, X, raw_score: bool = False, **kw):
-        if raw_score or kw.get("pred_leaf"):
+        if raw_score or kw.get("pred_leaf") or kw.get("pred_contrib"):
             return self.booster_.predict(X, raw_score=raw_score, **kw)
         p = self.booster_.predict(X, **kw)
+        if p.ndim == 2:
+            return self.classes_[p.argmax(axis=1)]
         return self.classes_[(p > 0.5).astype(int)]

@@ -260,6 +260,29 @@ def test_gpu_binary_matches_cpu_quality_and_first_tree():
     assert abs(ec["training"]["binary_logloss"][-1] - eg["training"]["binary_logloss"][-1]) < 1e-3
 
 
+@pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
+def test_gpu_multiclass_matches_cpu(objective):
+    """num_class score / gradient vectors on the device: the first iteration (scores all zero, so the
+    gradients hold no device-specific exp() rounding) grows the CPU's trees; after that the metrics agree."""
+    rng = np.random.RandomState(5)
+    X = rng.randn(30000, 8)
+    y = (X @ rng.randn(8, 4) + 0.4 * rng.randn(30000, 4)).argmax(axis=1).astype(np.float64)
+    p = {"objective": objective, "num_class": 4, "num_leaves": 31, "boost_from_average": False,
+         "metric": ["multi_logloss", "multi_error"]}
+    ec, eg = {}, {}
+    dc = lgb.Dataset(X, label=y, params=CPU); dg = lgb.Dataset(X, label=y, params=GPU)
+    a = lgb.train({**CPU, **p}, dc, 20, valid_sets=[dc], evals_result=ec)
+    b = lgb.train({**GPU, **p}, dg, 20, valid_sets=[dg], evals_result=eg, keep_training_booster=True)
+    sa, sb = a.model_to_string(), b.model_to_string()
+    assert sa[sa.index("Tree=0"):sa.index("Tree=4")] == sb[sb.index("Tree=0"):sb.index("Tree=4")]
+    for m in ("multi_logloss", "multi_error"):
+        assert abs(ec["training"][m][-1] - eg["training"][m][-1]) < 2e-3
+    assert b.num_trees() == 80 and b.predict(X[:9]).shape == (9, 4)
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
+    b.rollback_one_iter()
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
+
+
 @pytest.mark.parametrize("leaves,n", [(4, 5000), (31, 70000)])
 def test_device_auc_equals_host_auc(leaves, n):
     """Sort + scan AUC on the device against the host's sorted formulation, heavy ties included.
