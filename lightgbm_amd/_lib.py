@@ -1,7 +1,8 @@
 """ctypes binding of the native core.
 
 One of two in-tree libraries is loaded per process: ``_lga_hip.so`` when a GPU
-is visible (it contains the host engine too), otherwise ``_lga_host.so``.
+is visible (it contains the host engine too; ``LGA_DEBUG_LIB=1`` picks its checked build
+``_lga_hip_debug.so``), otherwise ``_lga_host.so``.
 ``LGA_FORCE_HOST=1`` forces the host library.  A missing library is built on
 first use on CPU-only machines; on a GPU machine a missing HIP library is an
 error (the kernels must be the code that runs, never a silent fallback).
@@ -118,7 +119,9 @@ def load():
     if _lib is not None:
         return _lib, _is_hip
     want_hip = _gpu_visible()
-    path = PKG / ("_lga_hip.so" if want_hip else "_lga_host.so")
+    # LGA_DEBUG_LIB=1: the -DLGA_DEBUG build of the HIP core, whose kernels check indices instead of faulting
+    hip_name = "_lga_hip_debug.so" if os.environ.get("LGA_DEBUG_LIB", "0") == "1" else "_lga_hip.so"
+    path = PKG / (hip_name if want_hip else "_lga_host.so")
     if not path.exists():
         if want_hip:
             raise LightGBMError(

@@ -94,16 +94,20 @@ def hipcc_path() -> str | None:
     return None
 
 
-def build_hip(verbose: bool = False, force: bool = False) -> Path:
+def build_hip(verbose: bool = False, force: bool = False, debug: bool = False) -> Path:
+    """debug=True builds ``_lga_hip_debug.so``: the same core with -DLGA_DEBUG, whose kernels check every
+    scattered index before use and report a violation instead of faulting (``LGA_DEBUG_LIB=1`` loads it)."""
     hipcc = hipcc_path()
     if hipcc is None:
         raise RuntimeError("hipcc not found; cannot build the HIP core")
-    out = PKG / "_lga_hip.so"
-    objdir = BUILD / "hip"
+    out = PKG / ("_lga_hip_debug.so" if debug else "_lga_hip.so")
+    objdir = BUILD / ("hip_debug" if debug else "hip")
     objdir.mkdir(parents=True, exist_ok=True)
     hdr_m = _headers_mtime()
     flags = [*COMMON_FLAGS, "--offload-arch=gfx950", "-fopenmp", "-DLGA_WITH_HIP=1", "-I", CSRC, "-I", CSRC / "hip",
              "-I", "/opt/rocm/include"]
+    if debug:
+        flags.append("-DLGA_DEBUG=1")
     jobs, objs = [], []
     for s in HOST_SOURCES + HIP_SOURCES:
         src = CSRC / s
@@ -119,7 +123,7 @@ def build_hip(verbose: bool = False, force: bool = False) -> Path:
 
 
 def build_all(verbose: bool = False, force: bool = False):
-    return build_host(verbose, force), build_hip(verbose, force)
+    return build_host(verbose, force), build_hip(verbose, force), build_hip(verbose, force, debug=True)
 
 
 if __name__ == "__main__":
@@ -129,3 +133,5 @@ if __name__ == "__main__":
         print(build_host(True, force))
     if not which or "hip" in which:
         print(build_hip(True, force))
+    if not which or "debug" in which:
+        print(build_hip(True, force, debug=True))

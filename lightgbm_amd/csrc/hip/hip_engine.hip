@@ -504,6 +504,10 @@ class HipBackend : public TreeBackend {
     }
     x.busy = false;
     prof.last_end = std::chrono::steady_clock::now();
+    if (k::device_checks_enabled()) {   // debug build: a kernel of this round may have refused an index
+      const std::string failure = k::take_check_failure(x.stream);
+      if (!failure.empty()) throw std::runtime_error(failure);
+    }
   }
 
   // Polls the completion flag the last scan workgroup writes into host-mapped memory.  The stream is
@@ -728,6 +732,7 @@ class HipEngine : public Engine {
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     TraceRange range("lga.train_tree");
+    debug_check();
     if (!have_max_) k::absmax(gr(), he(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
@@ -825,6 +830,7 @@ class HipEngine : public Engine {
 
   std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) override {
     TraceRange range("lga.eval");
+    debug_check();
     // class 0's vector; class k's follows at k * stride
     const double* sc; const DeviceMirror* m; const int32_t* rows; int64_t n; const Dataset* ds; int64_t stride;
     if (which < 0) { sc = scores_.get(); m = mir_; rows = base_rows_.get(); n = n_base_; ds = train_.get(); stride = N_; }
@@ -933,6 +939,12 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
     mark_upload();
     return L;
+  }
+
+  void debug_check() {
+    if (!k::device_checks_enabled()) return;
+    const std::string failure = k::take_check_failure(stream_);
+    if (!failure.empty()) throw std::runtime_error(failure);
   }
 
   void wait_upload() { if (upload_pending_) { LGA_HIP_CHECK(hipEventSynchronize(upload_ev_)); upload_pending_ = false; } }

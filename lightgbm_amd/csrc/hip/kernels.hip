@@ -12,6 +12,8 @@
 //    by shuffles, fp64 gains, wave arg-max; sibling histograms are derived in
 //    place (parent - smaller child) on the way in.
 #include "kernels.hpp"
+#include <sstream>
+#include <string>
 #include "device.hpp"
 #include "../percentile.hpp"
 
@@ -19,6 +21,34 @@ namespace lga {
 namespace k {
 
 namespace {
+
+// Debug builds (-DLGA_DEBUG, lightgbm_amd/build.py --debug): a kernel verifies every index it is about to
+// use for a scattered access - row ids, scatter targets, tree nodes - and, instead of faulting, records the
+// first violation in a small device buffer and skips the access.  The host reads the record after the round
+// (take_check_failure) and raises.  Release builds compile the checks away.
+#ifdef LGA_DEBUG
+__device__ int* g_check_sink = nullptr;   // [hits, code, block, value lo, value hi, bound lo, bound hi, -]
+__device__ __noinline__ bool check_failed(int code, long long value, long long bound) {
+  int* sink = g_check_sink;
+  if (sink && atomicAdd(&sink[0], 1) == 0) {
+    sink[1] = code;
+    sink[2] = (int)blockIdx.x;
+    sink[3] = (int)(value & 0xffffffffll); sink[4] = (int)(value >> 32);
+    sink[5] = (int)(bound & 0xffffffffll); sink[6] = (int)(bound >> 32);
+  }
+  return false;
+}
+#define LGA_DEV_CHECK(cond, code, value, bound) ((cond) || check_failed((code), (long long)(value), (long long)(bound)))
+#else
+#define LGA_DEV_CHECK(cond, code, value, bound) (true)
+#endif
+enum CheckCode : int {
+  kCheckHistRow = 1,          // histogram: row id outside [0, N)
+  kCheckPartitionRow = 2,     // partition: row id outside [0, N)
+  kCheckPartitionTarget = 3,  // partition: scatter position outside the leaf's range
+  kCheckWalkRow = 4,          // tree walk: row id outside [0, N)
+  kCheckWalkNode = 5,         // tree walk: child index outside the tree
+};
 
 constexpr int kWave = 64;
 
@@ -234,7 +264,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
     myrow[kk] = 0;
     if (pos < p.count) {
       myrow[kk] = src[pos];
-      left = goes_left(t, bins_fm, N, myrow[kk], bag);
+      if (t.feature < 0 || LGA_DEV_CHECK((unsigned)myrow[kk] < (unsigned long long)N, kCheckPartitionRow, myrow[kk], N))
+        left = goes_left(t, bins_fm, N, myrow[kk], bag);
     }
     const unsigned long long m = __ballot(left);
     if (lane == 0) smask[kk * (kPartThreads / kWave) + wave] = m;
@@ -263,7 +294,8 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
         const unsigned long long m = smask[w];
         const bool left = (m >> lane) & 1ull;
         const int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
-        dst[left ? lrank : lefts + (in_chunk - lrank)] = myrow[kk];
+        const int d = left ? lrank : lefts + (in_chunk - lrank);
+        if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = myrow[kk];
       }
     }
     if (threadIdx.x == 0) {
@@ -337,7 +369,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
       int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
       int in_chunk = w * kWave + lane;
       int d = left ? (before + lrank) : (all + right_before + (in_chunk - lrank));
-      dst[d] = src[pos];
+      if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = src[pos];
     }
   }
   if (c == 0 && threadIdx.x == 0) {
@@ -406,6 +438,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * kHistThreads;
       row[u] = i < hi ? rows[i] : -1;
+      if (i < hi && !LGA_DEV_CHECK((unsigned)row[u] < (unsigned long long)N, kCheckHistRow, row[u], N)) row[u] = -1;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -880,6 +913,7 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
   }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
+    if (!LGA_DEV_CHECK((unsigned long long)r < (unsigned long long)N, kCheckWalkRow, r, N)) continue;
     int node = num_leaves <= 1 ? ~0 : 0;
     while (node >= 0) {
       const TreeNodeDev t = tn[node];
@@ -887,8 +921,9 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
       const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
       const bool left = (b == mb) ? (dl != 0) : (b <= thr);
       node = left ? t.left : t.right;
+      if (!LGA_DEV_CHECK(node < n_internal && ~node < num_leaves, kCheckWalkNode, node, n_internal)) break;
     }
-    scores[r] += sign * lv[~node];
+    if (node < 0) scores[r] += sign * lv[~node];
   }
 }
 
@@ -1017,6 +1052,49 @@ __global__ __launch_bounds__(256) void iota_kernel(int32_t* dst, int64_t n) {
 // launch wrappers
 // ---------------------------------------------------------------------------
 #define LGA_LAUNCH_CHECK() LGA_HIP_CHECK(hipGetLastError())
+
+#ifdef LGA_DEBUG
+namespace {
+int* g_check_sink_host = nullptr;   // device buffer the kernels' g_check_sink points at
+void ensure_check_sink() {
+  if (g_check_sink_host) return;
+  LGA_HIP_CHECK(hipMalloc((void**)&g_check_sink_host, 8 * sizeof(int)));
+  LGA_HIP_CHECK(hipMemset(g_check_sink_host, 0, 8 * sizeof(int)));
+  LGA_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_check_sink), &g_check_sink_host, sizeof(int*)));
+}
+}  // namespace
+#endif
+
+bool device_checks_enabled() {
+#ifdef LGA_DEBUG
+  ensure_check_sink();
+  return true;
+#else
+  return false;
+#endif
+}
+
+std::string take_check_failure(hipStream_t s) {
+#ifdef LGA_DEBUG
+  ensure_check_sink();
+  int rec[8];
+  LGA_HIP_CHECK(hipStreamSynchronize(s));
+  LGA_HIP_CHECK(hipMemcpy(rec, g_check_sink_host, sizeof(rec), hipMemcpyDeviceToHost));
+  if (rec[0] == 0) return std::string();
+  LGA_HIP_CHECK(hipMemset(g_check_sink_host, 0, 8 * sizeof(int)));
+  static const char* what[] = {"?", "histogram: row id outside the dataset", "partition: row id outside the dataset",
+                               "partition: scatter position outside the leaf's range",
+                               "tree walk: row id outside the dataset", "tree walk: child index outside the tree"};
+  const long long value = ((long long)rec[4] << 32) | (unsigned)rec[3], bound = ((long long)rec[6] << 32) | (unsigned)rec[5];
+  std::ostringstream os;
+  os << "device check failed (" << rec[0] << " hits): " << what[rec[1] >= 1 && rec[1] <= 5 ? rec[1] : 0] << " (value "
+     << value << ", bound " << bound << ", workgroup " << rec[2] << ")";
+  return os.str();
+#else
+  (void)s;
+  return std::string();
+#endif
+}
 
 void gradients(const ObjectiveSpec& obj, const double* scores, const float* label, const float* weight,
                const int32_t* rows, int64_t n, float* g, float* h, uint32_t* maxbits, hipStream_t s) {

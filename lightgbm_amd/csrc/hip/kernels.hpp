@@ -1,5 +1,6 @@
 // Launch wrappers of the gfx950 training kernels (definitions in kernels.hip).
 #pragma once
+#include <string>
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "../common.hpp"
@@ -45,6 +46,12 @@ struct TreeNodeDev {       // internal node of a tree for binned traversal (16 b
   int32_t meta;            // threshold bin | default_left << 8 | (missing_bin + 1) << 16
   int32_t left, right;     // >= 0 internal node, < 0: ~leaf
 };
+
+// Debug builds (-DLGA_DEBUG): kernels check scattered indices before use and record the first violation
+// instead of faulting.  take_check_failure waits for the stream and returns a description of it ("" when
+// there was none, and always in release builds); device_checks_enabled tells which build this is.
+bool device_checks_enabled();
+std::string take_check_failure(hipStream_t s);
 
 struct LeafSpan {          // rows [begin, end) of arena buffer `buf` belong to final leaf `leaf`
   int32_t begin, end, buf, leaf;

@@ -3,6 +3,7 @@
 // device arrays so each kernel can be checked against a host oracle in isolation.
 #include "hip_engine.hpp"
 #include "kernels.hpp"
+#include <stdexcept>
 #include <string>
 
 namespace lga {
@@ -19,8 +20,22 @@ __global__ __launch_bounds__(256) void gather_rows_bytes_kernel(const char* __re
 }
 }  // namespace
 
+namespace {
+int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int nint, hipStream_t s);
+}
+
 int hip_run_op(const std::string& name, void** p, int nptr, const int64_t* a, int nint) {
   hipStream_t s = current_stream();
+  const int rc = run_op(name, p, nptr, a, nint, s);
+  if (rc == 0 && k::device_checks_enabled()) {
+    const std::string failure = k::take_check_failure(s);
+    if (!failure.empty()) throw std::runtime_error(failure);
+  }
+  return rc;
+}
+
+namespace {
+int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int nint, hipStream_t s) {
   if (name == "gather_rows_bytes") {
     // ptrs: src, idx(int64), dst ; ints: n, row_bytes
     if (nptr < 3 || nint < 2) return -1;
@@ -64,5 +79,6 @@ int hip_run_op(const std::string& name, void** p, int nptr, const int64_t* a, in
   }
   return -1;
 }
+}  // namespace
 
 }  // namespace lga

@@ -232,6 +232,44 @@ def test_randomised_parity_sweep(first):
         assert same, f"seed {seed}: {case}"
 
 
+def test_index_checking_build_catches_a_bad_row_and_passes_clean_runs():
+    """The -DLGA_DEBUG build of the HIP core (LGA_DEBUG_LIB=1): a row id beyond the dataset handed to the
+    histogram kernel is reported as an error instead of faulting the GPU, and ordinary training (with
+    bagging, missing values, out-of-bag tree walks) trips no check and still matches the CPU engine."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import lightgbm_amd as lgb
+        from lightgbm_amd import _lib, ops
+        assert _lib.is_hip() and str(_lib.PKG / "_lga_hip_debug.so")
+        import parity_sweep
+        for seed in (0, 2, 4, 7, 12):
+            same, case = parity_sweep.run_case(seed, 600000)
+            assert same, case
+        N = 5000
+        bins = torch.randint(0, 256, (1, N, 32), dtype=torch.uint8, device="cuda")
+        packed = torch.ones(N, dtype=torch.int64, device="cuda")
+        rows = torch.arange(1000, dtype=torch.int32, device="cuda")
+        g, h, head = ops.hist_build(bins, rows, packed, 28)
+        assert int(head[0]) == 1000
+        rows[17] = N + 5
+        try:
+            ops.hist_build(bins, rows, packed, 28)
+        except _lib.LightGBMError as e:
+            assert "row id outside the dataset" in str(e), e
+            print("CAUGHT", e)
+        else:
+            raise SystemExit("the bad row id went unnoticed")
+        g, h, head = ops.hist_build(bins, torch.arange(1000, dtype=torch.int32, device="cuda"), packed, 28)
+        assert int(head[0]) == 1000     # the device is fine afterwards
+        print("OK")
+    """) % (os.path.join(os.path.dirname(__file__), ".."), os.path.join(os.path.dirname(__file__), "..", "tools"))
+    env = dict(os.environ, LGA_DEBUG_LIB="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+    assert r.returncode == 0 and "CAUGHT" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2")])
 def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     """The large-data paths - bin records interleaved with the packed gradients, two growth rounds in
@@ -455,3 +493,48 @@ def test_rccl_single_rank_communicator(tmp_path):
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [2, 4, 8])
+def test_rccl_data_parallel_over_several_gpus(P, tmp_path):
+    """One process per GPU, histograms summed by RCCL: every rank ends with the serial learner's trees.
+    Needs P visible GPUs (skipped on a smaller box); started through torch.distributed.run on 127.0.0.1."""
+    import os, socket, subprocess, sys, textwrap
+    import torch
+    if torch.cuda.device_count() < P:
+        pytest.skip(f"needs {P} GPUs, {torch.cuda.device_count()} visible")
+    script = tmp_path / "dp_rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import lightgbm_amd as lgb
+        from lightgbm_amd.parallel import RcclComm
+        from lightgbm_amd.utils.datasets import make_regression
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+        dist.init_process_group("nccl")
+        GPU = {"device_type": "gpu", "verbose": -1}
+        X, y = make_regression(60000, 12, seed=3)
+        bounds = np.linspace(0, len(y), world + 1).astype(int)
+        sl = slice(bounds[rank], bounds[rank + 1])
+        comm = RcclComm()
+        p = {**GPU, "num_leaves": 31, "tree_learner": "data"}
+        b = lgb.train(p, lgb.Dataset(X[sl], label=y[sl], bin_sample=X, params=GPU), 8, comm=comm)
+        text = b.model_to_string()
+        cut = text[text.index("Tree=0"):text.index("end of trees")]
+        if rank == 0:
+            s = lgb.train({**GPU, "num_leaves": 31}, lgb.Dataset(X, label=y, bin_sample=X, params=GPU), 8).model_to_string()
+            assert cut == s[s.index("Tree=0"):s.index("end of trees")], "data-parallel trees differ from serial"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, cut)
+        assert all(g == gathered[0] for g in gathered), "ranks disagree"
+        comm.close()
+        dist.destroy_process_group()
+        print("rank", rank, "ok")
+    """) % os.path.join(os.path.dirname(__file__), ".."))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and r.stdout.count("ok") == P, r.stdout[-2000:] + r.stderr[-2000:]

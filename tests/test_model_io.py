@@ -125,3 +125,18 @@ def test_feature_importance_and_dump():
     assert gain.argmax() == 1
     d = b.dump_model()
     assert len(d["tree_info"]) == 5 and d["tree_info"][0]["num_leaves"] == 7
+
+
+def test_upstream_lightgbm_reads_our_model_when_it_is_installed():
+    """Interop with the real library, when it is importable (it is not in the build image: the test then skips
+    and the format is held to upstream's rules by the strict parser tests above)."""
+    upstream = pytest.importorskip("lightgbm")
+    import numpy as np
+    import lightgbm_amd as lgb
+    from lightgbm_amd.utils.datasets import make_regression
+    X, y = make_regression(2000, 6, seed=1)
+    ours = lgb.train({"device_type": "cpu", "verbose": -1, "num_leaves": 15}, lgb.Dataset(X, label=y), 10)
+    theirs = upstream.Booster(model_str=ours.model_to_string())
+    np.testing.assert_allclose(theirs.predict(X), ours.predict(X), rtol=0, atol=1e-9)
+    back = lgb.Booster(model_str=theirs.model_to_string())
+    np.testing.assert_allclose(back.predict(X), ours.predict(X), rtol=0, atol=1e-9)
