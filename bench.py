@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--stats", action="store_true", help="report round/host-time counters (no device event timers)")
     ap.add_argument("--auc", action="store_true", help="also report train AUC after the timed steps")
+    ap.add_argument("--extra", default="", help="JSON object of extra training parameters (experiments only: the "
+                                                "reported config then names them)")
     args = ap.parse_args()
 
     import torch
@@ -70,6 +72,8 @@ def main():
         "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 100.0, "verbose": -1, "device_type": "gpu",
         "tree_learner": "data" if distributed else "serial", "profile": bool(args.profile),
     }
+    extra = json.loads(args.extra) if args.extra else {}
+    params.update(extra)
     if args.auc:
         params["metric"] = ["auc", "binary_logloss"]   # evaluated once, after the timed steps
     t0 = time.time()
@@ -121,6 +125,8 @@ def main():
                    "features": 28, "trees_timed": args.steps, "parallelism": f"dp{world}" if distributed else "single",
                    "binning_seconds": round(t_bin, 3)},
     }
+    if extra:
+        out["config"]["extra_params"] = extra
     if args.auc:
         res = dict((m, v) for _, m, v, _ in booster._eval(-1, "training"))
         out["config"]["train_metric"] = res

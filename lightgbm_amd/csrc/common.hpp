@@ -228,6 +228,31 @@ LGA_HD float rng_uniform(uint64_t seed, uint64_t stream, uint64_t index) {
   return (float)(rng_u64(seed, stream, index) >> 40) * (1.0f / 16777216.0f);
 }
 
+// Gradient-based one-side sampling: the counts and factors both engines derive from the local row count.
+struct GossPlan {
+  int64_t top_k, other_k;
+  float keep_prob;    // chance of a row outside the top to stay
+  float multiplier;   // applied to the gradients / hessians of such a row
+};
+inline GossPlan goss_plan(int64_t n, double top_rate, double other_rate) {
+  GossPlan p;
+  p.top_k = (int64_t)((double)n * top_rate);
+  p.other_k = (int64_t)((double)n * other_rate);
+  if (p.top_k < 1) p.top_k = 1;
+  if (p.other_k < 1) p.other_k = 1;
+  if (p.top_k > n) p.top_k = n;
+  const int64_t rest = n - p.top_k;
+  p.keep_prob = rest > 0 ? (float)((double)p.other_k / (double)rest) : 0.0f;
+  p.multiplier = rest > 0 ? (float)((double)rest / (double)p.other_k) : 1.0f;
+  return p;
+}
+// A row's sampling weight: sum over classes of |g * h| in float arithmetic, class 0 first.
+LGA_HD float goss_weight(const float* g, const float* h, int64_t row, int num_class, int64_t stride) {
+  float w = 0.0f;
+  for (int k = 0; k < num_class; ++k) w += fabsf(g[(int64_t)k * stride + row] * h[(int64_t)k * stride + row]);
+  return w;
+}
+
 // Per-node feature sampling (feature_fraction_bynode).  A node is named by its POSITION in the tree - a key
 // derived from its parent's key and its side - so the subset does not depend on the order in which leaves
 // happen to be partitioned.  Every feature is kept with probability `bynode_fraction`, one (hashed from the

@@ -46,6 +46,9 @@ const ParamDef kParams[] = {
     P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
+    P(data_sample_strategy, "", String, kNone, kNone),
+    P(top_rate, "", Double, 0, 1.0),
+    P(other_rate, "", Double, 0, 1.0),
     P(feature_fraction, "sub_feature,colsample_bytree", Double, 1e-300, 1.0),
     P(feature_fraction_bynode, "sub_feature_bynode,colsample_bynode", Double, 1e-300, 1.0),
     P(feature_fraction_seed, "", Int, kNone, kNone),
@@ -317,7 +320,19 @@ void Config::check() {
   std::string b = lower(boosting);
   if (b == "gbrt" || b == "gbdt") boosting = "gbdt";
   else if (b == "rf" || b == "random_forest") boosting = "rf";
-  else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf)");
+  else if (b == "goss") { boosting = "gbdt"; data_sample_strategy = "goss"; }   // the older spelling
+  else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf, goss)");
+  {
+    std::string d = lower(data_sample_strategy);
+    if (d != "bagging" && d != "goss")
+      throw std::runtime_error("unknown data_sample_strategy \"" + data_sample_strategy + "\" (supported: bagging, goss)");
+    data_sample_strategy = d;
+    if (d == "goss") {
+      if (boosting == "rf") throw std::runtime_error("data_sample_strategy=goss cannot be combined with boosting=rf");
+      if (!(top_rate > 0.0) || !(other_rate > 0.0) || top_rate + other_rate > 1.0)
+        throw std::runtime_error("goss needs top_rate > 0, other_rate > 0 and top_rate + other_rate <= 1");
+    }
+  }
   {
     const std::string o = canonical_objective(objective);
     const bool multi = o == "multiclass" || o == "multiclassova";

@@ -30,6 +30,9 @@ struct Config {
   double bagging_fraction = 1.0;
   int bagging_freq = 0;
   int bagging_seed = 3;
+  std::string data_sample_strategy = "bagging";   // bagging | goss
+  double top_rate = 0.2;     // goss: share of rows kept for their large gradients
+  double other_rate = 0.1;   // goss: share of rows sampled from the rest
   double feature_fraction = 1.0;
   double feature_fraction_bynode = 1.0;
   int feature_fraction_seed = 2;

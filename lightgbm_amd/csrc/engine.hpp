@@ -50,6 +50,12 @@ class Engine {
   // Draw a new bag (every row when fraction >= 1).
   virtual void resample(double fraction, uint64_t seed, uint64_t iter) = 0;
 
+  // Gradient-based one-side sampling on the gradients just computed: a row's weight is the sum over classes
+  // of |g * h|; the top_k heaviest rows stay (ties with the k-th included), every other row stays with
+  // probability other_k / (n - top_k) and has its gradients and hessians multiplied by (n - top_k) / other_k.
+  // The kept rows become the bag.  n, top_k = max(1, top_rate * n), other_k = max(1, other_rate * n) are local.
+  virtual void goss_sample(double top_rate, double other_rate, uint64_t seed, uint64_t iter) = 0;
+
   // Grow a tree on the current gradients/bag.  Leaf values are unshrunk.
   // Index of the iteration the next train_tree() belongs to (seeds per-node feature sampling).
   virtual void set_tree_index(int64_t i) = 0;

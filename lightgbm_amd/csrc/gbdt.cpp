@@ -172,8 +172,7 @@ bool Booster::update_one_iter() {
   if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
   ensure_scores();
   if (!is_rf_) engine_->compute_gradients(obj_);
-  bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
-  if (bagging) draw_bag();
+  sample_rows();
   bool all_stumps = true;
   for (int k = 0; k < num_class_; ++k) {
     engine_->select_class(k);
@@ -203,6 +202,18 @@ void Booster::renew_leaf_outputs(Tree& tree) {
   for (int l = 0; l < tree.num_leaves; ++l) tree.set_leaf_value(l, values[(size_t)l]);
 }
 
+// Row sampling of the iteration: gradient-based one-side sampling (after a warm-up of 1 / learning_rate
+// iterations on all rows, like the reference implementation) or bagging.
+void Booster::sample_rows() {
+  if (cfg_.data_sample_strategy == "goss") {
+    const int warmup = (int)(1.0 / cfg_.learning_rate);
+    if (iter_ - cfg_.iteration_offset < warmup) return;
+    engine_->goss_sample(cfg_.top_rate, cfg_.other_rate, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
+    return;
+  }
+  if (cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0) draw_bag();
+}
+
 // The bag of iteration k is drawn at the last multiple of bagging_freq <= k, also when training starts
 // in the middle of such a period (iteration_offset).
 void Booster::draw_bag() {
@@ -228,8 +239,7 @@ bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64
     engine_->select_class(k);
     engine_->set_gradients(grad + (int64_t)k * rows, hess + (int64_t)k * rows, rows);
   }
-  bool bagging = cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0;
-  if (bagging) draw_bag();
+  sample_rows();
   bool all_stumps = true;
   for (int k = 0; k < num_class_; ++k) {
     engine_->select_class(k);

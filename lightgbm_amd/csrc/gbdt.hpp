@@ -98,6 +98,7 @@ class Booster {
   int iter_ = 0;                 // iterations attempted (drives bagging / feature sampling streams)
   bool bag_drawn_ = false;
   void draw_bag();
+  void sample_rows();
   void renew_leaf_outputs(Tree& tree);
   std::vector<Tree> trees_;
   // model meta

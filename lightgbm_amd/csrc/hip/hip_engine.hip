@@ -269,13 +269,20 @@ class HipBackend : public TreeBackend {
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
   int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
                         uint64_t iter, uint64_t salt) {
+    k::BagParams bp{};
+    bp.seed = seed; bp.iter = iter; bp.salt = salt; bp.fraction = (float)fraction;
+    return sample_partition(base_rows, n, out, -1, bp);
+  }
+
+  // feature: -1 bagging, -2 gradient-based one-side sampling (kernels.hpp: BagParams)
+  int64_t sample_partition(const int32_t* base_rows, int64_t n, int32_t* out, int feature, const k::BagParams& bp) {
     if (n == 0) return 0;
     SplitTask t{};
     // Scratch node entries beyond the grower's range.  The children must not alias the parent: the first
     // chunk's workgroup writes the child ranges while the other chunks still read the parent's.
     const int node_id = 2 * capacity_splits_ + 1;
     t.parent_node = node_id; t.left_node = node_id + 1; t.right_node = node_id + 2;
-    t.feature = -1; t.first_pchunk = 0; t.num_pchunk = ceil_div(n, k::kPartChunk);
+    t.feature = feature; t.first_pchunk = 0; t.num_pchunk = ceil_div(n, k::kPartChunk);
     if (t.num_pchunk > max_pchunks_) throw std::runtime_error("bagging chunk table overflow");
     RoundCtx& x = ctx_[0];
     char* st = x.stage_host.get();
@@ -290,8 +297,7 @@ class HipBackend : public TreeBackend {
     const int32_t* dpc = reinterpret_cast<const int32_t*>(x.stage_dev.get() + off_pch_);
     k::InlineTasks none{};
     k::partition(dt, dpc, none, t.num_pchunk, t.num_pchunk > 1, nodes_.get(), base_rows, nullptr, nullptr, out, nullptr,
-                 N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(), k::BagParams{seed, iter, salt, (float)fraction},
-                 nullptr, 0, stream_);
+                 N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(), bp, nullptr, 0, stream_);
     int32_t nl = 0;
     LGA_HIP_CHECK(hipMemcpyAsync(&nl, x.task_left.get(), sizeof(int32_t), hipMemcpyDeviceToHost, stream_));
     sync();
@@ -407,7 +413,7 @@ class HipBackend : public TreeBackend {
     if (!root)
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
-                   k::BagParams{0, 0, 0, 0.f}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
+                   k::BagParams{}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
                    (int64_t)slot_words_ * B, st_);
     prof.mark(PhaseProfile::kHist, st_);
     {
@@ -729,6 +735,26 @@ class HipEngine : public Engine {
     oob_n_ = n_base_ - bag_n_;
   }
 
+  void goss_sample(double top_rate, double other_rate, uint64_t seed, uint64_t iter) override {
+    if (n_base_ == 0) return;
+    const GossPlan plan = goss_plan(n_base_, top_rate, other_rate);
+    tmp_f32_.resize((size_t)n_base_ + 8);
+    select_scratch_.resize(2048 + 8);
+    float* w = tmp_f32_.get();
+    float* threshold = tmp_f32_.get() + n_base_;
+    k::goss_weights(grad_.get(), hess_.get(), K_, N_, base_or_null(), n_base_, w, stream_);
+    k::kth_largest(w, n_base_, plan.top_k, select_scratch_.get(), threshold, stream_);
+    k::BagParams bp{};
+    bp.seed = seed; bp.iter = iter; bp.salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
+    bp.fraction = plan.keep_prob;
+    bp.g = grad_.get(); bp.h = hess_.get(); bp.threshold = threshold; bp.num_class = K_; bp.stride = N_;
+    bag_n_ = backend_->sample_partition(base_rows_.get(), n_base_, bag_rows_.get(), -2, bp);
+    bag_ptr_ = bag_rows_.get();
+    oob_n_ = n_base_ - bag_n_;
+    k::goss_amplify(grad_.get(), hess_.get(), K_, N_, bag_ptr_, bag_n_, threshold, plan.multiplier, stream_);
+    have_max_ = false;   // the amplified rows may exceed the maxima taken with the gradients
+  }
+
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     TraceRange range("lga.train_tree");
@@ -1021,7 +1047,7 @@ class HipEngine : public Engine {
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;
   DeviceBuffer<int64_t> packed_;
-  DeviceBuffer<uint32_t> maxbits_;
+  DeviceBuffer<uint32_t> maxbits_, select_scratch_;
   DeviceBuffer<k::LeafSpan> span_dev_;
   DeviceBuffer<uint64_t> sort_keys_;
   DeviceBuffer<double> pct_values_;

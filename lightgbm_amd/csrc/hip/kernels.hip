@@ -170,6 +170,77 @@ __global__ __launch_bounds__(256) void multiclass_gradients_kernel(ObjectiveSpec
   }
 }
 
+// ---------------------------------------------------------------------------
+// gradient-based one-side sampling
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void goss_weights_kernel(const float* __restrict__ g, const float* __restrict__ h,
+                                                           int num_class, int64_t stride,
+                                                           const int32_t* __restrict__ rows, int64_t n,
+                                                           float* __restrict__ w) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    w[i] = goss_weight(g, h, rows ? rows[i] : i, num_class, stride);
+}
+
+__global__ __launch_bounds__(256) void goss_amplify_kernel(float* __restrict__ g, float* __restrict__ h, int num_class,
+                                                           int64_t stride, const int32_t* __restrict__ rows, int64_t n,
+                                                           const float* __restrict__ threshold, float multiplier) {
+  const float thr = *threshold;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    if (goss_weight(g, h, r, num_class, stride) >= thr) continue;
+    for (int k = 0; k < num_class; ++k) {
+      g[(int64_t)k * stride + r] *= multiplier;
+      h[(int64_t)k * stride + r] *= multiplier;
+    }
+  }
+}
+
+// Radix select of the k-th largest value.  state: [0] prefix bits found so far, [1] their mask, [2..3] the
+// rank still to find inside the prefix (64 bit), after kSelectBins histogram words.
+constexpr int kSelectBins = 2048;
+__global__ __launch_bounds__(256) void select_init_kernel(uint32_t* scratch, unsigned long long k) {
+  for (int i = threadIdx.x; i < kSelectBins + 8; i += blockDim.x) scratch[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>(scratch + kSelectBins + 2) = k;
+}
+__global__ __launch_bounds__(256) void select_count_kernel(const float* __restrict__ v, int64_t n, int shift, int bits,
+                                                           uint32_t* __restrict__ scratch) {
+  __shared__ unsigned lds[kSelectBins];
+  for (int i = threadIdx.x; i < kSelectBins; i += blockDim.x) lds[i] = 0u;
+  __syncthreads();
+  const uint32_t prefix = scratch[kSelectBins], mask = scratch[kSelectBins + 1];
+  const uint32_t digit_mask = (1u << bits) - 1u;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = __float_as_uint(v[i]);
+    if ((key & mask) == prefix) atomicAdd(&lds[(key >> shift) & digit_mask], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSelectBins; i += blockDim.x)
+    if (lds[i]) atomicAdd(&scratch[i], lds[i]);
+}
+// One workgroup: walks the digit histogram from the top, fixes the digit that holds the wanted rank,
+// clears the histogram for the next pass; the last pass writes the value.
+__global__ __launch_bounds__(256) void select_pick_kernel(uint32_t* __restrict__ scratch, int shift, int bits, int last,
+                                                          float* __restrict__ out) {
+  __shared__ unsigned lds[kSelectBins];
+  for (int i = threadIdx.x; i < kSelectBins; i += blockDim.x) { lds[i] = scratch[i]; scratch[i] = 0u; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long want = *reinterpret_cast<unsigned long long*>(scratch + kSelectBins + 2);
+    unsigned long long seen = 0;
+    int digit = 0;
+    for (int b = (1 << bits) - 1; b >= 0; --b) {
+      if (seen + lds[b] >= want) { digit = b; break; }
+      seen += lds[b];
+    }
+    *reinterpret_cast<unsigned long long*>(scratch + kSelectBins + 2) = want - seen;
+    const uint32_t prefix = scratch[kSelectBins] | ((uint32_t)digit << shift);
+    scratch[kSelectBins] = prefix;
+    scratch[kSelectBins + 1] |= ((1u << bits) - 1u) << shift;
+    if (last) *out = __uint_as_float(prefix);
+  }
+}
+
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g, const float* __restrict__ h,
                                                      const int32_t* __restrict__ rows, int64_t n, uint32_t* maxbits) {
   float mg = 0.f, mh = 0.f;
@@ -204,7 +275,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __restrict__ bins_fm, int64_t N,
                                           int32_t row, const BagParams& bag) {
-  if (t.feature < 0) return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < bag.fraction;
+  if (t.feature < 0) {
+    if (t.feature == -2 && goss_weight(bag.g, bag.h, row, bag.num_class, bag.stride) >= *bag.threshold) return true;
+    return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < bag.fraction;
+  }
   int b = bins_fm[(int64_t)t.feature * N + row];
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
@@ -1102,6 +1176,33 @@ void gradients(const ObjectiveSpec& obj, const double* scores, const float* labe
   if (n <= 0) return;
   hipLaunchKernelGGL(gradients_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, obj, scores, label, weight, rows, n, g,
                      h, maxbits);
+  LGA_LAUNCH_CHECK();
+}
+
+void goss_weights(const float* g, const float* h, int num_class, int64_t stride, const int32_t* rows, int64_t n,
+                  float* w, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(goss_weights_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, num_class, stride, rows, n, w);
+  LGA_LAUNCH_CHECK();
+}
+
+void kth_largest(const float* v, int64_t n, int64_t k, uint32_t* scratch, float* out, hipStream_t s) {
+  if (n <= 0) return;
+  k = std::max<int64_t>(1, std::min(k, n));
+  hipLaunchKernelGGL(select_init_kernel, dim3(1), dim3(256), 0, s, scratch, (unsigned long long)k);
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  for (int p = 0; p < 3; ++p) {
+    hipLaunchKernelGGL(select_count_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, v, n, shifts[p], bits[p], scratch);
+    hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(256), 0, s, scratch, shifts[p], bits[p], p == 2 ? 1 : 0, out);
+  }
+  LGA_LAUNCH_CHECK();
+}
+
+void goss_amplify(float* g, float* h, int num_class, int64_t stride, const int32_t* rows, int64_t n,
+                  const float* threshold, float multiplier, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(goss_amplify_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, num_class, stride, rows, n,
+                     threshold, multiplier);
   LGA_LAUNCH_CHECK();
 }
 

@@ -65,6 +65,15 @@ void multiclass_gradients(const ObjectiveSpec& obj, const double* scores, int64_
                           const float* weight, const int32_t* rows, int64_t n, float* g, float* h, hipStream_t s);
 void multi_metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, int64_t stride, const float* label,
                       const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s);
+// Gradient-based one-side sampling.  goss_weights: w[i] = goss_weight of row rows[i].  kth_largest: the k-th
+// largest of n non-negative floats (exact, by three radix passes over the bit patterns) -> *out, all on the
+// stream; scratch holds 2048 + 8 uint32.  goss_amplify: rows of the bag whose weight is below *threshold get
+// their gradients and hessians (all classes) multiplied.
+void goss_weights(const float* g, const float* h, int num_class, int64_t stride, const int32_t* rows, int64_t n,
+                  float* w, hipStream_t s);
+void kth_largest(const float* v, int64_t n, int64_t k, uint32_t* scratch, float* out, hipStream_t s);
+void goss_amplify(float* g, float* h, int num_class, int64_t stride, const int32_t* rows, int64_t n,
+                  const float* threshold, float multiplier, hipStream_t s);
 void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s);
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
               int64_t* packed, hipStream_t s);
@@ -74,7 +83,18 @@ inline int64_t row_line_bytes(int64_t N) { return ((N + 2) / 3) * 128; }
 void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hipStream_t s);
 
 // Partition (or bagging when task.feature < 0): a0/a1 are the two row-index buffers a node's `buf` selects.
-struct BagParams { uint64_t seed, iter, salt; float fraction; };
+// Row sampling predicate of a partition task with feature < 0.  feature == -1 (bagging): a row goes left
+// (= stays in the bag) with probability `fraction`.  feature == -2 (gradient-based one-side sampling): rows
+// whose weight goss_weight(g, h) reaches *threshold always stay, the others with probability `fraction`.
+struct BagParams {
+  uint64_t seed, iter, salt;
+  float fraction;
+  const float* g = nullptr;
+  const float* h = nullptr;
+  const float* threshold = nullptr;
+  int num_class = 1;
+  int64_t stride = 0;
+};
 // tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.
 // zero_ptr/zero_words: int64 range the partition workgroups clear on the way (the round's new histogram slots).
 void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,

@@ -64,7 +64,7 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     k::InlineTasks none{};
     k::partition((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], a[0] > 1, (NodeRange*)p[2],
                  (const int32_t*)p[3], (const int32_t*)p[4], (int32_t*)p[3], (int32_t*)p[4], (const uint8_t*)p[5], a[1],
-                 (uint64_t*)p[6], (int32_t*)p[7], (int32_t*)p[8], k::BagParams{0, 0, 0, 0.f}, nullptr, 0, s);
+                 (uint64_t*)p[6], (int32_t*)p[7], (int32_t*)p[8], k::BagParams{}, nullptr, 0, s);
     return 0;
   }
   if (name == "scan") {

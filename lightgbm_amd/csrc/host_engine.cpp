@@ -2,6 +2,7 @@
 #include "metric.hpp"
 #include "percentile.hpp"
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -448,6 +449,32 @@ class HostEngine : public Engine {
     float fr = (float)fraction;
     for (int32_t r : base_) {
       if (rng_uniform(seed, iter, salt + (uint64_t)r) < fr) bag_.push_back(r); else oob_.push_back(r);
+    }
+  }
+
+  void goss_sample(double top_rate, double other_rate, uint64_t seed, uint64_t iter) override {
+    const int64_t n = (int64_t)base_.size();
+    bag_.clear(); oob_.clear();
+    if (n == 0) return;
+    const GossPlan plan = goss_plan(n, top_rate, other_rate);
+    std::vector<float> w((size_t)n);
+    for (int64_t i = 0; i < n; ++i) w[(size_t)i] = goss_weight(grad_.data(), hess_.data(), base_[(size_t)i], K_, N_);
+    std::vector<float> sorted = w;
+    std::nth_element(sorted.begin(), sorted.begin() + (plan.top_k - 1), sorted.end(), std::greater<float>());
+    const float threshold = sorted[(size_t)(plan.top_k - 1)];   // the top_k-th largest weight
+    const uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int32_t r = base_[(size_t)i];
+      if (w[(size_t)i] >= threshold) { bag_.push_back(r); continue; }
+      if (rng_uniform(seed, iter, salt + (uint64_t)r) < plan.keep_prob) {
+        bag_.push_back(r);
+        for (int k = 0; k < K_; ++k) {
+          grad_[(size_t)k * (size_t)N_ + (size_t)r] *= plan.multiplier;
+          hess_[(size_t)k * (size_t)N_ + (size_t)r] *= plan.multiplier;
+        }
+      } else {
+        oob_.push_back(r);
+      }
     }
   }
 

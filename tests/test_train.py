@@ -187,6 +187,30 @@ def test_other_objectives_train():
     assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
 
 
+def test_goss_keeps_the_large_gradients_and_learns_almost_as_well():
+    """Gradient-based one-side sampling: after the warm-up (1 / learning_rate iterations on all rows) every
+    tree is grown on ~top_rate + other_rate of the rows, the heavy-gradient ones always among them."""
+    X, y = make_regression(8000, 8, seed=31)
+    d = lgb.Dataset(X, label=y, params=CPU)
+    base = {**CPU, "num_leaves": 31, "learning_rate": 0.2}
+    full = lgb.train(base, d, 60)
+    goss = lgb.train({**base, "data_sample_strategy": "goss", "top_rate": 0.2, "other_rate": 0.1}, d, 60)
+    old_name = lgb.train({**base, "boosting": "goss", "top_rate": 0.2, "other_rate": 0.1}, d, 60)
+    assert trees_of(goss) == trees_of(old_name)
+    # the first 1 / 0.2 = 5 trees see every row and equal plain boosting; later roots hold ~30 % of the rows
+    tf, tg = full.dump_model()["tree_info"], goss.dump_model()["tree_info"]
+    for i in range(5):
+        assert tf[i] == tg[i]
+    counts = [t["tree_structure"]["internal_count"] for t in tg[5:]]
+    assert all(0.27 * 8000 < c < 0.34 * 8000 for c in counts), counts[:5]
+    assert rmse(goss.predict(X), y) < 1.25 * rmse(full.predict(X), y)
+    again = lgb.train({**base, "data_sample_strategy": "goss", "top_rate": 0.2, "other_rate": 0.1}, d, 60)
+    assert trees_of(goss) == trees_of(again)
+    for bad in ({"top_rate": 0.8, "other_rate": 0.5}, {"boosting": "rf", "bagging_fraction": 0.5, "bagging_freq": 1}):
+        with pytest.raises(Exception):
+            lgb.train({**base, "data_sample_strategy": "goss", **bad}, d, 2)
+
+
 def test_l1_and_quantile_leaves_are_residual_percentiles():
     """One tree, learning rate 1, scores start at 0: a leaf's value is the percentile of the labels it holds."""
     X, y = make_regression(5000, 4, seed=8)

@@ -47,7 +47,12 @@ def draw_case(seed: int, max_rows: int):
         p["feature_fraction"] = 0.7
     if rng.rand() < 0.2:
         p["feature_fraction_bynode"] = 0.6
-    if rng.rand() < 0.15:
+    if rng.rand() < 0.2 and "bagging_fraction" not in p:
+        p["data_sample_strategy"] = "goss"
+        p["top_rate"] = float([0.1, 0.3][rng.randint(2)])
+        p["other_rate"] = float([0.1, 0.25][rng.randint(2)])
+        p["learning_rate"] = 0.5          # two warm-up iterations, then sampled ones
+    elif rng.rand() < 0.15:
         p["boosting"] = "rf"
         p.setdefault("bagging_fraction", 0.6)
         p.setdefault("bagging_freq", 1)
