@@ -46,6 +46,12 @@ const ParamDef kParams[] = {
     P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
+    P(drop_rate, "rate_drop", Double, 0, 1.0),
+    P(max_drop, "", Int, kNone, kNone),
+    P(skip_drop, "", Double, 0, 1.0),
+    P(uniform_drop, "", Bool, kNone, kNone),
+    P(xgboost_dart_mode, "", Bool, kNone, kNone),
+    P(drop_seed, "", Int, kNone, kNone),
     P(data_sample_strategy, "", String, kNone, kNone),
     P(top_rate, "", Double, 0, 1.0),
     P(other_rate, "", Double, 0, 1.0),
@@ -321,7 +327,8 @@ void Config::check() {
   if (b == "gbrt" || b == "gbdt") boosting = "gbdt";
   else if (b == "rf" || b == "random_forest") boosting = "rf";
   else if (b == "goss") { boosting = "gbdt"; data_sample_strategy = "goss"; }   // the older spelling
-  else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf, goss)");
+  else if (b == "dart") boosting = "dart";
+  else throw std::runtime_error("unknown boosting type \"" + boosting + "\" (supported: gbdt, rf, dart, goss)");
   {
     std::string d = lower(data_sample_strategy);
     if (d != "bagging" && d != "goss")

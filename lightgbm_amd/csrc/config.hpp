@@ -30,6 +30,13 @@ struct Config {
   double bagging_fraction = 1.0;
   int bagging_freq = 0;
   int bagging_seed = 3;
+  // dart
+  double drop_rate = 0.1;
+  int max_drop = 50;
+  double skip_drop = 0.5;
+  bool uniform_drop = false;
+  bool xgboost_dart_mode = false;
+  int drop_seed = 4;
   std::string data_sample_strategy = "bagging";   // bagging | goss
   double top_rate = 0.2;     // goss: share of rows kept for their large gradients
   double other_rate = 0.1;   // goss: share of rows sampled from the rest

@@ -13,6 +13,7 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
   cfg_.set(params);
   if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
   is_rf_ = cfg_.boosting == "rf";
+  is_dart_ = cfg_.boosting == "dart";
   average_output_ = is_rf_;
   iter_ = cfg_.iteration_offset;
   setup_objective();
@@ -171,6 +172,7 @@ bool Booster::update_one_iter() {
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
   ensure_scores();
+  if (is_dart_) dart_drop();
   if (!is_rf_) engine_->compute_gradients(obj_);
   sample_rows();
   bool all_stumps = true;
@@ -182,7 +184,83 @@ bool Booster::update_one_iter() {
     all_stumps = finish_tree(std::move(tree), k) && all_stumps;
   }
   engine_->select_class(0);
+  if (is_dart_) dart_normalize();
   return finish_iteration(all_stumps);
+}
+
+// ---------------------------------------------------------------------------
+// DART (Rashmi & Gilad-Bachrach 2015): every iteration a random subset of the existing iterations is
+// muted while the new trees are fitted, then the new trees and the muted ones are rescaled so that the
+// ensemble's output stays on the same scale: with k muted iterations the new trees get the factor
+// 1 / (k + 1) on top of the learning rate and the muted ones k / (k + 1) (xgboost_dart_mode: lr / (k + lr)
+// and k / (k + lr)).  The initial score stays out of it: it is folded into the first iteration's trees
+// only when the model is written, and taken out again (without_bias) whenever such a tree is replayed.
+// ---------------------------------------------------------------------------
+Tree Booster::without_bias(int tree_index) const {
+  Tree t = trees_[(size_t)tree_index];
+  const double init = init_scores_[(size_t)(tree_index % num_class_)];
+  if (tree_index < num_class_ && init != 0.0) t.add_bias(-init);
+  return t;
+}
+
+void Booster::dart_drop() {
+  dropped_.clear();
+  const int n_iter = current_iteration();
+  tree_weight_.resize((size_t)n_iter, cfg_.learning_rate);
+  const uint64_t seed = (uint64_t)cfg_.drop_seed;
+  const bool skip = rng_uniform(seed, (uint64_t)iter_, 0xffffffffull) < (float)cfg_.skip_drop;
+  if (!skip && n_iter > 0) {
+    double rate = cfg_.drop_rate;
+    if (!cfg_.uniform_drop) {
+      // a heavier iteration is proportionally more likely to be muted
+      const double inv_avg = (double)n_iter / sum_tree_weight_;
+      if (cfg_.max_drop > 0) rate = std::min(rate, (double)cfg_.max_drop * inv_avg / sum_tree_weight_);
+      for (int i = 0; i < n_iter; ++i)
+        if (rng_uniform(seed, (uint64_t)iter_, (uint64_t)i) < (float)(rate * tree_weight_[(size_t)i] * inv_avg))
+          dropped_.push_back(i);
+    } else {
+      if (cfg_.max_drop > 0) rate = std::min(rate, (double)cfg_.max_drop / (double)n_iter);
+      for (int i = 0; i < n_iter; ++i)
+        if (rng_uniform(seed, (uint64_t)iter_, (uint64_t)i) < (float)rate) dropped_.push_back(i);
+    }
+    if (cfg_.max_drop > 0 && (int)dropped_.size() > cfg_.max_drop) dropped_.resize((size_t)cfg_.max_drop);
+  }
+  // mute them in the training scores (validation scores keep them until the rescaling)
+  for (int it : dropped_)
+    for (int k = 0; k < num_class_; ++k) {
+      engine_->select_class(k);
+      engine_->add_tree_by_traversal(-1, without_bias(it * num_class_ + k), -1.0);
+    }
+  engine_->select_class(0);
+  const double k = (double)dropped_.size();
+  dart_shrinkage_ = cfg_.xgboost_dart_mode ? (dropped_.empty() ? cfg_.learning_rate : cfg_.learning_rate / (cfg_.learning_rate + k))
+                                           : cfg_.learning_rate / (1.0 + k);
+}
+
+void Booster::dart_normalize() {
+  const double k = (double)dropped_.size();
+  const double lr = cfg_.learning_rate;
+  // factor of a muted iteration afterwards
+  const double keep = cfg_.xgboost_dart_mode ? k / (k + lr) : k / (k + 1.0);
+  const int nv = engine_->num_valid();
+  for (int it : dropped_) {
+    for (int c = 0; c < num_class_; ++c) {
+      const int ti = it * num_class_ + c;
+      Tree plain = without_bias(ti);
+      engine_->select_class(c);
+      engine_->add_tree_by_traversal(-1, plain, keep);                 // was muted: comes back scaled
+      for (int v = 0; v < nv; ++v) engine_->add_tree_by_traversal(v, plain, keep - 1.0);   // was there in full
+      const double init = init_scores_[(size_t)c];
+      Tree& stored = trees_[(size_t)ti];
+      if (ti < num_class_ && init != 0.0) { stored.add_bias(-init); stored.apply_shrinkage(keep); stored.add_bias(init); }
+      else stored.apply_shrinkage(keep);
+    }
+    sum_tree_weight_ -= tree_weight_[(size_t)it] * (1.0 - keep);
+    tree_weight_[(size_t)it] *= keep;
+  }
+  engine_->select_class(0);
+  tree_weight_.push_back(dart_shrinkage_);
+  sum_tree_weight_ += dart_shrinkage_;
 }
 
 // regression_l1, quantile and mape take a sign step per row, whose Newton leaf value is bounded by one; the
@@ -227,6 +305,7 @@ void Booster::draw_bag() {
 bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64_t n) {
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (is_rf_) throw std::runtime_error("custom gradients are not supported with boosting=rf");
+  if (is_dart_) throw std::runtime_error("custom gradients are not supported with boosting=dart (they would be taken before the trees are muted)");
   const int64_t rows = engine_->num_rows(-1);
   if (n != rows * num_class_) throw std::runtime_error("custom gradients: expected num_class * num_rows values");
   if (!scores_initialised_) {
@@ -274,7 +353,7 @@ bool Booster::finish_tree(Tree&& tree, int cls) {
     return true;
   }
   if (!is_rf_) {
-    tree.apply_shrinkage(cfg_.learning_rate);
+    tree.apply_shrinkage(is_dart_ ? dart_shrinkage_ : cfg_.learning_rate);
     engine_->add_trained_tree_to_train_scores(tree);
     for (int v = 0; v < nv; ++v) engine_->add_tree_by_traversal(v, tree, 1.0);
     if (first_iteration && init != 0.0) tree.add_bias(init);
@@ -300,12 +379,16 @@ bool Booster::finish_tree(Tree&& tree, int cls) {
 bool Booster::finish_iteration(bool all_stumps) {
   ++iter_;
   if (!all_stumps) return false;
-  if (!is_rf_ && (int)trees_.size() > num_class_) trees_.resize(trees_.size() - (size_t)num_class_);
+  if (!is_rf_ && (int)trees_.size() > num_class_) {
+    trees_.resize(trees_.size() - (size_t)num_class_);
+    if (is_dart_ && !tree_weight_.empty()) { sum_tree_weight_ -= tree_weight_.back(); tree_weight_.pop_back(); }
+  }
   return true;
 }
 
 void Booster::rollback_one_iter() {
   if (!engine_ || (int)trees_.size() < num_class_) return;
+  if (is_dart_) throw std::runtime_error("boosting=dart rescales earlier trees every iteration; an iteration cannot be rolled back");
   const int K = num_class_;
   const int nv = engine_->num_valid();
   const bool only_iteration = (int)trees_.size() == K;

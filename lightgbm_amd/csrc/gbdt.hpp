@@ -99,6 +99,15 @@ class Booster {
   bool bag_drawn_ = false;
   void draw_bag();
   void sample_rows();
+  // dart: trees dropped for the running iteration, and the weights bookkeeping (gbdt.cpp)
+  void dart_drop();
+  void dart_normalize();
+  Tree without_bias(int tree_index) const;
+  bool is_dart_ = false;
+  std::vector<int> dropped_;            // iteration indices
+  std::vector<double> tree_weight_;     // per iteration: the factor its trees currently carry
+  double sum_tree_weight_ = 0.0;
+  double dart_shrinkage_ = 1.0;         // learning rate of the iteration in progress
   void renew_leaf_outputs(Tree& tree);
   std::vector<Tree> trees_;
   // model meta

@@ -187,6 +187,34 @@ def test_other_objectives_train():
     assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
 
 
+def test_dart_rescales_muted_trees_and_keeps_scores_and_model_in_step():
+    X, y = make_regression(5000, 8, seed=33)
+    d = lgb.Dataset(X[:4000], label=y[:4000], params=CPU)
+    v = d.create_valid(X[4000:], label=y[4000:])
+    p = {**CPU, "boosting": "dart", "num_leaves": 15, "learning_rate": 0.3, "drop_rate": 0.3, "skip_drop": 0.2,
+         "metric": "l2"}
+    ev = {}
+    b = lgb.train(p, d, 40, valid_sets=[d, v], valid_names=["train", "valid"], evals_result=ev, keep_training_booster=True)
+    assert b.num_trees() == 40
+    # the scores the engine carried along == what the saved model predicts, on both datasets
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X[:4000], raw_score=True), atol=1e-9)
+    np.testing.assert_allclose(b._inner_predict(0, raw=True), b.predict(X[4000:], raw_score=True), atol=1e-9)
+    assert abs(ev["valid"]["l2"][-1] - np.mean((b.predict(X[4000:]) - y[4000:].astype(np.float32)) ** 2)) < 1e-9
+    # muting happened: the stored shrinkage of early trees fell below the learning rate, and it learns
+    shr = [float(ln.split("=")[1]) for ln in b.model_to_string().splitlines() if ln.startswith("shrinkage=")]
+    assert min(shr) < 0.3 * 0.9 and max(shr) <= 0.3 + 1e-12
+    assert ev["valid"]["l2"][-1] < 0.6 * ev["valid"]["l2"][0]     # muting 30 % of the trees slows learning down
+    # deterministic; other seeds mute other trees; xgboost mode and uniform drop run too
+    again = lgb.train(p, d, 40)
+    assert trees_of(again) == trees_of(b)
+    assert trees_of(lgb.train({**p, "drop_seed": 9}, d, 40)) != trees_of(b)
+    for extra in ({"xgboost_dart_mode": True}, {"uniform_drop": True, "max_drop": 3}):
+        c = lgb.train({**p, **extra}, d, 25, keep_training_booster=True)
+        np.testing.assert_allclose(c._inner_predict(-1, raw=True), c.predict(X[:4000], raw_score=True), atol=1e-9)
+    with pytest.raises(Exception, match="rolled back"):
+        b.rollback_one_iter()
+
+
 def test_goss_keeps_the_large_gradients_and_learns_almost_as_well():
     """Gradient-based one-side sampling: after the warm-up (1 / learning_rate iterations on all rows) every
     tree is grown on ~top_rate + other_rate of the rows, the heavy-gradient ones always among them."""

@@ -53,11 +53,15 @@ def draw_case(seed: int, max_rows: int):
         p["other_rate"] = float([0.1, 0.25][rng.randint(2)])
         p["learning_rate"] = 0.5          # two warm-up iterations, then sampled ones
     elif rng.rand() < 0.15:
+        p["boosting"] = "dart"
+        p["drop_rate"] = 0.5
+        p["skip_drop"] = 0.0
+    elif rng.rand() < 0.15:
         p["boosting"] = "rf"
         p.setdefault("bagging_fraction", 0.6)
         p.setdefault("bagging_freq", 1)
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
-            "rounds": int(rng.randint(3, 7)), "subset": rng.rand() < 0.25}
+            "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25}
     return n, F, p, opts
 
 
