@@ -139,15 +139,22 @@ def test_data_parallel_multiclass_equals_serial():
     p = {**CPU, "objective": "multiclass", "num_class": 3, "num_leaves": 15}
     serial = lgb.train(p, lgb.Dataset(X, label=y, bin_sample=X), 1)
     comms = ThreadComm.make_group(2)
-    out = [None, None]
+    out, err = [None, None], [None, None]
 
     def work(r):
-        sl = slice(0, 2000) if r == 0 else slice(2000, None)
-        out[r] = lgb.train({**p, "tree_learner": "data"}, lgb.Dataset(X[sl], label=y[sl], bin_sample=X), 1,
-                           comm=comms[r]).model_to_string()
-    th = [threading.Thread(target=work, args=(r,)) for r in range(2)]
+        try:
+            sl = slice(0, 2000) if r == 0 else slice(2000, None)
+            out[r] = lgb.train({**p, "tree_learner": "data"}, lgb.Dataset(X[sl], label=y[sl], bin_sample=X), 1,
+                               comm=comms[r]).model_to_string()
+        except BaseException as e:   # noqa: a failing rank must not leave the other one waiting at the barrier
+            err[r] = e
+            comms[r]._hub.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(2)]
     [t.start() for t in th]
     [t.join(timeout=120) for t in th]
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
     [c.close() for c in comms]
     cut = lambda s: s[s.index("Tree=0"):s.index("end of trees")]
     assert out[0] is not None and cut(out[0]) == cut(out[1]) == cut(serial.model_to_string())
