@@ -51,13 +51,21 @@ def main():
     # LGA_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, agreed bin boundaries, RCCL
     # communicator) even with one rank - a plumbing check for boxes that have a single GPU
     distributed = world > 1 or os.environ.get("LGA_BENCH_FORCE_DIST") == "1"
+    # LGA_BENCH_BACKEND=gloo rehearses a multi-rank run on a machine with fewer GPUs than ranks: the ranks
+    # share the devices and reduce through host memory instead of RCCL (timings then mean nothing)
+    backend = os.environ.get("LGA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import lightgbm_amd as lgb
     from lightgbm_amd.utils.datasets import make_higgs_like
@@ -103,7 +111,7 @@ def main():
     sync()
     elapsed = time.time() - t1
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed * 1000.0 / max(args.steps, 1)
@@ -122,7 +130,9 @@ def main():
         "dtype": "int64-fixed-point histograms / fp64 split gain (no reduced precision; reference is fp32/fp64)",
         "data": "synthetic Higgs-shaped (make_higgs_like), random labels from a non-linear score; no real Higgs download possible",
         "config": {"model": "gbdt binary, 255 leaves, 255 bins, lr 0.1, min_sum_hessian 100", "rows": n_total,
-                   "features": 28, "trees_timed": args.steps, "parallelism": f"dp{world}" if distributed else "single",
+                   "features": 28, "trees_timed": args.steps,
+                   "parallelism": (f"dp{world}" + ("" if backend == "nccl" else f" ({backend} rehearsal, shared GPU)"))
+                   if distributed else "single",
                    "binning_seconds": round(t_bin, 3)},
     }
     if extra:

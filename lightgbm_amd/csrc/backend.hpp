@@ -20,6 +20,8 @@ class Comm {
   virtual ~Comm() {}
   virtual int rank() const = 0;
   virtual int size() const = 0;
+  // true: the communicator only takes host buffers (device engines then stage through pinned memory)
+  virtual bool host_only() const { return false; }
   // In-place sum over ranks.  `device` tells whether buf is device memory.
   virtual void allreduce_sum_i64(int64_t* buf, size_t n, bool device, void* stream) = 0;
   virtual void allreduce_sum_f64(double* buf, size_t n, bool device, void* stream) = 0;

@@ -20,6 +20,7 @@ class CallbackComm : public Comm {
   CallbackComm(int rank, int size, lga_allreduce_fn ar, lga_allgather_fn ag) : rank_(rank), size_(size), ar_(ar), ag_(ag) {}
   int rank() const override { return rank_; }
   int size() const override { return size_; }
+  bool host_only() const override { return true; }
   void allreduce_sum_i64(int64_t* buf, size_t n, bool device, void*) override { need_host(device); ar_(buf, (int64_t)n, 0, 0); }
   void allreduce_sum_f64(double* buf, size_t n, bool device, void*) override { need_host(device); ar_(buf, (int64_t)n, 1, 0); }
   void allreduce_max_f32(float* buf, size_t n, bool device, void*) override { need_host(device); ar_(buf, (int64_t)n, 2, 1); }

@@ -568,6 +568,54 @@ class HipBackend : public TreeBackend {
 };
 
 // ---------------------------------------------------------------------------
+// Lets a host-only communicator (torch.distributed / gloo callbacks, the thread loop-back) serve the device
+// engine: a device buffer travels through pinned host memory around each collective.  This is for rehearsing
+// multi-process runs on a machine that has fewer GPUs than ranks; production runs reduce with RCCL.
+// ---------------------------------------------------------------------------
+class StagingComm : public Comm {
+ public:
+  explicit StagingComm(Comm* inner) : inner_(inner) {}
+  int rank() const override { return inner_->rank(); }
+  int size() const override { return inner_->size(); }
+  void allreduce_sum_i64(int64_t* buf, size_t n, bool device, void* stream) override {
+    staged(buf, n * sizeof(int64_t), device, stream, [&](void* h) { inner_->allreduce_sum_i64((int64_t*)h, n, false, nullptr); });
+  }
+  void allreduce_sum_f64(double* buf, size_t n, bool device, void* stream) override {
+    staged(buf, n * sizeof(double), device, stream, [&](void* h) { inner_->allreduce_sum_f64((double*)h, n, false, nullptr); });
+  }
+  void allreduce_max_f32(float* buf, size_t n, bool device, void* stream) override {
+    staged(buf, n * sizeof(float), device, stream, [&](void* h) { inner_->allreduce_max_f32((float*)h, n, false, nullptr); });
+  }
+  void allgather_bytes(const void* in, void* out, size_t nbytes, bool device, void* stream) override {
+    if (!device) { inner_->allgather_bytes(in, out, nbytes, false, nullptr); return; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = nbytes * (size_t)size();
+    host_.resize(nbytes + total);
+    LGA_HIP_CHECK(hipMemcpyAsync(host_.get(), in, nbytes, hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    inner_->allgather_bytes(host_.get(), host_.get() + nbytes, nbytes, false, nullptr);
+    LGA_HIP_CHECK(hipMemcpyAsync(out, host_.get() + nbytes, total, hipMemcpyHostToDevice, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+  }
+
+ private:
+  template <typename F>
+  void staged(void* buf, size_t bytes, bool device, void* stream, F reduce_host) {
+    if (bytes == 0) return;
+    if (!device) { reduce_host(buf); return; }
+    hipStream_t s = (hipStream_t)stream;
+    host_.resize(bytes);
+    LGA_HIP_CHECK(hipMemcpyAsync(host_.get(), buf, bytes, hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    reduce_host(host_.get());
+    LGA_HIP_CHECK(hipMemcpyAsync(buf, host_.get(), bytes, hipMemcpyHostToDevice, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  Comm* inner_;
+  PinnedBuffer<char> host_;
+};
+
+// ---------------------------------------------------------------------------
 // engine
 // ---------------------------------------------------------------------------
 class HipEngine : public Engine {
@@ -575,6 +623,10 @@ class HipEngine : public Engine {
   HipEngine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm, ParallelMode mode)
       : train_(train), cfg_(cfg), comm_(comm), grower_(cfg, train.get()) {
     if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
+    if (comm_ && comm_->host_only()) {
+      staging_.reset(new StagingComm(comm_));
+      comm_ = comm = staging_.get();
+    }
     stream_ = current_stream();
     mir_ = ensure_device_mirror(train_->root());
     N_ = train_->root_rows();
@@ -1029,6 +1081,7 @@ class HipEngine : public Engine {
   std::shared_ptr<Dataset> train_;
   Config cfg_;
   Comm* comm_;
+  std::unique_ptr<StagingComm> staging_;
   TreeGrower grower_;
   hipStream_t stream_ = nullptr;
   DeviceMirror* mir_ = nullptr;

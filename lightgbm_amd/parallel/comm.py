@@ -182,8 +182,12 @@ class DeviceLoopbackComm:
 
 
 def default_comm(group=None):
-    """RCCL when training on GPUs, torch.distributed host collectives otherwise; None when not distributed."""
+    """RCCL when training on GPUs under an ``nccl`` process group, torch.distributed host collectives otherwise
+    (CPU engine, or a ``gloo`` group used to rehearse a multi-rank run on fewer GPUs than ranks: the device
+    engine then stages its buffers through host memory); None when not distributed."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return None
-    return RcclComm(group) if _lib.is_hip() else TorchComm(group)
+    if _lib.is_hip() and dist.get_backend(group) == "nccl":
+        return RcclComm(group)
+    return TorchComm(group)

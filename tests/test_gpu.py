@@ -538,3 +538,62 @@ def test_rccl_data_parallel_over_several_gpus(P, tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and r.stdout.count("ok") == P, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_multi_process_data_parallel_sharing_one_gpu(P, tmp_path):
+    """The multi-rank flow of a real run - one process per rank, torch.distributed rendezvous, bin boundaries
+    agreed over the ranks, one histogram all-reduce per growth round - rehearsed on ONE GPU: the ranks share the
+    device and reduce through gloo (the device engine stages its buffers through pinned memory).  Every rank must
+    end with the serial learner's trees.  Also runs bench.py's multi-rank path end to end."""
+    import json, os, socket, subprocess, sys, textwrap
+    root = os.path.join(os.path.dirname(__file__), "..")
+    script = tmp_path / "dp_rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import lightgbm_amd as lgb
+        from lightgbm_amd.parallel import default_comm, TorchComm
+        from lightgbm_amd.parallel.data_parallel import gather_bin_sample
+        from lightgbm_amd.utils.datasets import make_regression
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        GPU = {"device_type": "gpu", "verbose": -1}
+        X, y = make_regression(40000, 12, seed=3)
+        bounds = np.linspace(0, len(y), world + 1).astype(int)
+        sl = slice(bounds[rank], bounds[rank + 1])
+        p = {**GPU, "num_leaves": 31, "tree_learner": "data"}
+        comm = default_comm()
+        assert isinstance(comm, TorchComm)
+        sample = gather_bin_sample(X[sl], p)
+        b = lgb.train(p, lgb.Dataset(X[sl], label=y[sl], params=p, bin_sample=sample), 6, comm=comm)
+        text = b.model_to_string()
+        cut = text[text.index("Tree=0"):text.index("end of trees")]
+        if rank == 0:
+            q = {**GPU, "num_leaves": 31}
+            s = lgb.train(q, lgb.Dataset(X, label=y, params=q, bin_sample=sample), 6).model_to_string()
+            assert cut == s[s.index("Tree=0"):s.index("end of trees")], "data-parallel trees differ from serial"
+        gathered = [None] * world
+        dist.all_gather_object(gathered, cut)
+        assert all(g == gathered[0] for g in gathered), "ranks disagree"
+        comm.close()
+        dist.destroy_process_group()
+        print("rank", rank, "ok", flush=True)
+    """) % root)
+
+    def launch(args, env=None):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), *args],
+                              capture_output=True, text=True, timeout=170, env=env)
+    r = launch([str(script)])
+    assert r.returncode == 0 and r.stdout.count("ok") == P, r.stdout[-2000:] + r.stderr[-2000:]
+    r = launch([os.path.join(root, "bench.py"), "--gpus", str(P), "--rows", "300000", "--steps", "4", "--warmup", "1"],
+               env=dict(os.environ, LGA_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 alone reports
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == P and out["steps"] == 4 and out["value"] > 0 and out["config"]["rows"] == 300000
