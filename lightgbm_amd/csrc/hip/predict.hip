@@ -3,13 +3,15 @@
 // prediction with the first k trees, bagging_boosting.ipynb:136).
 //
 // Trees are packed into 24-byte nodes and staged tile by tile through LDS
-// (as many trees per tile as fit ~120 KiB); a workgroup owns 1024 rows (4 per
-// lane, sums in registers) and walks every staged tree for them, so each tile
-// is read from L2 once per 1024 rows.
+// (as many trees per tile as fit 36 KiB, so four workgroups share a CU); a
+// workgroup owns 1024 rows (4 per lane, walked side by side, sums in registers)
+// and walks every staged tree for them, so each tile is read from L2 once per
+// 1024 rows.
 #include "hip_engine.hpp"
 #include "../gbdt.hpp"
 #include "../objective.hpp"
 #include <cstring>
+#include <type_traits>
 
 namespace lga {
 
@@ -25,7 +27,8 @@ static_assert(sizeof(PNode) == 24, "PNode layout");
 
 constexpr int kRowsPerLane = 4;
 constexpr int kPredThreads = 256;
-constexpr size_t kTileBytes = 120 * 1024;
+constexpr size_t kTileBytes = 36 * 1024;      // four 255-leaf trees; four workgroups (16 waves) share a CU's LDS
+constexpr size_t kMaxTileBytes = 120 * 1024;  // a single larger tree may claim up to this much
 
 __device__ __forceinline__ bool go_left_dev(double v, double thr, int dtype) {
   const int mt = (dtype >> 2) & 3;
@@ -64,23 +67,37 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const T* __restri
       for (int i = threadIdx.x; i < nl; i += kPredThreads) sl[i] = leaves[l0 + i];
     }
     __syncthreads();
+    // the lane's rows walk a tree side by side: their node / feature loads are independent, so the memory
+    // latency of one overlaps with the others'
+    const T* x[kRowsPerLane];
+    bool live[kRowsPerLane];
 #pragma unroll
     for (int j = 0; j < kRowsPerLane; ++j) {
       const int64_t r = r0 + (int64_t)j * kPredThreads;
-      if (r >= nrow) continue;
-      const T* x = X + r * (int64_t)ncol;
-      double s = 0.0;
-      for (int t = t0; t < t1; ++t) {
-        const int nb = node_off[t] - n0, lb = leaf_off[t] - l0;
-        const int tn = node_off[t + 1] - node_off[t];
-        int node = tn > 0 ? 0 : ~0;
-        while (node >= 0) {
-          const PNode nd = sn[nb + node];
-          node = go_left_dev((double)x[nd.feature], nd.threshold, nd.dtype) ? nd.left : nd.right;
+      live[j] = r < nrow;
+      x[j] = X + (live[j] ? r : 0) * (int64_t)ncol;
+    }
+    for (int t = t0; t < t1; ++t) {
+      const int nb = node_off[t] - n0, lb = leaf_off[t] - l0;
+      const int tn = node_off[t + 1] - node_off[t];
+      int node[kRowsPerLane];
+#pragma unroll
+      for (int j = 0; j < kRowsPerLane; ++j) node[j] = (tn > 0 && live[j]) ? 0 : ~0;
+      bool any = tn > 0;
+      while (any) {
+        any = false;
+#pragma unroll
+        for (int j = 0; j < kRowsPerLane; ++j) {
+          if (node[j] >= 0) {
+            const PNode nd = sn[nb + node[j]];
+            node[j] = go_left_dev((double)x[j][nd.feature], nd.threshold, nd.dtype) ? nd.left : nd.right;
+            any = any || node[j] >= 0;
+          }
         }
-        s += sl[lb + (~node)];
       }
-      sum[j] += s;
+#pragma unroll
+      for (int j = 0; j < kRowsPerLane; ++j)
+        if (live[j]) sum[j] += sl[lb + (~node[j])];
     }
   }
 #pragma unroll
@@ -91,6 +108,103 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const T* __restri
     if (average && n_trees > 0) s /= (double)n_trees;
     out[r] = raw ? s : transform_score(obj_kind, sigmoid, s);
   }
+}
+
+
+// ---------------------------------------------------------------------------
+// Narrow matrices (the row tile fits LDS next to the tree tile): the workgroup first copies its rows into
+// LDS transposed - xs[feature][row], so the lanes of a wave, each on its own row, read one feature value
+// from 64 consecutive words whatever feature each lane asks for - and packs nodes into 16 bytes (one
+// ds_read_b128 per step).  A step then touches LDS only; in the kernel above every step is a load of 64
+// different cache lines through the vector cache.
+// ---------------------------------------------------------------------------
+struct QNode {
+  double threshold;
+  int16_t feature, left, right, dtype;
+};
+static_assert(sizeof(QNode) == 16, "QNode layout");
+constexpr size_t kQTileBytes = 20 * 1024;   // three 255-leaf trees
+
+template <typename T, int R>
+__global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __restrict__ X, int64_t nrow, int ncol,
+                                                                   int nfeat,   // columns the model reads (<= ncol)
+                                                                   const QNode* __restrict__ nodes,
+                                                                   const double* __restrict__ leaves,
+                                                                   const int32_t* __restrict__ node_off,
+                                                                   const int32_t* __restrict__ leaf_off,
+                                                                   const int32_t* __restrict__ tile_begin,
+                                                                   int n_tiles, int n_trees, int average, int obj_kind,
+                                                                   double sigmoid, int raw, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kRows = kPredThreads * R;
+  T* xs = reinterpret_cast<T*>(smem);                                   // [nfeat][kRows]
+  char* tile = smem + (((size_t)nfeat * kRows * sizeof(T) + 15) & ~(size_t)15);
+  const int64_t base = (int64_t)blockIdx.x * kRows;
+  // coalesced read of the row-major block, transposed store
+  const int64_t block_vals = (int64_t)min((int64_t)kRows, nrow - base) * ncol;
+  for (int64_t i = threadIdx.x; i < block_vals; i += kPredThreads) {
+    const int r = (int)(i / ncol), c = (int)(i - (int64_t)r * ncol);
+    if (c < nfeat) xs[c * kRows + r] = X[base * ncol + i];
+  }
+  double sum[R];
+  bool live[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) { sum[j] = 0.0; live[j] = base + j * kPredThreads + threadIdx.x < nrow; }
+  for (int tl = 0; tl < n_tiles; ++tl) {
+    const int t0 = tile_begin[tl], t1 = tile_begin[tl + 1];
+    const int n0 = node_off[t0], nn = node_off[t1] - n0;
+    const int l0 = leaf_off[t0], nl = leaf_off[t1] - l0;
+    QNode* sn = reinterpret_cast<QNode*>(tile);
+    double* sl = reinterpret_cast<double*>(tile + (size_t)nn * sizeof(QNode));
+    __syncthreads();   // the previous tile is done with (first pass: the rows are in place)
+    {
+      const double2* src = reinterpret_cast<const double2*>(nodes + n0);
+      double2* dst = reinterpret_cast<double2*>(sn);
+      for (int i = threadIdx.x; i < nn; i += kPredThreads) dst[i] = src[i];
+      for (int i = threadIdx.x; i < nl; i += kPredThreads) sl[i] = leaves[l0 + i];
+    }
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+      const int nb = node_off[t] - n0, lb = leaf_off[t] - l0;
+      const int tn = node_off[t + 1] - node_off[t];
+      int node[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) node[j] = (tn > 0 && live[j]) ? 0 : ~0;
+      bool any = tn > 0;
+      while (any) {
+        any = false;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (node[j] >= 0) {
+            const QNode nd = sn[nb + node[j]];
+            const double v = (double)xs[(int)nd.feature * kRows + j * kPredThreads + threadIdx.x];
+            node[j] = go_left_dev(v, nd.threshold, nd.dtype) ? (int)nd.left : (int)nd.right;
+            any = any || node[j] >= 0;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (live[j]) sum[j] += sl[lb + (~node[j])];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    if (!live[j]) continue;
+    double s = sum[j];
+    if (average && n_trees > 0) s /= (double)n_trees;
+    out[base + j * kPredThreads + threadIdx.x] = raw ? s : transform_score(obj_kind, sigmoid, s);
+  }
+}
+
+// first parameter (const T* X) of a predictor kernel, for casting the untyped matrix pointer
+template <typename T, typename... A>
+const T* kernel_arg0(void (*)(const T*, A...));
+
+// LDS bytes of the row tile + tree tile of predict_lds_kernel<T, R>
+template <typename T, int R>
+size_t lds_kernel_bytes(int nfeat, size_t tile_limit) {
+  return (((size_t)nfeat * kPredThreads * R * sizeof(T) + 15) & ~(size_t)15) + tile_limit;
 }
 
 }  // namespace
@@ -107,17 +221,113 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
   int total = (int)trees.size();
   start_iter = std::max(0, std::min(start_iter, total));
   int n_it = b.used_iterations(start_iter, num_iter);
-  // pack the model
+  ObjectiveSpec obj = b.objective_spec();
+  const size_t esz = dtype == 0 ? 4 : 8;
+  const int64_t chunk = on_device ? nrow : std::min<int64_t>(nrow, std::max<int64_t>(1, (int64_t)((512u << 20) / (esz * (size_t)ncol))));
+  DeviceBuffer<char> stage;
+  DeviceBuffer<double> d_out;
+  if (!on_device) stage.resize((size_t)chunk * (size_t)ncol * esz);
+  if (!out_on_device) d_out.resize((size_t)std::max<int64_t>(chunk, 1));
+  // Runs `launch(x, n, o)` over the matrix in chunks (host matrices are staged through HBM).
+  auto for_each_chunk = [&](auto launch) {
+    for (int64_t r0 = 0; r0 < nrow; r0 += chunk) {
+      const int64_t n = std::min(chunk, nrow - r0);
+      const void* x;
+      if (on_device) x = (const char*)data + (size_t)r0 * (size_t)ncol * esz;
+      else {
+        LGA_HIP_CHECK(hipMemcpyAsync(stage.get(), (const char*)data + (size_t)r0 * (size_t)ncol * esz,
+                                     (size_t)n * (size_t)ncol * esz, hipMemcpyHostToDevice, s));
+        x = stage.get();
+      }
+      double* o = out_on_device ? out + r0 : d_out.get();
+      launch(x, n, o);
+      LGA_HIP_CHECK(hipGetLastError());
+      if (!out_on_device)
+        LGA_HIP_CHECK(hipMemcpyAsync(out + r0, d_out.get(), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
+      LGA_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+  };
+
+  // ---- narrow matrices: rows and trees both in LDS
+  {
+    const int nfeat = b.num_features();
+    int max_leaves = 1;
+    for (int t = 0; t < n_it; ++t) max_leaves = std::max(max_leaves, trees[(size_t)(start_iter + t)].num_leaves);
+    const size_t biggest = (size_t)(max_leaves - 1) * sizeof(QNode) + (size_t)max_leaves * sizeof(double);
+    const size_t q_limit = std::max(kQTileBytes, biggest);
+    const size_t row_budget = 64 * 1024;
+    const int R = (size_t)nfeat * kPredThreads * 2 * esz <= row_budget ? 2
+                : (size_t)nfeat * kPredThreads * esz <= row_budget     ? 1 : 0;
+    if (R > 0 && max_leaves <= 32768 && nfeat <= 32767 && q_limit <= 40 * 1024 && n_it > 0) {
+      std::vector<QNode> nodes;
+      std::vector<double> leaves;
+      std::vector<int32_t> node_off(1, 0), leaf_off(1, 0), tile_begin(1, 0);
+      size_t tile_bytes = 0;
+      for (int t = 0; t < n_it; ++t) {
+        const Tree& tr = trees[(size_t)(start_iter + t)];
+        const int ni = tr.num_leaves - 1;
+        const size_t bytes = (size_t)ni * sizeof(QNode) + (size_t)tr.num_leaves * sizeof(double);
+        if (tile_bytes + bytes > q_limit) { tile_begin.push_back(t); tile_bytes = 0; }
+        tile_bytes += bytes;
+        for (int i = 0; i < ni; ++i) {
+          QNode n;
+          n.threshold = tr.threshold[(size_t)i];
+          n.feature = (int16_t)tr.split_feature[(size_t)i];
+          n.left = (int16_t)tr.left_child[(size_t)i];
+          n.right = (int16_t)tr.right_child[(size_t)i];
+          n.dtype = (int16_t)tr.decision_type[(size_t)i];
+          nodes.push_back(n);
+        }
+        for (int l = 0; l < tr.num_leaves; ++l) leaves.push_back(tr.leaf_value[(size_t)l]);
+        node_off.push_back((int32_t)nodes.size());
+        leaf_off.push_back((int32_t)leaves.size());
+      }
+      tile_begin.push_back(n_it);
+      const int n_tiles = (int)tile_begin.size() - 1;
+      DeviceBuffer<QNode> d_nodes(std::max<size_t>(nodes.size(), 1));
+      DeviceBuffer<double> d_leaves(leaves.size());
+      DeviceBuffer<int32_t> d_noff(node_off.size()), d_loff(leaf_off.size()), d_tb(tile_begin.size());
+      if (!nodes.empty()) d_nodes.upload(nodes.data(), nodes.size(), s);
+      d_leaves.upload(leaves.data(), leaves.size(), s);
+      d_noff.upload(node_off.data(), node_off.size(), s);
+      d_loff.upload(leaf_off.data(), leaf_off.size(), s);
+      d_tb.upload(tile_begin.data(), tile_begin.size(), s);
+      const int avg = b.average_output() ? 1 : 0, raw = type == kPredictRaw ? 1 : 0;
+      auto run = [&](auto kernel, size_t lds) {
+        LGA_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for_each_chunk([&](const void* x, int64_t n, double* o) {
+          const int rows_per_wg = kPredThreads * R;
+          dim3 grid((unsigned)((n + rows_per_wg - 1) / rows_per_wg));
+          using XT = typename std::remove_pointer<decltype(kernel_arg0(kernel))>::type;
+          hipLaunchKernelGGL(kernel, grid, dim3(kPredThreads), lds, s, (XT*)x, n, ncol, nfeat, d_nodes.get(),
+                             d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it, avg, obj.kind,
+                             obj.sigmoid, raw, o);
+        });
+      };
+      if (dtype == 0 && R == 2) run(predict_lds_kernel<float, 2>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
+      else if (dtype == 0) run(predict_lds_kernel<float, 1>, lds_kernel_bytes<float, 1>(nfeat, q_limit));
+      else if (R == 2) run(predict_lds_kernel<double, 2>, lds_kernel_bytes<double, 2>(nfeat, q_limit));
+      else run(predict_lds_kernel<double, 1>, lds_kernel_bytes<double, 1>(nfeat, q_limit));
+      return;
+    }
+  }
+
+  // ---- wide matrices: trees in LDS, feature values through the vector cache
   std::vector<PNode> nodes;
   std::vector<double> leaves;
   std::vector<int32_t> node_off(1, 0), leaf_off(1, 0), tile_begin(1, 0);
-  size_t tile_bytes = 0;
+  size_t tile_bytes = 0, tile_limit = kTileBytes;
+  for (int t = 0; t < n_it; ++t) {
+    const Tree& tr = trees[(size_t)(start_iter + t)];
+    tile_limit = std::max(tile_limit, (size_t)(tr.num_leaves - 1) * sizeof(PNode) + (size_t)tr.num_leaves * sizeof(double));
+  }
+  if (tile_limit > kMaxTileBytes) throw std::runtime_error("a tree is too large for the device predictor's LDS tile");
   for (int t = 0; t < n_it; ++t) {
     const Tree& tr = trees[(size_t)(start_iter + t)];
     int ni = tr.num_leaves - 1;
     size_t bytes = (size_t)ni * sizeof(PNode) + (size_t)tr.num_leaves * sizeof(double);
-    if (bytes > kTileBytes) throw std::runtime_error("a tree is too large for the device predictor's LDS tile");
-    if (tile_bytes + bytes > kTileBytes) { tile_begin.push_back(t); tile_bytes = 0; }
+    if (tile_bytes + bytes > tile_limit) { tile_begin.push_back(t); tile_bytes = 0; }
     tile_bytes += bytes;
     for (int i = 0; i < ni; ++i) {
       PNode n;
@@ -143,44 +353,23 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
   d_noff.upload(node_off.data(), node_off.size(), s);
   d_loff.upload(leaf_off.data(), leaf_off.size(), s);
   d_tb.upload(tile_begin.data(), tile_begin.size(), s);
-  ObjectiveSpec obj = b.objective_spec();
-  const size_t esz = dtype == 0 ? 4 : 8;
-  int64_t chunk = on_device ? nrow : std::min<int64_t>(nrow, std::max<int64_t>(1, (int64_t)((512u << 20) / (esz * (size_t)ncol))));
-  DeviceBuffer<char> stage;
-  DeviceBuffer<double> d_out;
-  if (!on_device) stage.resize((size_t)chunk * (size_t)ncol * esz);
-  if (!out_on_device) d_out.resize((size_t)std::max<int64_t>(chunk, 1));
   static bool attr_set[2] = {false, false};
   if (!attr_set[dtype]) {
-    if (dtype == 0) LGA_HIP_CHECK(hipFuncSetAttribute((const void*)predict_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileBytes));
-    else LGA_HIP_CHECK(hipFuncSetAttribute((const void*)predict_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTileBytes));
+    if (dtype == 0) LGA_HIP_CHECK(hipFuncSetAttribute((const void*)predict_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTileBytes));
+    else LGA_HIP_CHECK(hipFuncSetAttribute((const void*)predict_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTileBytes));
     attr_set[dtype] = true;
   }
-  for (int64_t r0 = 0; r0 < nrow; r0 += chunk) {
-    int64_t n = std::min(chunk, nrow - r0);
-    const void* x;
-    if (on_device) x = (const char*)data + (size_t)r0 * (size_t)ncol * esz;
-    else {
-      LGA_HIP_CHECK(hipMemcpyAsync(stage.get(), (const char*)data + (size_t)r0 * (size_t)ncol * esz,
-                                   (size_t)n * (size_t)ncol * esz, hipMemcpyHostToDevice, s));
-      x = stage.get();
-    }
-    double* o = out_on_device ? out + r0 : d_out.get();
+  for_each_chunk([&](const void* x, int64_t n, double* o) {
     dim3 grid((unsigned)((n + kPredThreads * kRowsPerLane - 1) / (kPredThreads * kRowsPerLane)));
     if (dtype == 0)
-      hipLaunchKernelGGL(predict_kernel<float>, grid, dim3(kPredThreads), kTileBytes, s, (const float*)x, n, ncol,
+      hipLaunchKernelGGL(predict_kernel<float>, grid, dim3(kPredThreads), tile_limit, s, (const float*)x, n, ncol,
                          d_nodes.get(), d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it,
                          b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
     else
-      hipLaunchKernelGGL(predict_kernel<double>, grid, dim3(kPredThreads), kTileBytes, s, (const double*)x, n, ncol,
+      hipLaunchKernelGGL(predict_kernel<double>, grid, dim3(kPredThreads), tile_limit, s, (const double*)x, n, ncol,
                          d_nodes.get(), d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it,
                          b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
-    LGA_HIP_CHECK(hipGetLastError());
-    if (!out_on_device)
-      LGA_HIP_CHECK(hipMemcpyAsync(out + r0, d_out.get(), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s));
-    LGA_HIP_CHECK(hipStreamSynchronize(s));
-  }
-  LGA_HIP_CHECK(hipStreamSynchronize(s));
+  });
 }
 
 }  // namespace lga

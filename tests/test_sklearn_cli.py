@@ -51,3 +51,21 @@ def test_cli_train_predict_convert(tmp_path):
     assert np.corrcoef(p, y)[0, 1] > 0.9
     r = run("task=convert_model", f"input_model={model}", f"convert_model={js}")
     assert r.returncode == 0 and len(json.load(open(js))["tree_info"]) == 20
+
+
+def test_estimators_work_inside_sklearn_grid_search():
+    """"While already available in Python's sklearn" ("LightGBM R.ipynb", purpose cell): the estimators clone,
+    take parameters and score like any scikit-learn regressor, so GridSearchCV drives them directly."""
+    from sklearn.base import clone
+    from sklearn.model_selection import GridSearchCV, cross_val_score
+    from lightgbm_amd.utils.datasets import make_diamonds_like
+    X, y = make_diamonds_like(3000, seed=3)
+    est = LGBMRegressor(n_estimators=30, device_type="cpu", verbose=-1)
+    twin = clone(est)
+    assert twin.get_params()["n_estimators"] == 30 and twin is not est
+    gs = GridSearchCV(est, {"learning_rate": [0.3, 0.03], "num_leaves": [7, 31]}, cv=3,
+                      scoring="neg_root_mean_squared_error").fit(X, y)
+    assert set(gs.best_params_) == {"learning_rate", "num_leaves"} and gs.best_params_["learning_rate"] == 0.3
+    assert gs.best_estimator_.predict(X[:5]).shape == (5,)
+    scores = cross_val_score(LGBMClassifier(n_estimators=10, device_type="cpu", verbose=-1), X, (y > np.median(y)).astype(int), cv=3)
+    assert scores.mean() > 0.9
