@@ -50,6 +50,9 @@ class TreeBackend {
   // task i's left / right child.  The backend fills the chunk fields of the tasks.
   virtual void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) = 0;
   virtual QuantScale quant_scale() const = 0;
+  // Monotone constraints: the output range of a node, announced before the round that creates the node is
+  // submitted (node 0 is unbounded).  Never called when no feature is constrained.
+  virtual void set_node_bounds(int node, double lo, double hi) = 0;
   // Local row count of a node (after the round that created it).
   virtual int64_t node_local_count(int node) const = 0;
 

@@ -44,6 +44,9 @@ struct SplitParams {
   int32_t max_depth;  // <=0: unlimited
   double bynode_fraction;   // feature_fraction_bynode (>= 1: every enabled feature at every node)
   uint64_t bynode_seed;     // differs per tree
+  // Monotone constraints (device backend): output range [2 * node], [2 * node + 1] of every node, in the
+  // backend's memory space; nullptr when no feature of the tree is constrained.
+  const double* node_bounds;
 };
 
 // Power-of-two scales of the current boosting iteration: real = q * 2^-k.
@@ -108,7 +111,7 @@ struct FeatureMeta {
   int32_t num_bin;      // bins in use (<=256)
   int32_t missing_bin;  // index of the NaN bin or -1
   int32_t enabled;      // 0 when masked out by feature_fraction for this tree
-  int32_t pad;
+  int32_t monotone;     // +1: the output may not decrease with the feature, -1: may not increase, 0: free
 };
 
 // ---- arithmetic ----------------------------------------------------------
@@ -181,14 +184,33 @@ struct LeafScanCtx {
   double gunit, hunit;
   double cnt_factor;    // rows per quantised hessian unit
   double parent_gain;
+  double lo, hi;        // monotone constraints: the range this leaf's (and its descendants') outputs must stay in
+  int32_t bounded;      // lo / hi are not both infinite
 };
 
-LGA_HD LeafScanCtx make_scan_ctx(int64_t tg, int64_t th, int64_t tc, double gunit, double hunit, const SplitParams& p) {
+LGA_HD double clamp_output(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Objective reduction of a leaf that is given the output `out` (equals leaf_gain at the unconstrained optimum).
+LGA_HD double gain_given_output(double g, double h, double l1, double l2, double out) {
+  const double t = threshold_l1(g, l1);
+  return -(2.0 * t * out + (h + l2) * out * out);
+}
+
+LGA_HD LeafScanCtx make_scan_ctx(int64_t tg, int64_t th, int64_t tc, double gunit, double hunit, const SplitParams& p,
+                                 double lo = -std::numeric_limits<double>::infinity(),
+                                 double hi = std::numeric_limits<double>::infinity()) {
   LeafScanCtx c;
   c.total_g = tg; c.total_h = th; c.total_cnt = tc;
   c.gunit = gunit; c.hunit = hunit;
   c.cnt_factor = th > 0 ? (double)tc / (double)th : 0.0;
-  c.parent_gain = leaf_gain((double)tg * gunit, (double)th * hunit, p.lambda_l1, p.lambda_l2);
+  c.lo = lo; c.hi = hi;
+  c.bounded = (lo > -std::numeric_limits<double>::infinity() || hi < std::numeric_limits<double>::infinity()) ? 1 : 0;
+  const double G = (double)tg * gunit, H = (double)th * hunit;
+  if (c.bounded) {
+    const double out = clamp_output(leaf_output(G, H, p.lambda_l1, p.lambda_l2, p.max_delta_step), lo, hi);
+    c.parent_gain = gain_given_output(G, H, p.lambda_l1, p.lambda_l2, out);
+  } else {
+    c.parent_gain = leaf_gain(G, H, p.lambda_l1, p.lambda_l2);
+  }
   return c;
 }
 
@@ -197,8 +219,10 @@ LGA_HD int64_t est_count(int64_t part_h, const LeafScanCtx& c) {
   return (int64_t)((double)part_h * c.cnt_factor + 0.5);
 }
 
-// Gain of one candidate split or -inf when a constraint fails.
-LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const SplitParams& p) {
+// Gain of one candidate split or -inf when a constraint fails.  monotone: the split feature's constraint.
+// In a leaf with an output range, or on a constrained feature, the children's outputs are clamped to the
+// range, must be ordered as the constraint asks, and the gain is the one those outputs really achieve.
+LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const SplitParams& p, int monotone = 0) {
   const double ninf = -std::numeric_limits<double>::infinity();
   int64_t rg = c.total_g - lg, rh = c.total_h - lh;
   int64_t lc = est_count(lh, c);
@@ -207,7 +231,16 @@ LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const Spl
   double lhr = (double)lh * c.hunit, rhr = (double)rh * c.hunit;
   if (lhr < p.min_sum_hessian_in_leaf || rhr < p.min_sum_hessian_in_leaf) return ninf;
   double lgr = (double)lg * c.gunit, rgr = (double)rg * c.gunit;
-  double gain = leaf_gain(lgr, lhr, p.lambda_l1, p.lambda_l2) + leaf_gain(rgr, rhr, p.lambda_l1, p.lambda_l2) - c.parent_gain;
+  double gain;
+  if (c.bounded || monotone != 0) {
+    const double lo_ = clamp_output(leaf_output(lgr, lhr, p.lambda_l1, p.lambda_l2, p.max_delta_step), c.lo, c.hi);
+    const double ro_ = clamp_output(leaf_output(rgr, rhr, p.lambda_l1, p.lambda_l2, p.max_delta_step), c.lo, c.hi);
+    if ((monotone > 0 && lo_ > ro_) || (monotone < 0 && lo_ < ro_)) return ninf;
+    gain = gain_given_output(lgr, lhr, p.lambda_l1, p.lambda_l2, lo_) + gain_given_output(rgr, rhr, p.lambda_l1, p.lambda_l2, ro_) -
+           c.parent_gain;
+  } else {
+    gain = leaf_gain(lgr, lhr, p.lambda_l1, p.lambda_l2) + leaf_gain(rgr, rhr, p.lambda_l1, p.lambda_l2) - c.parent_gain;
+  }
   if (!(gain > p.min_gain_to_split)) return ninf;
   return gain;
 }

@@ -9,7 +9,7 @@
 namespace lga {
 namespace {
 
-enum class PType { Int, Double, Bool, String, StringList };
+enum class PType { Int, Double, Bool, String, StringList, IntList };
 
 struct ParamDef {
   const char* name;
@@ -46,6 +46,7 @@ const ParamDef kParams[] = {
     P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
+    P(monotone_constraints, "mc,monotone_constraint,monotonic_cst", IntList, -1, 1),
     P(drop_rate, "rate_drop", Double, 0, 1.0),
     P(max_drop, "", Int, kNone, kNone),
     P(skip_drop, "", Double, 0, 1.0),
@@ -218,6 +219,21 @@ void Config::set(const std::map<std::string, std::string>& kv) {
         }
         break;
       }
+      case PType::IntList: {
+        auto& lst = field<std::vector<int>>(this, p->offset);
+        lst.clear();
+        for (auto& m : split(val, ',')) {
+          std::string t = trim(m);
+          if (t.empty()) continue;
+          double d = std::strtod(t.c_str(), &end);
+          if (end == t.c_str() || *end != '\0' || d != (double)(long long)d)
+            throw std::runtime_error("parameter " + key + " expects integers, got \"" + t + "\"");
+          if ((p->lo == p->lo && d < p->lo) || (p->hi == p->hi && d > p->hi))
+            throw std::runtime_error("parameter " + key + ": value " + t + " is out of range");
+          lst.push_back((int)d);
+        }
+        break;
+      }
     }
     if (std::find(explicit_keys.begin(), explicit_keys.end(), p->name) == explicit_keys.end())
       explicit_keys.push_back(p->name);
@@ -385,6 +401,11 @@ std::string Config::to_model_string() const {
       case PType::String: os << cfield<std::string>(this, p.offset); break;
       case PType::StringList: {
         const auto& l = cfield<std::vector<std::string>>(this, p.offset);
+        for (size_t i = 0; i < l.size(); ++i) os << (i ? "," : "") << l[i];
+        break;
+      }
+      case PType::IntList: {
+        const auto& l = cfield<std::vector<int>>(this, p.offset);
         for (size_t i = 0; i < l.size(); ++i) os << (i ? "," : "") << l[i];
         break;
       }

@@ -167,7 +167,7 @@ std::vector<FeatureMeta> Dataset::feature_meta() const {
     m[(size_t)f].num_bin = bm.num_bin;
     m[(size_t)f].missing_bin = bm.missing_bin;
     m[(size_t)f].enabled = 1;
-    m[(size_t)f].pad = 0;
+    m[(size_t)f].monotone = 0;
   }
   return m;
 }

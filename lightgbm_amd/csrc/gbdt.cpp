@@ -114,6 +114,12 @@ double Booster::boost_from_average() {
 std::vector<FeatureMeta> Booster::sample_features(int cls) {
   std::vector<FeatureMeta> meta = train_->feature_meta();
   int F = (int)meta.size();
+  if (!cfg_.monotone_constraints.empty()) {
+    if ((int)cfg_.monotone_constraints.size() != train_->num_total_features())
+      throw std::runtime_error("monotone_constraints lists " + std::to_string(cfg_.monotone_constraints.size()) +
+                               " values, the data has " + std::to_string(train_->num_total_features()) + " features");
+    for (int f = 0; f < F; ++f) meta[(size_t)f].monotone = cfg_.monotone_constraints[(size_t)train_->real_feature(f)];
+  }
   double ff = cfg_.feature_fraction;
   if (ff >= 1.0 || F <= 1) return meta;
   int k = std::max(1, (int)(F * ff + 0.5));

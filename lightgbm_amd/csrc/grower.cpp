@@ -23,6 +23,7 @@ SplitParams TreeGrower::split_params() const {
   p.min_data_in_leaf = cfg_.min_data_in_leaf;
   p.max_depth = cfg_.max_depth;
   p.bynode_fraction = cfg_.feature_fraction_bynode;
+  p.node_bounds = nullptr;
   p.bynode_seed = mix64((uint64_t)cfg_.feature_fraction_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x51ed27ull);
   return p;
 }
@@ -82,6 +83,16 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   stats_.rounds = 1;
   const QuantScale qs = be.quant_scale();
   const double gunit = unit_of(qs.kg), hunit = unit_of(qs.kh);
+  bool any_monotone = false;
+  for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
+  // outputs of the two children of `n`'s best split, inside n's range
+  auto child_outputs = [&](const Node& n, double* lv, double* rv) {
+    const SplitInfo& s = n.best;
+    const double lg = (double)s.left_g * gunit, lh = (double)s.left_h * hunit;
+    const double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
+    *lv = clamp_output(leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step), n.lo, n.hi);
+    *rv = clamp_output(leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step), n.lo, n.hi);
+  };
 
   auto depth_blocked = [&](int depth) { return cfg_.max_depth > 0 && depth >= cfg_.max_depth; };
   if (depth_blocked(0)) nodes[0].best.feature = -1;
@@ -204,6 +215,22 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
         l.depth = r.depth = c.depth + 1;
         l.slot = t.hist_child == 0 ? t.new_slot : t.parent_slot;
         r.slot = t.hist_child == 1 ? t.new_slot : t.parent_slot;
+        if (any_monotone) {
+          // children inherit the range; a split on a constrained feature also separates them at the
+          // midpoint of their outputs, which keeps every later descendant on its side
+          l.lo = r.lo = c.lo;
+          l.hi = r.hi = c.hi;
+          const int mono = meta[(size_t)c.best.feature].monotone;
+          if (mono != 0) {
+            double lv, rv;
+            child_outputs(c, &lv, &rv);
+            const double mid = 0.5 * (lv + rv);
+            if (mono > 0) { l.hi = std::min(l.hi, mid); r.lo = std::max(r.lo, mid); }
+            else { l.lo = std::max(l.lo, mid); r.hi = std::min(r.hi, mid); }
+          }
+          be.set_node_bounds(t.left_node, l.lo, l.hi);
+          be.set_node_bounds(t.right_node, r.lo, r.hi);
+        }
         c.left = t.left_node;
         c.right = t.right_node;
         nodes.push_back(l);
@@ -267,6 +294,10 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
     double lv = leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
     double rv = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+    if (any_monotone) {
+      lv = clamp_output(lv, nodes[(size_t)n.left].lo, nodes[(size_t)n.left].hi);
+      rv = clamp_output(rv, nodes[(size_t)n.right].lo, nodes[(size_t)n.right].hi);
+    }
     // exact child counts come from the children's own scans
     int64_t lc = nodes[(size_t)n.left].best.total_cnt, rc = nodes[(size_t)n.right].best.total_cnt;
     // "every value left, only missing right" has an infinite bin bound: keep the model text finite

@@ -15,6 +15,7 @@
 // leaf whose speculative split never gets its turn stays a leaf; its rows are
 // then found in the ranges of its partitioned descendants (LeafPiece).
 #pragma once
+#include <limits>
 #include "backend.hpp"
 #include "config.hpp"
 #include "dataset.hpp"
@@ -54,6 +55,8 @@ class TreeGrower {
     int left = -1, right = -1;   // children node ids once the leaf's split has been submitted
     bool ready = false;          // ... and once that round's results are in
     uint32_t key = kRootNodeKey; // position key (per-node feature sampling)
+    double lo = -std::numeric_limits<double>::infinity();   // output range (monotone constraints)
+    double hi = std::numeric_limits<double>::infinity();
     SplitInfo best;
   };
   const Config cfg_;

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <numeric>
 #include <sstream>
 
@@ -222,8 +223,26 @@ class HipBackend : public TreeBackend {
   ParallelMode mode() const { return mode_; }
   PhaseProfile prof;
 
+  void set_node_bounds(int node, double lo, double hi) override {
+    double* b = reinterpret_cast<double*>(bounds_host_.get());
+    b[2 * (size_t)node] = lo;
+    b[2 * (size_t)node + 1] = hi;
+  }
+
   void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
     sp_ = params;
+    // Monotone constraints: node output ranges live in a device array the scan reads (SplitParams::
+    // node_bounds); the grower announces them per node, every round uploads the entries of its children.
+    ranged_ = false;
+    for (const FeatureMeta& m : meta) ranged_ = ranged_ || (m.enabled && m.monotone != 0);
+    if (ranged_) {
+      const size_t n_nodes = (size_t)(2 * capacity_splits_ + 2);
+      bounds_host_.resize(n_nodes * 2);
+      bounds_dev_.resize(n_nodes * 2);
+      set_node_bounds(0, -std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity());
+      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get(), bounds_host_.get(), 2 * sizeof(double), hipMemcpyHostToDevice, stream_));
+      sp_.node_bounds = bounds_dev_.get();
+    }
     if (meta.size() != meta_host_.size() ||
         std::memcmp(meta.data(), meta_host_.data(), sizeof(FeatureMeta) * meta.size()) != 0) {
       meta_host_ = meta;
@@ -433,6 +452,13 @@ class HipBackend : public TreeBackend {
       comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true,
                                st_);
     prof.mark(PhaseProfile::kScan, st_);
+    if (ranged_ && !root) {
+      // the children of a round's tasks have consecutive node ids
+      int first = tasks[0].left_node, last = tasks[0].right_node;
+      for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
+      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get() + 2 * (size_t)first, bounds_host_.get() + 2 * (size_t)first,
+                                   2 * sizeof(double) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    }
     char* hres = x.host_block.get() + k::kHostDataOffset;
     if (fused) {
       if (++x.seq == 0) ++x.seq;   // never 0
@@ -559,6 +585,9 @@ class HipBackend : public TreeBackend {
   std::vector<NodeRange> ranges_host_;
   size_t off_tasks_ = 0, off_scan_ = 0, off_pch_ = 0, off_hch_ = 0, stage_bytes_ = 0;
   SplitParams sp_{};
+  bool ranged_ = false;                 // a feature of the current tree carries a monotone constraint
+  PinnedBuffer<double> bounds_host_;    // [node][lo, hi]
+  DeviceBuffer<double> bounds_dev_;
   QuantScale qs_host_{0, 0};
   const int32_t* bag_ = nullptr;
   int64_t bag_n_ = 0;

@@ -666,9 +666,9 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
     const int thr = lane * 4 + j;
     if (thr <= last) {
       const int64_t lg = eg + g[j], lh = eh + h[j];
-      take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp), cand_key(f, thr, 0), lg, lh);
+      take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp, m.monotone), cand_key(f, thr, 0), lg, lh);
       if (mb >= 0 && thr <= vb - 2)
-        take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp), cand_key(f, thr, 1), lg + mg, lh + mh);
+        take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp, m.monotone), cand_key(f, thr, 1), lg + mg, lh + mh);
     }
   }
 #pragma unroll
@@ -717,7 +717,10 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
     return;
   }
   const QuantScale q = *qs;
-  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp);
+  const double kInf = std::numeric_limits<double>::infinity();
+  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
+                                        sp.node_bounds ? sp.node_bounds[2 * t.node] : -kInf,
+                                        sp.node_bounds ? sp.node_bounds[2 * t.node + 1] : kInf);
   const int64_t* sb = t.parent_slot >= 0 ? pool + (int64_t)t.sibling_slot * slot_words : nullptr;
   double bg = ninf;
   uint64_t bkey = ~0ull;
@@ -803,7 +806,10 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
     tc = pt[0] - sh[0]; tg = pt[1] - sh[1]; th = pt[2] - sh[2];
   }
   const QuantScale q = *qs;
-  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp);
+  const double kInf = std::numeric_limits<double>::infinity();
+  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
+                                        sp.node_bounds ? sp.node_bounds[2 * node] : -kInf,
+                                        sp.node_bounds ? sp.node_bounds[2 * node + 1] : kInf);
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;

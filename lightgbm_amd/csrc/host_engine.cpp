@@ -64,6 +64,14 @@ class HostBackend : public TreeBackend {
   int node_capacity() const override { return 2 * capacity_splits_ + 1; }
   QuantScale quant_scale() const override { return qs_; }
   int64_t node_local_count(int node) const override { return ranges_[(size_t)node].count; }
+  void set_node_bounds(int node, double lo, double hi) override {
+    if (bounds_.empty()) {
+      bounds_.assign(ranges_.size() * 2, 0.0);
+      for (size_t i = 0; i < ranges_.size(); ++i) { bounds_[2 * i] = -kInf; bounds_[2 * i + 1] = kInf; }
+    }
+    bounds_[2 * (size_t)node] = lo;
+    bounds_[2 * (size_t)node + 1] = hi;
+  }
   // Rounds run at submission here; LGA_HOST_IN_FLIGHT=2 lets the tests drive the grower's
   // several-rounds-in-flight logic through this backend.
   int max_in_flight() const override {
@@ -76,6 +84,7 @@ class HostBackend : public TreeBackend {
   void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
     meta_ = meta;
     sp_ = params;
+    bounds_.clear();   // filled again by the grower when a feature of this tree is constrained
     for (int b = 0; b < 2; ++b)
       if ((int64_t)arena_[b].size() < bag_n_) arena_[b].resize((size_t)bag_n_);
     std::memcpy(arena_[0].data(), bag_, (size_t)bag_n_ * sizeof(int32_t));
@@ -211,11 +220,11 @@ class HostBackend : public TreeBackend {
     for (int t = 0; t <= last; ++t) {
       lg += g[t];
       lh += h[t];
-      double ga = split_gain(lg, lh, ctx, sp_);
+      double ga = split_gain(lg, lh, ctx, sp_, m.monotone);
       uint64_t ka = cand_key(f, t, 0);
       if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, lg, lh};
       if (mb >= 0 && t <= vb - 2) {
-        double gb = split_gain(lg + mg, lh + mh, ctx, sp_);
+        double gb = split_gain(lg + mg, lh + mh, ctx, sp_, m.monotone);
         uint64_t kb = cand_key(f, t, 1);
         if (cand_better(gb, kb, best->gain, best->key)) *best = Cand{gb, kb, lg + mg, lh + mh};
       }
@@ -238,7 +247,9 @@ class HostBackend : public TreeBackend {
       }
       const int64_t* hd = self + 2 * plane_;
       int64_t tc = hd[0], tg = hd[1], th = hd[2];
-      LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_);
+      const bool ranged = !bounds_.empty();
+      LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_, ranged ? bounds_[2 * (size_t)s.node] : -kInf,
+                                      ranged ? bounds_[2 * (size_t)s.node + 1] : kInf);
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
         if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_)) continue;
@@ -279,6 +290,8 @@ class HostBackend : public TreeBackend {
     }
   }
 
+  static constexpr double kInf = std::numeric_limits<double>::infinity();
+  std::vector<double> bounds_;   // [node][lo, hi]; empty unless monotone constraints are active
   const Dataset* root_;
   Comm* comm_;
   ParallelMode mode_;

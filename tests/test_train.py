@@ -187,6 +187,42 @@ def test_other_objectives_train():
     assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
 
 
+def test_monotone_constraints_hold_everywhere():
+    """+1 / -1 constraints: along a constrained feature, with all other features held fixed, the prediction
+    never moves the wrong way - checked on sweeps through many random base points; the unconstrained model on
+    the same noisy data does violate it."""
+    rng = np.random.RandomState(41)
+    n = 6000
+    X = rng.rand(n, 4) * 4 - 2
+    y = 1.5 * X[:, 0] + np.sin(4 * X[:, 0]) - X[:, 1] ** 3 / 3 + np.cos(3 * X[:, 2]) + 0.5 * rng.randn(n)
+    d = lgb.Dataset(X, label=y, params=CPU)
+    p = {**CPU, "num_leaves": 31, "min_data_in_leaf": 10, "learning_rate": 0.2}
+    free = lgb.train(p, d, 40)
+    mono = lgb.train({**p, "monotone_constraints": [1, -1, 0, 0]}, d, 40)
+
+    def violations(b, feature, sign):
+        grid = np.linspace(-2, 2, 60)
+        worst = 0.0
+        for base in X[:80]:
+            rows = np.tile(base, (len(grid), 1))
+            rows[:, feature] = grid
+            step = np.diff(b.predict(rows)) * sign
+            worst = min(worst, step.min())
+        return worst
+    assert violations(mono, 0, +1) >= -1e-12 and violations(mono, 1, -1) >= -1e-12
+    assert violations(free, 0, +1) < -0.05          # sin(4x) + noise: the free model wiggles
+    assert rmse(mono.predict(X), y) < 1.5 * rmse(free.predict(X), y)
+    assert "[monotone_constraints: 1,-1,0,0]" in mono.model_to_string()
+    # deterministic batching: speculative growth picks the same splits as one leaf at a time
+    one = lgb.train({**p, "monotone_constraints": [1, -1, 0, 0], "max_batch_leaves": 1}, d, 10)
+    many = lgb.train({**p, "monotone_constraints": [1, -1, 0, 0]}, d, 10)
+    assert trees_of(one) == trees_of(many)
+    with pytest.raises(Exception, match="monotone_constraints"):
+        lgb.train({**p, "monotone_constraints": [1, 0]}, d, 2)
+    with pytest.raises(Exception):
+        lgb.train({**p, "monotone_constraints": [2, 0, 0, 0]}, d, 2)
+
+
 def test_dart_rescales_muted_trees_and_keeps_scores_and_model_in_step():
     X, y = make_regression(5000, 8, seed=33)
     d = lgb.Dataset(X[:4000], label=y[:4000], params=CPU)
