@@ -1,0 +1,120 @@
+"""Writes docs/PARAMETERS.md from the native parameter table (names, aliases, defaults) plus the notes below.
+
+    python tools/gen_param_docs.py
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+NOTES = {
+    "boosting": "`gbdt`, `rf` (random forest: bagged trees on the initial gradients, averaged output), `dart`; `goss` is accepted and means `gbdt` with `data_sample_strategy=goss`",
+    "objective": "`regression`, `regression_l1`, `huber`, `fair`, `poisson`, `quantile`, `mape`, `gamma`, `tweedie`, `binary`, `cross_entropy`, `multiclass`, `multiclassova`, `custom` (gradients from `fobj`)",
+    "metric": "comma list; empty = the objective's own loss. `l2`, `rmse`, `l1`, `huber`, `fair`, `poisson`, `quantile`, `mape`, `gamma`, `gamma_deviance`, `tweedie`, `binary_logloss`, `binary_error`, `auc`, `cross_entropy`, `multi_logloss`, `multi_error`, `none`",
+    "tree_learner": "`serial`, `data` (rows sharded over ranks, one integer histogram all-reduce per growth round), `feature` (every rank scans its feature tiles, winners exchanged); `voting` is served by `data`",
+    "device_type": "`gpu` (HIP engine, default when a GPU is visible) or `cpu` (OpenMP engine, same numerics)",
+    "num_iterations": "boosting rounds (`nrounds` in the R-style entry points)",
+    "learning_rate": "shrinkage of every tree",
+    "num_leaves": "leaf budget of the best-first growth",
+    "max_depth": "<= 0: unlimited",
+    "min_data_in_leaf": "minimum rows per child",
+    "min_sum_hessian_in_leaf": "minimum hessian sum per child",
+    "min_gain_to_split": "a split must improve the objective by more than this",
+    "lambda_l1": "L1 regularisation of leaf outputs",
+    "lambda_l2": "L2 regularisation of leaf outputs",
+    "max_delta_step": "cap on |leaf output| (<= 0: none)",
+    "max_bin": "bins per feature, at most 255 value bins + a missing-value bin",
+    "min_data_in_bin": "minimum sampled rows per bin",
+    "bin_construct_sample_cnt": "rows sampled to find the bin boundaries",
+    "use_missing": "NaN gets its own bin and a learned default direction",
+    "zero_as_missing": "refused (NaN is the missing value)",
+    "feature_fraction": "share of the features offered to each tree",
+    "feature_fraction_bynode": "share of the features offered at each node (random-forest `mtry`)",
+    "feature_fraction_seed": "",
+    "bagging_fraction": "share of the rows in a bag (without replacement)",
+    "bagging_freq": "draw a new bag every k iterations (0: no bagging)",
+    "bagging_seed": "also seeds goss",
+    "data_sample_strategy": "`bagging` or `goss` (keep the `top_rate` rows with the largest |g h|, sample `other_rate` of the rest and up-weight them)",
+    "top_rate": "goss", "other_rate": "goss",
+    "monotone_constraints": "comma list, one of -1 / 0 / +1 per column: the prediction may not increase / is free / may not decrease with that feature",
+    "drop_rate": "dart: share of the existing iterations muted per iteration",
+    "max_drop": "dart: at most this many (<= 0: no limit)",
+    "skip_drop": "dart: chance of an iteration without muting",
+    "uniform_drop": "dart: mute uniformly instead of proportionally to the trees' weights",
+    "xgboost_dart_mode": "dart: xgboost's normalisation",
+    "drop_seed": "dart",
+    "sigmoid": "binary / multiclassova: steepness of the link",
+    "num_class": "multiclass objectives: number of classes (= trees per iteration)",
+    "is_unbalance": "binary: weigh the classes to equal total weight",
+    "scale_pos_weight": "binary: weight multiplier of the positive class",
+    "boost_from_average": "start from the label mean / log-odds / class priors",
+    "alpha": "huber threshold; quantile level",
+    "fair_c": "fair loss constant",
+    "poisson_max_delta_step": "poisson: safeguard term in the hessian",
+    "tweedie_variance_power": "tweedie: in [1, 2)",
+    "num_threads": "CPU engine threads (0: OpenMP default)",
+    "seed": "sets the other seeds",
+    "verbose": "< 0 fatal only, 0 warnings, 1 info",
+    "early_stopping_round": "stop when no validation metric improved for this many rounds",
+    "first_metric_only": "early stopping looks at the first metric only",
+    "metric_freq": "evaluate every k iterations",
+    "is_provide_training_metric": "record the training metric too",
+    "snapshot_freq": "write `<output_model>.snapshot_iter_<k>` every k iterations (resume with `init_model`)",
+    "output_model": "CLI: model file written by `task=train`",
+    "input_model": "CLI: model file read by `task=predict` / continued training",
+    "num_machines": "informational; the communicator defines the world",
+    "gpu_device_id": "informational; the current torch device is used",
+    "max_batch_leaves": "leaves split per device round (0: as many as the speculative growth wants; 1 reproduces one-leaf-at-a-time growth)",
+    "profile": "per-phase HIP-event timers, read with `Booster.profile()`",
+    "device_bin_find": "find bin boundaries on the device for GPU datasets (default on)",
+    "deterministic": "always on: integer histograms make every run, engine and rank count give the same trees",
+    "verbosity": "alias kept for LightGBM configs; see `verbose`",
+    "data_random_seed": "seed of the row sample for bin finding",
+    "feature_pre_filter": "accepted for compatibility; single-valued features are always dropped",
+    "iteration_offset": "first iteration index (tree-parallel forests: keeps every iteration's random streams)",
+}
+
+
+def main():
+    import numpy as np
+    import lightgbm_amd as lgb
+    from lightgbm_amd import _lib
+    lib, _ = _lib.load()
+    table = json.loads(lib.lga_alias_table_json().decode())
+    X = np.random.RandomState(0).randn(200, 3)
+    b = lgb.train({"device_type": "cpu", "verbose": -1}, lgb.Dataset(X, label=X[:, 0]), 1)
+    txt = b.model_to_string()
+    block = txt[txt.index("parameters:"):txt.index("end of parameters")]
+    defaults = {}
+    for ln in block.splitlines():
+        if ln.startswith("[") and ln.endswith("]") and ":" in ln:
+            k, v = ln[1:-1].split(":", 1)
+            defaults[k.strip()] = v.strip()
+    defaults["verbose"] = "1"
+    defaults["device_type"] = "gpu when visible, else cpu"
+    lines = ["# Parameters", "",
+             "Generated by `tools/gen_param_docs.py` from the native parameter table (`csrc/config.cpp`). Names and",
+             "aliases follow LightGBM; unknown keys produce a warning, out-of-range values an error. Parameters are",
+             "given as a dict (`params`), as keyword arguments of the R-style entry points, or as a one-row data frame",
+             "(a parameter-grid row: every value may arrive as a double).", "",
+             "| parameter | aliases | default | notes |", "|---|---|---|---|"]
+    for name, aliases in table.items():
+        d = defaults.get(name, "")
+        try:
+            d = repr(float(d)) if "." in d or "e" in d else d
+            d = d[:-2] if d.endswith(".0") else d
+        except ValueError:
+            pass
+        lines.append(f"| `{name}` | {', '.join('`%s`' % a for a in aliases)} | {d or '(empty)'} | {NOTES.get(name, '')} |")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "docs", "PARAMETERS.md")
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    missing = [n for n in table if n not in NOTES]
+    print(f"wrote {out}: {len(table)} parameters" + (f"; without a note: {missing}" if missing else ""))
+
+
+if __name__ == "__main__":
+    main()
