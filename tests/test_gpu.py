@@ -597,3 +597,24 @@ def test_multi_process_data_parallel_sharing_one_gpu(P, tmp_path):
     assert len(lines) == 1, r.stdout            # rank 0 alone reports
     out = json.loads(lines[0])
     assert out["n_gpus"] == P and out["steps"] == 4 and out["value"] > 0 and out["config"]["rows"] == 300000
+
+
+def test_grid_search_with_worker_processes_on_the_gpu(tmp_path):
+    """The task-parallel grid search (one worker process per listed device, rows pulled from a queue, durable
+    checkpoint): here three workers share GPU 0.  Same table as the in-process search; a finished checkpoint is
+    not recomputed."""
+    from lightgbm_amd.grid import expand_grid, grid_search_cv
+    X, y = make_diamonds_like(6000, seed=8)
+    grid = expand_grid(iteration=None, score=None, learning_rate=[0.3, 0.1], num_leaves=[7, 31], min_data_in_leaf=[20],
+                       bagging_fraction=[0.8, 1.0], bagging_freq=[4])
+    kw = dict(nrounds=60, nfold=3, objective="regression", early_stopping_rounds=3, seed=5, dataset_params=GPU,
+              base_params=GPU)
+    here = grid_search_cv(grid, X=X, y=y, **kw)
+    ck = str(tmp_path / "grid.jsonl")
+    spread = grid_search_cv(grid, X=X, y=y, workers=[0, 0, 0], checkpoint=ck, **kw)
+    assert spread["iteration"].tolist() == here["iteration"].tolist()
+    np.testing.assert_allclose(spread["score"].to_numpy(), here["score"].to_numpy(), rtol=0, atol=1e-12)
+    again = grid_search_cv(grid, X=X, y=y, workers=[0], checkpoint=ck, **kw)       # everything is in the checkpoint
+    assert again["score"].tolist() == spread["score"].tolist()
+    workers_used = {__import__("json").loads(ln)["worker"] for ln in open(ck)}
+    assert workers_used <= {"0"} and len(open(ck).readlines()) == len(grid)
