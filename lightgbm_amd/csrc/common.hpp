@@ -44,6 +44,9 @@ struct SplitParams {
   int32_t max_depth;  // <=0: unlimited
   double bynode_fraction;   // feature_fraction_bynode (>= 1: every enabled feature at every node)
   uint64_t bynode_seed;     // differs per tree
+  int32_t extra_trees;      // 1: only one random threshold per (node, feature) is a candidate
+  int32_t pad_;
+  uint64_t extra_seed;      // differs per tree
   // Monotone constraints (device backend): output range [2 * node], [2 * node + 1] of every node, in the
   // backend's memory space; nullptr when no feature of the tree is constrained.
   const double* node_bounds;
@@ -298,6 +301,13 @@ LGA_HD bool node_feature_on(const SplitParams& sp, uint32_t key, int f, int num_
   if (!(sp.bynode_fraction < 1.0)) return true;
   if ((int)(mix64(sp.bynode_seed ^ ((uint64_t)key << 24)) % (uint64_t)(num_features > 0 ? num_features : 1)) == f) return true;
   return rng_uniform(sp.bynode_seed, (uint64_t)key, (uint64_t)f) < (float)sp.bynode_fraction;
+}
+
+// extra_trees: the one threshold bin of feature f that is a candidate at the node with position key `key`
+// (thresholds 0 .. n_thresholds-1 exist); -1 = every threshold is a candidate.
+LGA_HD int extra_trees_threshold(const SplitParams& sp, uint32_t key, int f, int n_thresholds) {
+  if (!sp.extra_trees || n_thresholds <= 1) return -1;
+  return (int)(rng_u64(sp.extra_seed, (uint64_t)key, (uint64_t)f) % (uint64_t)n_thresholds);
 }
 
 LGA_HD double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }

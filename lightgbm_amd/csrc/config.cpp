@@ -58,6 +58,8 @@ const ParamDef kParams[] = {
     P(other_rate, "", Double, 0, 1.0),
     P(feature_fraction, "sub_feature,colsample_bytree", Double, 1e-300, 1.0),
     P(feature_fraction_bynode, "sub_feature_bynode,colsample_bynode", Double, 1e-300, 1.0),
+    P(extra_trees, "extra_tree", Bool, kNone, kNone),
+    P(extra_seed, "", Int, kNone, kNone),
     P(feature_fraction_seed, "", Int, kNone, kNone),
     P(early_stopping_round, "early_stopping_rounds,early_stopping,n_iter_no_change", Int, kNone, kNone),
     P(first_metric_only, "", Bool, kNone, kNone),

@@ -43,6 +43,8 @@ struct Config {
   double other_rate = 0.1;   // goss: share of rows sampled from the rest
   double feature_fraction = 1.0;
   double feature_fraction_bynode = 1.0;
+  bool extra_trees = false;    // extremely randomised trees: one random threshold per feature and node
+  int extra_seed = 6;
   int feature_fraction_seed = 2;
   int early_stopping_round = 0;
   bool first_metric_only = false;

@@ -24,6 +24,9 @@ SplitParams TreeGrower::split_params() const {
   p.max_depth = cfg_.max_depth;
   p.bynode_fraction = cfg_.feature_fraction_bynode;
   p.node_bounds = nullptr;
+  p.extra_trees = cfg_.extra_trees ? 1 : 0;
+  p.pad_ = 0;
+  p.extra_seed = mix64((uint64_t)cfg_.extra_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x7e57ull);
   p.bynode_seed = mix64((uint64_t)cfg_.feature_fraction_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x51ed27ull);
   return p;
 }

@@ -613,7 +613,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
                                                   const int64_t* __restrict__ sib, int64_t plane,
                                                   const FeatureMeta m, const LeafScanCtx& ctx, const SplitParams& sp,
                                                   double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh,
-                                                  bool evaluate = true) {
+                                                  bool evaluate = true, uint32_t key = kRootNodeKey) {
   const int64_t e = (int64_t)f * kMaxBins + lane * 4;
   int64_t g[4], h[4];
   {
@@ -657,6 +657,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
   }
   const int64_t eg = ig - g[3], eh = ih - h[3];
   const int last = mb >= 0 ? vb - 1 : vb - 2;
+  const int only = extra_trees_threshold(sp, key, f, last + 1);
   const double ninf = -std::numeric_limits<double>::infinity();
   double lbg = ninf;
   uint64_t lkey = ~0ull;
@@ -664,7 +665,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int thr = lane * 4 + j;
-    if (thr <= last) {
+    if (thr <= last && (only < 0 || thr == only)) {
       const int64_t lg = eg + g[j], lh = eh + h[j];
       take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp, m.monotone), cand_key(f, thr, 0), lg, lh);
       if (mb >= 0 && thr <= vb - 2)
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F));
+  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F), t.key);
   if (lane == 0) *out = Cand{bg, bkey, blg, blh};
 }
 
@@ -816,7 +817,7 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
   for (int f = wave; f < F; f += kFusedWaves) {
     const FeatureMeta m = meta[f];
     if (!m.enabled) continue;
-    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F));
+    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F), key);
   }
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();

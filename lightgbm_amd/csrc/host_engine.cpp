@@ -210,16 +210,18 @@ class HostBackend : public TreeBackend {
     int64_t lg, lh;
   };
 
-  void scan_feature(const int64_t* g, const int64_t* h, int f, const LeafScanCtx& ctx, Cand* best) const {
+  void scan_feature(const int64_t* g, const int64_t* h, int f, const LeafScanCtx& ctx, uint32_t key, Cand* best) const {
     const FeatureMeta& m = meta_[(size_t)f];
     int nb = m.num_bin, mb = m.missing_bin;
     int vb = mb >= 0 ? nb - 1 : nb;   // value bins
     int64_t mg = mb >= 0 ? g[mb] : 0, mh = mb >= 0 ? h[mb] : 0;
     int64_t lg = 0, lh = 0;
     int last = mb >= 0 ? vb - 1 : vb - 2;
+    const int only = extra_trees_threshold(sp_, key, f, last + 1);
     for (int t = 0; t <= last; ++t) {
       lg += g[t];
       lh += h[t];
+      if (only >= 0 && t != only) continue;
       double ga = split_gain(lg, lh, ctx, sp_, m.monotone);
       uint64_t ka = cand_key(f, t, 0);
       if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, lg, lh};
@@ -253,7 +255,7 @@ class HostBackend : public TreeBackend {
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
         if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_)) continue;
-        scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, &best);
+        scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, s.key, &best);
       }
       local[(size_t)i] = best;
       SplitInfo& o = out[i];

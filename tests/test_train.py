@@ -187,6 +187,27 @@ def test_other_objectives_train():
     assert np.mean((b.predict(X) > 0.5) == yb) > 0.95
 
 
+def test_extra_trees_draws_one_threshold_per_feature_and_node():
+    """extra_trees: a node only considers one random threshold per feature, so the trees differ from the greedy
+    ones, depend on extra_seed, are reproducible, identical under one-leaf-at-a-time growth - and still learn."""
+    X, y = make_regression(6000, 8, seed=17)
+    d = lgb.Dataset(X, label=y, params=CPU)
+    p = {**CPU, "num_leaves": 31, "learning_rate": 0.2}
+    greedy = lgb.train(p, d, 30)
+    et = lgb.train({**p, "extra_trees": True}, d, 30)
+    assert trees_of(et) != trees_of(greedy)
+    assert trees_of(et) == trees_of(lgb.train({**p, "extra_trees": True}, d, 30))
+    assert trees_of(et) != trees_of(lgb.train({**p, "extra_trees": True, "extra_seed": 99}, d, 30))
+    assert trees_of(lgb.train({**p, "extra_trees": True, "max_batch_leaves": 1}, d, 8)) == \
+        trees_of(lgb.train({**p, "extra_trees": True}, d, 8))
+    r_greedy, r_et = rmse(greedy.predict(X), y), rmse(et.predict(X), y)
+    assert r_greedy < r_et < 2.5 * r_greedy          # randomised thresholds fit the training data less tightly
+    # per node, the chosen gain can never beat the greedy root split
+    g0 = greedy.dump_model()["tree_info"][0]["tree_structure"]["split_gain"]
+    e0 = et.dump_model()["tree_info"][0]["tree_structure"]["split_gain"]
+    assert e0 <= g0 + 1e-9
+
+
 def test_monotone_constraints_hold_everywhere():
     """+1 / -1 constraints: along a constrained feature, with all other features held fixed, the prediction
     never moves the wrong way - checked on sweeps through many random base points; the unconstrained model on

@@ -34,6 +34,8 @@ NOTES = {
     "feature_fraction": "share of the features offered to each tree",
     "feature_fraction_bynode": "share of the features offered at each node (random-forest `mtry`)",
     "feature_fraction_seed": "",
+    "extra_trees": "extremely randomised trees: every node considers one random threshold per feature",
+    "extra_seed": "",
     "bagging_fraction": "share of the rows in a bag (without replacement)",
     "bagging_freq": "draw a new bag every k iterations (0: no bagging)",
     "bagging_seed": "also seeds goss",

@@ -60,6 +60,8 @@ def draw_case(seed: int, max_rows: int):
         p["boosting"] = "rf"
         p.setdefault("bagging_fraction", 0.6)
         p.setdefault("bagging_freq", 1)
+    if rng.rand() < 0.15:
+        p["extra_trees"] = True
     if rng.rand() < 0.25:
         p["monotone_constraints"] = [int(v) for v in rng.randint(-1, 2, size=F)]
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
