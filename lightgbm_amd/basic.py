@@ -156,6 +156,29 @@ def _to_matrix(data) -> Tuple[Any, List[str] | None]:
     return arr, names
 
 
+def _encode_pandas_categories(data, known: Optional[List[List[Any]]] = None):
+    """pandas frames: columns of dtype category become their integer codes (NaN for missing / unknown levels).
+    Returns (data, indices of those columns, their level lists); `known` pins the levels (validation and
+    prediction frames are coded like the training frame)."""
+    if not (hasattr(data, "columns") and hasattr(data, "dtypes")):
+        return data, [], known
+    cat_cols = [i for i, dt in enumerate(data.dtypes) if str(dt) == "category"]
+    if not cat_cols:
+        return data, [], known
+    import pandas as pd
+    out = data.copy()
+    levels = []
+    for j, i in enumerate(cat_cols):
+        col = out.iloc[:, i]
+        if known is not None and j < len(known):
+            col = col.cat.set_categories(known[j])
+        levels.append(list(col.cat.categories))
+        codes = col.cat.codes.to_numpy().astype(np.float64)
+        codes[codes < 0] = np.nan
+        out[out.columns[i]] = pd.Series(codes, index=out.index)
+    return out, cat_cols, levels
+
+
 def _to_1d(x, dtype) -> np.ndarray:
     if _is_torch(x):
         x = x.detach().cpu().numpy()
@@ -184,8 +207,14 @@ class Dataset:
 
     def __init__(self, data, label=None, reference: Optional["Dataset"] = None, weight=None, init_score=None,
                  feature_name: Union[str, Sequence[str]] = "auto", params: Optional[Dict[str, Any]] = None,
-                 free_raw_data: bool = True, bin_sample=None):
+                 free_raw_data: bool = True, bin_sample=None,
+                 categorical_feature: Union[str, Sequence[Union[int, str]]] = "auto"):
         self.data = data
+        # columns holding category codes (non-negative integers): indices or names; "auto" takes the pandas
+        # columns of dtype category (their codes are used).  A split on such a column sends one category left.
+        self.categorical_feature = categorical_feature
+        self.pandas_categorical: Optional[List[List[Any]]] = None
+        self._has_categorical = False
         # rows to derive the bin boundaries from instead of this matrix (data-parallel ranks pass the
         # same gathered sample so that every shard is binned identically)
         self.bin_sample = bin_sample
@@ -213,6 +242,8 @@ class Dataset:
             check(lib.lga_dataset_subset(self._parent._handle, idx.ctypes.data_as(ctypes.c_void_p), len(idx),
                                          ctypes.byref(h)))
             self._handle = h
+            self._has_categorical = self._parent._has_categorical
+            self.pandas_categorical = self._parent.pandas_categorical
             self._set_fields()
             return self
         if self.data is None:
@@ -224,10 +255,23 @@ class Dataset:
             self._handle = h
             self._set_fields()
             return self
-        mat, names = _to_matrix(self.data)
-        params = _with_device(self.params)
         if self.reference is not None:
             self.reference.construct()   # bin boundaries come from the reference
+        raw, auto_cat, self.pandas_categorical = _encode_pandas_categories(
+            self.data, self.reference.pandas_categorical if self.reference is not None else None)
+        mat, names = _to_matrix(raw)
+        params = _with_device(self.params)
+        cat_idx = self._categorical_indices(names, auto_cat, mat.shape[1], params)
+        if self.reference is not None:
+            self._has_categorical = self.reference._has_categorical
+        else:
+            self._has_categorical = bool(cat_idx)
+            if cat_idx:
+                params["categorical_feature"] = cat_idx
+            else:
+                pop_param(params, "categorical_feature")
+        if self._has_categorical and _is_torch(mat):
+            mat = mat.cpu().numpy()      # category lookup runs on the host; the bins are uploaded afterwards
         _warn_unknown(params)
         pstr = params_to_string(params)
         on_gpu = hip and get_param(params, "device_type") in ("gpu", "hip", "cuda", "rocm")
@@ -247,21 +291,22 @@ class Dataset:
                 raise LightGBMError("bin_sample must be a 2-D array with the data's number of columns")
             check(lib.lga_dataset_from_sample(smp.ctypes.data_as(ctypes.c_void_p), smp.shape[0], ncol, nrow,
                                               c_str(pstr), ctypes.byref(h)))
-        elif _is_torch(mat):
+        elif _is_torch(mat) and not self._has_categorical:
             dtype = 0 if str(mat.dtype).endswith("float32") else 1
             check(lib.lga_hip_dataset_from_device_mat(ctypes.c_void_p(mat.data_ptr()), dtype, nrow, ncol, c_str(pstr),
                                                       None, ctypes.byref(h)))
             mat_binned = True
-        elif on_gpu and bool(get_param(params, "device_bin_find", True)):
+        elif on_gpu and bool(get_param(params, "device_bin_find", True)) and not self._has_categorical:
             # host matrix, device dataset: boundaries are found and bins are built on the GPU
             ptr, dtype, _, _, rm = _mat_args(mat)
             check(lib.lga_hip_dataset_from_host_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), ctypes.byref(h)))
             mat_binned = True
         else:
             ptr, dtype, _, _, rm = _mat_args(mat)
-            check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), None, 0 if on_gpu else 1,
+            host_bins = (not on_gpu) or self._has_categorical
+            check(lib.lga_dataset_from_mat(ptr, dtype, nrow, ncol, rm, c_str(pstr), None, 1 if host_bins else 0,
                                            ctypes.byref(h)))
-            mat_binned = not on_gpu
+            mat_binned = host_bins
         # 2. bins
         if not locals().get("mat_binned", False):
             if _is_torch(mat):
@@ -269,7 +314,7 @@ class Dataset:
                 check(lib.lga_hip_dataset_bin_device(h, ctypes.c_void_p(mat.data_ptr()), dtype, nrow, ncol))
             else:
                 ptr, dtype, _, _, rm = _mat_args(mat)
-                if on_gpu:
+                if on_gpu and not self._has_categorical:
                     check(lib.lga_hip_dataset_upload_raw(h, ptr, dtype, nrow, ncol, rm))
                 else:
                     check(lib.lga_dataset_bin_matrix(h, ptr, dtype, nrow, ncol, rm))
@@ -289,6 +334,27 @@ class Dataset:
         if self.free_raw_data:
             self.data = None
         return self
+
+    def _categorical_indices(self, names, auto_cat, ncol: int, params) -> List[int]:
+        spec = self.categorical_feature
+        if isinstance(spec, str) and spec == "auto":
+            from_params = get_param(params, "categorical_feature", None)
+            if from_params not in (None, "", []):
+                spec = [int(v) for v in str(from_params).split(",")] if isinstance(from_params, str) else list(from_params)
+            else:
+                return sorted(auto_cat)
+        out = set(auto_cat)
+        for c in spec or []:
+            if isinstance(c, str):
+                pool = names if names is not None else (list(self.feature_name) if isinstance(self.feature_name, (list, tuple)) else None)
+                if pool is None or c not in pool:
+                    raise LightGBMError(f"categorical_feature: unknown column name {c!r}")
+                out.add(pool.index(c))
+            else:
+                if not 0 <= int(c) < ncol:
+                    raise LightGBMError(f"categorical_feature: column index {c} out of range")
+                out.add(int(c))
+        return sorted(out)
 
     def save_binary(self, filename: str) -> "Dataset":
         """Writes the binned dataset (bin boundaries, bins, label / weight / init_score) to ``filename``;
@@ -460,6 +526,7 @@ class Booster:
         self._train_data_name = "training"
         self._comm = comm
         self._init_predictor: Optional[Booster] = None
+        self.pandas_categorical: Optional[List[List[Any]]] = None
         if train_set is not None:
             if not isinstance(train_set, Dataset):
                 raise TypeError("train_set must be a Dataset")
@@ -475,6 +542,7 @@ class Booster:
             check(lib.lga_booster_create(train_set._handle, c_str(params_to_string(p)), comm_h,
                                          ctypes.byref(self._handle)))
             self.params = p
+            self.pandas_categorical = train_set.pandas_categorical
         elif model_file is not None:
             with open(model_file, "r") as f:
                 self._load(f.read())
@@ -486,6 +554,13 @@ class Booster:
 
     def _load(self, text: str):
         lib, _ = _lib.load()
+        # the levels of pandas category columns travel in the model's last line, as in upstream files
+        tail = text.rfind("pandas_categorical:")
+        if tail >= 0:
+            try:
+                self.pandas_categorical = json.loads(text[tail + len("pandas_categorical:"):].strip() or "null")
+            except ValueError:
+                self.pandas_categorical = None
         check(lib.lga_booster_from_string(c_str(text), ctypes.byref(self._handle)))
 
     def __del__(self):
@@ -642,6 +717,7 @@ class Booster:
             num_iteration = self.best_iteration if self.best_iteration > 0 else -1
         if num_iteration is None or num_iteration <= 0:
             num_iteration = -1
+        data, _, _ = _encode_pandas_categories(data, self.pandas_categorical)
         mat, _ = _to_matrix(data)
         ptype = 3 if pred_contrib else (2 if pred_leaf else (1 if raw_score else 0))
         used = ctypes.c_int()
@@ -675,7 +751,10 @@ class Booster:
         out, n = ctypes.c_char_p(), ctypes.c_int64()
         check(lib.lga_booster_save_string(self._handle, start_iteration, num_iteration or -1,
                                           0 if importance_type == "split" else 1, ctypes.byref(out), ctypes.byref(n)))
-        return ctypes.string_at(out, n.value).decode()
+        text = ctypes.string_at(out, n.value).decode()
+        if self.pandas_categorical:
+            text = text.replace("pandas_categorical:null", "pandas_categorical:" + json.dumps(self.pandas_categorical, default=str))
+        return text
 
     def save_model(self, filename: str, num_iteration: Optional[int] = None, start_iteration: int = 0,
                    importance_type: str = "split") -> "Booster":

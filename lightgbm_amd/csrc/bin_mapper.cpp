@@ -2,6 +2,7 @@
 #include "binning_core.hpp"
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <sstream>
 
 namespace lga {
@@ -41,8 +42,44 @@ void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data
   trivial = num_bin <= 1;
 }
 
+void BinMapper::find_bins_categorical(const std::vector<double>& values, int max_bin, int min_data_in_bin) {
+  categorical = true;
+  std::map<int64_t, int64_t> counts;
+  for (double v : values)
+    if (v >= 0.0) ++counts[(int64_t)v];
+  std::vector<std::pair<int64_t, int64_t>> order(counts.begin(), counts.end());   // (category, count)
+  std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+  const size_t cap = (size_t)std::max(1, std::min(max_bin, 256) - 1);
+  upper.clear();
+  for (const auto& e : order) {
+    if (upper.size() >= cap || e.second < std::max(1, min_data_in_bin)) break;
+    upper.push_back((double)e.first);
+  }
+  const int k = (int)upper.size();
+  missing = MissingType::NaN;
+  missing_bin = k;
+  num_bin = k + 1;
+  min_val = max_val = k ? upper[0] : 0.0;
+  for (double c : upper) { min_val = std::min(min_val, c); max_val = std::max(max_val, c); }
+  trivial = k < 1;
+  if (trivial) upper.assign(1, 0.0);   // keep the "one bound at least" shape of every mapper
+  build_cat_lookup();
+}
+
+void BinMapper::build_cat_lookup() {
+  cat_lookup.clear();
+  if (!categorical || trivial) return;
+  for (size_t i = 0; i < upper.size(); ++i) cat_lookup.emplace_back((int64_t)upper[i], (int32_t)i);
+  std::sort(cat_lookup.begin(), cat_lookup.end());
+}
+
 std::string BinMapper::info_string() const {
   if (trivial) return "none";
+  if (categorical) {
+    std::ostringstream os;
+    for (size_t i = 0; i < upper.size(); ++i) os << (i ? ":" : "") << (long long)upper[i];
+    return os.str();
+  }
   std::ostringstream os;
   os.precision(17);
   os << "[" << min_val << ":" << max_val << "]";

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace lga {
@@ -18,14 +19,33 @@ struct BinMapper {
   int32_t missing_bin = -1;    // == num_bin-1 when missing == NaN
   double min_val = 0.0, max_val = 0.0;
   bool trivial = true;         // a single bin: the feature cannot split
+  // Categorical feature: values are non-negative integer codes.  `upper` then holds the kept category
+  // values (bin i = the i-th most frequent category), and one more bin (missing_bin == upper.size()) takes
+  // everything else: NaN, negative codes, categories too rare or unseen when the bins were found.
+  bool categorical = false;
+  std::vector<std::pair<int64_t, int32_t>> cat_lookup;   // (category, bin) sorted by category
 
   // Build from a sample of one feature.  `values` may contain NaN; it is
   // modified (sorted).  total_sample_cnt is the number of sampled rows.
   void find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing);
+  // Categorical form: the (max_bin - 1) most frequent categories that occur at least min_data_in_bin times
+  // (ties: smaller category first) get a bin each.
+  void find_bins_categorical(const std::vector<double>& values, int max_bin, int min_data_in_bin);
+  void build_cat_lookup();
 
   // value -> bin.  NaN goes to the NaN bin when one exists, otherwise it is
   // treated as 0.0 (the rule the predictor applies too).
   inline int value_to_bin(double v) const {
+    if (categorical) {
+      if (!(v >= 0.0)) return missing_bin;            // NaN and negative codes
+      const int64_t c = (int64_t)v;
+      size_t lo = 0, hi = cat_lookup.size();
+      while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (cat_lookup[mid].first < c) lo = mid + 1; else hi = mid;
+      }
+      return (lo < cat_lookup.size() && cat_lookup[lo].first == c) ? cat_lookup[lo].second : missing_bin;
+    }
     if (v != v) {
       if (missing == MissingType::NaN) return missing_bin;
       v = 0.0;
@@ -41,7 +61,7 @@ struct BinMapper {
 
   // Real threshold written to the model for "bin <= t".
   double bin_to_threshold(int t) const { return upper[t]; }
-  std::string info_string() const;   // "[min:max]" or "none"
+  std::string info_string() const;   // "[min:max]", "none", or the categories "c0:c1:..." of a categorical feature
 };
 
 // Greedy equal-frequency cut of sorted distinct values into <= max_bin bins.

@@ -72,6 +72,9 @@ struct SplitInfo {
 };
 static_assert(sizeof(SplitInfo) == 72, "SplitInfo layout");
 
+// SplitTask::default_left value of a categorical split: rows whose bin EQUALS `threshold` go left.
+constexpr int32_t kCategoricalTask = 2;
+
 // One leaf to split in a batched growth round.
 struct SplitTask {
   int32_t parent_node;   // node-table index of the leaf being split
@@ -114,8 +117,10 @@ struct FeatureMeta {
   int32_t num_bin;      // bins in use (<=256)
   int32_t missing_bin;  // index of the NaN bin or -1
   int32_t enabled;      // 0 when masked out by feature_fraction for this tree
-  int32_t monotone;     // +1: the output may not decrease with the feature, -1: may not increase, 0: free
+  int16_t monotone;     // +1: the output may not decrease with the feature, -1: may not increase, 0: free
+  int16_t categorical;  // 1: bins are categories; a split sends ONE category left (one against the rest)
 };
+static_assert(sizeof(FeatureMeta) == 16, "FeatureMeta layout");
 
 // ---- arithmetic ----------------------------------------------------------
 LGA_HD double threshold_l1(double g, double l1) {

@@ -46,6 +46,7 @@ const ParamDef kParams[] = {
     P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
+    P(categorical_feature, "cat_feature,categorical_column,cat_column,categorical_features", IntList, 0, kNone),
     P(monotone_constraints, "mc,monotone_constraint,monotonic_cst", IntList, -1, 1),
     P(drop_rate, "rate_drop", Double, 0, 1.0),
     P(max_drop, "", Int, kNone, kNone),

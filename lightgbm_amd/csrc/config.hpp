@@ -30,6 +30,7 @@ struct Config {
   double bagging_fraction = 1.0;
   int bagging_freq = 0;
   int bagging_seed = 3;
+  std::vector<int> categorical_feature;    // column indices holding integer category codes
   std::vector<int> monotone_constraints;   // per feature of the raw matrix: -1 / 0 / +1
   // dart
   double drop_rate = 0.1;

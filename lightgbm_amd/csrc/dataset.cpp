@@ -41,7 +41,9 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
   for (int f = 0; f < ncol; ++f) {
     std::vector<double> col((size_t)nsample);
     for (int64_t i = 0; i < nsample; ++i) col[(size_t)i] = sample[i * ncol + f];
-    ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing);
+    const bool cat = std::find(cfg.categorical_feature.begin(), cfg.categorical_feature.end(), f) != cfg.categorical_feature.end();
+    if (cat) ds->mappers_[f].find_bins_categorical(col, cfg.max_bin, cfg.min_data_in_bin);
+    else ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing);
   }
   ds->finish_mappers();
   return ds;
@@ -168,6 +170,7 @@ std::vector<FeatureMeta> Dataset::feature_meta() const {
     m[(size_t)f].missing_bin = bm.missing_bin;
     m[(size_t)f].enabled = 1;
     m[(size_t)f].monotone = 0;
+    m[(size_t)f].categorical = bm.categorical ? 1 : 0;
   }
   return m;
 }
@@ -261,7 +264,7 @@ void Dataset::save_binary(const std::string& path) const {
       w.pod<int32_t>(m.missing_bin);
       w.pod<double>(m.min_val);
       w.pod<double>(m.max_val);
-      w.pod<int32_t>(m.trivial ? 1 : 0);
+      w.pod<int32_t>((m.trivial ? 1 : 0) | (m.categorical ? 2 : 0));
       w.str(feature_names[i]);
     }
     w.vec(bins_fm_);
@@ -295,7 +298,10 @@ std::shared_ptr<Dataset> Dataset::load_binary(const std::string& path) {
     m.missing_bin = r.pod<int32_t>();
     m.min_val = r.pod<double>();
     m.max_val = r.pod<double>();
-    m.trivial = r.pod<int32_t>() != 0;
+    const int32_t flags = r.pod<int32_t>();
+    m.trivial = (flags & 1) != 0;
+    m.categorical = (flags & 2) != 0;
+    m.build_cat_lookup();
     if (m.num_bin < 1 || m.num_bin > kMaxBins || m.upper.empty()) throw std::runtime_error("load_binary: bad bin mapper");
     ds->feature_names[(size_t)i] = r.str();
   }

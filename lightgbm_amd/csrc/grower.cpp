@@ -203,7 +203,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
         t.right_node = (int)nodes.size() + 1;
         t.feature = c.best.feature;
         t.threshold = c.best.threshold;
-        t.default_left = c.best.default_left;
+        t.default_left = meta[(size_t)c.best.feature].categorical ? kCategoricalTask : c.best.default_left;
         t.missing_bin = meta[(size_t)c.best.feature].missing_bin;
         int64_t lc = c.best.left_cnt, rc = c.best.total_cnt - c.best.left_cnt;
         t.hist_child = lc <= rc ? 0 : 1;
@@ -306,9 +306,14 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     // "every value left, only missing right" has an infinite bin bound: keep the model text finite
     double real_thr = bm.bin_to_threshold(s.threshold);
     if (std::isinf(real_thr)) real_thr = 1e300;
-    int right_leaf = tree.split(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
-                                real_thr, s.default_left != 0, (int)bm.missing, s.gain, lv, rv,
-                                lc, rc, lh, rh);
+    int right_leaf;
+    if (bm.categorical)
+      right_leaf = tree.split_categorical(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
+                                          (int64_t)bm.upper[(size_t)s.threshold], s.gain, lv, rv, lc, rc, lh, rh);
+    else
+      right_leaf = tree.split(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
+                              real_thr, s.default_left != 0, (int)bm.missing, s.gain, lv, rv,
+                              lc, rc, lh, rh);
     leaf_of_node[(size_t)n.left] = leaf;
     leaf_of_node[(size_t)n.right] = right_leaf;
     leaf_nodes[(size_t)leaf] = n.left;

@@ -1080,7 +1080,7 @@ class HipEngine : public Engine {
       const int mb = train_->inner_mapper(f).missing_bin;
       np[i].feature = f;
       np[i].meta = (tree.threshold_bin[(size_t)i] & 255) | ((tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 256 : 0) |
-                   ((mb + 1) << 16);
+                   ((tree.decision_type[(size_t)i] & kCategoricalMask) ? 512 : 0) | ((mb + 1) << 16);
       np[i].left = tree.left_child[(size_t)i];
       np[i].right = tree.right_child[(size_t)i];
     }

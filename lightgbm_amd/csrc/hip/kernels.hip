@@ -280,6 +280,7 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
     return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < bag.fraction;
   }
   int b = bins_fm[(int64_t)t.feature * N + row];
+  if (t.default_left == kCategoricalTask) return b == t.threshold;
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
@@ -637,6 +638,29 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
   if (!evaluate) return;   // feature not offered at this node: only its histogram had to be derived
   const int nb = m.num_bin, mb = m.missing_bin;
   const int vb = mb >= 0 ? nb - 1 : nb;
+  if (m.categorical) {
+    // one category against the rest: the left child is a single value bin (no prefix sums)
+    const int only_c = extra_trees_threshold(sp, key, f, vb);
+    const double ninf_c = -std::numeric_limits<double>::infinity();
+    double cbg = ninf_c;
+    uint64_t ckey = ~0ull;
+    int64_t clg = 0, clh = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int thr = lane * 4 + j;
+      if (thr < vb && (only_c < 0 || thr == only_c))
+        take_better(cbg, ckey, clg, clh, split_gain(g[j], h[j], ctx, sp, 0), cand_key(f, thr, 0), g[j], h[j]);
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      double g2 = shfl_xor_f64(cbg, msk);
+      uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)ckey, msk);
+      int64_t lg2 = shfl_xor_i64(clg, msk), lh2 = shfl_xor_i64(clh, msk);
+      take_better(cbg, ckey, clg, clh, g2, k2, lg2, lh2);
+    }
+    take_better(bg, bkey, blg, blh, cbg, ckey, clg, clh);
+    return;
+  }
   // stats of the missing-value bin, broadcast from the lane that holds it
   int64_t mg = 0, mh = 0;
   if (mb >= 0) {
@@ -1000,7 +1024,7 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
       const TreeNodeDev t = tn[node];
       const int b = bins_fm[(int64_t)t.feature * N + r];
       const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
-      const bool left = (b == mb) ? (dl != 0) : (b <= thr);
+      const bool left = (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
       node = left ? t.left : t.right;
       if (!LGA_DEV_CHECK(node < n_internal && ~node < num_leaves, kCheckWalkNode, node, n_internal)) break;
     }

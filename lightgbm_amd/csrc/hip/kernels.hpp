@@ -43,7 +43,7 @@ struct ScanTaskDev {
 
 struct TreeNodeDev {       // internal node of a tree for binned traversal (16 bytes, one LDS read)
   int32_t feature;         // inner feature
-  int32_t meta;            // threshold bin | default_left << 8 | (missing_bin + 1) << 16
+  int32_t meta;            // threshold bin | default_left << 8 | categorical (bin == threshold) << 9 | (missing_bin + 1) << 16
   int32_t left, right;     // >= 0 internal node, < 0: ~leaf
 };
 

@@ -30,7 +30,10 @@ constexpr int kPredThreads = 256;
 constexpr size_t kTileBytes = 36 * 1024;      // four 255-leaf trees; four workgroups (16 waves) share a CU's LDS
 constexpr size_t kMaxTileBytes = 120 * 1024;  // a single larger tree may claim up to this much
 
+// Categorical nodes reach the device with their single category in `threshold` (trees grown here send one
+// category left; models with larger sets predict on the host).
 __device__ __forceinline__ bool go_left_dev(double v, double thr, int dtype) {
+  if (dtype & 1) return v >= 0.0 && (double)(long long)v == thr;
   const int mt = (dtype >> 2) & 3;
   if (v != v && mt != 2) v = 0.0;
   if ((mt == 1 && v > -1e-35 && v < 1e-35) || (mt == 2 && v != v)) return (dtype & 2) != 0;
@@ -207,6 +210,15 @@ size_t lds_kernel_bytes(int nfeat, size_t tile_limit) {
   return (((size_t)nfeat * kPredThreads * R * sizeof(T) + 15) & ~(size_t)15) + tile_limit;
 }
 
+// Numerical node: its threshold; categorical node: the one category that goes left.
+double node_threshold(const Tree& tr, int i) {
+  if (!(tr.decision_type[(size_t)i] & kCategoricalMask)) return tr.threshold[(size_t)i];
+  const std::vector<int64_t> cats = tr.node_categories(i);
+  if (cats.size() != 1)
+    throw std::runtime_error("the device predictor handles categorical splits on a single category; this model predicts on the host");
+  return (double)cats[0];
+}
+
 }  // namespace
 
 void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, int64_t nrow, int ncol, int start_iter,
@@ -272,7 +284,7 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
         tile_bytes += bytes;
         for (int i = 0; i < ni; ++i) {
           QNode n;
-          n.threshold = tr.threshold[(size_t)i];
+          n.threshold = node_threshold(tr, i);
           n.feature = (int16_t)tr.split_feature[(size_t)i];
           n.left = (int16_t)tr.left_child[(size_t)i];
           n.right = (int16_t)tr.right_child[(size_t)i];
@@ -331,7 +343,7 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
     tile_bytes += bytes;
     for (int i = 0; i < ni; ++i) {
       PNode n;
-      n.threshold = tr.threshold[(size_t)i];
+      n.threshold = node_threshold(tr, i);
       n.feature = tr.split_feature[(size_t)i];
       n.left = tr.left_child[(size_t)i];
       n.right = tr.right_child[(size_t)i];

@@ -152,14 +152,16 @@ class HostBackend : public TreeBackend {
     int32_t nl = 0;
     for (int32_t i = 0; i < p.count; ++i) {
       int b = col[src[i]];
-      bool left = (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+      bool left = t.default_left == kCategoricalTask ? (b == t.threshold)
+                                                       : ((b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold));
       nl += left ? 1 : 0;
     }
     int32_t li = 0, ri = nl;
     for (int32_t i = 0; i < p.count; ++i) {
       int32_t row = src[i];
       int b = col[row];
-      bool left = (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+      bool left = t.default_left == kCategoricalTask ? (b == t.threshold)
+                                                       : ((b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold));
       if (left) dst[li++] = row; else dst[ri++] = row;
     }
     ranges_[(size_t)t.left_node] = NodeRange{p.begin, nl, 1 - p.buf, 0};
@@ -218,6 +220,16 @@ class HostBackend : public TreeBackend {
     int64_t lg = 0, lh = 0;
     int last = mb >= 0 ? vb - 1 : vb - 2;
     const int only = extra_trees_threshold(sp_, key, f, last + 1);
+    if (m.categorical) {
+      // one category against the rest: the left child is a single value bin
+      for (int t = 0; t < vb; ++t) {
+        if (only >= 0 && t != only) continue;
+        double ga = split_gain(g[t], h[t], ctx, sp_, 0);
+        uint64_t ka = cand_key(f, t, 0);
+        if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, g[t], h[t]};
+      }
+      return;
+    }
     for (int t = 0; t <= last; ++t) {
       lg += g[t];
       lh += h[t];

@@ -17,7 +17,36 @@ void Tree::reset(int max_leaves) {
   rs(internal_count, m);
   leaf_value.assign(1, 0.0); leaf_weight.assign(1, 0.0); leaf_count.assign(1, 0);
   leaf_depth.assign(1, 0); leaf_parent.assign(1, -1);
+  cat_boundaries.clear(); cat_threshold.clear();
   shrinkage = 1.0;
+}
+
+int Tree::split_categorical(int leaf, int feature_real, int feature_inner, int category_bin, int64_t category, double gain,
+                            double left_value, double right_value, int64_t left_cnt, int64_t right_cnt,
+                            double left_weight, double right_weight) {
+  if (category < 0) throw std::runtime_error("categorical split on a negative category");
+  if (cat_boundaries.empty()) cat_boundaries.push_back(0);
+  const int k = (int)cat_boundaries.size() - 1;
+  const size_t words = (size_t)(category >> 5) + 1;
+  const size_t base = cat_threshold.size();
+  cat_threshold.resize(base + words, 0u);
+  cat_threshold[base + (size_t)(category >> 5)] |= 1u << (category & 31);
+  cat_boundaries.push_back((int32_t)cat_threshold.size());
+  // missing type NaN: unknown values fall to the right, like every value outside the set
+  int right = split(leaf, feature_real, feature_inner, category_bin, (double)k, false, 2, gain, left_value, right_value,
+                    left_cnt, right_cnt, left_weight, right_weight);
+  decision_type.back() |= kCategoricalMask;
+  return right;
+}
+
+std::vector<int64_t> Tree::node_categories(int node) const {
+  std::vector<int64_t> out;
+  if (!(decision_type[(size_t)node] & kCategoricalMask)) return out;
+  const int k = (int)threshold[(size_t)node];
+  for (int32_t w = cat_boundaries[(size_t)k]; w < cat_boundaries[(size_t)k + 1]; ++w)
+    for (int b = 0; b < 32; ++b)
+      if ((cat_threshold[(size_t)w] >> b) & 1u) out.push_back((int64_t)(w - cat_boundaries[(size_t)k]) * 32 + b);
+  return out;
 }
 
 int Tree::split(int leaf, int feature_real, int feature_inner, int thr_bin, double thr, bool default_left,
@@ -74,7 +103,7 @@ int Tree::predict_leaf(const double* row) const {
   int node = 0;
   while (node >= 0) {
     double v = row[split_feature[(size_t)node]];
-    node = go_left(v, threshold[(size_t)node], decision_type[(size_t)node]) ? left_child[(size_t)node]
+    node = decide(node, v) ? left_child[(size_t)node]
                                                                              : right_child[(size_t)node];
   }
   return ~node;
@@ -153,7 +182,7 @@ struct ShapWalk {
       return;
     }
     const int f = t.split_feature[(size_t)node];
-    const bool left = Tree::go_left(row[f], t.threshold[(size_t)node], t.decision_type[(size_t)node]);
+    const bool left = t.decide(node, row[f]);
     const int hot = left ? t.left_child[(size_t)node] : t.right_child[(size_t)node];
     const int cold = left ? t.right_child[(size_t)node] : t.left_child[(size_t)node];
     const double w = (double)t.internal_count[(size_t)node];
@@ -222,7 +251,7 @@ std::string Tree::to_string(int index) const {
   std::ostringstream os;
   os << "Tree=" << index << "\n";
   os << "num_leaves=" << num_leaves << "\n";
-  os << "num_cat=0\n";
+  os << "num_cat=" << num_cat() << "\n";
   size_t ni = (size_t)num_leaves - 1, nl = (size_t)num_leaves;
   auto id = [](auto v) { return std::to_string((long long)v); };
   auto dd = [](double v) { return g17(v); };
@@ -239,6 +268,10 @@ std::string Tree::to_string(int index) const {
     join(os, "internal_value", internal_value, ni, dd);
     join(os, "internal_weight", internal_weight, ni, dd);
     join(os, "internal_count", internal_count, ni, id);
+    if (num_cat() > 0) {
+      join(os, "cat_boundaries", cat_boundaries, cat_boundaries.size(), id);
+      join(os, "cat_threshold", cat_threshold, cat_threshold.size(), id);
+    }
   } else {
     join(os, "leaf_value", leaf_value, 1, dd);
   }
@@ -266,8 +299,8 @@ Tree Tree::from_string(const std::string& block) {
   Tree t;
   t.num_leaves = std::atoi(need("num_leaves").c_str());
   if (t.num_leaves < 1) throw std::runtime_error("model parse: num_leaves < 1");
-  if (kv.count("num_cat") && std::atoi(kv["num_cat"].c_str()) != 0)
-    throw std::runtime_error("model parse: categorical splits are not supported");
+  const int n_cat = kv.count("num_cat") ? std::atoi(kv["num_cat"].c_str()) : 0;
+  if (n_cat < 0) throw std::runtime_error("model parse: num_cat < 0");
   size_t ni = (size_t)t.num_leaves - 1, nl = (size_t)t.num_leaves;
   auto ints = [&](const std::string& s, size_t n, auto& out, const char* k) {
     auto tk = tokens(s);
@@ -294,8 +327,21 @@ Tree Tree::from_string(const std::string& block) {
     if (kv.count("internal_value")) dbls(kv["internal_value"], ni, t.internal_value, "internal_value"); else t.internal_value.assign(ni, 0.0);
     if (kv.count("internal_weight")) dbls(kv["internal_weight"], ni, t.internal_weight, "internal_weight"); else t.internal_weight.assign(ni, 0.0);
     if (kv.count("internal_count")) ints(kv["internal_count"], ni, t.internal_count, "internal_count"); else t.internal_count.assign(ni, 0);
+    if (n_cat > 0) {
+      ints(need("cat_boundaries"), (size_t)n_cat + 1, t.cat_boundaries, "cat_boundaries");
+      if (t.cat_boundaries[0] != 0) throw std::runtime_error("model parse: cat_boundaries must start at 0");
+      for (int k = 0; k < n_cat; ++k)
+        if (t.cat_boundaries[(size_t)k + 1] < t.cat_boundaries[(size_t)k]) throw std::runtime_error("model parse: cat_boundaries decrease");
+      std::vector<int64_t> words;
+      ints(need("cat_threshold"), (size_t)t.cat_boundaries.back(), words, "cat_threshold");
+      t.cat_threshold.assign(words.begin(), words.end());
+    }
     for (size_t i = 0; i < ni; ++i) {
-      if (t.decision_type[i] & kCategoricalMask) throw std::runtime_error("model parse: categorical splits are not supported");
+      if (t.decision_type[i] & kCategoricalMask) {
+        const double k = t.threshold[i];
+        if (!(k >= 0.0) || k != (double)(int)k || (int)k >= n_cat)
+          throw std::runtime_error("model parse: categorical node points outside cat_boundaries");
+      }
       auto ok = [&](int c) { return (c >= 0 && c < (int)ni) || (c < 0 && ~c < (int)nl); };
       if (!ok(t.left_child[i]) || !ok(t.right_child[i])) throw std::runtime_error("model parse: child index out of range");
     }
@@ -325,7 +371,7 @@ Tree Tree::from_string(const std::string& block) {
 
 std::string Tree::to_json(int index) const {
   std::ostringstream os;
-  os << "{\"tree_index\":" << index << ",\"num_leaves\":" << num_leaves << ",\"num_cat\":0,\"shrinkage\":" << g17(shrinkage)
+  os << "{\"tree_index\":" << index << ",\"num_leaves\":" << num_leaves << ",\"num_cat\":" << num_cat() << ",\"shrinkage\":" << g17(shrinkage)
      << ",\"tree_structure\":";
   // recursive lambda over nodes
   struct Rec {
@@ -339,8 +385,19 @@ std::string Tree::to_json(int index) const {
       if (n < 0) { leaf(~n); return; }
       size_t i = (size_t)n;
       int mt = (t.decision_type[i] >> 2) & 3;
+      const bool cat = (t.decision_type[i] & kCategoricalMask) != 0;
       os << "{\"split_index\":" << n << ",\"split_feature\":" << t.split_feature[i] << ",\"split_gain\":" << g17(t.split_gain[i])
-         << ",\"threshold\":" << g17(t.threshold[i]) << ",\"decision_type\":\"<=\",\"default_left\":"
+         << ",\"threshold\":";
+      if (cat) {
+        // the categories that go left, "a||b||c"
+        os << "\"";
+        bool first = true;
+        for (int64_t c : t.node_categories(n)) { os << (first ? "" : "||") << c; first = false; }
+        os << "\"";
+      } else {
+        os << g17(t.threshold[i]);
+      }
+      os << ",\"decision_type\":\"" << (cat ? "==" : "<=") << "\",\"default_left\":"
          << ((t.decision_type[i] & kDefaultLeftMask) ? "true" : "false") << ",\"missing_type\":\""
          << (mt == 0 ? "None" : mt == 1 ? "Zero" : "NaN") << "\",\"internal_value\":" << g17(t.internal_value[i])
          << ",\"internal_weight\":" << g17(t.internal_weight[i]) << ",\"internal_count\":" << t.internal_count[i]

@@ -32,6 +32,12 @@ struct Tree {
   std::vector<int32_t> leaf_depth;           // not serialised
   std::vector<int32_t> leaf_parent;          // not serialised
   double shrinkage = 1.0;
+  // Categorical splits (decision_type bit 0): the node's `threshold` is an index k into cat_boundaries;
+  // words cat_threshold[cat_boundaries[k] .. cat_boundaries[k+1]) form a bitset over category values - a row
+  // goes left when its (non-negative, integer) value has its bit set.  Splits grown here send one category left.
+  std::vector<int32_t> cat_boundaries;   // starts with 0 once a categorical split exists
+  std::vector<uint32_t> cat_threshold;
+  int num_cat() const { return cat_boundaries.empty() ? 0 : (int)cat_boundaries.size() - 1; }
 
   Tree() { reset(1); }
   void reset(int max_leaves);
@@ -40,6 +46,11 @@ struct Tree {
   int split(int leaf, int feature_real, int feature_inner, int threshold_bin, double threshold, bool default_left,
             int missing_type, double gain, double left_value, double right_value, int64_t left_cnt,
             int64_t right_cnt, double left_weight, double right_weight);
+
+  // The categorical form: rows whose bin == category_bin (value == category) go left, everything else right.
+  int split_categorical(int leaf, int feature_real, int feature_inner, int category_bin, int64_t category, double gain,
+                        double left_value, double right_value, int64_t left_cnt, int64_t right_cnt, double left_weight,
+                        double right_weight);
 
   void apply_shrinkage(double rate);
   void add_bias(double v);
@@ -53,6 +64,21 @@ struct Tree {
       return (dtype & kDefaultLeftMask) != 0;
     return fval <= thr;
   }
+  // Decision of internal node `node` on a raw feature value (numerical or categorical).
+  inline bool decide(int node, double fval) const {
+    const int8_t dt = decision_type[(size_t)node];
+    if (dt & kCategoricalMask) {
+      if (!(fval >= 0.0)) return false;                       // NaN / negative codes: right
+      const int64_t c = (int64_t)fval;
+      const int k = (int)threshold[(size_t)node];
+      const int64_t words = cat_boundaries[(size_t)k + 1] - cat_boundaries[(size_t)k];
+      if ((c >> 5) >= words) return false;
+      return (cat_threshold[(size_t)cat_boundaries[(size_t)k] + (size_t)(c >> 5)] >> (c & 31)) & 1u;
+    }
+    return go_left(fval, threshold[(size_t)node], dt);
+  }
+  // Categories of a categorical node (ascending).
+  std::vector<int64_t> node_categories(int node) const;
   int predict_leaf(const double* row) const;
   double predict(const double* row) const { return leaf_value[(size_t)predict_leaf(row)]; }
   // Adds this tree's per-feature contributions (path-dependent SHAP values weighted by the training row
@@ -69,7 +95,8 @@ struct Tree {
       int f = split_feature_inner[(size_t)node];
       int b = bins(f);
       bool left;
-      if (b == missing_bin_of_inner[f]) left = (decision_type[(size_t)node] & kDefaultLeftMask) != 0;
+      if (decision_type[(size_t)node] & kCategoricalMask) left = b == threshold_bin[(size_t)node];
+      else if (b == missing_bin_of_inner[f]) left = (decision_type[(size_t)node] & kDefaultLeftMask) != 0;
       else left = b <= threshold_bin[(size_t)node];
       node = left ? left_child[(size_t)node] : right_child[(size_t)node];
     }

@@ -34,6 +34,20 @@ class TreeArrays:
     internal_count: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
     internal_value: np.ndarray = field(default_factory=lambda: np.zeros(0))
     shrinkage: float = 1.0
+    # categorical nodes (decision_type bit 0): threshold = k, bitset words cat_threshold[cat_boundaries[k]:[k+1]]
+    cat_boundaries: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
+    cat_threshold: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))
+
+    def _in_category_set(self, nd: np.ndarray, v: np.ndarray) -> np.ndarray:
+        """For categorical nodes nd and values v: is the (integer, non-negative) value in the node's set?"""
+        ok = v >= 0                                   # NaN and negative codes are never in a set
+        c = np.where(ok, v, 0).astype(np.int64)
+        k = self.threshold[nd].astype(np.int64)
+        lo, hi = self.cat_boundaries[k], self.cat_boundaries[k + 1]
+        word = lo + (c >> 5)
+        ok &= word < hi
+        bits = self.cat_threshold[np.where(ok, word, 0)]
+        return ok & (((bits >> (c & 31)) & 1) == 1)
 
     def predict_leaf(self, X: np.ndarray) -> np.ndarray:
         """Leaf index of every row of X (float64 [n, F])."""
@@ -54,6 +68,12 @@ class TreeArrays:
             is_missing = ((missing_type == 1) & (np.abs(v) < 1e-35)) | ((missing_type == 2) & isnan)
             with np.errstate(invalid="ignore"):
                 left = np.where(is_missing, (dt & _DEFAULT_LEFT) != 0, v <= self.threshold[nd])
+            is_cat = (dt & 1) != 0
+            if is_cat.any():
+                raw = X[idx[is_cat], self.split_feature[nd[is_cat]]].astype(np.float64)
+                left = left.copy()
+                with np.errstate(invalid="ignore"):
+                    left[is_cat] = self._in_category_set(nd[is_cat], raw)
             nxt = np.where(left, self.left_child[nd], self.right_child[nd])
             node[idx] = nxt
             active[idx] = nxt >= 0
@@ -125,8 +145,7 @@ class TreeEnsemble:
             lines = c.splitlines()
             d = _block_to_dict(lines[1:])
             L = int(d["num_leaves"])
-            if int(d.get("num_cat", "0")) != 0:
-                raise ValueError("model parse: categorical splits are not supported")
+            n_cat = int(d.get("num_cat", "0"))
             ni = L - 1
             trees.append(TreeArrays(
                 num_leaves=L,
@@ -141,6 +160,8 @@ class TreeEnsemble:
                 internal_count=_arr(d, "internal_count", np.int64, ni),
                 internal_value=_arr(d, "internal_value", float, ni),
                 shrinkage=float(d.get("shrinkage", "1")),
+                cat_boundaries=_arr(d, "cat_boundaries", np.int64, n_cat + 1) if n_cat else np.zeros(0, dtype=np.int64),
+                cat_threshold=np.asarray(d.get("cat_threshold", "").split(), dtype=np.int64) if n_cat else np.zeros(0, dtype=np.int64),
             ))
         params: Dict[str, str] = {}
         if "parameters:" in tail:

@@ -232,6 +232,24 @@ def test_randomised_parity_sweep(first):
         assert same, f"seed {seed}: {case}"
 
 
+def test_gpu_categorical_features_match_the_cpu_and_the_device_predictor_agrees():
+    rng = np.random.RandomState(3)
+    n = 50000
+    city = rng.randint(0, 40, size=n)
+    effect = rng.randn(40) * 2
+    X = np.c_[rng.randn(n), city.astype(float), rng.randn(n), rng.randint(0, 5, size=n).astype(float)]
+    X[::19, 1] = np.nan
+    y = np.where(np.isnan(X[:, 1]), 0.0, effect[city]) + 0.5 * X[:, 0] + 0.3 * (X[:, 3] == 2) + 0.2 * rng.randn(n)
+    p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.8, "bagging_freq": 1}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, categorical_feature=[1, 3], params=CPU), 10)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, categorical_feature=[1, 3], params=GPU), 10, keep_training_booster=True)
+    assert trees_of(a) == trees_of(b) and "cat_threshold=" in trees_of(b)
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
+    np.testing.assert_allclose(b.predict(X, device="gpu"), b.predict(X, device="cpu"), atol=1e-12)
+    Xf = X.astype(np.float32)
+    np.testing.assert_allclose(b.predict(Xf, device="gpu"), b.predict(Xf, device="cpu"), atol=1e-12)
+
+
 def test_index_checking_build_catches_a_bad_row_and_passes_clean_runs():
     """The -DLGA_DEBUG build of the HIP core (LGA_DEBUG_LIB=1): a row id beyond the dataset handed to the
     histogram kernel is reported as an error instead of faulting the GPU, and ordinary training (with

@@ -41,6 +41,7 @@ NOTES = {
     "bagging_seed": "also seeds goss",
     "data_sample_strategy": "`bagging` or `goss` (keep the `top_rate` rows with the largest |g h|, sample `other_rate` of the rest and up-weight them)",
     "top_rate": "goss", "other_rate": "goss",
+    "categorical_feature": "comma list of column indices holding non-negative integer category codes (the Python `Dataset(categorical_feature=...)` argument also takes names and finds pandas `category` columns); every category frequent enough gets a bin, a split sends one category left",
     "monotone_constraints": "comma list, one of -1 / 0 / +1 per column: the prediction may not increase / is free / may not decrease with that feature",
     "drop_rate": "dart: share of the existing iterations muted per iteration",
     "max_drop": "dart: at most this many (<= 0: no limit)",

@@ -65,7 +65,10 @@ def draw_case(seed: int, max_rows: int):
     if rng.rand() < 0.25:
         p["monotone_constraints"] = [int(v) for v in rng.randint(-1, 2, size=F)]
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
-            "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25}
+            "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25,
+            "categorical": rng.rand() < 0.3}
+    if opts["categorical"] and "monotone_constraints" in p:
+        p["monotone_constraints"][F - 2 if F > 1 else 0] = 0
     return n, F, p, opts
 
 
@@ -76,6 +79,11 @@ def make_data(seed, n, F, opts):
         X[:, F - 1] = rng.randint(0, 3, size=n)
         X[:, 0] = np.round(X[:, 0], 1)
     y = X[:, 0] * 1.5 + np.abs(X[:, 1 % F]) - 0.7 * X[:, 2 % F] * (X[:, 0] > 0) + 0.1 * rng.randn(n)
+    if opts.get("categorical"):
+        c = F - 2 if F > 1 else 0
+        codes = rng.randint(0, 9, size=n)
+        X[:, c] = codes
+        y = y + np.array([2.0, -1.0, 0.5, 3.0, -2.5, 0.0, 1.0, -0.5, 1.5])[codes]
     if opts["nan"]:
         X[rng.rand(n) < 0.07, 1 % F] = np.nan
         X[rng.rand(n) < 0.01, F - 1] = np.nan
@@ -90,7 +98,8 @@ def run_case(seed: int, max_rows: int):
     models = []
     for dev in ("cpu", "gpu"):
         base = {"device_type": dev, "verbose": -1}
-        d = lgb.Dataset(X, label=y, weight=w, params={**base, "max_bin": p["max_bin"]})
+        cats = [F - 2 if F > 1 else 0] if opts.get("categorical") else "auto"
+        d = lgb.Dataset(X, label=y, weight=w, params={**base, "max_bin": p["max_bin"]}, categorical_feature=cats)
         if opts["subset"]:
             d = d.construct().subset(np.arange(0, n, 2))
         b = lgb.train({**base, **p}, d, opts["rounds"])
