@@ -208,8 +208,10 @@ class Dataset:
     def __init__(self, data, label=None, reference: Optional["Dataset"] = None, weight=None, init_score=None,
                  feature_name: Union[str, Sequence[str]] = "auto", params: Optional[Dict[str, Any]] = None,
                  free_raw_data: bool = True, bin_sample=None,
-                 categorical_feature: Union[str, Sequence[Union[int, str]]] = "auto"):
+                 categorical_feature: Union[str, Sequence[Union[int, str]]] = "auto", group=None):
         self.data = data
+        # ranking: sizes of the queries, in row order (the rows of one query are contiguous)
+        self.group = group
         # columns holding category codes (non-negative integers): indices or names; "auto" takes the pandas
         # columns of dtype category (their codes are used).  A split on such a column sends one category left.
         self.categorical_feature = categorical_feature
@@ -375,6 +377,8 @@ class Dataset:
             self.set_weight(self.weight)
         if self.init_score is not None:
             self.set_init_score(self.init_score)
+        if self.group is not None:
+            self.set_group(self.group)
 
     def _set_field(self, name: str, values, dtype):
         lib, _ = _lib.load()
@@ -402,6 +406,19 @@ class Dataset:
         if self._handle is not None:
             self._set_field("init_score", init_score, np.float64)
         return self
+
+    def set_group(self, group) -> "Dataset":
+        """Query sizes of ranking data: ``group=[10, 20]`` makes rows 0-9 one query and rows 10-29 the next."""
+        self.group = group
+        if self._handle is not None:
+            self._set_field("group", group, np.float64)
+        return self
+
+    def get_group(self) -> Optional[np.ndarray]:
+        if self._handle is None:
+            return None if self.group is None else _to_1d(self.group, np.int64)
+        g = self._get_field("group")
+        return None if g is None else g.astype(np.int64)
 
     def _get_field(self, name: str) -> Optional[np.ndarray]:
         self.construct()
@@ -436,8 +453,8 @@ class Dataset:
         return self.data
 
     # -- derived datasets --
-    def create_valid(self, data, label=None, weight=None, init_score=None, params=None) -> "Dataset":
-        return Dataset(data, label=label, reference=self, weight=weight, init_score=init_score,
+    def create_valid(self, data, label=None, weight=None, init_score=None, params=None, group=None) -> "Dataset":
+        return Dataset(data, label=label, reference=self, weight=weight, init_score=init_score, group=group,
                        params=params if params is not None else self.params, free_raw_data=self.free_raw_data)
 
     def subset(self, used_indices: Iterable[int], params: Optional[Dict[str, Any]] = None) -> "Dataset":
@@ -447,6 +464,14 @@ class Dataset:
         ds._used_indices = np.sort(np.asarray(list(used_indices) if not isinstance(used_indices, np.ndarray)
                                               else used_indices, dtype=np.int64))
         ds.reference = self
+        if self.group is not None:
+            # the subset's queries: what is left of each of this dataset's queries, in order
+            sizes = _to_1d(self.group, np.int64)
+            qid = np.repeat(np.arange(len(sizes)), sizes)
+            if len(qid) and len(ds._used_indices) and ds._used_indices[-1] >= len(qid):
+                raise LightGBMError("subset: row index beyond the rows covered by group")
+            kept = qid[ds._used_indices]
+            ds.group = np.bincount(kept, minlength=len(sizes))[np.unique(kept)] if len(kept) else np.zeros(0, np.int64)
         return ds
 
     # -- shape / names --
@@ -671,6 +696,19 @@ class Booster:
         check(lib.lga_booster_inner_predict(self._handle, which, 1 if raw else 0, out.ctypes.data_as(ctypes.c_void_p)))
         # multiclass: the core's [class][row] layout becomes one row of num_class values per data row
         return out if K == 1 else np.ascontiguousarray(out.reshape(K, n.value).T)
+
+    def get_gradients(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Gradients and hessians of the last iteration over the training rows (float32; multiclass:
+        ``[class][row]`` flattened) - what the trees of that iteration were fitted to."""
+        lib, _ = _lib.load()
+        n = ctypes.c_int64()
+        check(lib.lga_booster_inner_nrows(self._handle, -1, ctypes.byref(n)))
+        K = self.num_model_per_iteration()
+        g = np.empty(n.value * K, dtype=np.float32)
+        h = np.empty(n.value * K, dtype=np.float32)
+        check(lib.lga_booster_get_gradients(self._handle, g.ctypes.data_as(ctypes.c_void_p),
+                                            h.ctypes.data_as(ctypes.c_void_p)))
+        return g, h
 
     def _eval(self, which: int, name: str, feval=None) -> List[Tuple[str, str, float, bool]]:
         lib, _ = _lib.load()

@@ -25,7 +25,7 @@ BUILD = PKG.parent / "build"
 
 HOST_SOURCES = [
     "config.cpp", "bin_mapper.cpp", "dataset.cpp", "tree.cpp", "grower.cpp", "host_engine.cpp",
-    "metric.cpp", "gbdt.cpp", "model_io.cpp", "c_api.cpp",
+    "metric.cpp", "ranking.cpp", "gbdt.cpp", "model_io.cpp", "c_api.cpp",
 ]
 HOST_ONLY = ["engine_factory_host.cpp"]
 HIP_SOURCES = [

@@ -121,6 +121,14 @@ int lga_dataset_set_field(LgaDataset ds, const char* name, const void* data, int
       std::vector<double> v((size_t)n);
       for (int64_t i = 0; i < n; ++i) v[(size_t)i] = dtype == 0 ? (double)((const float*)data)[i] : ((const double*)data)[i];
       d->set_init_score(v.data(), n);
+    } else if (f == "group") {
+      std::vector<int32_t> v((size_t)n);
+      for (int64_t i = 0; i < n; ++i) {
+        const double x = dtype == 0 ? (double)((const float*)data)[i] : ((const double*)data)[i];
+        if (!(x >= 0.0) || x != (double)(int32_t)x) throw std::runtime_error("group sizes must be non-negative integers");
+        v[(size_t)i] = (int32_t)x;
+      }
+      d->set_group(v.data(), n);
     } else throw std::runtime_error("unknown field " + f);
   });
 }
@@ -138,6 +146,9 @@ int lga_dataset_get_field(LgaDataset ds, const char* name, double* out, int64_t 
         if (d->used_indices()) for (int32_t r : *d->used_indices()) v.push_back(is[(size_t)r]);
         else v = is;
       }
+    } else if (f == "group") {
+      const auto& b = d->query_boundaries();
+      for (size_t q = 0; q + 1 < b.size(); ++q) v.push_back((double)(b[q + 1] - b[q]));
     } else throw std::runtime_error("unknown field " + f);
     *n = (int64_t)v.size();
     if (out) {
@@ -254,9 +265,9 @@ int lga_booster_num_feature(LgaBooster b, int* out) { return guard([&] { *out = 
 int lga_booster_eval_names(LgaBooster b, char* out, int cap) {
   return guard([&] {
     std::string s;
-    for (const auto& m : B(b)->config().resolved_metrics()) {
+    for (const auto& m : B(b)->eval_names()) {
       if (!s.empty()) s += ",";
-      s += m + ":" + (m == "auc" ? "1" : "0");
+      s += m.first + ":" + (m.second ? "1" : "0");
     }
     if ((int)s.size() + 1 > cap) throw std::runtime_error("buffer too small");
     std::strcpy(out, s.c_str());

@@ -9,7 +9,7 @@
 namespace lga {
 namespace {
 
-enum class PType { Int, Double, Bool, String, StringList, IntList };
+enum class PType { Int, Double, Bool, String, StringList, IntList, DoubleList };
 
 struct ParamDef {
   const char* name;
@@ -85,6 +85,11 @@ const ParamDef kParams[] = {
     P(fair_c, "", Double, 1e-300, kNone),
     P(poisson_max_delta_step, "", Double, 1e-300, kNone),
     P(tweedie_variance_power, "", Double, 1.0, 1.999999999),
+    P(lambdarank_truncation_level, "", Int, 1, kNone),
+    P(lambdarank_norm, "", Bool, kNone, kNone),
+    P(label_gain, "", DoubleList, 0, kNone),
+    P(objective_seed, "", Int, kNone, kNone),
+    P(eval_at, "ndcg_eval_at,ndcg_at,map_eval_at,map_at", IntList, 1, kNone),
     P(metric_freq, "output_freq", Int, 1, kNone),
     P(is_provide_training_metric, "training_metric,is_training_metric,train_metric", Bool, kNone, kNone),
     P(snapshot_freq, "save_period", Int, kNone, kNone),
@@ -237,6 +242,21 @@ void Config::set(const std::map<std::string, std::string>& kv) {
         }
         break;
       }
+      case PType::DoubleList: {
+        auto& lst = field<std::vector<double>>(this, p->offset);
+        lst.clear();
+        for (auto& m : split(val, ',')) {
+          std::string t = trim(m);
+          if (t.empty()) continue;
+          double d = std::strtod(t.c_str(), &end);
+          if (end == t.c_str() || *end != '\0')
+            throw std::runtime_error("parameter " + key + " expects numbers, got \"" + t + "\"");
+          if ((p->lo == p->lo && d < p->lo) || (p->hi == p->hi && d > p->hi))
+            throw std::runtime_error("parameter " + key + ": value " + t + " is out of range");
+          lst.push_back(d);
+        }
+        break;
+      }
     }
     if (std::find(explicit_keys.begin(), explicit_keys.end(), p->name) == explicit_keys.end())
       explicit_keys.push_back(p->name);
@@ -288,6 +308,8 @@ std::string Config::canonical_objective(const std::string& name0) {
       {"ovr", "multiclassova"},
       {"binary", "binary"}, {"binary_logloss", "binary"}, {"binary:logistic", "binary"},
       {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
+      {"lambdarank", "lambdarank"}, {"rank_xendcg", "rank_xendcg"}, {"xendcg", "rank_xendcg"},
+      {"xe_ndcg", "rank_xendcg"}, {"xe_ndcg_mart", "rank_xendcg"}, {"xendcg_mart", "rank_xendcg"},
       {"custom", "custom"}, {"none", "custom"}, {"null", "custom"}, {"na", "custom"},
   };
   auto it = m.find(name);
@@ -311,6 +333,9 @@ std::string Config::canonical_metric(const std::string& name0) {
       {"binary_error", "binary_error"}, {"error", "binary_error"},
       {"auc", "auc"},
       {"cross_entropy", "cross_entropy"}, {"xentropy", "cross_entropy"},
+      {"ndcg", "ndcg"}, {"lambdarank", "ndcg"}, {"rank_xendcg", "ndcg"}, {"xendcg", "ndcg"}, {"xe_ndcg", "ndcg"},
+      {"xe_ndcg_mart", "ndcg"}, {"xendcg_mart", "ndcg"},
+      {"map", "map"}, {"mean_average_precision", "map"},
       {"none", "none"}, {"null", "none"}, {"custom", "none"}, {"na", "none"}, {"", "none"},
   };
   auto it = m.find(name);
@@ -331,6 +356,7 @@ std::vector<std::string> Config::resolved_metrics() const {
     else if (o == "multiclass" || o == "multiclassova") out.push_back("multi_logloss");
     else if (o == "binary") out.push_back("binary_logloss");
     else if (o == "cross_entropy") out.push_back("cross_entropy");
+    else if (o == "lambdarank" || o == "rank_xendcg") out.push_back("ndcg");
     return out;
   }
   for (const auto& m : metric) {
@@ -410,6 +436,11 @@ std::string Config::to_model_string() const {
       case PType::IntList: {
         const auto& l = cfield<std::vector<int>>(this, p.offset);
         for (size_t i = 0; i < l.size(); ++i) os << (i ? "," : "") << l[i];
+        break;
+      }
+      case PType::DoubleList: {
+        const auto& l = cfield<std::vector<double>>(this, p.offset);
+        for (size_t i = 0; i < l.size(); ++i) os << (i ? "," : "") << fmt_double(l[i]);
         break;
       }
     }

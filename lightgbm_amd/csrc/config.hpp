@@ -72,6 +72,12 @@ struct Config {
   double fair_c = 1.0;
   double poisson_max_delta_step = 0.7;
   double tweedie_variance_power = 1.5;
+  // ranking
+  int lambdarank_truncation_level = 30;   // pairs need one document among the best-scored this many
+  bool lambdarank_norm = true;
+  std::vector<double> label_gain;         // gain per relevance grade; empty: 2^grade - 1
+  int objective_seed = 5;                 // rank_xendcg's per-document noise
+  std::vector<int> eval_at;               // cut-offs of ndcg / map; empty: 1..5
   // metric
   std::vector<std::string> metric;   // empty: derived from the objective
   int metric_freq = 1;

@@ -199,6 +199,20 @@ void Dataset::set_init_score(const double* v, int64_t n) {
   scatter_field(root_mut()->init_score_, root_rows_, used_indices_.get(), v, n, num_data(), "init_score");
 }
 
+void Dataset::set_group(const int32_t* sizes, int64_t n) {
+  query_bounds_.clear();
+  if (n == 0) return;
+  std::vector<int64_t> b((size_t)n + 1, 0);
+  for (int64_t q = 0; q < n; ++q) {
+    if (sizes[q] < 0) throw std::runtime_error("group sizes must be non-negative");
+    b[(size_t)q + 1] = b[(size_t)q] + sizes[q];
+  }
+  if (b.back() != num_data())
+    throw std::runtime_error("group sizes add up to " + std::to_string(b.back()) + ", the data has " +
+                             std::to_string(num_data()) + " rows");
+  query_bounds_ = std::move(b);
+}
+
 std::vector<float> Dataset::local_label() const {
   const auto& l = root_label();
   if (!used_indices_) return l;

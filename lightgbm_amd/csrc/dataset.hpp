@@ -78,6 +78,10 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   const std::vector<double>& root_init_score() const { return root()->init_score_; }
   std::vector<float> local_label() const;
   std::vector<float> local_weight() const;
+  // Ranking: sizes of the queries, in row order; they must add up to num_data().  Kept per dataset (a
+  // subset carries its own).  n == 0 clears.  query_boundaries() holds num_queries + 1 LOCAL row offsets.
+  void set_group(const int32_t* sizes, int64_t n);
+  const std::vector<int64_t>& query_boundaries() const { return query_bounds_; }
 
   std::vector<std::string> feature_names;   // per real feature
   void set_feature_names(const std::vector<std::string>& names);
@@ -94,6 +98,7 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   std::vector<uint8_t> bins_rt_, bins_fm_;
   std::vector<float> label_, weight_;
   std::vector<double> init_score_;
+  std::vector<int64_t> query_bounds_;         // of THIS dataset's rows (not read through to the root)
   std::shared_ptr<const Dataset> parent_;
   std::shared_ptr<std::vector<int32_t>> used_indices_;
 

@@ -75,6 +75,8 @@ class Engine {
   virtual std::vector<EvalResult> eval(int which, const std::vector<int32_t>& metrics, const ObjectiveSpec& obj) = 0;
   virtual void get_scores(int which, double* out) = 0;   // dataset-local row order
   virtual void get_gradients(float* g, float* h) = 0;    // dataset-local row order
+  // In-place sum of host values over the ranks of a distributed run (no-op on a single rank).
+  virtual void sum_over_ranks(double* v, size_t n) = 0;
   virtual std::string profile_json() const { return "{}"; }
   virtual GrowStats grow_stats() const = 0;
 };

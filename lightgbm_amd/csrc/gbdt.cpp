@@ -19,8 +19,17 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
   setup_objective();
   num_class_ = obj_.num_class;
   init_scores_.assign((size_t)num_class_, 0.0);
-  for (const auto& m : cfg_.resolved_metrics()) metrics_.push_back(metric_kind_from_name(m));
+  rank_.label_gain = cfg_.label_gain.empty() ? default_label_gain() : cfg_.label_gain;
+  for (const auto& m : cfg_.resolved_metrics()) {
+    if (m == "ndcg" || m == "map") {
+      std::vector<int> at = cfg_.eval_at.empty() ? std::vector<int>{1, 2, 3, 4, 5} : cfg_.eval_at;
+      for (int k : at) rank_metrics_.push_back(RankMetric{m == "ndcg", k});
+    } else {
+      metrics_.push_back(metric_kind_from_name(m));
+    }
+  }
   engine_ = factory(train_, cfg_);
+  if (is_ranking()) setup_ranking();
   max_feature_idx_ = train_->num_total_features() - 1;
   feature_names_ = train_->names();
   feature_infos_.clear();
@@ -55,6 +64,8 @@ void Booster::setup_objective() {
     os << "binary sigmoid:" << cfg_.sigmoid;
     objective_str_ = os.str();
   } else if (o == "cross_entropy") { obj_.kind = kObjCrossEntropy; objective_str_ = "cross_entropy"; }
+  else if (o == "lambdarank") { obj_.kind = kObjLambdarank; objective_str_ = "lambdarank"; }
+  else if (o == "rank_xendcg") { obj_.kind = kObjXendcg; objective_str_ = "rank_xendcg"; }
   else if (o == "multiclass" || o == "multiclassova") {
     obj_.kind = o == "multiclass" ? kObjMulticlass : kObjMulticlassOva;
     obj_.num_class = cfg_.num_class;
@@ -171,7 +182,62 @@ void Booster::ensure_scores() {
     engine_->reset_scores(init_scores_[(size_t)k]);
   }
   engine_->select_class(0);
-  if (is_rf_) engine_->compute_gradients(obj_);
+  if (is_rf_) compute_gradients();
+}
+
+// ---------------------------------------------------------------------------
+// ranking
+// ---------------------------------------------------------------------------
+void Booster::setup_ranking() {
+  if (train_->query_boundaries().empty())
+    throw std::runtime_error("objective=" + objective_str_ + " needs query information (Dataset group=)");
+  rank_.xendcg = obj_.kind == kObjXendcg;
+  rank_.sigmoid = cfg_.sigmoid;
+  rank_.norm = cfg_.lambdarank_norm;
+  rank_.truncation_level = cfg_.lambdarank_truncation_level;
+  rank_.seed = (uint64_t)cfg_.objective_seed;
+  rank_label_ = train_->local_label();
+  rank_weight_ = train_->local_weight();
+  check_rank_labels(rank_label_.data(), (int64_t)rank_label_.size(), rank_.label_gain);
+  if (!rank_.xendcg)
+    inv_max_dcg_ = inverse_max_dcg(rank_label_.data(), train_->query_boundaries(), rank_.label_gain, rank_.truncation_level);
+}
+
+void Booster::compute_gradients() {
+  if (!is_ranking()) { engine_->compute_gradients(obj_); return; }
+  const int64_t n = engine_->num_rows(-1);
+  std::vector<double> score((size_t)n);
+  std::vector<float> g((size_t)n), h((size_t)n);
+  engine_->get_scores(-1, score.data());
+  ranking_gradients(rank_, score.data(), rank_label_.data(), rank_weight_.empty() ? nullptr : rank_weight_.data(),
+                    train_->query_boundaries(), inv_max_dcg_, (uint64_t)iter_, g.data(), h.data());
+  engine_->set_gradients(g.data(), h.data(), n);
+}
+
+void Booster::eval_ranking(int which, std::vector<EvalResult>* out) {
+  if (rank_metrics_.empty()) return;
+  const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
+  if (ds->query_boundaries().empty())
+    throw std::runtime_error("the ndcg / map metrics need query information (Dataset group=) on every evaluated dataset");
+  const int64_t n = engine_->num_rows(which);
+  std::vector<double> score((size_t)n * (size_t)num_class_);
+  engine_->get_scores(which, score.data());
+  const std::vector<float> label = ds->local_label(), weight = ds->local_weight();
+  check_rank_labels(label.data(), (int64_t)label.size(), rank_.label_gain);
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool ndcg = pass == 0;
+    std::vector<int> at;
+    for (const auto& m : rank_metrics_) if (m.ndcg == ndcg) at.push_back(m.at);
+    if (at.empty()) continue;
+    std::vector<double> sums;
+    if (ndcg) ndcg_sums(score.data(), label.data(), weight.empty() ? nullptr : weight.data(), ds->query_boundaries(),
+                        rank_.label_gain, at, &sums);
+    else map_sums(score.data(), label.data(), weight.empty() ? nullptr : weight.data(), ds->query_boundaries(), at, &sums);
+    engine_->sum_over_ranks(sums.data(), sums.size());
+    for (size_t k = 0; k < at.size(); ++k)
+      out->push_back(EvalResult{std::string(ndcg ? "ndcg@" : "map@") + std::to_string(at[k]),
+                                sums.back() > 0.0 ? sums[k] / sums.back() : 0.0, true});
+  }
 }
 
 bool Booster::update_one_iter() {
@@ -179,7 +245,7 @@ bool Booster::update_one_iter() {
   if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
   ensure_scores();
   if (is_dart_) dart_drop();
-  if (!is_rf_) engine_->compute_gradients(obj_);
+  if (!is_rf_) compute_gradients();
   sample_rows();
   bool all_stumps = true;
   for (int k = 0; k < num_class_; ++k) {
@@ -437,7 +503,18 @@ void Booster::reset_parameter(const std::string& params) {
 std::vector<EvalResult> Booster::eval(int which) {
   if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
   ensure_scores();
-  return engine_->eval(which, metrics_, obj_);
+  std::vector<EvalResult> out = engine_->eval(which, metrics_, obj_);
+  eval_ranking(which, &out);
+  return out;
+}
+
+std::vector<std::pair<std::string, bool>> Booster::eval_names() const {
+  std::vector<std::pair<std::string, bool>> out;
+  for (int32_t m : metrics_) out.emplace_back(metric_name(m), metric_higher_better(m));
+  for (int pass = 0; pass < 2; ++pass)
+    for (const auto& m : rank_metrics_)
+      if (m.ndcg == (pass == 0)) out.emplace_back(std::string(m.ndcg ? "ndcg@" : "map@") + std::to_string(m.at), true);
+  return out;
 }
 
 // Link function over one row's num_class raw scores (in place).

@@ -6,6 +6,7 @@
 #include "config.hpp"
 #include "dataset.hpp"
 #include "engine.hpp"
+#include "ranking.hpp"
 #include "tree.hpp"
 #include <functional>
 #include <memory>
@@ -47,6 +48,8 @@ class Booster {
   int num_valid() const { return engine_ ? engine_->num_valid() : 0; }
   const std::vector<std::string>& valid_names() const { return valid_names_; }
   std::vector<EvalResult> eval(int which);
+  // (name, higher is better) of the values eval() returns, in its order.
+  std::vector<std::pair<std::string, bool>> eval_names() const;
   // Current (transformed unless raw) predictions for training (-1) / validation data.
   void inner_predict(int which, bool raw, double* out);
   int64_t inner_num_rows(int which) const { return engine_->num_rows(which); }
@@ -109,6 +112,16 @@ class Booster {
   double sum_tree_weight_ = 0.0;
   double dart_shrinkage_ = 1.0;         // learning rate of the iteration in progress
   void renew_leaf_outputs(Tree& tree);
+  // ranking (ranking.hpp): per-query gradients and ndcg / map evaluation on the host
+  struct RankMetric { bool ndcg; int at; };
+  bool is_ranking() const { return obj_.kind == kObjLambdarank || obj_.kind == kObjXendcg; }
+  void setup_ranking();
+  void compute_gradients();
+  void eval_ranking(int which, std::vector<EvalResult>* out);
+  RankingSpec rank_;
+  std::vector<RankMetric> rank_metrics_;
+  std::vector<double> inv_max_dcg_;
+  std::vector<float> rank_label_, rank_weight_;   // training rows, local order
   std::vector<Tree> trees_;
   // model meta
   int max_feature_idx_ = -1;

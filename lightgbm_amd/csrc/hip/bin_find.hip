@@ -44,7 +44,6 @@ __global__ __launch_bounds__(256) void sample_to_keys_kernel(const T* __restrict
     }
     keys[(int64_t)f * npad + i] = k;
   }
-  (void)nf;
 }
 
 struct FeatureBins {      // result record per feature
@@ -96,8 +95,6 @@ __global__ __launch_bounds__(256) void rle_and_cut_kernel(const uint64_t* __rest
   __threadfence_block();
   __syncthreads();
   // head positions -> run lengths (read the neighbour before anyone overwrites: two phases)
-  int32_t tmp[1];
-  (void)tmp;
   for (int base = 0; base < nd; base += 256) {
     const int d = base + t;
     int32_t c = 0;

@@ -993,6 +993,9 @@ class HipEngine : public Engine {
 
   std::string profile_json() const override { return backend_->prof.json(); }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
+  void sum_over_ranks(double* v, size_t n) override {
+    if (dist()) comm_->allreduce_sum_f64(v, n, false, stream_);
+  }
 
   // raw device pointers (used by the bindings for zero-copy access)
   double* scores_device() { return scores_.get(); }

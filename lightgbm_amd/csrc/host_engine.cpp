@@ -600,6 +600,9 @@ class HostEngine : public Engine {
     }
   }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
+  void sum_over_ranks(double* v, size_t n) override {
+    if (dist()) comm_->allreduce_sum_f64(v, n, false, nullptr);
+  }
 
  private:
   struct Valid {

@@ -22,6 +22,8 @@ enum ObjectiveKind : int32_t {
   kObjTweedie = 11,
   kObjMulticlass = 12,      // softmax over num_class score vectors
   kObjMulticlassOva = 13,   // one binary (sigmoid) model per class
+  kObjLambdarank = 14,      // ranking objectives: gradients per query on the host (ranking.hpp)
+  kObjXendcg = 15,
 };
 
 enum MetricKind : int32_t {

@@ -325,12 +325,20 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     objective = str(get_param(params, "objective", "regression"))
     classification = objective in ("binary", "binary_logloss", "binary:logistic", "multiclass", "softmax",
                                    "multiclassova", "multiclass_ova", "ova", "ovr")
+    group = train_set.get_group()
+    qid = np.repeat(np.arange(len(group)), group) if group is not None else None
     if folds is not None:
         if hasattr(folds, "split"):
             y = train_set.get_label()
-            folds = list(folds.split(X=np.empty((n, 1)), y=y))
+            folds = list(folds.split(X=np.empty((n, 1)), y=y, groups=qid))
         else:
             folds = [(np.asarray(a), np.asarray(b)) for a, b in folds]
+    elif qid is not None:
+        # ranking data: whole queries are dealt to the folds
+        if len(group) < nfold:
+            raise ValueError("more folds than queries")
+        folds = [(np.flatnonzero(np.isin(qid, tr_q)), np.flatnonzero(np.isin(qid, te_q)))
+                 for tr_q, te_q in make_folds(len(group), nfold, None, False, shuffle, seed)]
     else:
         label = train_set.get_label() if stratified else None
         folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)

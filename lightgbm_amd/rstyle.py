@@ -156,7 +156,7 @@ def lgb_cv(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3,
     out.record_evals = rec if record else {}
     if first_key is not None:
         means = np.asarray(res[f"{first_key}-mean"], dtype=np.float64)
-        higher_better = first_key in ("auc",)
+        higher_better = first_key == "auc" or first_key.startswith(("ndcg@", "map@"))
         factor = 1.0 if higher_better else -1.0
         bi = cvb.best_iteration if cvb.best_iteration > 0 else int(np.argmax(factor * means)) + 1
         # the 2017 R callback only recorded a best iteration when the patience criterion fired
@@ -196,16 +196,18 @@ def lgb_Dataset_save(dataset: Dataset, fname: str) -> Dataset:
 
 
 def getinfo(dataset: Dataset, name: str):
-    getter = {"label": dataset.get_label, "weight": dataset.get_weight, "init_score": dataset.get_init_score}
+    getter = {"label": dataset.get_label, "weight": dataset.get_weight, "init_score": dataset.get_init_score,
+              "group": dataset.get_group}
     if name not in getter:
-        raise ValueError("getinfo: name must be one of label, weight, init_score")
+        raise ValueError("getinfo: name must be one of label, weight, init_score, group")
     return getter[name]()
 
 
 def setinfo(dataset: Dataset, name: str, info) -> Dataset:
-    setter = {"label": dataset.set_label, "weight": dataset.set_weight, "init_score": dataset.set_init_score}
+    setter = {"label": dataset.set_label, "weight": dataset.set_weight, "init_score": dataset.set_init_score,
+              "group": dataset.set_group}
     if name not in setter:
-        raise ValueError("setinfo: name must be one of label, weight, init_score")
+        raise ValueError("setinfo: name must be one of label, weight, init_score, group")
     return setter[name](info)
 
 

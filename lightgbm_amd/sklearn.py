@@ -1,4 +1,4 @@
-"""scikit-learn style estimators (``LGBMRegressor``, ``LGBMClassifier``, ``LGBMRandomForestRegressor``).
+"""scikit-learn style estimators (``LGBMRegressor``, ``LGBMClassifier``, ``LGBMRanker``, ``LGBMRandomForestRegressor``).
 
 bagging_boosting.ipynb:204 drives its forest through the sklearn estimator interface
 (``RandomForestRegressor(n_estimators, max_leaf_nodes, ...).fit(x, y).predict(x)``); these wrappers
@@ -25,7 +25,7 @@ except Exception:   # pragma: no cover
     class ClassifierMixin:   # type: ignore
         pass
 
-__all__ = ["LGBMModel", "LGBMRegressor", "LGBMClassifier", "LGBMRandomForestRegressor"]
+__all__ = ["LGBMModel", "LGBMRegressor", "LGBMClassifier", "LGBMRanker", "LGBMRandomForestRegressor"]
 
 
 class LGBMModel(BaseEstimator):
@@ -84,18 +84,19 @@ class LGBMModel(BaseEstimator):
         return p
 
     def fit(self, X, y, sample_weight=None, init_score=None, eval_set=None, eval_names=None, eval_metric=None,
-            early_stopping_rounds=None, callbacks=None, init_model=None):
+            early_stopping_rounds=None, callbacks=None, init_model=None, group=None, eval_group=None):
         params = self._params()
         if eval_metric is not None:
             params["metric"] = eval_metric
         dtrain = Dataset(X, label=self._encode_label(y), weight=sample_weight, init_score=init_score, params=params,
-                         free_raw_data=init_model is None)
+                         free_raw_data=init_model is None, group=group)
         valid_sets, valid_names = [], []
         for i, (vx, vy) in enumerate(eval_set or []):
             if vx is X and vy is y:
                 valid_sets.append(dtrain)
             else:
-                valid_sets.append(dtrain.create_valid(vx, label=self._encode_label(vy)))
+                valid_sets.append(dtrain.create_valid(vx, label=self._encode_label(vy),
+                                                      group=eval_group[i] if eval_group is not None else None))
             valid_names.append(eval_names[i] if eval_names else f"valid_{i}")
         self.evals_result_ = {}
         self._Booster = train(params, dtrain, num_boost_round=self.n_estimators, valid_sets=valid_sets or None,
@@ -125,6 +126,23 @@ class LGBMModel(BaseEstimator):
 
 class LGBMRegressor(RegressorMixin, LGBMModel):
     pass
+
+
+class LGBMRanker(LGBMModel):
+    """Learning to rank (``lambdarank`` unless another objective is given): ``fit`` needs ``group``, the sizes
+    of the queries in row order; every ``eval_set`` entry needs its ``eval_group``.  ``eval_at`` lists the
+    cut-offs of the ndcg / map metrics.  ``predict`` returns relevance scores (rank within a query by them)."""
+
+    def _default_objective(self) -> str:
+        return "lambdarank"
+
+    def fit(self, X, y, group=None, eval_set=None, eval_group=None, eval_at=(1, 2, 3, 4, 5), **kwargs):
+        if group is None:
+            raise ValueError("LGBMRanker.fit needs group (the query sizes)")
+        if eval_set is not None and (eval_group is None or len(eval_group) != len(eval_set)):
+            raise ValueError("LGBMRanker.fit needs one eval_group entry per eval_set entry")
+        self._other_params["eval_at"] = [int(k) for k in eval_at]
+        return super().fit(X, y, group=group, eval_set=eval_set, eval_group=eval_group, **kwargs)
 
 
 class LGBMRandomForestRegressor(RegressorMixin, LGBMModel):

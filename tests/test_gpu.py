@@ -339,6 +339,31 @@ def test_gpu_multiclass_matches_cpu(objective):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
 
 
+@pytest.mark.parametrize("objective", ["lambdarank", "rank_xendcg"])
+def test_gpu_ranking_grows_the_cpu_trees(objective):
+    """Ranking gradients are taken per query on the host from the engine's scores, which are bit-identical
+    between the engines, so the device grows the very trees of the CPU engine - bagging and weights included."""
+    rng = np.random.RandomState(2)
+    sizes = rng.randint(3, 60, size=1500)
+    n = int(sizes.sum())
+    X = rng.randn(n, 10)
+    y = np.clip(np.round(X[:, 0] + np.sin(X[:, 1]) + 0.4 * rng.randn(n) + 1.5), 0, 4)
+    w = 0.5 + rng.rand(n)
+    ntr = int(sizes[:1200].sum())
+    p = {"objective": objective, "num_leaves": 31, "min_data_in_leaf": 10, "eval_at": [1, 5], "metric": ["ndcg", "map"],
+         "bagging_fraction": 0.7, "bagging_freq": 1}
+    out = []
+    for dev in (CPU, GPU):
+        dtr = lgb.Dataset(X[:ntr], label=y[:ntr], weight=w[:ntr], group=sizes[:1200], params=dev)
+        dva = lgb.Dataset(X[ntr:], label=y[ntr:], group=sizes[1200:], reference=dtr, params=dev)
+        ev = {}
+        b = lgb.train({**dev, **p}, dtr, 15, valid_sets=[dva], valid_names=["va"], evals_result=ev)
+        out.append((trees_of(b), ev["va"]))
+    assert out[0][0] == out[1][0]
+    assert out[0][1] == out[1][1]
+    assert out[1][1]["ndcg@5"][-1] > out[1][1]["ndcg@5"][0]
+
+
 @pytest.mark.parametrize("leaves,n", [(4, 5000), (31, 70000)])
 def test_device_auc_equals_host_auc(leaves, n):
     """Sort + scan AUC on the device against the host's sorted formulation, heavy ties included.

@@ -1,0 +1,189 @@
+"""Learning to rank: lambdarank / rank_xendcg objectives, ndcg@k / map@k metrics, query groups.
+
+Parity: upstream's own test fixtures for ranking (examples/lambdarank/rank.train + .query) are not part of the
+reference checkout and the lightgbm package is not installed, so the gradients are checked against an
+independent NumPy transcription of the published pairwise formula and the metrics against scikit-learn's
+ndcg_score (parity with upstream's numbers is unpinned)."""
+import numpy as np
+import pytest
+
+import lightgbm_amd as lgb
+from test_parallel import run_ranks, trees_of
+
+CPU = {"device_type": "cpu", "verbose": -1}
+
+
+def make_rank_data(nq=200, seed=0, lo=5, hi=40, F=8):
+    rng = np.random.RandomState(seed)
+    sizes = rng.randint(lo, hi, size=nq)
+    n = int(sizes.sum())
+    X = rng.randn(n, F)
+    rel = X[:, 0] * 1.2 + np.sin(X[:, 1]) + 0.3 * rng.randn(n)
+    y = np.clip(np.round(rel + 1.5), 0, 4)
+    return X, y, sizes
+
+
+def lambdarank_reference(score, label, sigmoid=1.0, trunc=30, norm=True):
+    """Plain O(n^2) transcription of the pairwise lambdas of one query."""
+    n = len(score)
+    order = np.argsort(-score, kind="stable")
+    gain = 2.0 ** label - 1
+    best = np.sort(gain)[::-1]
+    disc = 1.0 / np.log2(2.0 + np.arange(n))
+    max_dcg = float(np.sum(best[:trunc] * disc[:trunc]))
+    lam, hes = np.zeros(n), np.zeros(n)
+    if n < 2 or max_dcg <= 0:
+        return lam, hes
+    smax, smin = score[order[0]], score[order[-1]]
+    total = 0.0
+    for i in range(min(n, trunc)):
+        for j in range(i + 1, n):
+            a, b = order[i], order[j]
+            if label[a] == label[b]:
+                continue
+            (hi, hr), (lo, lr) = ((a, i), (b, j)) if label[a] > label[b] else ((b, j), (a, i))
+            ds = score[hi] - score[lo]
+            delta = (gain[hi] - gain[lo]) * abs(disc[hr] - disc[lr]) / max_dcg
+            if norm and smax != smin:
+                delta /= 0.01 + abs(ds)
+            p = 1.0 / (1.0 + np.exp(sigmoid * ds))
+            lam[hi] -= sigmoid * delta * p
+            lam[lo] += sigmoid * delta * p
+            hes[hi] += sigmoid * sigmoid * delta * p * (1 - p)
+            hes[lo] += sigmoid * sigmoid * delta * p * (1 - p)
+            total += 2 * sigmoid * delta * p
+    if norm and total > 0:
+        f = np.log2(1 + total) / total
+        lam *= f
+        hes *= f
+    return lam, hes
+
+
+@pytest.mark.parametrize("norm", [True, False])
+def test_lambdarank_gradients_match_the_pairwise_formula(norm):
+    X, y, sizes = make_rank_data(nq=12, seed=3, lo=2, hi=45)
+    rng = np.random.RandomState(1)
+    init = rng.randn(len(y))
+    d = lgb.Dataset(X, label=y, group=sizes, init_score=init)
+    b = lgb.Booster({**CPU, "objective": "lambdarank", "lambdarank_norm": norm, "sigmoid": 1.3,
+                     "lambdarank_truncation_level": 7, "min_data_in_leaf": 1}, d)
+    b.update()
+    g, h = b.get_gradients()
+    pos = 0
+    for s in sizes:
+        lam, hes = lambdarank_reference(init[pos:pos + s], y[pos:pos + s], sigmoid=1.3, trunc=7, norm=norm)
+        np.testing.assert_allclose(g[pos:pos + s], lam, rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(h[pos:pos + s], hes, rtol=2e-5, atol=1e-7)
+        pos += s
+
+
+def test_ndcg_matches_sklearn_with_linear_gain():
+    from sklearn.metrics import ndcg_score
+    X, y, sizes = make_rank_data(nq=60, seed=5, lo=6, hi=30)
+    # a distinct offset per row: no tied scores, whose order the two implementations settle differently
+    jitter = np.random.RandomState(9).permutation(len(y)) * 1e-7
+    d = lgb.Dataset(X, label=y, group=sizes, init_score=jitter)
+    ev = {}
+    b = lgb.train({**CPU, "objective": "lambdarank", "label_gain": [0, 1, 2, 3, 4], "eval_at": [3, 10], "metric": "ndcg",
+                   "min_data_in_leaf": 5}, d, 5, valid_sets=[d], evals_result=ev)
+    p = b.predict(X) + jitter
+    for k in (3, 10):
+        vals, pos = [], 0
+        for s in sizes:
+            yy, pp = y[pos:pos + s], p[pos:pos + s]
+            vals.append(ndcg_score([yy], [pp], k=k, ignore_ties=True) if yy.max() > 0 else 1.0)
+            pos += s
+        assert abs(np.mean(vals) - ev["training"][f"ndcg@{k}"][-1]) < 1e-9
+
+
+def test_map_metric_by_hand():
+    # one query, scores given through init_score: relevant documents at ranks 1, 3 and 6
+    y = np.array([1, 0, 1, 0, 0, 1, 0], dtype=float)
+    s = -np.arange(7, dtype=float)
+    X = np.random.RandomState(0).randn(7, 2)
+    d = lgb.Dataset(np.tile(X, (4, 1)), label=np.tile(y, 4), group=[7] * 4, init_score=np.tile(s, 4))
+    b = lgb.Booster({**CPU, "objective": "lambdarank", "metric": "map", "eval_at": [1, 3, 7], "min_data_in_leaf": 1}, d)
+    b._train_data_name = "training"
+    got = {name: v for _, name, v, _ in b.eval_train()}
+    assert got["map@1"] == pytest.approx(1.0)
+    assert got["map@3"] == pytest.approx((1.0 + 2.0 / 3.0) / 3.0)
+    assert got["map@7"] == pytest.approx((1.0 + 2.0 / 3.0 + 3.0 / 6.0) / 3.0)
+
+
+@pytest.mark.parametrize("objective", ["lambdarank", "rank_xendcg"])
+def test_ranking_learns_and_round_trips(objective):
+    X, y, sizes = make_rank_data(nq=300, seed=0)
+    ntr = int(sizes[:240].sum())
+    dtr = lgb.Dataset(X[:ntr], label=y[:ntr], group=sizes[:240])
+    dva = lgb.Dataset(X[ntr:], label=y[ntr:], group=sizes[240:], reference=dtr)
+    ev = {}
+    b = lgb.train({**CPU, "objective": objective, "min_data_in_leaf": 5, "eval_at": [1, 5]}, dtr, 30,
+                  valid_sets=[dva], valid_names=["va"], evals_result=ev)
+    assert list(ev["va"]) == ["ndcg@1", "ndcg@5"]
+    assert ev["va"]["ndcg@5"][-1] > ev["va"]["ndcg@5"][0] + 0.01
+    assert ev["va"]["ndcg@5"][-1] > 0.93
+    s = b.model_to_string()
+    assert f"objective={objective}" in s
+    b2 = lgb.Booster(model_str=s)
+    np.testing.assert_array_equal(b2.predict(X[ntr:]), b.predict(X[ntr:]))
+    # early stopping maximises ndcg
+    b3 = lgb.train({**CPU, "objective": objective, "min_data_in_leaf": 5, "eval_at": [5], "learning_rate": 0.5}, dtr, 200,
+                   valid_sets=[dva], early_stopping_rounds=5)
+    assert 0 < b3.best_iteration < 200
+
+
+def test_ranking_needs_groups_and_integer_labels():
+    X, y, sizes = make_rank_data(nq=20)
+    with pytest.raises(lgb.LightGBMError, match="query"):
+        lgb.train({**CPU, "objective": "lambdarank"}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="integers"):
+        lgb.train({**CPU, "objective": "lambdarank"}, lgb.Dataset(X, label=y + 0.5, group=sizes), 2)
+    with pytest.raises(lgb.LightGBMError, match="add up"):
+        lgb.Dataset(X, label=y, group=sizes[:-1]).construct()
+    with pytest.raises(lgb.LightGBMError, match="label_gain"):
+        lgb.train({**CPU, "objective": "lambdarank", "label_gain": [0, 1]}, lgb.Dataset(X, label=y, group=sizes), 2)
+
+
+def test_subset_and_cv_keep_queries_whole():
+    X, y, sizes = make_rank_data(nq=90, seed=2)
+    d = lgb.Dataset(X, label=y, group=sizes)
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    rows = np.concatenate([np.arange(bounds[q], bounds[q + 1]) for q in (3, 4, 10, 50)])
+    sub = d.subset(rows).construct()
+    np.testing.assert_array_equal(sub.get_group(), sizes[[3, 4, 10, 50]])
+    r = lgb.cv({**CPU, "objective": "lambdarank", "min_data_in_leaf": 5, "eval_at": [3]}, d, 8, nfold=3, seed=1)
+    assert list(r) == ["ndcg@3-mean", "ndcg@3-stdv"] and len(r["ndcg@3-mean"]) == 8
+    assert r["ndcg@3-mean"][-1] > 0.85
+
+
+def test_sklearn_ranker():
+    from lightgbm_amd.sklearn import LGBMRanker
+    X, y, sizes = make_rank_data(nq=150, seed=4)
+    ntr = int(sizes[:120].sum())
+    m = LGBMRanker(n_estimators=25, min_child_samples=5, device_type="cpu", verbose=-1)
+    m.fit(X[:ntr], y[:ntr], group=sizes[:120], eval_set=[(X[ntr:], y[ntr:])], eval_group=[sizes[120:]], eval_at=[5])
+    assert m.evals_result_["valid_0"]["ndcg@5"][-1] > 0.9
+    assert m.predict(X[ntr:]).shape == (len(y) - ntr,)
+    with pytest.raises(ValueError):
+        LGBMRanker().fit(X, y)
+
+
+def test_data_parallel_ranking_equals_serial():
+    # every query lives on one rank: gradients need no communication, the metric is summed over ranks
+    X, y, sizes = make_rank_data(nq=120, seed=6)
+    params = {**CPU, "objective": "lambdarank", "min_data_in_leaf": 5, "eval_at": [3], "boost_from_average": False}
+    full = lgb.Dataset(X, label=y, group=sizes, bin_sample=X)
+    ev0 = {}
+    serial = lgb.train(params, full, 6, valid_sets=[full], evals_result=ev0)
+    qcut = [0, 70, 120]
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+
+    def rank(r, comm):
+        sl = slice(bounds[qcut[r]], bounds[qcut[r + 1]])
+        d = lgb.Dataset(X[sl], label=y[sl], group=sizes[qcut[r]:qcut[r + 1]], bin_sample=X)
+        ev = {}
+        b = lgb.train({**params, "tree_learner": "data"}, d, 6, comm=comm, valid_sets=[d], evals_result=ev)
+        return b.model_to_string(), ev["training"]["ndcg@3"][-1]
+    for s, m in run_ranks(2, rank):
+        assert trees_of(s) == trees_of(serial)
+        assert m == pytest.approx(ev0["training"]["ndcg@3"][-1], abs=1e-12)
