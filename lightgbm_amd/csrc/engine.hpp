@@ -8,6 +8,7 @@
 #include "dataset.hpp"
 #include "grower.hpp"
 #include "objective.hpp"
+#include "ranking.hpp"
 #include "tree.hpp"
 #include <memory>
 #include <string>
@@ -45,6 +46,14 @@ class Engine {
   virtual void compute_gradients(const ObjectiveSpec& obj) = 0;
   // Weighted number of training rows per class label (summed over ranks).
   virtual void class_weights(int num_class, std::vector<double>* out) = 0;
+  // Ranking gradients (ranking.hpp) taken by the engine itself from its current scores; bounds are the
+  // training dataset's query boundaries.  false: the engine leaves them to the caller (who reads the scores,
+  // computes on the host and calls set_gradients) - the host engine, or a query too large for the device kernels.
+  virtual bool ranking_gradients(const RankingSpec& spec, const std::vector<int64_t>& bounds,
+                                 const std::vector<double>& inv_max_dcg, uint64_t iter) {
+    (void)spec; (void)bounds; (void)inv_max_dcg; (void)iter;
+    return false;
+  }
   // Gradients supplied by the caller, ordered like the training dataset's rows.
   virtual void set_gradients(const float* g, const float* h, int64_t n) = 0;
   // Draw a new bag (every row when fraction >= 1).

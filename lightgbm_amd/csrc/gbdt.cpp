@@ -205,6 +205,7 @@ void Booster::setup_ranking() {
 
 void Booster::compute_gradients() {
   if (!is_ranking()) { engine_->compute_gradients(obj_); return; }
+  if (engine_->ranking_gradients(rank_, train_->query_boundaries(), inv_max_dcg_, (uint64_t)iter_)) return;
   const int64_t n = engine_->num_rows(-1);
   std::vector<double> score((size_t)n);
   std::vector<float> g((size_t)n), h((size_t)n);

@@ -787,6 +787,52 @@ class HipEngine : public Engine {
                  hess_.get(), maxbits_.get(), stream_);
     have_max_ = true;
   }
+  bool ranking_gradients(const RankingSpec& spec, const std::vector<int64_t>& bounds,
+                         const std::vector<double>& inv_max_dcg, uint64_t iter) override {
+    if (!rank_ready_) {
+      // per-query tables go up once; a query beyond the kernels' LDS budget leaves ranking to the host
+      rank_ready_ = true;
+      int64_t longest = 0;
+      for (size_t q = 0; q + 1 < bounds.size(); ++q) longest = std::max(longest, bounds[q + 1] - bounds[q]);
+      rank_on_device_ = longest <= k::kMaxDeviceQuery && !std::getenv("LGA_RANK_ON_HOST");
+      if (rank_on_device_) {
+        rank_max_query_ = (int)std::max<int64_t>(longest, 1);
+        rank_bounds_.upload(bounds.data(), bounds.size(), stream_);
+        std::vector<double> imd = inv_max_dcg;
+        imd.resize(bounds.size(), 0.0);   // rank_xendcg has none
+        rank_imd_.upload(imd.data(), imd.size(), stream_);
+        rank_gain_.upload(spec.label_gain.data(), spec.label_gain.size(), stream_);
+        std::vector<double> disc((size_t)rank_max_query_);
+        for (int r = 0; r < rank_max_query_; ++r) disc[(size_t)r] = rank_discount(r);
+        rank_disc_.upload(disc.data(), disc.size(), stream_);
+        LGA_HIP_CHECK(hipStreamSynchronize(stream_));   // the host vectors above go out of scope
+      }
+    }
+    if (!rank_on_device_) return false;
+    TraceRange range("lga.gradients");
+    k::RankArgs a{};
+    a.score = sc();
+    a.label = mir_->label.get();
+    a.weight = weight_ptr(mir_);
+    a.to_root = base_or_null();
+    a.bounds = rank_bounds_.get();
+    a.inv_max_dcg = rank_imd_.get();
+    a.label_gain = rank_gain_.get();
+    a.discount = rank_disc_.get();
+    a.g = gr();
+    a.h = he();
+    a.nq = (int)bounds.size() - 1;
+    a.max_query = rank_max_query_;
+    a.sigmoid = spec.sigmoid;
+    a.norm = spec.norm ? 1 : 0;
+    a.trunc = spec.truncation_level;
+    a.seed = spec.seed;
+    a.iter = iter;
+    if (spec.xendcg) k::xendcg_gradients(a, stream_);
+    else k::lambdarank_gradients(a, stream_);
+    have_max_ = false;
+    return true;
+  }
   void set_gradients(const float* g, const float* h, int64_t n) override {
     if (n != n_base_) throw std::runtime_error("custom gradients: wrong length");
     tmp_f32_.resize((size_t)n * 2);
@@ -1131,6 +1177,11 @@ class HipEngine : public Engine {
   int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;
+  // ranking: per-query tables of the training data (ranking_gradients)
+  bool rank_ready_ = false, rank_on_device_ = false;
+  int rank_max_query_ = 0;
+  DeviceBuffer<int64_t> rank_bounds_;
+  DeviceBuffer<double> rank_imd_, rank_gain_, rank_disc_;
   DeviceBuffer<int64_t> packed_;
   DeviceBuffer<uint32_t> maxbits_, select_scratch_;
   DeviceBuffer<k::LeafSpan> span_dev_;

@@ -157,5 +157,26 @@ void gather_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hi
 void scatter_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s);
 void iota(int32_t* dst, int64_t n, hipStream_t s);
 
+// ---- ranking gradients (ranking.hip): one workgroup per query ----
+constexpr int kMaxDeviceQuery = 4096;   // documents of the largest query the kernels hold in LDS
+struct RankArgs {
+  const double* score;        // root-indexed scores
+  const float* label;         // root-indexed relevance grades
+  const float* weight;        // root-indexed, or null
+  const int32_t* to_root;     // dataset row -> root row, or null when they coincide
+  const int64_t* bounds;      // nq + 1 dataset-row offsets of the queries
+  const double* inv_max_dcg;  // per query (lambdarank)
+  const double* label_gain;   // per grade
+  const double* discount;     // per 0-based rank, max_query entries
+  float* g;
+  float* h;                   // root-indexed outputs
+  int nq, max_query;
+  double sigmoid;
+  int norm, trunc;
+  uint64_t seed, iter;        // rank_xendcg noise stream
+};
+void lambdarank_gradients(const RankArgs& a, hipStream_t s);
+void xendcg_gradients(const RankArgs& a, hipStream_t s);
+
 }  // namespace k
 }  // namespace lga

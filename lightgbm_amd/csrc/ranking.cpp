@@ -9,7 +9,7 @@ namespace lga {
 
 namespace {
 
-inline double discount(int rank) { return 1.0 / std::log2(2.0 + (double)rank); }
+inline double discount(int rank) { return rank_discount(rank); }
 
 // Positions of a query's documents by descending score; equal scores keep their row order.
 void order_by_score(const double* score, int64_t cnt, std::vector<int>* idx) {
@@ -18,8 +18,7 @@ void order_by_score(const double* score, int64_t cnt, std::vector<int>* idx) {
   std::stable_sort(idx->begin(), idx->end(), [&](int a, int b) { return score[a] > score[b]; });
 }
 
-// Pairwise logistic loss weighted by the NDCG change of swapping the pair (Burges, "From RankNet to
-// LambdaRank to LambdaMART").
+// Lambdas of one query, every document summing its own pair terms by ascending partner rank (ranking.hpp).
 void lambdarank_query(const RankingSpec& s, const double* score, const float* label, int64_t cnt, double inv_max_dcg,
                       float* g, float* h, std::vector<int>& idx, std::vector<double>& lam, std::vector<double>& hes) {
   lam.assign((size_t)cnt, 0.0);
@@ -27,34 +26,36 @@ void lambdarank_query(const RankingSpec& s, const double* score, const float* la
   if (cnt > 1 && inv_max_dcg > 0.0) {
     order_by_score(score, cnt, &idx);
     const double best = score[idx[0]], worst = score[idx[(size_t)cnt - 1]];
-    double sum_lambdas = 0.0;
+    const bool normalise = s.norm && best != worst;
     const int64_t top = std::min<int64_t>(cnt, s.truncation_level);
-    for (int64_t i = 0; i < top; ++i) {
-      for (int64_t j = i + 1; j < cnt; ++j) {
-        const int a = idx[(size_t)i], b = idx[(size_t)j];
-        if (label[a] == label[b]) continue;
-        // hi: the more relevant document of the pair
-        const bool a_high = label[a] > label[b];
-        const int hi = a_high ? a : b, lo = a_high ? b : a;
-        const int64_t hi_rank = a_high ? i : j, lo_rank = a_high ? j : i;
-        const double delta_score = score[hi] - score[lo];
-        const double gain_gap = s.label_gain[(size_t)label[hi]] - s.label_gain[(size_t)label[lo]];
-        const double disc_gap = std::fabs(discount((int)hi_rank) - discount((int)lo_rank));
-        double delta_ndcg = gain_gap * disc_gap * inv_max_dcg;
-        if (s.norm && best != worst) delta_ndcg /= 0.01 + std::fabs(delta_score);
-        double p = 1.0 / (1.0 + std::exp(s.sigmoid * delta_score));   // probability of the wrong order
-        double ph = p * (1.0 - p);
-        p *= -s.sigmoid * delta_ndcg;
-        ph *= s.sigmoid * s.sigmoid * delta_ndcg;
-        lam[(size_t)lo] -= p;
-        hes[(size_t)lo] += ph;
-        lam[(size_t)hi] += p;
-        hes[(size_t)hi] += ph;
-        sum_lambdas -= 2.0 * p;
+    double total = 0.0;
+    for (int64_t r = 0; r < cnt; ++r) {
+      const int me = idx[(size_t)r];
+      const double my_gain = s.label_gain[(size_t)label[me]], my_disc = discount((int)r);
+      // a pair needs one member among the first `top` ranks
+      const int64_t partners = r < top ? cnt : top;
+      double l = 0.0, hh = 0.0, part = 0.0;
+      for (int64_t q = 0; q < partners; ++q) {
+        const int other = idx[(size_t)q];
+        if (q == r || label[other] == label[me]) continue;
+        const double o_gain = s.label_gain[(size_t)label[other]], o_disc = discount((int)q);
+        double pl, ph;
+        if (label[me] > label[other]) {
+          rank_pair(score[me], score[other], my_gain, o_gain, my_disc, o_disc, inv_max_dcg, s.sigmoid, normalise, &pl, &ph);
+          l += pl;
+        } else {
+          rank_pair(score[other], score[me], o_gain, my_gain, o_disc, my_disc, inv_max_dcg, s.sigmoid, normalise, &pl, &ph);
+          l -= pl;
+        }
+        hh += ph;
+        if (q > r) part -= 2.0 * pl;
       }
+      lam[(size_t)me] = l;
+      hes[(size_t)me] = hh;
+      total += part;
     }
-    if (s.norm && sum_lambdas > 0.0) {
-      const double f = std::log2(1.0 + sum_lambdas) / sum_lambdas;
+    if (s.norm && total > 0.0) {
+      const double f = std::log2(1.0 + total) / total;
       for (int64_t i = 0; i < cnt; ++i) { lam[(size_t)i] *= f; hes[(size_t)i] *= f; }
     }
   }
@@ -79,7 +80,7 @@ void xendcg_query(const RankingSpec& s, const double* score, const float* label,
   double sum_labels = 0.0;
   for (int64_t i = 0; i < cnt; ++i) {
     const double u = (double)rng_uniform(s.seed, iter, (uint64_t)(first_row + i));
-    par[(size_t)i] = std::pow(2.0, (double)(int)label[i]) - u;
+    par[(size_t)i] = std::ldexp(1.0, (int)label[i]) - u;
     sum_labels += par[(size_t)i];
   }
   const double inv_denominator = 1.0 / std::max(sum_labels, 1e-15);

@@ -6,12 +6,35 @@
 // engine's caller-supplied-gradients entry; the trees are then grown by the engine (host or HIP) exactly as
 // for any other objective.  A distributed run keeps every query on one rank: gradients need no
 // communication, the metrics are sums over queries that the caller reduces.
+//
+// Summation order (so that the host code and the device kernels of csrc/hip/ranking.hip add the same doubles
+// in the same order): a document's lambda / hessian is the sum of its pair terms by ascending RANK of the
+// partner document; the normalisation total of a query is the sum, by ascending rank r, of document r's
+// partial sum over its partners of higher rank number; rank_xendcg's per-query totals run in row order.
 #pragma once
+#include "common.hpp"
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
 
 namespace lga {
+
+// Pairwise logistic loss weighted by the NDCG change of swapping the pair (Burges, "From RankNet to
+// LambdaRank to LambdaMART").  hi is the more relevant document.  lambda is hi's gradient term (<= 0; lo
+// receives -lambda), hessian the term both receive.
+LGA_HD void rank_pair(double score_hi, double score_lo, double gain_hi, double gain_lo, double disc_hi, double disc_lo,
+                      double inv_max_dcg, double sigmoid, bool normalise, double* lambda, double* hessian) {
+  const double delta_score = score_hi - score_lo;
+  double delta_ndcg = (gain_hi - gain_lo) * fabs(disc_hi - disc_lo) * inv_max_dcg;
+  if (normalise) delta_ndcg /= 0.01 + fabs(delta_score);
+  double p = 1.0 / (1.0 + exp(sigmoid * delta_score));   // probability of the wrong order
+  *hessian = p * (1.0 - p) * (sigmoid * sigmoid * delta_ndcg);
+  *lambda = p * (-sigmoid * delta_ndcg);
+}
+
+// Discount of a 0-based rank.
+inline double rank_discount(int rank) { return 1.0 / std::log2(2.0 + (double)rank); }
 
 struct RankingSpec {
   bool xendcg = false;                // false: lambdarank

@@ -339,29 +339,63 @@ def test_gpu_multiclass_matches_cpu(objective):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
 
 
-@pytest.mark.parametrize("objective", ["lambdarank", "rank_xendcg"])
-def test_gpu_ranking_grows_the_cpu_trees(objective):
-    """Ranking gradients are taken per query on the host from the engine's scores, which are bit-identical
-    between the engines, so the device grows the very trees of the CPU engine - bagging and weights included."""
-    rng = np.random.RandomState(2)
-    sizes = rng.randint(3, 60, size=1500)
+def _rank_data(seed, nq, lo, hi, F=10):
+    rng = np.random.RandomState(seed)
+    sizes = rng.randint(lo, hi, size=nq)
     n = int(sizes.sum())
-    X = rng.randn(n, 10)
+    X = rng.randn(n, F)
     y = np.clip(np.round(X[:, 0] + np.sin(X[:, 1]) + 0.4 * rng.randn(n) + 1.5), 0, 4)
-    w = 0.5 + rng.rand(n)
+    return X, y, sizes, 0.5 + rng.rand(n), rng.randn(n)
+
+
+@pytest.mark.parametrize("objective", ["lambdarank", "rank_xendcg"])
+@pytest.mark.parametrize("lo,hi,nq", [(1, 60, 400), (200, 900, 12), (1500, 4096, 3)])
+def test_device_ranking_gradients_match_the_host(objective, lo, hi, nq):
+    """One workgroup per query (LDS sort + per-document pair sums) against the host's per-query loop, from
+    random scores (tied ones included), with weights, on a row subset (dataset row -> root row indirection)
+    and for every documents-per-thread instantiation of the kernel.  Same formula, same summation order:
+    what is left is the last bits of the device's exp() / log2()."""
+    X, y, sizes, w, init = _rank_data(11, nq, lo, hi)
+    init = np.round(init, 1)                      # plenty of tied scores
+    keep_q = np.arange(nq) % 3 != 1               # a subset made of whole queries
+    bounds = np.concatenate([[0], np.cumsum(sizes)])
+    rows = np.concatenate([np.arange(bounds[q], bounds[q + 1]) for q in np.flatnonzero(keep_q)])
+    p = {"objective": objective, "min_data_in_leaf": 1, "lambdarank_truncation_level": 20, "sigmoid": 1.2}
+    grads = []
+    for dev in (CPU, GPU):
+        d = lgb.Dataset(X, label=y, weight=w, group=sizes, init_score=init, params=dev).construct().subset(rows)
+        b = lgb.Booster({**dev, **p}, d)
+        b.update()
+        grads.append(b.get_gradients())
+    for host, device in zip(*grads):
+        assert np.abs(host).max() > 0
+        np.testing.assert_allclose(device, host, rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("objective", ["lambdarank", "rank_xendcg"])
+def test_gpu_ranking_matches_cpu(objective, monkeypatch):
+    """Device gradients: the first tree (all scores equal, so no exp() rounding enters) is the CPU's and the
+    metrics stay together.  Host gradients under the device engine (LGA_RANK_ON_HOST): every tree is the CPU's."""
+    X, y, sizes, w, _ = _rank_data(2, 1500, 3, 60)
     ntr = int(sizes[:1200].sum())
     p = {"objective": objective, "num_leaves": 31, "min_data_in_leaf": 10, "eval_at": [1, 5], "metric": ["ndcg", "map"],
          "bagging_fraction": 0.7, "bagging_freq": 1}
-    out = []
-    for dev in (CPU, GPU):
+
+    def run(dev):
         dtr = lgb.Dataset(X[:ntr], label=y[:ntr], weight=w[:ntr], group=sizes[:1200], params=dev)
         dva = lgb.Dataset(X[ntr:], label=y[ntr:], group=sizes[1200:], reference=dtr, params=dev)
         ev = {}
         b = lgb.train({**dev, **p}, dtr, 15, valid_sets=[dva], valid_names=["va"], evals_result=ev)
-        out.append((trees_of(b), ev["va"]))
-    assert out[0][0] == out[1][0]
-    assert out[0][1] == out[1][1]
-    assert out[1][1]["ndcg@5"][-1] > out[1][1]["ndcg@5"][0]
+        return trees_of(b), ev["va"]
+    cpu_trees, cpu_ev = run(CPU)
+    gpu_trees, gpu_ev = run(GPU)
+    assert cpu_trees[:cpu_trees.index("Tree=1")] == gpu_trees[:gpu_trees.index("Tree=1")]
+    for m in cpu_ev:
+        assert abs(cpu_ev[m][-1] - gpu_ev[m][-1]) < 0.01
+    assert gpu_ev["ndcg@5"][-1] > gpu_ev["ndcg@5"][0]
+    monkeypatch.setenv("LGA_RANK_ON_HOST", "1")
+    host_trees, host_ev = run(GPU)
+    assert host_trees == cpu_trees and host_ev == cpu_ev
 
 
 @pytest.mark.parametrize("leaves,n", [(4, 5000), (31, 70000)])
