@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's evidence on an MI355X box: the 500-tree benchmark, a per-kernel trace of 32 trees, three
-# hardware-counter passes over 7 trees, the predictor benchmark.  Summaries land in gpurun_out/final/ (the raw
+# hardware-counter passes over 7 trees, the predictor and the learning-to-rank benchmarks.  Summaries land in gpurun_out/final/ (the raw
 # rocprofv3 databases stay in /tmp: they exceed what is copied back).
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -12,6 +12,8 @@ timeout -k 10 200 python $ROOT/bench.py --steps 500 --warmup 5 --stats | tail -1
 echo "bench done"
 timeout -k 10 200 python $ROOT/bench/predict_bench.py | tail -1 > "$OUT/predict_bench.json"
 echo "predict bench done"
+timeout -k 10 300 python $ROOT/bench/rank_bench.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/rank_bench.txt"
+echo "ranking bench done"
 rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $ROOT/bench.py --steps 32 --warmup 3 > /tmp/kt.log 2>&1
 python $ROOT/tools/rocpd_stats.py "$(find /tmp/kt -name '*.db' | sort | tail -1)" "$OUT/kernel_stats_32trees.csv" > /dev/null
 echo "kernel trace done"
