@@ -28,7 +28,8 @@ def _fmt_value(v: Any) -> str:
     if isinstance(v, bool) or isinstance(v, np.bool_):
         return "true" if v else "false"
     if isinstance(v, (list, tuple, set)):
-        return ",".join(_fmt_value(x) for x in v)
+        # a list of lists (interaction_constraints) keeps its brackets: [[0, 1], [2, 3]] -> "[0,1],[2,3]"
+        return ",".join("[" + _fmt_value(x) + "]" if isinstance(x, (list, tuple, set)) else _fmt_value(x) for x in v)
     if isinstance(v, (float, np.floating)):
         return repr(float(v))
     if isinstance(v, (int, np.integer)):

@@ -50,9 +50,13 @@ class TreeBackend {
   // task i's left / right child.  The backend fills the chunk fields of the tasks.
   virtual void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) = 0;
   virtual QuantScale quant_scale() const = 0;
-  // Monotone constraints: the output range of a node, announced before the round that creates the node is
-  // submitted (node 0 is unbounded).  Never called when no feature is constrained.
-  virtual void set_node_bounds(int node, double lo, double hi) = 0;
+  // Monotone constraints / path smoothing: the output range of a node and the node's own output, announced
+  // before the round that creates the node is submitted (node 0 is unbounded, its output the plain optimum).
+  // Never called when neither is active.
+  virtual void set_node_bounds(int node, double lo, double hi, double out) = 0;
+  // Interaction constraints: the features (bits over inner features, mask_words(F) words) that may split a
+  // node; node 0's mask is announced between begin_tree and root_round.  Never called without constraints.
+  virtual void set_node_mask(int node, const uint64_t* words) = 0;
   // Local row count of a node (after the round that created it).
   virtual int64_t node_local_count(int node) const = 0;
 

@@ -45,12 +45,17 @@ struct SplitParams {
   double bynode_fraction;   // feature_fraction_bynode (>= 1: every enabled feature at every node)
   uint64_t bynode_seed;     // differs per tree
   int32_t extra_trees;      // 1: only one random threshold per (node, feature) is a candidate
-  int32_t pad_;
+  int32_t mask_words;       // 64-bit words per node of node_masks
   uint64_t extra_seed;      // differs per tree
-  // Monotone constraints (device backend): output range [2 * node], [2 * node + 1] of every node, in the
-  // backend's memory space; nullptr when no feature of the tree is constrained.
+  // Monotone constraints / path smoothing (device backend): kNodeInfoStride doubles per node - the output
+  // range [lo, hi] and the node's own output - in the backend's memory space; nullptr when neither is active.
   const double* node_bounds;
+  // Interaction constraints (device backend): mask_words words per node, bit f = inner feature f may split
+  // the node; nullptr when there are none.
+  const uint64_t* node_masks;
+  double path_smooth;       // > 0: child outputs are pulled towards the parent's, less so the more rows they hold
 };
+constexpr int kNodeInfoStride = 3;
 
 // Power-of-two scales of the current boosting iteration: real = q * 2^-k.
 struct QuantScale {
@@ -193,7 +198,9 @@ struct LeafScanCtx {
   double cnt_factor;    // rows per quantised hessian unit
   double parent_gain;
   double lo, hi;        // monotone constraints: the range this leaf's (and its descendants') outputs must stay in
+  double node_out;      // path smoothing: this leaf's own output, which its children's outputs are pulled towards
   int32_t bounded;      // lo / hi are not both infinite
+  int32_t smooth;       // path smoothing is on
 };
 
 LGA_HD double clamp_output(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -203,17 +210,30 @@ LGA_HD double gain_given_output(double g, double h, double l1, double l2, double
   return -(2.0 * t * out + (h + l2) * out * out);
 }
 
+// Path smoothing: a child with n rows gets raw * w + parent * (1 - w), w = (n / s) / (n / s + 1).
+LGA_HD double smoothed_output(double raw, int64_t n, double parent_out, double path_smooth) {
+  const double r = (double)n / path_smooth;
+  return raw * r / (r + 1.0) + parent_out / (r + 1.0);
+}
+
+// node_out: the leaf's own output (NaN: take the unconstrained optimum - the root); only read with smoothing.
 LGA_HD LeafScanCtx make_scan_ctx(int64_t tg, int64_t th, int64_t tc, double gunit, double hunit, const SplitParams& p,
                                  double lo = -std::numeric_limits<double>::infinity(),
-                                 double hi = std::numeric_limits<double>::infinity()) {
+                                 double hi = std::numeric_limits<double>::infinity(),
+                                 double node_out = std::numeric_limits<double>::quiet_NaN()) {
   LeafScanCtx c;
   c.total_g = tg; c.total_h = th; c.total_cnt = tc;
   c.gunit = gunit; c.hunit = hunit;
   c.cnt_factor = th > 0 ? (double)tc / (double)th : 0.0;
   c.lo = lo; c.hi = hi;
   c.bounded = (lo > -std::numeric_limits<double>::infinity() || hi < std::numeric_limits<double>::infinity()) ? 1 : 0;
+  c.smooth = p.path_smooth > 0.0 ? 1 : 0;
   const double G = (double)tg * gunit, H = (double)th * hunit;
-  if (c.bounded) {
+  c.node_out = 0.0;
+  if (c.smooth) {
+    c.node_out = node_out == node_out ? node_out : leaf_output(G, H, p.lambda_l1, p.lambda_l2, p.max_delta_step);
+    c.parent_gain = gain_given_output(G, H, p.lambda_l1, p.lambda_l2, c.node_out);
+  } else if (c.bounded) {
     const double out = clamp_output(leaf_output(G, H, p.lambda_l1, p.lambda_l2, p.max_delta_step), lo, hi);
     c.parent_gain = gain_given_output(G, H, p.lambda_l1, p.lambda_l2, out);
   } else {
@@ -240,9 +260,15 @@ LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const Spl
   if (lhr < p.min_sum_hessian_in_leaf || rhr < p.min_sum_hessian_in_leaf) return ninf;
   double lgr = (double)lg * c.gunit, rgr = (double)rg * c.gunit;
   double gain;
-  if (c.bounded || monotone != 0) {
-    const double lo_ = clamp_output(leaf_output(lgr, lhr, p.lambda_l1, p.lambda_l2, p.max_delta_step), c.lo, c.hi);
-    const double ro_ = clamp_output(leaf_output(rgr, rhr, p.lambda_l1, p.lambda_l2, p.max_delta_step), c.lo, c.hi);
+  if (c.bounded || c.smooth || monotone != 0) {
+    double lo_ = leaf_output(lgr, lhr, p.lambda_l1, p.lambda_l2, p.max_delta_step);
+    double ro_ = leaf_output(rgr, rhr, p.lambda_l1, p.lambda_l2, p.max_delta_step);
+    if (c.smooth) {
+      lo_ = smoothed_output(lo_, lc, c.node_out, p.path_smooth);
+      ro_ = smoothed_output(ro_, rc, c.node_out, p.path_smooth);
+    }
+    lo_ = clamp_output(lo_, c.lo, c.hi);
+    ro_ = clamp_output(ro_, c.lo, c.hi);
     if ((monotone > 0 && lo_ > ro_) || (monotone < 0 && lo_ < ro_)) return ninf;
     gain = gain_given_output(lgr, lhr, p.lambda_l1, p.lambda_l2, lo_) + gain_given_output(rgr, rhr, p.lambda_l1, p.lambda_l2, ro_) -
            c.parent_gain;
@@ -301,6 +327,11 @@ LGA_HD float goss_weight(const float* g, const float* h, int64_t row, int num_cl
 constexpr uint32_t kRootNodeKey = 1u;
 LGA_HD uint32_t child_node_key(uint32_t parent_key, int side) {
   return (uint32_t)mix64(((uint64_t)parent_key << 1) | (uint64_t)(side & 1)) | 1u;
+}
+// Interaction constraints: may inner feature f split backend node `node`?
+LGA_HD bool node_allows(const SplitParams& sp, int node, int f) {
+  if (!sp.node_masks) return true;
+  return (sp.node_masks[(size_t)node * (size_t)sp.mask_words + (size_t)(f >> 6)] >> (f & 63)) & 1ull;
 }
 LGA_HD bool node_feature_on(const SplitParams& sp, uint32_t key, int f, int num_features) {
   if (!(sp.bynode_fraction < 1.0)) return true;

@@ -68,6 +68,8 @@ const ParamDef kParams[] = {
     P(lambda_l1, "reg_alpha,l1_regularization", Double, 0, kNone),
     P(lambda_l2, "reg_lambda,lambda,l2_regularization", Double, 0, kNone),
     P(min_gain_to_split, "min_split_gain", Double, 0, kNone),
+    P(path_smooth, "", Double, 0, kNone),
+    P(interaction_constraints, "", String, kNone, kNone),
     P(verbosity, "verbose", Int, kNone, kNone),
     P(max_bin, "max_bins", Int, 2, 255),
     P(min_data_in_bin, "", Int, 1, kNone),

@@ -53,6 +53,8 @@ struct Config {
   double lambda_l1 = 0.0;
   double lambda_l2 = 0.0;
   double min_gain_to_split = 0.0;
+  double path_smooth = 0.0;                // > 0: pull a child's output towards its parent's (less with more rows)
+  std::string interaction_constraints;     // "[0,1,2],[2,3]": features that may appear together on a branch
   int verbosity = 1;
   // dataset
   int max_bin = 255;

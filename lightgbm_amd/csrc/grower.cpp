@@ -11,6 +11,43 @@ namespace lga {
 
 TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds) {
   if (const char* e = std::getenv("LGA_SPEC_FLOOR")) spec_floor_ = std::atof(e);
+  // interaction_constraints = "[0,1,2],[2,3]": groups of raw-matrix columns; columns without a usable
+  // feature (constant ones) drop out
+  const std::string& ic = cfg_.interaction_constraints;
+  if (!ic.empty()) {
+    const int F = ds_->num_features(), total = ds_->num_total_features();
+    mask_words_ = (F + 63) / 64;
+    std::vector<uint64_t> cur;
+    bool open = false;
+    size_t i = 0;
+    auto bad = [&]() { throw std::runtime_error("interaction_constraints: expected a list like [0,1,2],[2,3], got \"" + ic + "\""); };
+    while (i < ic.size()) {
+      const char ch = ic[i];
+      if (ch == '[') {
+        if (open) bad();
+        open = true;
+        cur.assign((size_t)std::max(mask_words_, 1), 0ull);
+        ++i;
+      } else if (ch == ']') {
+        if (!open) bad();
+        open = false;
+        groups_.push_back(cur);
+        ++i;
+      } else if (ch == ',' || ch == ' ') {
+        ++i;
+      } else if (ch >= '0' && ch <= '9') {
+        if (!open) bad();
+        long v = 0;
+        while (i < ic.size() && ic[i] >= '0' && ic[i] <= '9') { v = v * 10 + (ic[i] - '0'); ++i; if (v > 1000000000) bad(); }
+        if (v >= total) throw std::runtime_error("interaction_constraints: feature " + std::to_string(v) + " does not exist");
+        const int inner = ds_->inner_feature((int)v);
+        if (inner >= 0) cur[(size_t)(inner >> 6)] |= 1ull << (inner & 63);
+      } else {
+        bad();
+      }
+    }
+    if (open || groups_.empty()) bad();
+  }
 }
 
 SplitParams TreeGrower::split_params() const {
@@ -24,8 +61,10 @@ SplitParams TreeGrower::split_params() const {
   p.max_depth = cfg_.max_depth;
   p.bynode_fraction = cfg_.feature_fraction_bynode;
   p.node_bounds = nullptr;
+  p.node_masks = nullptr;
+  p.mask_words = 0;
+  p.path_smooth = cfg_.path_smooth;
   p.extra_trees = cfg_.extra_trees ? 1 : 0;
-  p.pad_ = 0;
   p.extra_seed = mix64((uint64_t)cfg_.extra_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x7e57ull);
   p.bynode_seed = mix64((uint64_t)cfg_.feature_fraction_seed * 0x9e3779b97f4a7c15ull + (uint64_t)tree_index_ + 0x51ed27ull);
   return p;
@@ -81,6 +120,26 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   std::vector<Node> nodes;
   nodes.reserve((size_t)be.node_capacity());
   nodes.emplace_back();
+  // Interaction constraints: a node may be split on the features already on its branch and on those of every
+  // group that holds all of them; the root on any feature of any group.
+  const bool constrained = !groups_.empty();
+  const size_t W = (size_t)mask_words_;
+  std::vector<uint64_t> path_bits;   // [node][W]: features on the branch down to the node
+  std::vector<uint64_t> allowed(W);
+  auto allowed_for = [&](const uint64_t* path) {
+    for (size_t w = 0; w < W; ++w) allowed[w] = path[w];
+    for (const auto& g : groups_) {
+      bool holds_all = true;
+      for (size_t w = 0; w < W; ++w) holds_all = holds_all && (path[w] & ~g[w]) == 0;
+      if (holds_all)
+        for (size_t w = 0; w < W; ++w) allowed[w] |= g[w];
+    }
+  };
+  if (constrained) {
+    path_bits.assign(W, 0ull);
+    allowed_for(path_bits.data());
+    be.set_node_mask(0, allowed.data());
+  }
   be.root_round(&nodes[0].best);
   if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_enter, t_last_backend); }
   stats_.rounds = 1;
@@ -88,13 +147,26 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   const double gunit = unit_of(qs.kg), hunit = unit_of(qs.kh);
   bool any_monotone = false;
   for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
-  // outputs of the two children of `n`'s best split, inside n's range
+  const bool smooth = sp.path_smooth > 0.0;
+  const bool node_info = any_monotone || smooth;   // nodes carry an output range and their own output
+  {
+    const SplitInfo& r = nodes[0].best;
+    nodes[0].out = leaf_output((double)r.total_g * gunit, (double)r.total_h * hunit, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+  }
+  // outputs of the two children of `n`'s best split as the scan valued them: smoothed towards n's output
+  // (with the scan's row estimates), inside n's range
   auto child_outputs = [&](const Node& n, double* lv, double* rv) {
     const SplitInfo& s = n.best;
     const double lg = (double)s.left_g * gunit, lh = (double)s.left_h * hunit;
     const double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
-    *lv = clamp_output(leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step), n.lo, n.hi);
-    *rv = clamp_output(leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step), n.lo, n.hi);
+    double l = leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+    double r = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+    if (smooth) {
+      l = smoothed_output(l, s.left_cnt, n.out, sp.path_smooth);
+      r = smoothed_output(r, s.total_cnt - s.left_cnt, n.out, sp.path_smooth);
+    }
+    *lv = clamp_output(l, n.lo, n.hi);
+    *rv = clamp_output(r, n.lo, n.hi);
   };
 
   auto depth_blocked = [&](int depth) { return cfg_.max_depth > 0 && depth >= cfg_.max_depth; };
@@ -218,21 +290,32 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
         l.depth = r.depth = c.depth + 1;
         l.slot = t.hist_child == 0 ? t.new_slot : t.parent_slot;
         r.slot = t.hist_child == 1 ? t.new_slot : t.parent_slot;
-        if (any_monotone) {
+        if (node_info) {
           // children inherit the range; a split on a constrained feature also separates them at the
           // midpoint of their outputs, which keeps every later descendant on its side
           l.lo = r.lo = c.lo;
           l.hi = r.hi = c.hi;
+          child_outputs(c, &l.out, &r.out);
           const int mono = meta[(size_t)c.best.feature].monotone;
           if (mono != 0) {
-            double lv, rv;
-            child_outputs(c, &lv, &rv);
-            const double mid = 0.5 * (lv + rv);
+            const double mid = 0.5 * (l.out + r.out);
             if (mono > 0) { l.hi = std::min(l.hi, mid); r.lo = std::max(r.lo, mid); }
             else { l.lo = std::max(l.lo, mid); r.hi = std::min(r.hi, mid); }
           }
-          be.set_node_bounds(t.left_node, l.lo, l.hi);
-          be.set_node_bounds(t.right_node, r.lo, r.hi);
+          be.set_node_bounds(t.left_node, l.lo, l.hi, l.out);
+          be.set_node_bounds(t.right_node, r.lo, r.hi, r.out);
+        }
+        if (constrained) {
+          // both children: the parent's branch plus the split feature
+          path_bits.resize((nodes.size() + 2) * W, 0ull);
+          for (int side = 0; side < 2; ++side) {
+            uint64_t* cp = &path_bits[(nodes.size() + (size_t)side) * W];
+            for (size_t w = 0; w < W; ++w) cp[w] = path_bits[(size_t)e.node * W + w];
+            cp[(size_t)(c.best.feature >> 6)] |= 1ull << (c.best.feature & 63);
+          }
+          allowed_for(&path_bits[nodes.size() * W]);
+          be.set_node_mask(t.left_node, allowed.data());
+          be.set_node_mask(t.right_node, allowed.data());
         }
         c.left = t.left_node;
         c.right = t.right_node;
@@ -297,9 +380,10 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
     double lv = leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
     double rv = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
-    if (any_monotone) {
-      lv = clamp_output(lv, nodes[(size_t)n.left].lo, nodes[(size_t)n.left].hi);
-      rv = clamp_output(rv, nodes[(size_t)n.right].lo, nodes[(size_t)n.right].hi);
+    if (node_info) {
+      // the outputs the split was valued with (smoothed / clamped), kept inside the children's own ranges
+      lv = clamp_output(nodes[(size_t)n.left].out, nodes[(size_t)n.left].lo, nodes[(size_t)n.left].hi);
+      rv = clamp_output(nodes[(size_t)n.right].out, nodes[(size_t)n.right].lo, nodes[(size_t)n.right].hi);
     }
     // exact child counts come from the children's own scans
     int64_t lc = nodes[(size_t)n.left].best.total_cnt, rc = nodes[(size_t)n.right].best.total_cnt;

@@ -57,8 +57,12 @@ class TreeGrower {
     uint32_t key = kRootNodeKey; // position key (per-node feature sampling)
     double lo = -std::numeric_limits<double>::infinity();   // output range (monotone constraints)
     double hi = std::numeric_limits<double>::infinity();
+    double out = std::numeric_limits<double>::quiet_NaN();   // the node's own output (monotone / path smoothing)
     SplitInfo best;
   };
+  // interaction constraints as bit sets over inner features (empty: none)
+  std::vector<std::vector<uint64_t>> groups_;
+  int mask_words_ = 0;
   const Config cfg_;
   const Dataset* ds_;
   GrowStats stats_;

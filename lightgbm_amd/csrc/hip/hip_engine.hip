@@ -223,24 +223,41 @@ class HipBackend : public TreeBackend {
   ParallelMode mode() const { return mode_; }
   PhaseProfile prof;
 
-  void set_node_bounds(int node, double lo, double hi) override {
-    double* b = reinterpret_cast<double*>(bounds_host_.get());
-    b[2 * (size_t)node] = lo;
-    b[2 * (size_t)node + 1] = hi;
+  void set_node_bounds(int node, double lo, double hi, double out) override {
+    double* b = reinterpret_cast<double*>(bounds_host_.get()) + (size_t)kNodeInfoStride * (size_t)node;
+    b[0] = lo; b[1] = hi; b[2] = out;
+  }
+  // Interaction constraints: masks live in a device array like the ranges (SplitParams::node_masks).
+  void set_node_mask(int node, const uint64_t* words) override {
+    const size_t W = (size_t)((F_ + 63) / 64);
+    if (!masked_) {
+      masked_ = true;
+      const size_t n_nodes = (size_t)(2 * capacity_splits_ + 2);
+      masks_host_.resize(n_nodes * W);
+      masks_dev_.resize(n_nodes * W);
+      sp_.node_masks = masks_dev_.get();
+      sp_.mask_words = (int32_t)W;
+    }
+    for (size_t w = 0; w < W; ++w) masks_host_.get()[(size_t)node * W + w] = words[w];
+    if (node == 0)
+      LGA_HIP_CHECK(hipMemcpyAsync(masks_dev_.get(), masks_host_.get(), W * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
   }
 
   void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
     sp_ = params;
     // Monotone constraints: node output ranges live in a device array the scan reads (SplitParams::
     // node_bounds); the grower announces them per node, every round uploads the entries of its children.
-    ranged_ = false;
+    masked_ = false;
+    ranged_ = params.path_smooth > 0.0;
     for (const FeatureMeta& m : meta) ranged_ = ranged_ || (m.enabled && m.monotone != 0);
     if (ranged_) {
       const size_t n_nodes = (size_t)(2 * capacity_splits_ + 2);
-      bounds_host_.resize(n_nodes * 2);
-      bounds_dev_.resize(n_nodes * 2);
-      set_node_bounds(0, -std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity());
-      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get(), bounds_host_.get(), 2 * sizeof(double), hipMemcpyHostToDevice, stream_));
+      bounds_host_.resize(n_nodes * kNodeInfoStride);
+      bounds_dev_.resize(n_nodes * kNodeInfoStride);
+      set_node_bounds(0, -std::numeric_limits<double>::infinity(), std::numeric_limits<double>::infinity(),
+                      std::numeric_limits<double>::quiet_NaN());
+      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get(), bounds_host_.get(), kNodeInfoStride * sizeof(double),
+                                   hipMemcpyHostToDevice, stream_));
       sp_.node_bounds = bounds_dev_.get();
     }
     if (meta.size() != meta_host_.size() ||
@@ -456,8 +473,16 @@ class HipBackend : public TreeBackend {
       // the children of a round's tasks have consecutive node ids
       int first = tasks[0].left_node, last = tasks[0].right_node;
       for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
-      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get() + 2 * (size_t)first, bounds_host_.get() + 2 * (size_t)first,
-                                   2 * sizeof(double) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get() + kNodeInfoStride * (size_t)first,
+                                   bounds_host_.get() + kNodeInfoStride * (size_t)first,
+                                   kNodeInfoStride * sizeof(double) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    }
+    if (masked_ && !root) {
+      int first = tasks[0].left_node, last = tasks[0].right_node;
+      for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
+      const size_t W = (size_t)sp_.mask_words;
+      LGA_HIP_CHECK(hipMemcpyAsync(masks_dev_.get() + W * (size_t)first, masks_host_.get() + W * (size_t)first,
+                                   W * sizeof(uint64_t) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
     }
     char* hres = x.host_block.get() + k::kHostDataOffset;
     if (fused) {
@@ -585,9 +610,12 @@ class HipBackend : public TreeBackend {
   std::vector<NodeRange> ranges_host_;
   size_t off_tasks_ = 0, off_scan_ = 0, off_pch_ = 0, off_hch_ = 0, stage_bytes_ = 0;
   SplitParams sp_{};
-  bool ranged_ = false;                 // a feature of the current tree carries a monotone constraint
-  PinnedBuffer<double> bounds_host_;    // [node][lo, hi]
+  bool ranged_ = false;                 // monotone constraints or path smoothing: node_bounds is in use
+  PinnedBuffer<double> bounds_host_;    // [node][lo, hi, out]
   DeviceBuffer<double> bounds_dev_;
+  bool masked_ = false;                 // interaction constraints are active for the current tree
+  PinnedBuffer<uint64_t> masks_host_;   // [node][words]
+  DeviceBuffer<uint64_t> masks_dev_;
   QuantScale qs_host_{0, 0};
   const int32_t* bag_ = nullptr;
   int64_t bag_n_ = 0;

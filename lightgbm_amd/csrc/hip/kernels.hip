@@ -743,14 +743,16 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
   }
   const QuantScale q = *qs;
   const double kInf = std::numeric_limits<double>::infinity();
+  const double kNaN = std::numeric_limits<double>::quiet_NaN();
   const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
-                                        sp.node_bounds ? sp.node_bounds[2 * t.node] : -kInf,
-                                        sp.node_bounds ? sp.node_bounds[2 * t.node + 1] : kInf);
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node] : -kInf,
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node + 1] : kInf,
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node + 2] : kNaN);
   const int64_t* sb = t.parent_slot >= 0 ? pool + (int64_t)t.sibling_slot * slot_words : nullptr;
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F), t.key);
+  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F) && node_allows(sp, t.node, f), t.key);
   if (lane == 0) *out = Cand{bg, bkey, blg, blh};
 }
 
@@ -832,16 +834,18 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
   }
   const QuantScale q = *qs;
   const double kInf = std::numeric_limits<double>::infinity();
+  const double kNaN = std::numeric_limits<double>::quiet_NaN();
   const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
-                                        sp.node_bounds ? sp.node_bounds[2 * node] : -kInf,
-                                        sp.node_bounds ? sp.node_bounds[2 * node + 1] : kInf);
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node] : -kInf,
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 1] : kInf,
+                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 2] : kNaN);
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
   for (int f = wave; f < F; f += kFusedWaves) {
     const FeatureMeta m = meta[f];
     if (!m.enabled) continue;
-    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F), key);
+    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F) && node_allows(sp, node, f), key);
   }
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();

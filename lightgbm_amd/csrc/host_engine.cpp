@@ -64,13 +64,20 @@ class HostBackend : public TreeBackend {
   int node_capacity() const override { return 2 * capacity_splits_ + 1; }
   QuantScale quant_scale() const override { return qs_; }
   int64_t node_local_count(int node) const override { return ranges_[(size_t)node].count; }
-  void set_node_bounds(int node, double lo, double hi) override {
+  void set_node_bounds(int node, double lo, double hi, double out) override {
     if (bounds_.empty()) {
-      bounds_.assign(ranges_.size() * 2, 0.0);
-      for (size_t i = 0; i < ranges_.size(); ++i) { bounds_[2 * i] = -kInf; bounds_[2 * i + 1] = kInf; }
+      bounds_.assign(ranges_.size() * kNodeInfoStride, std::numeric_limits<double>::quiet_NaN());
+      for (size_t i = 0; i < ranges_.size(); ++i) { bounds_[kNodeInfoStride * i] = -kInf; bounds_[kNodeInfoStride * i + 1] = kInf; }
     }
-    bounds_[2 * (size_t)node] = lo;
-    bounds_[2 * (size_t)node + 1] = hi;
+    double* b = &bounds_[(size_t)kNodeInfoStride * (size_t)node];
+    b[0] = lo; b[1] = hi; b[2] = out;
+  }
+  void set_node_mask(int node, const uint64_t* words) override {
+    const size_t W = (size_t)((F_ + 63) / 64);
+    if (masks_.empty()) masks_.assign(ranges_.size() * W, ~0ull);
+    for (size_t w = 0; w < W; ++w) masks_[(size_t)node * W + w] = words[w];
+    sp_.node_masks = masks_.data();
+    sp_.mask_words = (int32_t)W;
   }
   // Rounds run at submission here; LGA_HOST_IN_FLIGHT=2 lets the tests drive the grower's
   // several-rounds-in-flight logic through this backend.
@@ -85,6 +92,7 @@ class HostBackend : public TreeBackend {
     meta_ = meta;
     sp_ = params;
     bounds_.clear();   // filled again by the grower when a feature of this tree is constrained
+    masks_.clear();
     for (int b = 0; b < 2; ++b)
       if ((int64_t)arena_[b].size() < bag_n_) arena_[b].resize((size_t)bag_n_);
     std::memcpy(arena_[0].data(), bag_, (size_t)bag_n_ * sizeof(int32_t));
@@ -262,11 +270,14 @@ class HostBackend : public TreeBackend {
       const int64_t* hd = self + 2 * plane_;
       int64_t tc = hd[0], tg = hd[1], th = hd[2];
       const bool ranged = !bounds_.empty();
-      LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_, ranged ? bounds_[2 * (size_t)s.node] : -kInf,
-                                      ranged ? bounds_[2 * (size_t)s.node + 1] : kInf);
+      const double* nb = ranged ? &bounds_[(size_t)kNodeInfoStride * (size_t)s.node] : nullptr;
+      LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_, ranged ? nb[0] : -kInf, ranged ? nb[1] : kInf,
+                                      ranged ? nb[2] : std::numeric_limits<double>::quiet_NaN());
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
-        if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_)) continue;
+        if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_) ||
+            !node_allows(sp_, s.node, f))
+          continue;
         scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, s.key, &best);
       }
       local[(size_t)i] = best;
@@ -305,7 +316,8 @@ class HostBackend : public TreeBackend {
   }
 
   static constexpr double kInf = std::numeric_limits<double>::infinity();
-  std::vector<double> bounds_;   // [node][lo, hi]; empty unless monotone constraints are active
+  std::vector<double> bounds_;   // [node][lo, hi, out]; empty unless monotone constraints / path smoothing are active
+  std::vector<uint64_t> masks_;  // [node][words]; empty unless interaction constraints are active
   const Dataset* root_;
   Comm* comm_;
   ParallelMode mode_;

@@ -428,3 +428,70 @@ def test_feature_fraction_bynode_samples_per_node_and_is_order_independent():
     # different trees draw different subsets
     used = [set(t["split_feature"] for t in _internal_nodes(tr["tree_structure"])) for tr in a.dump_model()["tree_info"][:4]]
     assert len({frozenset(u) for u in used}) > 1
+
+
+def _branches(booster):
+    """Feature sets of all root-to-leaf branches of a model."""
+    out = []
+
+    def walk(node, used):
+        if "split_feature" in node:
+            u = used | {node["split_feature"]}
+            walk(node["left_child"], u)
+            walk(node["right_child"], u)
+        else:
+            out.append(used)
+    for t in booster.dump_model()["tree_info"]:
+        walk(t["tree_structure"], frozenset())
+    return out
+
+
+def test_interaction_constraints_keep_every_branch_inside_one_group():
+    rng = np.random.RandomState(0)
+    X = rng.randn(8000, 6)
+    y = X[:, 0] * X[:, 1] + X[:, 2] * X[:, 3] + 0.5 * X[:, 4] + X[:, 5] + 0.1 * rng.randn(8000)
+    base = {**CPU, "num_leaves": 31, "min_data_in_leaf": 20}
+    b = lgb.train({**base, "interaction_constraints": [[0, 1], [2, 3, 4]]}, lgb.Dataset(X, label=y), 25)
+    paths = _branches(b)
+    assert all(p <= {0, 1} or p <= {2, 3, 4} for p in paths)
+    assert set().union(*paths) == {0, 1, 2, 3, 4}            # column 5 is in no group: never used
+    assert any(len(p) >= 2 for p in paths)
+    # overlapping groups: a branch that has used the shared feature only may still go either way
+    b2 = lgb.train({**base, "interaction_constraints": "[0,1,2],[2,3]"}, lgb.Dataset(X, label=y), 25)
+    assert all(p <= {0, 1, 2} or p <= {2, 3} for p in _branches(b2))
+    # the string survives the model file
+    assert "[interaction_constraints: [0,1,2],[2,3]]" in b2.model_to_string()
+    with pytest.raises(lgb.LightGBMError, match="does not exist"):
+        lgb.train({**base, "interaction_constraints": [[0, 9]]}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="expected a list"):
+        lgb.train({**base, "interaction_constraints": "0,1"}, lgb.Dataset(X, label=y), 2)
+
+
+def test_path_smooth_shrinks_small_leaves_towards_their_parents():
+    rng = np.random.RandomState(1)
+    X = rng.randn(3000, 5)
+    y = X[:, 0] + 3.0 * rng.randn(3000)                     # noisy: small leaves overfit
+    Xv = rng.randn(3000, 5)
+    yv = Xv[:, 0] + 3.0 * rng.randn(3000)
+    base = {**CPU, "num_leaves": 63, "min_data_in_leaf": 2, "learning_rate": 0.3}
+    plain = lgb.train(base, lgb.Dataset(X, label=y), 20)
+    smooth = lgb.train({**base, "path_smooth": 30.0}, lgb.Dataset(X, label=y), 20)
+    l2 = lambda m, A, t: float(np.mean((m.predict(A) - t) ** 2))
+    assert l2(smooth, X, y) > l2(plain, X, y)               # fits the training noise less ...
+    assert l2(smooth, Xv, yv) < l2(plain, Xv, yv)           # ... and generalises better
+    # one tree by hand: a stump's children are w * raw + (1 - w) * root output, w = (n / s) / (n / s + 1)
+    st = lgb.train({**CPU, "num_leaves": 2, "min_data_in_leaf": 2, "learning_rate": 1.0, "path_smooth": 30.0,
+                    "boost_from_average": False}, lgb.Dataset(X, label=y), 1)
+    t = st.dump_model()["tree_info"][0]["tree_structure"]
+    thr, f = t["threshold"], t["split_feature"]
+    left = X[:, f] <= thr
+    root_out = y.mean()
+    for child, rows in ((t["left_child"], left), (t["right_child"], ~left)):
+        n = rows.sum()
+        w = (n / 30.0) / (n / 30.0 + 1.0)
+        assert child["leaf_value"] == pytest.approx(w * y[rows].mean() + (1 - w) * root_out, rel=2e-3)
+    # with monotone constraints on top the ordering still holds
+    m = lgb.train({**base, "path_smooth": 30.0, "monotone_constraints": [1, 0, 0, 0, 0]}, lgb.Dataset(X, label=y), 10)
+    grid = np.tile(X[:1], (50, 1))
+    grid[:, 0] = np.linspace(-3, 3, 50)
+    assert np.all(np.diff(m.predict(grid)) >= -1e-12)

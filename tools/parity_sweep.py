@@ -64,6 +64,11 @@ def draw_case(seed: int, max_rows: int):
         p["extra_trees"] = True
     if rng.rand() < 0.25:
         p["monotone_constraints"] = [int(v) for v in rng.randint(-1, 2, size=F)]
+    if rng.rand() < 0.2:
+        p["path_smooth"] = float([5.0, 50.0][rng.randint(2)])
+    if rng.rand() < 0.2 and F >= 6:
+        cut = int(rng.randint(2, F - 2))
+        p["interaction_constraints"] = [list(range(0, cut)), list(range(cut - 1, F - 1))]   # last column in no group
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
             "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25,
             "categorical": rng.rand() < 0.3}
