@@ -60,8 +60,9 @@ def device_bytes_in_use() -> int:
         return sum(t.numel() for t in _live.values())
 
 
-def predict(lib, booster_handle, mat, start_iteration: int, num_iteration: int, ptype: int) -> np.ndarray:
-    """Runs the LDS-tiled ensemble kernel; ``mat`` is a numpy array or a cuda tensor (row-major)."""
+def predict(lib, booster_handle, mat, start_iteration: int, num_iteration: int, ptype: int, num_class: int = 1) -> np.ndarray:
+    """Runs the LDS-tiled ensemble kernel; ``mat`` is a numpy array or a cuda tensor (row-major).
+    Multiclass models return ``[rows, num_class]``."""
     import torch
     sync_stream(lib)
     if hasattr(mat, "data_ptr"):
@@ -69,14 +70,15 @@ def predict(lib, booster_handle, mat, start_iteration: int, num_iteration: int, 
         if t.dtype not in (torch.float32, torch.float64):
             t = t.float()
         t = t.contiguous()
-        out = torch.empty(t.shape[0], dtype=torch.float64, device="cuda")
+        out = torch.empty(t.shape[0] * num_class, dtype=torch.float64, device="cuda")
         _lib.check(lib.lga_hip_predict(booster_handle, ctypes.c_void_p(t.data_ptr()), 1,
                                        0 if t.dtype == torch.float32 else 1, t.shape[0], t.shape[1],
                                        start_iteration, num_iteration, ptype, ctypes.c_void_p(out.data_ptr()), 1))
-        return out.cpu().numpy()
+        res = out.cpu().numpy()
+        return res if num_class == 1 else res.reshape(t.shape[0], num_class)
     arr = np.ascontiguousarray(mat)
-    out = np.empty(arr.shape[0], dtype=np.float64)
+    out = np.empty(arr.shape[0] * num_class, dtype=np.float64)
     _lib.check(lib.lga_hip_predict(booster_handle, arr.ctypes.data_as(ctypes.c_void_p), 0,
                                    0 if arr.dtype == np.float32 else 1, arr.shape[0], arr.shape[1], start_iteration,
                                    num_iteration, ptype, out.ctypes.data_as(ctypes.c_void_p), 0))
-    return out
+    return out if num_class == 1 else out.reshape(arr.shape[0], num_class)

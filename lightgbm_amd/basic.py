@@ -763,11 +763,11 @@ class Booster:
         check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
         nrow = mat.shape[0]
         K = self.num_model_per_iteration()
-        use_gpu = hip and K == 1 and not pred_leaf and not pred_contrib and (device == "gpu" or _is_torch(mat) or
-                                             (device is None and nrow * max(used.value, 1) >= 2_000_000))
+        use_gpu = hip and not pred_leaf and not pred_contrib and (device == "gpu" or _is_torch(mat) or
+                                             (device is None and nrow * max(used.value, 1) * K >= 2_000_000))
         if use_gpu:
             from . import _device
-            return _device.predict(lib, self._handle, mat, start_iteration, num_iteration, ptype)
+            return _device.predict(lib, self._handle, mat, start_iteration, num_iteration, ptype, K)
         if _is_torch(mat):
             mat = mat.cpu().numpy()
         width = K * ((mat.shape[1] + 1) if pred_contrib else (used.value if pred_leaf else 1))

@@ -221,18 +221,45 @@ double node_threshold(const Tree& tr, int i) {
 
 }  // namespace
 
-void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, int64_t nrow, int ncol, int start_iter,
-                 int num_iter, int type, double* out, bool out_on_device) {
-  if (ncol < b.num_features())
-    throw std::runtime_error("predict: the data has " + std::to_string(ncol) + " features, the model needs " +
-                             std::to_string(b.num_features()));
-  if (type == kPredictLeaf) throw std::runtime_error("device prediction does not produce leaf indices");
+namespace {
+
+// Multiclass: raw scores arrive class-major ([class][row]); one thread per row applies the link function
+// and writes the row's num_class values next to each other.
+__global__ __launch_bounds__(256) void multiclass_finish_kernel(const double* __restrict__ raw, int64_t n, int K,
+                                                                int32_t kind, double sigmoid, int keep_raw,
+                                                                double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep_raw || (kind != kObjMulticlass && kind != kObjMulticlassOva)) {
+    for (int k = 0; k < K; ++k) out[i * K + k] = raw[(int64_t)k * n + i];
+    return;
+  }
+  if (kind == kObjMulticlassOva) {
+    for (int k = 0; k < K; ++k) out[i * K + k] = 1.0 / (1.0 + exp(-sigmoid * raw[(int64_t)k * n + i]));
+    return;
+  }
+  double mx = raw[i];
+  for (int k = 1; k < K; ++k) mx = fmax(mx, raw[(int64_t)k * n + i]);
+  double sum = 0.0;
+  for (int k = 0; k < K; ++k) sum += exp(raw[(int64_t)k * n + i] - mx);
+  for (int k = 0; k < K; ++k) out[i * K + k] = exp(raw[(int64_t)k * n + i] - mx) / sum;
+}
+
+// Scores of ONE class of the model: class k's trees are trees[(iteration) * K + k].
+void predict_class(const Booster& b, int K, int k, const void* data, bool on_device, int dtype, int64_t nrow, int ncol,
+                   int start_iter, int num_iter, int type, double* out, bool out_on_device) {
   hipStream_t s = current_stream();
-  if (b.num_class() != 1) throw std::runtime_error("the device predictor serves single-output models; multiclass models predict on the host");
-  const auto& trees = b.trees();
-  int total = (int)trees.size();
+  const auto& all_trees = b.trees();
+  int total = (int)all_trees.size() / K;
   start_iter = std::max(0, std::min(start_iter, total));
   int n_it = b.used_iterations(start_iter, num_iter);
+  // the iteration's tree of this class, under the name the single-output code below uses
+  struct ClassTrees {
+    const std::vector<Tree>& all;
+    int K, k;
+    const Tree& operator[](size_t iteration) const { return all[iteration * (size_t)K + (size_t)k]; }
+  };
+  const ClassTrees trees{all_trees, K, k};
   ObjectiveSpec obj = b.objective_spec();
   const size_t esz = dtype == 0 ? 4 : 8;
   const int64_t chunk = on_device ? nrow : std::min<int64_t>(nrow, std::max<int64_t>(1, (int64_t)((512u << 20) / (esz * (size_t)ncol))));
@@ -382,6 +409,50 @@ void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, 
                          d_nodes.get(), d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it,
                          b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
   });
+}
+
+}  // namespace
+
+// out: one value per row; num_class values per row (row-major) for multiclass models.
+void hip_predict(const Booster& b, const void* data, bool on_device, int dtype, int64_t nrow, int ncol, int start_iter,
+                 int num_iter, int type, double* out, bool out_on_device) {
+  if (ncol < b.num_features())
+    throw std::runtime_error("predict: the data has " + std::to_string(ncol) + " features, the model needs " +
+                             std::to_string(b.num_features()));
+  if (type == kPredictLeaf) throw std::runtime_error("device prediction does not produce leaf indices");
+  const int K = b.num_class();
+  if (K == 1) {
+    predict_class(b, 1, 0, data, on_device, dtype, nrow, ncol, start_iter, num_iter, type, out, out_on_device);
+    return;
+  }
+  // One pass per class over row blocks that stay on the device between the passes, then the link function.
+  hipStream_t s = current_stream();
+  const ObjectiveSpec obj = b.objective_spec();
+  const size_t esz = dtype == 0 ? 4 : 8;
+  const int64_t block = std::min<int64_t>(std::max<int64_t>(nrow, 1),
+                                          std::max<int64_t>(1, (int64_t)((1024ull << 20) / (esz * (size_t)ncol))));
+  DeviceBuffer<char> stage;
+  DeviceBuffer<double> raw((size_t)block * (size_t)K), fin;
+  if (!on_device) stage.resize((size_t)block * (size_t)ncol * esz);
+  if (!out_on_device) fin.resize((size_t)block * (size_t)K);
+  for (int64_t r0 = 0; r0 < nrow; r0 += block) {
+    const int64_t n = std::min(block, nrow - r0);
+    const char* src = (const char*)data + (size_t)r0 * (size_t)ncol * esz;
+    const void* x = src;
+    if (!on_device) {
+      LGA_HIP_CHECK(hipMemcpyAsync(stage.get(), src, (size_t)n * (size_t)ncol * esz, hipMemcpyHostToDevice, s));
+      x = stage.get();
+    }
+    for (int k = 0; k < K; ++k)
+      predict_class(b, K, k, x, true, dtype, n, ncol, start_iter, num_iter, kPredictRaw, raw.get() + (size_t)k * (size_t)n, true);
+    double* o = out_on_device ? out + r0 * K : fin.get();
+    hipLaunchKernelGGL(multiclass_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, raw.get(), n, K,
+                       obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
+    LGA_HIP_CHECK(hipGetLastError());
+    if (!out_on_device)
+      LGA_HIP_CHECK(hipMemcpyAsync(out + r0 * K, fin.get(), sizeof(double) * (size_t)n * (size_t)K, hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+  }
 }
 
 }  // namespace lga

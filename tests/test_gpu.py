@@ -339,6 +339,25 @@ def test_gpu_multiclass_matches_cpu(objective):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
 
 
+@pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
+def test_device_predictor_serves_multiclass_models(objective):
+    """One pass per class over device-resident rows plus the softmax / sigmoid kernel, against the host predictor:
+    normal and raw output, staged prediction, float32 / float64 rows, host and device matrices, rf averaging."""
+    import torch
+    rng = np.random.RandomState(8)
+    X = rng.randn(20000, 12)
+    y = (X[:, :5] @ rng.randn(5, 5) + 0.5 * rng.randn(20000, 5)).argmax(axis=1).astype(np.float64)
+    for extra in ({}, {"boosting": "rf", "bagging_fraction": 0.6, "bagging_freq": 1}):
+        b = lgb.train({**GPU, "objective": objective, "num_class": 5, "num_leaves": 15, **extra}, lgb.Dataset(X, label=y), 12)
+        for kw in ({}, {"raw_score": True}, {"num_iteration": 5}, {"start_iteration": 3, "num_iteration": 4}):
+            want = b.predict(X, device="cpu", **kw)
+            assert want.shape == (20000, 5)
+            np.testing.assert_allclose(b.predict(X, device="gpu", **kw), want, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(b.predict(torch.from_numpy(X).cuda(), **kw), want, rtol=1e-12, atol=1e-12)
+        X32 = X.astype(np.float32)
+        np.testing.assert_allclose(b.predict(X32, device="gpu"), b.predict(X32, device="cpu"), rtol=1e-12, atol=1e-12)
+
+
 def _rank_data(seed, nq, lo, hi, F=10):
     rng = np.random.RandomState(seed)
     sizes = rng.randint(lo, hi, size=nq)
