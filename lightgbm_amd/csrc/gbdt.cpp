@@ -24,6 +24,8 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
     if (m == "ndcg" || m == "map") {
       std::vector<int> at = cfg_.eval_at.empty() ? std::vector<int>{1, 2, 3, 4, 5} : cfg_.eval_at;
       for (int k : at) rank_metrics_.push_back(RankMetric{m == "ndcg", k});
+    } else if (m == "average_precision") {
+      eval_average_precision_ = true;
     } else {
       metrics_.push_back(metric_kind_from_name(m));
     }
@@ -216,6 +218,21 @@ void Booster::compute_gradients() {
 }
 
 void Booster::eval_ranking(int which, std::vector<EvalResult>* out) {
+  if (eval_average_precision_) {
+    const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
+    const int64_t n = engine_->num_rows(which);
+    std::vector<double> score((size_t)n * (size_t)num_class_);
+    engine_->get_scores(which, score.data());
+    const std::vector<float> label = ds->local_label(), weight = ds->local_weight();
+    std::vector<std::pair<double, std::pair<float, float>>> items((size_t)n);
+    for (int64_t i = 0; i < n; ++i) items[(size_t)i] = {score[(size_t)i], {label[(size_t)i], weight.empty() ? 1.0f : weight[(size_t)i]}};
+    double pos = 0.0;
+    const double ap = average_precision_host(items, &pos);
+    // distributed: the mean of the ranks' values, weighted by their positives
+    double b[2] = {ap * pos, pos};
+    engine_->sum_over_ranks(b, 2);
+    out->push_back(EvalResult{"average_precision", b[1] > 0.0 ? b[0] / b[1] : 1.0, true});
+  }
   if (rank_metrics_.empty()) return;
   const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
   if (ds->query_boundaries().empty())
@@ -512,6 +529,7 @@ std::vector<EvalResult> Booster::eval(int which) {
 std::vector<std::pair<std::string, bool>> Booster::eval_names() const {
   std::vector<std::pair<std::string, bool>> out;
   for (int32_t m : metrics_) out.emplace_back(metric_name(m), metric_higher_better(m));
+  if (eval_average_precision_) out.emplace_back("average_precision", true);
   for (int pass = 0; pass < 2; ++pass)
     for (const auto& m : rank_metrics_)
       if (m.ndcg == (pass == 0)) out.emplace_back(std::string(m.ndcg ? "ndcg@" : "map@") + std::to_string(m.at), true);

@@ -11,6 +11,7 @@
 #include "device.hpp"
 #include "kernels.hpp"
 #include "../ranking.hpp"
+#include <mutex>
 
 namespace lga {
 namespace k {
@@ -232,13 +233,17 @@ __global__ __launch_bounds__(kRankThreads) void xendcg_kernel(RankArgs a, int P)
   }
 }
 
+// The LDS budget of every instantiation is raised once, to what the largest supported query needs
+// (boosters on several host threads launch these kernels concurrently).
 template <typename Kernel>
-void launch_rank(Kernel kernel, const RankArgs& a, size_t per_doc, hipStream_t s) {
+void launch_rank(Kernel kernel, std::once_flag& once, const RankArgs& a, size_t per_doc, hipStream_t s) {
+  std::call_once(once, [&] {
+    LGA_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(per_doc * (size_t)kMaxDeviceQuery)));
+  });
   int P = 1;
   while (P < a.max_query) P <<= 1;
-  const size_t lds = per_doc * (size_t)P;
-  LGA_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)a.nq), dim3(kRankThreads), lds, s, a, P);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.nq), dim3(kRankThreads), per_doc * (size_t)P, s, a, P);
   LGA_LAUNCH_CHECK();
 }
 
@@ -248,15 +253,17 @@ void lambdarank_gradients(const RankArgs& a, hipStream_t s) {
   if (a.nq <= 0) return;
   if (a.max_query > kMaxDeviceQuery) throw std::runtime_error("lambdarank_gradients: query larger than the device kernel holds");
   constexpr size_t per_doc = sizeof(uint64_t) + sizeof(double) + 2 * sizeof(int32_t);
-  if (a.max_query <= kRankThreads) launch_rank(lambdarank_kernel<1>, a, per_doc, s);
-  else if (a.max_query <= 4 * kRankThreads) launch_rank(lambdarank_kernel<4>, a, per_doc, s);
-  else launch_rank(lambdarank_kernel<kMaxDeviceQuery / kRankThreads>, a, per_doc, s);
+  static std::once_flag once[3];
+  if (a.max_query <= kRankThreads) launch_rank(lambdarank_kernel<1>, once[0], a, per_doc, s);
+  else if (a.max_query <= 4 * kRankThreads) launch_rank(lambdarank_kernel<4>, once[1], a, per_doc, s);
+  else launch_rank(lambdarank_kernel<kMaxDeviceQuery / kRankThreads>, once[2], a, per_doc, s);
 }
 
 void xendcg_gradients(const RankArgs& a, hipStream_t s) {
   if (a.nq <= 0) return;
   if (a.max_query > kMaxDeviceQuery) throw std::runtime_error("xendcg_gradients: query larger than the device kernel holds");
-  launch_rank(xendcg_kernel, a, 2 * sizeof(double), s);
+  static std::once_flag once;
+  launch_rank(xendcg_kernel, once, a, 2 * sizeof(double), s);
 }
 
 }  // namespace k

@@ -72,6 +72,26 @@ double auc_host(std::vector<std::pair<double, std::pair<float, float>>>& items) 
   return accum / (total_pos * total_neg);
 }
 
+double average_precision_host(std::vector<std::pair<double, std::pair<float, float>>>& items, double* total_pos) {
+  std::sort(items.begin(), items.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+  double seen_pos = 0.0, seen_neg = 0.0, cur_pos = 0.0, cur_neg = 0.0, ap = 0.0;
+  auto close_group = [&]() {
+    seen_pos += cur_pos;
+    seen_neg += cur_neg;
+    if (cur_pos > 0.0) ap += cur_pos * seen_pos / (seen_pos + seen_neg);
+    cur_pos = cur_neg = 0.0;
+  };
+  for (size_t i = 0; i < items.size(); ++i) {
+    if (i > 0 && items[i].first != items[i - 1].first) close_group();
+    const double w = items[i].second.second;
+    if (items[i].second.first > 0.0f) cur_pos += w; else cur_neg += w;
+  }
+  close_group();
+  if (total_pos) *total_pos = seen_pos;
+  if (seen_pos <= 0.0 || seen_neg <= 0.0) return 1.0;
+  return ap / seen_pos;
+}
+
 namespace {
 // AUC over ranks: scores are mapped to a common 2^20-cell grid, per-cell
 // positive / negative weights are summed over ranks, ties inside a cell count half.

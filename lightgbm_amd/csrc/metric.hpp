@@ -23,6 +23,11 @@ std::vector<EvalResult> eval_metrics_host(const double* scores, const float* lab
                                           const ObjectiveSpec& obj, Comm* comm, int64_t class_stride = 0);
 // class_stride: multiclass metrics read class k's score of a row at scores[k * class_stride + row].
 
+// Weighted average precision of (score, label>0) pairs: the mean over positives of the precision at their
+// score threshold (tied scores share a threshold).  Also returns, through the pointers, the weight of the
+// positives (what a mean over ranks is weighted with).  1 when a class is missing.
+double average_precision_host(std::vector<std::pair<double, std::pair<float, float>>>& items, double* total_pos);
+
 // Weighted AUC of (score, label>0) pairs, ties counted half.
 double auc_host(std::vector<std::pair<double, std::pair<float, float>>>& items);
 

@@ -176,12 +176,26 @@ class LGBMClassifier(ClassifierMixin, LGBMModel):
             return (y == self.classes_[1]).astype(np.float64)
         return np.searchsorted(self.classes_, y).astype(np.float64)
 
-    def fit(self, X, y, **kwargs):
+    def fit(self, X, y, sample_weight=None, **kwargs):
         self.classes_ = np.unique(np.asarray(y))
         self.n_classes_ = len(self.classes_)
         if self.n_classes_ < 2:
             raise ValueError("LGBMClassifier needs at least two classes")
-        return super().fit(X, y, **kwargs)
+        cw = self._other_params.pop("class_weight", getattr(self, "class_weight", None))
+        self.class_weight = cw
+        if cw is not None:
+            # "balanced": n / (n_classes * count(class)); a dict: weight per class label (missing labels: 1)
+            ya = np.asarray(y)
+            if isinstance(cw, str):
+                if cw != "balanced":
+                    raise ValueError("class_weight must be 'balanced' or a dict")
+                counts = np.array([(ya == c).sum() for c in self.classes_], dtype=np.float64)
+                per_class = len(ya) / (self.n_classes_ * counts)
+            else:
+                per_class = np.array([float(cw.get(c.item() if hasattr(c, "item") else c, 1.0)) for c in self.classes_])
+            w = per_class[np.searchsorted(self.classes_, ya)]
+            sample_weight = w if sample_weight is None else w * np.asarray(sample_weight, dtype=np.float64)
+        return super().fit(X, y, sample_weight=sample_weight, **kwargs)
 
     def predict_proba(self, X, **kw) -> np.ndarray:
         p = self.booster_.predict(X, **kw)

@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from lightgbm_amd.sklearn import LGBMClassifier, LGBMRandomForestRegressor, LGBMRegressor
 from lightgbm_amd.utils.datasets import make_curve_1d, make_regression
@@ -69,3 +70,17 @@ def test_estimators_work_inside_sklearn_grid_search():
     assert gs.best_estimator_.predict(X[:5]).shape == (5,)
     scores = cross_val_score(LGBMClassifier(n_estimators=10, device_type="cpu", verbose=-1), X, (y > np.median(y)).astype(int), cv=3)
     assert scores.mean() > 0.9
+
+
+def test_classifier_class_weight():
+    from lightgbm_amd.sklearn import LGBMClassifier
+    rng = np.random.RandomState(0)
+    X = rng.randn(4000, 5)
+    y = np.where(X[:, 0] + rng.randn(4000) > 1.2, "rare", "common")
+    plain = LGBMClassifier(n_estimators=15, device_type="cpu", verbose=-1).fit(X, y)
+    balanced = LGBMClassifier(n_estimators=15, class_weight="balanced", device_type="cpu", verbose=-1).fit(X, y)
+    by_hand = LGBMClassifier(n_estimators=15, class_weight={"rare": 3.0}, device_type="cpu", verbose=-1).fit(X, y)
+    rate = lambda m: float((m.predict(X) == "rare").mean())
+    assert rate(balanced) > rate(by_hand) > rate(plain)
+    with pytest.raises(ValueError):
+        LGBMClassifier(class_weight="heavy", device_type="cpu").fit(X, y)

@@ -495,3 +495,22 @@ def test_path_smooth_shrinks_small_leaves_towards_their_parents():
     grid = np.tile(X[:1], (50, 1))
     grid[:, 0] = np.linspace(-3, 3, 50)
     assert np.all(np.diff(m.predict(grid)) >= -1e-12)
+
+
+def test_average_precision_matches_sklearn():
+    from sklearn.metrics import average_precision_score
+    rng = np.random.RandomState(0)
+    X = rng.randn(5000, 6)
+    y = (X[:, 0] + rng.randn(5000) > 1.0).astype(float)
+    w = 0.5 + rng.rand(5000)
+    d = lgb.Dataset(X, label=y, weight=w)
+    ev = {}
+    b = lgb.train({**CPU, "objective": "binary", "metric": ["auc", "average_precision"], "num_leaves": 7}, d, 10,
+                  valid_sets=[d], evals_result=ev)
+    assert list(ev["training"]) == ["auc", "average_precision"]
+    want = average_precision_score(y, b.predict(X, raw_score=True), sample_weight=w)    # few leaves: tied scores
+    assert ev["training"]["average_precision"][-1] == pytest.approx(want, abs=1e-8)
+    # maximised by early stopping
+    b2 = lgb.train({**CPU, "objective": "binary", "metric": "average_precision", "learning_rate": 0.5}, d, 300,
+                   valid_sets=[lgb.Dataset(X[:1000] + rng.randn(1000, 6), label=y[:1000], reference=d)], early_stopping_rounds=5)
+    assert 0 < b2.best_iteration < 300
