@@ -644,6 +644,26 @@ class Booster:
         check(lib.lga_booster_rollback(self._handle))
         return self
 
+    def refit(self, data, label, decay_rate: float = 0.9, weight=None, **kwargs) -> "Booster":
+        """A new booster with this model's tree structures and leaf values refitted to ``data``:
+        ``leaf = decay_rate * old + (1 - decay_rate) * new``, ``new`` being the Newton step of the rows that
+        reach the leaf (``lambda_l1`` / ``lambda_l2`` / ``max_delta_step`` may be given as keywords)."""
+        lib, _ = _lib.load()
+        raw, _, _ = _encode_pandas_categories(data, self.pandas_categorical)
+        mat, _ = _to_matrix(raw)
+        if _is_torch(mat):
+            mat = mat.cpu().numpy()
+        y = _to_1d(label, np.float32)
+        if len(y) != mat.shape[0]:
+            raise LightGBMError("refit: label length differs from the number of rows")
+        w = None if weight is None else _to_1d(weight, np.float32)
+        out = Booster(model_str=self.model_to_string(num_iteration=-1))
+        ptr, dtype, nr, nc, rm = _mat_args(mat)
+        check(lib.lga_booster_refit(out._handle, ptr, dtype, nr, nc, rm, y.ctypes.data_as(ctypes.c_void_p),
+                                    None if w is None else w.ctypes.data_as(ctypes.c_void_p), float(decay_rate),
+                                    c_str(params_to_string(kwargs))))
+        return out
+
     def reset_parameter(self, params: Dict[str, Any]) -> "Booster":
         lib, _ = _lib.load()
         check(lib.lga_booster_reset_parameter(self._handle, c_str(params_to_string(params))))

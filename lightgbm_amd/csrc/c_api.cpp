@@ -258,6 +258,10 @@ int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess
   return guard([&] { *finished = B(b)->update_one_iter_custom(grad, hess, n) ? 1 : 0; });
 }
 int lga_booster_rollback(LgaBooster b) { return guard([&] { B(b)->rollback_one_iter(); }); }
+int lga_booster_refit(LgaBooster b, const void* data, int dtype, int64_t nrow, int ncol, int row_major, const float* label,
+                      const float* weight, double decay, const char* params) {
+  return guard([&] { B(b)->refit(data, dtype, nrow, ncol, row_major != 0, label, weight, decay, params ? params : ""); });
+}
 int lga_booster_num_trees(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_trees(); }); }
 int lga_booster_num_class(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_class(); }); }
 int lga_booster_num_feature(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_features(); }); }

@@ -52,6 +52,9 @@ int lga_booster_add_valid(LgaBooster b, LgaDataset ds, const char* name);
 int lga_booster_update(LgaBooster b, int* finished);
 int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess, int64_t n, int* finished);
 int lga_booster_rollback(LgaBooster b);
+// Refits the leaf values of a (prediction-only) booster in place; weight may be null.
+int lga_booster_refit(LgaBooster b, const void* data, int dtype, int64_t nrow, int ncol, int row_major, const float* label,
+                      const float* weight, double decay, const char* params);
 int lga_booster_num_trees(LgaBooster b, int* out);
 int lga_booster_num_feature(LgaBooster b, int* out);
 int lga_booster_eval_names(LgaBooster b, char* out, int cap);    // "l2:0,auc:1" (name:higher_better)

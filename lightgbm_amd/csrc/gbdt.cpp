@@ -518,6 +518,59 @@ void Booster::reset_parameter(const std::string& params) {
   cfg_.feature_fraction = c.feature_fraction;
 }
 
+void Booster::refit(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, const float* label,
+                    const float* weight, double decay, const std::string& params) {
+  if (ncol <= max_feature_idx_) throw std::runtime_error("refit: the data has fewer features than the model");
+  if (is_ranking() || obj_.kind == kObjCustom)
+    throw std::runtime_error("refit needs an objective with per-row gradients (not ranking, not custom)");
+  if (average_output_) throw std::runtime_error("refit is not defined for averaged (boosting=rf) models");
+  if (!(decay >= 0.0 && decay <= 1.0)) throw std::runtime_error("refit: decay_rate must be in [0, 1]");
+  Config c = cfg_;
+  c.set(params);
+  const int K = num_class_, n_it = current_iteration();
+  std::vector<double> scores((size_t)K * (size_t)nrow, 0.0);
+  std::vector<float> g((size_t)K * (size_t)nrow), h((size_t)K * (size_t)nrow);
+  std::vector<int32_t> leaf((size_t)nrow);
+  for (int it = 0; it < n_it; ++it) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nrow; ++i) {
+      const float w = weight ? weight[i] : 1.0f;
+      if (K == 1) grad_hess(obj_, scores[(size_t)i], label[i], w, &g[(size_t)i], &h[(size_t)i]);
+      else multiclass_grad_hess(obj_, scores.data(), nrow, i, label[i], w, g.data(), h.data());
+    }
+    for (int k = 0; k < K; ++k) {
+      Tree& tr = trees_[(size_t)it * (size_t)K + (size_t)k];
+#pragma omp parallel
+      {
+        std::vector<double> row((size_t)ncol);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < nrow; ++i) {
+          for (int col = 0; col < ncol; ++col) {
+            const int64_t off = row_major ? i * (int64_t)ncol + col : (int64_t)col * nrow + i;
+            row[(size_t)col] = dtype == 0 ? (double)((const float*)data)[off] : ((const double*)data)[off];
+          }
+          leaf[(size_t)i] = tr.predict_leaf(row.data());
+        }
+      }
+      std::vector<double> sg((size_t)tr.num_leaves, 0.0), sh((size_t)tr.num_leaves, 0.0);
+      std::vector<int64_t> cnt((size_t)tr.num_leaves, 0);
+      for (int64_t i = 0; i < nrow; ++i) {     // in row order: the sums do not depend on the thread count
+        const size_t l = (size_t)leaf[(size_t)i];
+        sg[l] += (double)g[(size_t)k * (size_t)nrow + (size_t)i];
+        sh[l] += (double)h[(size_t)k * (size_t)nrow + (size_t)i];
+        ++cnt[l];
+      }
+      for (int l = 0; l < tr.num_leaves; ++l) {
+        if (cnt[(size_t)l] == 0) continue;       // no row reaches the leaf: it keeps its value
+        const double fresh = leaf_output(sg[(size_t)l], sh[(size_t)l], c.lambda_l1, c.lambda_l2, c.max_delta_step) * tr.shrinkage;
+        tr.set_leaf_value(l, decay * tr.leaf_value[(size_t)l] + (1.0 - decay) * fresh);
+      }
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < nrow; ++i) scores[(size_t)k * (size_t)nrow + (size_t)i] += tr.leaf_value[(size_t)leaf[(size_t)i]];
+    }
+  }
+}
+
 std::vector<EvalResult> Booster::eval(int which) {
   if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
   ensure_scores();

@@ -34,6 +34,12 @@ class Booster {
   bool update_one_iter_custom(const float* grad, const float* hess, int64_t n);
   void rollback_one_iter();
   void reset_parameter(const std::string& params);
+  // Keeps every tree's structure and refits its leaf values to other data: a leaf becomes
+  // decay * old + (1 - decay) * new, new being the Newton step of the leaf's rows at the scores of the
+  // iterations before it (times the tree's shrinkage).  lambda_l1 / lambda_l2 / max_delta_step come from
+  // `params` over this booster's configuration.  weight may be null.
+  void refit(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, const float* label, const float* weight,
+             double decay, const std::string& params);
   // Put `first`'s trees in front of this booster's (continued training from init_model).
   void prepend_trees(const Booster& first) {
     if (first.num_class_ != num_class_) throw std::runtime_error("init_model has a different number of classes");

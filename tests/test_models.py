@@ -171,3 +171,29 @@ def test_r_style_helper_surface(tmp_path):
     assert fit.lower_bound() <= R.predict(fit, X).min() and R.predict(fit, X).max() <= fit.upper_bound()
     leaf = R.predict(fit, X[:5], predleaf=True)
     assert leaf.shape == (5, 15) and fit.get_leaf_output(0, int(leaf[0, 0])) == fit._tree_arrays()[0]["leaf_value"][leaf[0, 0]]
+
+
+def test_refit_keeps_the_structure_and_moves_the_leaf_values():
+    rng = np.random.RandomState(0)
+    X = rng.randn(6000, 6)
+    y = X[:, 0] + np.sin(X[:, 1]) + 0.1 * rng.randn(6000)
+    b = lgb.train({"device_type": "cpu", "verbose": -1, "num_leaves": 15}, lgb.Dataset(X[:3000], label=y[:3000]), 30)
+    l2 = lambda m, A, t: float(np.mean((m.predict(A) - t) ** 2))
+    # on its own training data the Newton steps are (up to the histogram quantisation) the ones it was built with
+    same = b.refit(X[:3000], y[:3000], decay_rate=0.0)
+    assert np.abs(same.predict(X) - b.predict(X)).max() < 0.01
+    # a shifted target is picked up without touching a single split
+    r = b.refit(X[3000:], y[3000:] + 2.0, decay_rate=0.0)
+    assert l2(r, X[3000:], y[3000:] + 2.0) < 0.05 < l2(b, X[3000:], y[3000:] + 2.0)
+    structure = lambda m: m.trees_to_dataframe()[["tree_index", "node_index", "split_feature", "threshold"]].fillna(-1).to_dict("list")
+    assert structure(r) == structure(b)
+    half = b.refit(X[3000:], y[3000:] + 2.0, decay_rate=0.5)
+    assert l2(r, X[3000:], y[3000:] + 2.0) < l2(half, X[3000:], y[3000:] + 2.0) < l2(b, X[3000:], y[3000:] + 2.0)
+    np.testing.assert_array_equal(b.refit(X[3000:], y[3000:], decay_rate=1.0).predict(X), b.predict(X))
+    # multiclass and binary go through their own gradients
+    yc = (X[:, 0] > 0).astype(float) + (X[:, 1] > 0.5)
+    mc = lgb.train({"device_type": "cpu", "verbose": -1, "objective": "multiclass", "num_class": 3}, lgb.Dataset(X[:3000], label=yc[:3000]), 10)
+    rc = mc.refit(X[3000:], yc[3000:], decay_rate=0.3)
+    assert rc.predict(X).shape == (6000, 3) and (rc.predict(X[3000:]).argmax(axis=1) == yc[3000:]).mean() > 0.9
+    with pytest.raises(lgb.LightGBMError):
+        b.refit(X[:, :3], y)

@@ -514,3 +514,16 @@ def test_average_precision_matches_sklearn():
     b2 = lgb.train({**CPU, "objective": "binary", "metric": "average_precision", "learning_rate": 0.5}, d, 300,
                    valid_sets=[lgb.Dataset(X[:1000] + rng.randn(1000, 6), label=y[:1000], reference=d)], early_stopping_rounds=5)
     assert 0 < b2.best_iteration < 300
+
+
+def test_scipy_sparse_input_is_accepted_for_training_and_prediction():
+    sp = pytest.importorskip("scipy.sparse")
+    rng = np.random.RandomState(0)
+    X = rng.randn(2000, 10) * (rng.rand(2000, 10) < 0.2)
+    y = X[:, 0] - X[:, 1] + 0.1 * rng.randn(2000)
+    dense = lgb.train(CPU, lgb.Dataset(X, label=y), 5)
+    for fmt in (sp.csr_matrix, sp.csc_matrix, sp.coo_matrix):
+        S = fmt(X)
+        b = lgb.train(CPU, lgb.Dataset(S, label=y), 5)
+        assert b.model_to_string() == dense.model_to_string()
+        np.testing.assert_array_equal(b.predict(S), dense.predict(X))
