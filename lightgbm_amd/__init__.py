@@ -12,6 +12,21 @@ from .engine import CVBooster, cv, make_folds, train
 
 __version__ = "0.1.0"
 
+_LAZY = {
+    "LGBMModel": "sklearn", "LGBMRegressor": "sklearn", "LGBMClassifier": "sklearn", "LGBMRanker": "sklearn",
+    "LGBMRandomForestRegressor": "sklearn",
+    "plot_importance": "plotting", "plot_metric": "plotting", "plot_split_value_histogram": "plotting",
+    "plot_tree": "plotting", "create_tree_digraph": "plotting",
+}
+
+
+def __getattr__(name):
+    # scikit-learn / matplotlib are only imported when one of these names is asked for
+    if name in _LAZY:
+        import importlib
+        return getattr(importlib.import_module(f".{_LAZY[name]}", __name__), name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
 __all__ = [
     "Dataset", "Booster", "CVBooster", "LightGBMError", "train", "cv", "make_folds",
     "early_stopping", "log_evaluation", "print_evaluation", "record_evaluation", "reset_parameter",

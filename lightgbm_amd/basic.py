@@ -891,6 +891,37 @@ class Booster:
         ens = TreeEnsemble.from_string(self.model_to_string(num_iteration=-1))
         return [{"leaf_value": t.leaf_value} for t in ens.trees]
 
+    def get_split_value_histogram(self, feature: Union[int, str], bins=None, xgboost_style: bool = False):
+        """Histogram of the thresholds the model splits ``feature`` (index or name) at: ``(counts, bin_edges)`` like
+        ``numpy.histogram``; ``xgboost_style=True`` gives a two-column array (``SplitValue``, ``Count``) of the
+        non-empty bins instead.  ``bins=None`` takes one bin per distinct threshold (at most the feature's count)."""
+        model = self.dump_model(num_iteration=-1)
+        names = model["feature_names"]
+        if isinstance(feature, str):
+            if feature not in names:
+                raise LightGBMError(f"unknown feature name {feature!r}")
+            feature = names.index(feature)
+        values: List[float] = []
+
+        def walk(node):
+            if "split_feature" in node:
+                if node["split_feature"] == feature:
+                    if node.get("decision_type") == "==":
+                        raise LightGBMError("Cannot compute split value histogram for the categorical feature")
+                    values.append(float(node["threshold"]))
+                walk(node["left_child"])
+                walk(node["right_child"])
+        for t in model["tree_info"]:
+            walk(t["tree_structure"])
+        if bins is None or (isinstance(bins, int) and xgboost_style):
+            n_unique = len(np.unique(values))
+            bins = max(min(n_unique, bins) if bins is not None else n_unique, 1)
+        hist, edges = np.histogram(values, bins=bins)
+        if xgboost_style:
+            ret = np.column_stack((edges[1:], hist))
+            return ret[ret[:, 1] > 0]
+        return hist, edges
+
     def trees_to_dataframe(self):
         """One row per node of every tree (pandas), with the python-package's column set: ``tree_index,
         node_depth, node_index, left_child, right_child, parent_index, split_feature, split_gain, threshold,

@@ -39,7 +39,8 @@ from .engine import train as _train
 __all__ = ["lgb_Dataset", "lgb_train", "lgb_cv", "RCVBooster", "as_list", "predict", "lgb_Dataset_create_valid",
            "lgb_Dataset_construct", "lgb_Dataset_save", "getinfo", "setinfo", "dim", "slice_rows", "lgb_save",
            "lgb_load", "lgb_dump", "lgb_importance", "lgb_interprete", "lgb_model_dt_tree", "lgb_get_eval_result",
-           "saveRDS_lgb_Booster", "readRDS_lgb_Booster"]
+           "saveRDS_lgb_Booster", "readRDS_lgb_Booster", "lgb_prepare", "lgb_prepare_rules", "lgb_Dataset_set_categorical",
+           "lgb_Dataset_set_reference", "dimnames", "lgb_plot_importance", "lgb_plot_interpretation", "lgb_unloader"]
 
 
 def lgb_Dataset(data, label=None, weight=None, **kwargs) -> Dataset:
@@ -304,3 +305,98 @@ def lgb_get_eval_result(booster, data_name: str, eval_name: str, iters=None, is_
     if iters is not None:
         vals = vals[np.asarray(list(iters), dtype=np.int64) - 1]
     return vals
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Data preparation (``lgb.prepare`` / ``lgb.prepare_rules``): the reference turns its factor columns into
+# integers by hand before building the matrix (r/gridsearchCV.R:11-13); these helpers do the same for a
+# pandas data frame.
+# ---------------------------------------------------------------------------------------------------------
+def lgb_prepare_rules(data, rules: Optional[Dict[str, Dict[Any, int]]] = None):
+    """Converts the non-numeric columns (category / object / bool) of a data frame to integer codes 1, 2, ...
+    Returns ``{"data": converted frame, "rules": {column: {level: code}}}``; passing the rules of an earlier
+    call applies the same codes to new data (levels without a code become NaN)."""
+    import pandas as pd
+    out = data.copy()
+    new_rules: Dict[str, Dict[Any, int]] = {}
+    for col in out.columns:
+        s = out[col]
+        if rules is not None:
+            if col in rules:
+                out[col] = s.map(rules[col]).astype(np.float64)
+                new_rules[col] = dict(rules[col])
+            continue
+        if isinstance(s.dtype, pd.CategoricalDtype):
+            levels = list(s.cat.categories)
+        elif s.dtype == object or s.dtype == bool or pd.api.types.is_string_dtype(s.dtype):
+            levels = sorted(s.dropna().unique().tolist())
+        else:
+            continue
+        mapping = {lev: i + 1 for i, lev in enumerate(levels)}
+        out[col] = s.map(mapping).astype(np.float64)
+        new_rules[col] = mapping
+    return {"data": out, "rules": new_rules}
+
+
+def lgb_prepare(data):
+    """``lgb.prepare``: the converted frame only (see ``lgb_prepare_rules``)."""
+    return lgb_prepare_rules(data)["data"]
+
+
+def lgb_Dataset_set_categorical(dataset: Dataset, categorical_feature) -> Dataset:
+    """``lgb.Dataset.set.categorical``: columns (indices or names) holding category codes; before construction only."""
+    if dataset._handle is not None:
+        raise ValueError("lgb_Dataset_set_categorical: the dataset is already constructed; create a new one")
+    dataset.categorical_feature = list(categorical_feature)
+    return dataset
+
+
+def lgb_Dataset_set_reference(dataset: Dataset, reference: Dataset) -> Dataset:
+    """``lgb.Dataset.set.reference``: bin ``dataset`` with ``reference``'s boundaries; before construction only."""
+    if dataset._handle is not None:
+        raise ValueError("lgb_Dataset_set_reference: the dataset is already constructed; create a new one")
+    dataset.reference = reference
+    return dataset
+
+
+def dimnames(dataset: Dataset):
+    """``dimnames(dataset)``: ``(None, column names)``."""
+    return (None, dataset.construct().get_feature_name())
+
+
+def lgb_plot_importance(tree_imp, top_n: int = 10, measure: str = "Gain", ax=None, **kwargs):
+    """``lgb.plot.importance``: bars of one measure (``Gain`` / ``Cover`` / ``Frequency``) of an ``lgb_importance`` table."""
+    import matplotlib.pyplot as plt
+    if measure not in tree_imp.columns:
+        raise ValueError(f"measure must be one of {[c for c in tree_imp.columns if c != 'Feature']}")
+    top = tree_imp.sort_values(measure, ascending=False).head(int(top_n)).iloc[::-1]
+    if ax is None:
+        _, ax = plt.subplots(1, 1)
+    ax.barh(top["Feature"].astype(str), top[measure], **kwargs)
+    ax.set_xlabel(measure)
+    ax.set_title("Feature Importance")
+    return ax
+
+
+def lgb_plot_interpretation(tree_interpretation, top_n: int = 10, ax=None, **kwargs):
+    """``lgb.plot.interpretation``: the largest per-feature contributions of one row of ``lgb_interprete``."""
+    import matplotlib.pyplot as plt
+    df = tree_interpretation
+    col = [c for c in df.columns if c != "Feature"][0]
+    top = df.reindex(df[col].abs().sort_values(ascending=False).index).head(int(top_n)).iloc[::-1]
+    if ax is None:
+        _, ax = plt.subplots(1, 1)
+    ax.barh(top["Feature"].astype(str), top[col], color=["#d62728" if v < 0 else "#1f77b4" for v in top[col]], **kwargs)
+    ax.set_xlabel(col)
+    ax.set_title("Feature Contribution")
+    return ax
+
+
+def lgb_unloader(restore: bool = True, wipe: bool = False, envir: Optional[Dict[str, Any]] = None) -> None:
+    """``lgb.unloader``: drops the boosters / datasets held in ``envir`` (a dict of names, e.g. ``globals()``)
+    when ``wipe`` is set, and collects garbage so that their native handles are released."""
+    import gc
+    if wipe and envir is not None:
+        for name in [k for k, v in envir.items() if isinstance(v, (Booster, Dataset, RCVBooster))]:
+            del envir[name]
+    gc.collect()
