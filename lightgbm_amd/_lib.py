@@ -73,6 +73,8 @@ def _declare(lib, hip: bool):
         "lga_booster_update": (c_int, [c_void_p, P(c_int)]),
         "lga_booster_update_custom": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, P(c_int)]),
         "lga_booster_rollback": (c_int, [c_void_p]),
+        "lga_booster_set_leaf_value": (c_int, [c_void_p, c_int, c_int, c_double]),
+        "lga_booster_shuffle": (c_int, [c_void_p, c_int, c_int, c_int64]),
         "lga_booster_refit": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_double, c_char_p]),
         "lga_booster_num_trees": (c_int, [c_void_p, P(c_int)]),
         "lga_booster_num_feature": (c_int, [c_void_p, P(c_int)]),

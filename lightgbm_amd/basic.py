@@ -448,6 +448,80 @@ class Dataset:
             return None if self.init_score is None else _to_1d(self.init_score, np.float64)
         return self._get_field("init_score")
 
+    def set_reference(self, reference: "Dataset") -> "Dataset":
+        """Bin this data with ``reference``'s boundaries; before construction only."""
+        if self._handle is not None:
+            raise LightGBMError("Cannot set reference after the Dataset was constructed; create a new Dataset")
+        self.reference = reference
+        return self
+
+    def set_categorical_feature(self, categorical_feature) -> "Dataset":
+        if self._handle is not None and list(categorical_feature) != list(self.categorical_feature or []):
+            raise LightGBMError("Cannot set categorical features after the Dataset was constructed; create a new Dataset")
+        self.categorical_feature = categorical_feature
+        return self
+
+    def set_feature_name(self, feature_name) -> "Dataset":
+        self.feature_name = feature_name
+        if self._handle is not None and isinstance(feature_name, (list, tuple)):
+            lib, _ = _lib.load()
+            if len(feature_name) != self.num_feature():
+                raise LightGBMError("Length of feature_name does not match the number of columns")
+            check(lib.lga_dataset_set_feature_names(self._handle, c_str("\n".join(str(n).replace(" ", "_") for n in feature_name))))
+        return self
+
+    def get_params(self) -> Dict[str, Any]:
+        return dict(self.params)
+
+    def get_ref_chain(self, ref_limit: int = 100) -> set:
+        """This dataset and the datasets it takes its bin boundaries from, transitively."""
+        chain, head = set(), self
+        while head is not None and len(chain) < ref_limit and head not in chain:
+            chain.add(head)
+            head = head.reference
+        return chain
+
+    def get_field(self, field_name: str) -> Optional[np.ndarray]:
+        if field_name == "group":
+            return self.get_group()
+        return self._get_field(field_name)
+
+    def set_field(self, field_name: str, data) -> "Dataset":
+        setter = {"label": self.set_label, "weight": self.set_weight, "init_score": self.set_init_score,
+                  "group": self.set_group}
+        if field_name not in setter:
+            raise LightGBMError(f"unknown field {field_name!r}")
+        return setter[field_name](data)
+
+    def feature_num_bin(self, feature: Union[int, str]) -> int:
+        if isinstance(feature, str):
+            feature = self.get_feature_name().index(feature)
+        return int(self.bin_info(int(feature))["num_bin"])
+
+    def add_features_from(self, other: "Dataset") -> "Dataset":
+        """Appends ``other``'s columns.  Both datasets must still hold their raw data (``free_raw_data=False``);
+        the combined matrix is binned again at the next ``construct()``."""
+        if self.data is None or other.data is None:
+            raise LightGBMError("add_features_from needs the raw data of both datasets (free_raw_data=False)")
+        a, an = _to_matrix(_encode_pandas_categories(self.data, None)[0])
+        b, bn = _to_matrix(_encode_pandas_categories(other.data, None)[0])
+        if _is_torch(a):
+            a = a.cpu().numpy()
+        if _is_torch(b):
+            b = b.cpu().numpy()
+        if a.shape[0] != b.shape[0]:
+            raise LightGBMError("Cannot add features from a Dataset with a different number of rows")
+        if self._handle is not None:
+            names = self.get_feature_name()
+            onames = other.get_feature_name() if other._handle is not None else (bn or [f"D2_Column_{i}" for i in range(b.shape[1])])
+            clash = set(names) & set(onames)
+            self.feature_name = names + [f"D2_{n}" if n in clash else n for n in onames]
+            lib, _ = _lib.load()
+            lib.lga_dataset_free(self._handle)
+            self._handle = None
+        self.data = np.hstack([np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)])
+        return self
+
     def get_data(self):
         if self.data is None:
             raise LightGBMError("Raw data was freed (free_raw_data=True)")
@@ -870,6 +944,45 @@ class Booster:
 
     def get_leaf_output(self, tree_id: int, leaf_id: int) -> float:
         return float(self._tree_arrays()[tree_id]["leaf_value"][leaf_id])
+
+    def set_leaf_output(self, tree_id: int, leaf_id: int, value: float) -> "Booster":
+        """Overwrites one leaf value of the model (scores accumulated during training are left alone)."""
+        lib, _ = _lib.load()
+        check(lib.lga_booster_set_leaf_value(self._handle, int(tree_id), int(leaf_id), float(value)))
+        return self
+
+    def shuffle_models(self, start_iteration: int = 0, end_iteration: int = -1, seed: int = 0) -> "Booster":
+        """Puts the iterations ``[start_iteration, end_iteration)`` into a (seeded) random order; predictions over
+        all iterations do not change, staged ones (``num_iteration``) do."""
+        lib, _ = _lib.load()
+        check(lib.lga_booster_shuffle(self._handle, int(start_iteration), int(end_iteration), int(seed)))
+        return self
+
+    def set_train_data_name(self, name: str) -> "Booster":
+        self._train_data_name = name
+        return self
+
+    def attr(self, key: str) -> Optional[str]:
+        return getattr(self, "_attr", {}).get(key)
+
+    def set_attr(self, **kwargs) -> "Booster":
+        """String attributes kept with the Python object (``None`` deletes one)."""
+        store = self.__dict__.setdefault("_attr", {})
+        for k, v in kwargs.items():
+            if v is None:
+                store.pop(k, None)
+            elif not isinstance(v, str):
+                raise ValueError("Only string values are accepted")
+            else:
+                store[k] = v
+        return self
+
+    def set_network(self, *args, **kwargs) -> "Booster":
+        raise LightGBMError("socket networks are not used here: pass comm= (lightgbm_amd.parallel) to train(), "
+                            "one process per GPU under torch.distributed")
+
+    def free_network(self) -> "Booster":
+        return self
 
     def lower_bound(self) -> float:
         """Smallest raw score the model can produce (sum of the per-tree minimum leaf values)."""

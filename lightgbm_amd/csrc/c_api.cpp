@@ -262,6 +262,12 @@ int lga_booster_refit(LgaBooster b, const void* data, int dtype, int64_t nrow, i
                       const float* weight, double decay, const char* params) {
   return guard([&] { B(b)->refit(data, dtype, nrow, ncol, row_major != 0, label, weight, decay, params ? params : ""); });
 }
+int lga_booster_set_leaf_value(LgaBooster b, int tree, int leaf, double value) {
+  return guard([&] { B(b)->set_leaf_value(tree, leaf, value); });
+}
+int lga_booster_shuffle(LgaBooster b, int start_iter, int end_iter, int64_t seed) {
+  return guard([&] { B(b)->shuffle_iterations(start_iter, end_iter, (uint64_t)seed); });
+}
 int lga_booster_num_trees(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_trees(); }); }
 int lga_booster_num_class(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_class(); }); }
 int lga_booster_num_feature(LgaBooster b, int* out) { return guard([&] { *out = B(b)->num_features(); }); }

@@ -52,6 +52,8 @@ int lga_booster_add_valid(LgaBooster b, LgaDataset ds, const char* name);
 int lga_booster_update(LgaBooster b, int* finished);
 int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess, int64_t n, int* finished);
 int lga_booster_rollback(LgaBooster b);
+int lga_booster_set_leaf_value(LgaBooster b, int tree, int leaf, double value);
+int lga_booster_shuffle(LgaBooster b, int start_iter, int end_iter, int64_t seed);
 // Refits the leaf values of a (prediction-only) booster in place; weight may be null.
 int lga_booster_refit(LgaBooster b, const void* data, int dtype, int64_t nrow, int ncol, int row_major, const float* label,
                       const float* weight, double decay, const char* params);

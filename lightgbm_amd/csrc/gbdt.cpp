@@ -571,6 +571,30 @@ void Booster::refit(const void* data, int dtype, int64_t nrow, int ncol, bool ro
   }
 }
 
+void Booster::shuffle_iterations(int start, int end, uint64_t seed) {
+  const int K = num_class_, n_it = current_iteration();
+  start = std::max(0, start);
+  end = end <= 0 ? n_it : std::min(end, n_it);
+  if (end - start < 2) return;
+  // the first iteration's trees carry the initial score: it moves with them, which leaves every sum unchanged
+  std::vector<int> order((size_t)n_it);
+  std::iota(order.begin(), order.end(), 0);
+  for (int i = end - 1; i > start; --i) {
+    const int j = start + (int)(rng_u64(seed, 0x5aff1eull, (uint64_t)i) % (uint64_t)(i - start + 1));
+    std::swap(order[(size_t)i], order[(size_t)j]);
+  }
+  std::vector<Tree> shuffled;
+  shuffled.reserve(trees_.size());
+  for (int it = 0; it < n_it; ++it)
+    for (int k = 0; k < K; ++k) shuffled.push_back(std::move(trees_[(size_t)order[(size_t)it] * (size_t)K + (size_t)k]));
+  trees_ = std::move(shuffled);
+  if (!tree_weight_.empty() && (int)tree_weight_.size() == n_it) {
+    std::vector<double> w((size_t)n_it);
+    for (int it = 0; it < n_it; ++it) w[(size_t)it] = tree_weight_[(size_t)order[(size_t)it]];
+    tree_weight_ = std::move(w);
+  }
+}
+
 std::vector<EvalResult> Booster::eval(int which) {
   if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
   ensure_scores();

@@ -54,6 +54,14 @@ class Booster {
   int num_valid() const { return engine_ ? engine_->num_valid() : 0; }
   const std::vector<std::string>& valid_names() const { return valid_names_; }
   std::vector<EvalResult> eval(int which);
+  // Overwrites one leaf value of the model (scores already accumulated during training stay as they are).
+  void set_leaf_value(int tree, int leaf, double v) {
+    if (tree < 0 || tree >= (int)trees_.size() || leaf < 0 || leaf >= trees_[(size_t)tree].num_leaves)
+      throw std::runtime_error("set_leaf_value: tree or leaf out of range");
+    trees_[(size_t)tree].set_leaf_value(leaf, v);
+  }
+  // Puts iterations [start, end) (end <= 0: to the last one) into a seeded random order.
+  void shuffle_iterations(int start, int end, uint64_t seed);
   // (name, higher is better) of the values eval() returns, in its order.
   std::vector<std::pair<std::string, bool>> eval_names() const;
   // Current (transformed unless raw) predictions for training (-1) / validation data.

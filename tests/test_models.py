@@ -197,3 +197,35 @@ def test_refit_keeps_the_structure_and_moves_the_leaf_values():
     assert rc.predict(X).shape == (6000, 3) and (rc.predict(X[3000:]).argmax(axis=1) == yc[3000:]).mean() > 0.9
     with pytest.raises(lgb.LightGBMError):
         b.refit(X[:, :3], y)
+
+
+def test_booster_and_dataset_housekeeping_methods():
+    rng = np.random.RandomState(0)
+    X = rng.randn(2000, 4)
+    y = X[:, 0] + 0.1 * rng.randn(2000)
+    d = lgb.Dataset(X, label=y, free_raw_data=False)
+    b = lgb.train({"device_type": "cpu", "verbose": -1, "num_leaves": 7}, d, 10)
+    everything = b.predict(X)
+    staged = b.predict(X, num_iteration=3)
+    b.shuffle_models(seed=3)
+    np.testing.assert_allclose(b.predict(X), everything, atol=1e-12)       # a sum does not care about the order
+    assert not np.allclose(b.predict(X, num_iteration=3), staged)
+    old = b.get_leaf_output(2, 1)
+    b.set_leaf_output(2, 1, old + 1.0)
+    assert b.get_leaf_output(2, 1) == pytest.approx(old + 1.0)
+    with pytest.raises(lgb.LightGBMError):
+        b.set_leaf_output(99, 0, 0.0)
+    b.set_attr(note="x")
+    assert b.attr("note") == "x" and b.set_attr(note=None).attr("note") is None
+    with pytest.raises(lgb.LightGBMError, match="comm="):
+        b.set_network("a,b")
+    # dataset side
+    d.add_features_from(lgb.Dataset(rng.randn(2000, 2), free_raw_data=False))
+    assert d.construct().num_feature() == 6 and d.get_feature_name()[4:] == ["D2_Column_0", "D2_Column_1"]
+    assert d.feature_num_bin(5) > 10 and d.get_field("label").shape == (2000,)
+    v = lgb.Dataset(X[:10]).set_reference(d)
+    assert v.get_ref_chain() == {v, d}
+    with pytest.raises(lgb.LightGBMError):
+        d.set_reference(v)
+    d.set_field("weight", np.ones(2000))
+    assert d.get_weight().sum() == 2000
