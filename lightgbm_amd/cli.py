@@ -2,9 +2,18 @@
 
 Mirrors the ``key=value`` / ``config=file`` style of the LightGBM application:
 
-* ``task=train``    data=<csv> [valid=<csv>] label_column=<idx> output_model=<path> + any training parameter
-* ``task=predict``  data=<csv> input_model=<path> output_result=<path>
+* ``task=train``    data=<file> [valid=<file>[,<file>...]] label_column=<idx> output_model=<path>
+                    [input_model=<path> to continue training] + any training parameter
+* ``task=predict``  data=<file> input_model=<path> output_result=<path>
+                    [predict_raw_score / predict_leaf_index / predict_contrib = true]
+* ``task=refit``    data=<file> input_model=<path> output_model=<path> [refit_decay_rate=0.9]
+* ``task=save_binary``  data=<file> [output: <file>.bin]      (binned dataset cache, loadable as data=<file>.bin)
 * ``task=convert_model``  input_model=<path> convert_model=<json path>   (dumps the model as JSON)
+
+Data files are CSV, TSV or LibSVM (``label idx:value ...``), told apart by their first line; ``header=true``
+skips a header line.  Like the LightGBM application, side files next to a data file are picked up when they
+exist: ``<file>.weight`` (one weight per row), ``<file>.query`` (one query size per line, for ranking) and
+``<file>.init`` (one initial score per row).
 """
 from __future__ import annotations
 
@@ -32,40 +41,100 @@ def _parse(argv: List[str]) -> Dict[str, str]:
     return kv
 
 
-def _load_csv(path: str, label_column: int, has_header: bool):
-    arr = np.loadtxt(path, delimiter=",", skiprows=1 if has_header else 0, ndmin=2)
+def _load_table(path: str, label_column: int, has_header: bool, num_features: int = 0):
+    """(X, y) from a CSV / TSV / LibSVM file; y is None when label_column < 0 (CSV / TSV only)."""
+    with open(path) as f:
+        lines = [ln for ln in (line.strip() for line in f) if ln]
+    if has_header and lines:
+        lines = lines[1:]
+    if not lines:
+        raise SystemExit(f"{path}: no data rows")
+    first = lines[0]
+    tokens = first.replace(",", " ").replace("\t", " ").split()
+    if any(":" in t for t in tokens[1:]) or (len(tokens) == 1 and "," not in first and "\t" not in first):
+        # LibSVM: label then index:value pairs (indices count from 0, like LightGBM reads them)
+        rows, ys, width = [], [], num_features
+        for ln in lines:
+            parts = ln.split()
+            ys.append(float(parts[0]))
+            pairs = [(int(k), float(v)) for k, v in (t.split(":", 1) for t in parts[1:] if not t.startswith("qid"))]
+            rows.append(pairs)
+            if pairs:
+                width = max(width, max(k for k, _ in pairs) + 1)
+        X = np.zeros((len(rows), width), dtype=np.float64)
+        for i, pairs in enumerate(rows):
+            for k, v in pairs:
+                X[i, k] = v
+        return X, np.asarray(ys, dtype=np.float64)
+    sep = "\t" if "\t" in first else ","
+    conv = lambda t: float("nan") if t.strip().lower() in ("", "na", "nan", "null") else float(t)
+    arr = np.array([[conv(t) for t in ln.split(sep)] for ln in lines], dtype=np.float64)
     if label_column < 0:
         return arr, None
-    y = arr[:, label_column]
-    X = np.delete(arr, label_column, axis=1)
-    return X, y
+    return np.delete(arr, label_column, axis=1), arr[:, label_column]
+
+
+def _side_file(path: str, suffix: str):
+    import os
+    p = path + suffix
+    return np.loadtxt(p, ndmin=1) if os.path.exists(p) else None
+
+
+def _dataset(path: str, label_column: int, header: bool, params, reference=None):
+    """A Dataset from a data file (+ its .weight / .query / .init side files), or from a binned cache."""
+    from . import Dataset
+    if path.endswith(".bin"):
+        # the cache holds label / weight / init_score; query sizes still come from the text file's side file
+        return Dataset(path, params=params, group=_side_file(path[:-4], ".query")), None
+    X, y = _load_table(path, label_column, header, reference.num_feature() if reference is not None else 0)
+    if reference is not None and X.shape[1] < reference.num_feature():      # LibSVM rows without the last columns
+        X = np.hstack([X, np.zeros((X.shape[0], reference.num_feature() - X.shape[1]))])
+    return Dataset(X, label=y, weight=_side_file(path, ".weight"), group=_side_file(path, ".query"),
+                   init_score=_side_file(path, ".init"), params=params, reference=reference), X
+
+
+def _flag(kv, key: str) -> bool:
+    return kv.pop(key, "false").lower() in ("true", "1")
 
 
 def main(argv=None) -> int:
-    from . import Booster, Dataset, train
+    from . import Booster, train
     kv = _parse(list(sys.argv[1:] if argv is None else argv))
     task = kv.pop("task", "train")
     label_column = int(kv.pop("label_column", "0"))
-    header = kv.pop("header", "false").lower() in ("true", "1")
+    header = _flag(kv, "header")
     if task == "train":
-        X, y = _load_csv(kv.pop("data"), label_column, header)
-        valid = kv.pop("valid", None)
+        data = kv.pop("data")
+        valid = kv.pop("valid", kv.pop("valid_data", None))
         out = kv.pop("output_model", "LightGBM_model.txt")
+        init = kv.pop("input_model", None)
         rounds = int(kv.pop("num_iterations", kv.pop("num_trees", kv.pop("num_boost_round", "100"))))
         params = {k: v for k, v in kv.items()}
-        d = Dataset(X, label=y, params=params)
-        valid_sets = None
-        if valid:
-            vx, vy = _load_csv(valid, label_column, header)
-            valid_sets = [d.create_valid(vx, label=vy)]
-        b = train(params, d, num_boost_round=rounds, valid_sets=valid_sets, verbose_eval=bool(valid_sets))
+        d, _ = _dataset(data, label_column, header, params)
+        if init:
+            d.free_raw_data = False
+        valid_sets = [_dataset(v, label_column, header, params, reference=d)[0] for v in valid.split(",")] if valid else None
+        b = train(params, d, num_boost_round=rounds, valid_sets=valid_sets, verbose_eval=bool(valid_sets), init_model=init)
         b.save_model(out)
         print(f"finished training: {b.num_trees()} trees -> {out}")
     elif task == "predict":
         b = Booster(model_file=kv.pop("input_model"))
-        X, _ = _load_csv(kv.pop("data"), int(kv.pop("label_column_predict", str(label_column))), header)
-        p = b.predict(X, raw_score=kv.pop("predict_raw_score", "false").lower() in ("true", "1"))
-        np.savetxt(kv.pop("output_result", "LightGBM_predict_result.txt"), p)
+        X, _ = _load_table(kv.pop("data"), int(kv.pop("label_column_predict", str(label_column))), header, b.num_feature())
+        p = b.predict(X, raw_score=_flag(kv, "predict_raw_score"), pred_leaf=_flag(kv, "predict_leaf_index"),
+                      pred_contrib=_flag(kv, "predict_contrib"))
+        np.savetxt(kv.pop("output_result", "LightGBM_predict_result.txt"), p, fmt="%.17g", delimiter="\t")
+    elif task == "refit":
+        b = Booster(model_file=kv.pop("input_model"))
+        path = kv.pop("data")
+        X, y = _load_table(path, label_column, header, b.num_feature())
+        out = kv.pop("output_model", "LightGBM_model.txt")
+        b.refit(X, y, decay_rate=float(kv.pop("refit_decay_rate", "0.9")), weight=_side_file(path, ".weight")).save_model(out)
+        print(f"finished refitting -> {out}")
+    elif task == "save_binary":
+        path = kv.pop("data")
+        d, _ = _dataset(path, label_column, header, {k: v for k, v in kv.items()})
+        d.save_binary(path + ".bin")
+        print(f"saved {path}.bin")
     elif task == "convert_model":
         b = Booster(model_file=kv.pop("input_model"))
         with open(kv.pop("convert_model", "model.json"), "w") as f:

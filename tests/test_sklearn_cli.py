@@ -84,3 +84,50 @@ def test_classifier_class_weight():
     assert rate(balanced) > rate(by_hand) > rate(plain)
     with pytest.raises(ValueError):
         LGBMClassifier(class_weight="heavy", device_type="cpu").fit(X, y)
+
+
+def test_cli_libsvm_ranking_side_files_refit_and_binary_cache(tmp_path):
+    """The application's file conventions: LibSVM rows, <data>.query / <data>.weight side files, continued
+    training from input_model, the refit task and the binned-dataset cache."""
+    rng = np.random.RandomState(0)
+    sizes = rng.randint(5, 20, size=80)
+    n = int(sizes.sum())
+    X = np.round(rng.randn(n, 5), 3) * (rng.rand(n, 5) < 0.7)
+    y = np.clip(np.round(X[:, 0] + 1.5), 0, 3)
+    data = str(tmp_path / "rank.train")
+    with open(data, "w") as f:
+        for i in range(n):
+            f.write(f"{int(y[i])} " + " ".join(f"{j}:{X[i, j]}" for j in range(5) if X[i, j] != 0) + "\n")
+    np.savetxt(data + ".query", sizes, fmt="%d")
+    np.savetxt(data + ".weight", 0.5 + rng.rand(n))
+    env = {**os.environ, "LGA_FORCE_HOST": "1", "PYTHONPATH": ROOT}
+    run = lambda *a: subprocess.run([sys.executable, "-m", "lightgbm_amd.cli", *a], cwd=ROOT, env=env, capture_output=True,
+                                    text=True, timeout=300)
+    m1, m2, m3, pred = (str(tmp_path / k) for k in ("m1.txt", "m2.txt", "m3.txt", "p.txt"))
+    common = ("objective=lambdarank", "num_leaves=7", "min_data_in_leaf=5", "verbose=-1", "eval_at=3")
+    r = run("task=train", f"data={data}", f"valid={data}", f"output_model={m1}", "num_trees=8", *common)
+    assert r.returncode == 0, r.stderr
+    assert "ndcg@3" in r.stdout
+    r = run("task=train", f"data={data}", f"input_model={m1}", f"output_model={m2}", "num_trees=4", *common)
+    assert r.returncode == 0, r.stderr
+    import lightgbm_amd as lgb
+    assert lgb.Booster(model_file=m2).num_trees() == 12
+    r = run("task=predict", f"data={data}", f"input_model={m2}", f"output_result={pred}", "predict_leaf_index=true")
+    assert r.returncode == 0 and np.loadtxt(pred).shape == (n, 12), r.stderr
+    # regression model: refit on shifted labels, binned cache round trip
+    reg = str(tmp_path / "reg.tsv")
+    Xr = rng.randn(1500, 4)
+    yr = Xr[:, 0] + 0.1 * rng.randn(1500)
+    np.savetxt(reg, np.column_stack([yr, Xr]), delimiter="\t")
+    assert run("task=train", f"data={reg}", f"output_model={m3}", "num_trees=15", "verbose=-1").returncode == 0
+    shifted = str(tmp_path / "shift.tsv")
+    np.savetxt(shifted, np.column_stack([yr + 3.0, Xr]), delimiter="\t")
+    out = str(tmp_path / "refit.txt")
+    r = run("task=refit", f"data={shifted}", f"input_model={m3}", f"output_model={out}", "refit_decay_rate=0.0")
+    assert r.returncode == 0, r.stderr
+    # 15 shrunken Newton steps take up 1 - 0.9^15 = 79 % of the shift
+    assert abs(float(np.mean(lgb.Booster(model_file=out).predict(Xr) - yr)) - 3.0 * (1 - 0.9 ** 15)) < 0.05
+    assert run("task=save_binary", f"data={reg}", "verbose=-1").returncode == 0
+    r = run("task=train", f"data={reg}.bin", f"output_model={m1}", "num_trees=15", "verbose=-1")
+    assert r.returncode == 0, r.stderr
+    assert open(m1).read().split("parameters:")[0] == open(m3).read().split("parameters:")[0]
