@@ -57,6 +57,9 @@ class TreeBackend {
   // Interaction constraints: the features (bits over inner features, mask_words(F) words) that may split a
   // node; node 0's mask is announced between begin_tree and root_round.  Never called without constraints.
   virtual void set_node_mask(int node, const uint64_t* words) = 0;
+  // Category-set splits (SplitInfo::default_left == kCategoricalSetTask): the bins (kCatSetWords words) that
+  // go left in the best split reported for `node`.
+  virtual void node_cat_set(int node, uint64_t* words) const = 0;
   // Local row count of a node (after the round that created it).
   virtual int64_t node_local_count(int node) const = 0;
 

@@ -79,6 +79,14 @@ static_assert(sizeof(SplitInfo) == 72, "SplitInfo layout");
 
 // SplitTask::default_left value of a categorical split: rows whose bin EQUALS `threshold` go left.
 constexpr int32_t kCategoricalTask = 2;
+// ... of a split on a SET of categories: rows whose bin is in the parent node's set (TreeBackend::node_cat_set,
+// kCatSetWords words) go left.  SplitInfo::default_left carries the same value for such a split; its
+// `threshold` is then the number of categories in the set.
+constexpr int32_t kCategoricalSetTask = 3;
+constexpr int kCatSetWords = 4;   // 256 bins
+// FeatureMeta::categorical of a feature whose splits are searched over category sets (sorted by gradient
+// statistics, on the host: cat_search.hpp) instead of one category against the rest by the scan.
+constexpr int16_t kCategoricalSorted = 2;
 
 // One leaf to split in a batched growth round.
 struct SplitTask {
@@ -123,7 +131,7 @@ struct FeatureMeta {
   int32_t missing_bin;  // index of the NaN bin or -1
   int32_t enabled;      // 0 when masked out by feature_fraction for this tree
   int16_t monotone;     // +1: the output may not decrease with the feature, -1: may not increase, 0: free
-  int16_t categorical;  // 1: bins are categories; a split sends ONE category left (one against the rest)
+  int16_t categorical;  // 1: bins are categories; a split sends ONE category left (one against the rest); 2: kCategoricalSorted
 };
 static_assert(sizeof(FeatureMeta) == 16, "FeatureMeta layout");
 

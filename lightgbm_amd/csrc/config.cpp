@@ -47,6 +47,11 @@ const ParamDef kParams[] = {
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
     P(categorical_feature, "cat_feature,categorical_column,cat_column,categorical_features", IntList, 0, kNone),
+    P(max_cat_to_onehot, "", Int, 1, kNone),
+    P(cat_smooth, "", Double, 0, kNone),
+    P(cat_l2, "", Double, 0, kNone),
+    P(max_cat_threshold, "", Int, 1, kNone),
+    P(min_data_per_group, "", Int, 1, kNone),
     P(monotone_constraints, "mc,monotone_constraint,monotonic_cst", IntList, -1, 1),
     P(drop_rate, "rate_drop", Double, 0, 1.0),
     P(max_drop, "", Int, kNone, kNone),

@@ -31,6 +31,12 @@ struct Config {
   int bagging_freq = 0;
   int bagging_seed = 3;
   std::vector<int> categorical_feature;    // column indices holding integer category codes
+  // categorical features with more than max_cat_to_onehot categories are split on category SETS (cat_search.hpp)
+  int max_cat_to_onehot = 4;
+  double cat_smooth = 10.0;
+  double cat_l2 = 10.0;
+  int max_cat_threshold = 32;
+  int min_data_per_group = 100;
   std::vector<int> monotone_constraints;   // per feature of the raw matrix: -1 / 0 / +1
   // dart
   double drop_rate = 0.1;

@@ -133,6 +133,11 @@ std::vector<FeatureMeta> Booster::sample_features(int cls) {
                                " values, the data has " + std::to_string(train_->num_total_features()) + " features");
     for (int f = 0; f < F; ++f) meta[(size_t)f].monotone = cfg_.monotone_constraints[(size_t)train_->real_feature(f)];
   }
+  // categorical features with many categories are searched over category sets; not under feature-parallel
+  // learning (a rank only holds its own features' histograms) and not with extra_trees' single random threshold
+  if (cfg_.tree_learner != "feature" && !cfg_.extra_trees)
+    for (auto& m : meta)
+      if (m.categorical && (m.missing_bin >= 0 ? m.num_bin - 1 : m.num_bin) > cfg_.max_cat_to_onehot) m.categorical = kCategoricalSorted;
   double ff = cfg_.feature_fraction;
   if (ff >= 1.0 || F <= 1) return meta;
   int k = std::max(1, (int)(F * ff + 0.5));

@@ -159,8 +159,9 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     const SplitInfo& s = n.best;
     const double lg = (double)s.left_g * gunit, lh = (double)s.left_h * hunit;
     const double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
-    double l = leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
-    double r = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+    const double l2 = sp.lambda_l2 + (s.default_left == kCategoricalSetTask ? cfg_.cat_l2 : 0.0);   // as the search valued it
+    double l = leaf_output(lg, lh, sp.lambda_l1, l2, sp.max_delta_step);
+    double r = leaf_output(rg, rh, sp.lambda_l1, l2, sp.max_delta_step);
     if (smooth) {
       l = smoothed_output(l, s.left_cnt, n.out, sp.path_smooth);
       r = smoothed_output(r, s.total_cnt - s.left_cnt, n.out, sp.path_smooth);
@@ -275,7 +276,9 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
         t.right_node = (int)nodes.size() + 1;
         t.feature = c.best.feature;
         t.threshold = c.best.threshold;
-        t.default_left = meta[(size_t)c.best.feature].categorical ? kCategoricalTask : c.best.default_left;
+        t.default_left = c.best.default_left == kCategoricalSetTask ? kCategoricalSetTask
+                         : meta[(size_t)c.best.feature].categorical   ? kCategoricalTask
+                                                                      : c.best.default_left;
         t.missing_bin = meta[(size_t)c.best.feature].missing_bin;
         int64_t lc = c.best.left_cnt, rc = c.best.total_cnt - c.best.left_cnt;
         t.hist_child = lc <= rc ? 0 : 1;
@@ -378,8 +381,10 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     const BinMapper& bm = ds_->inner_mapper(s.feature);
     double lg = (double)s.left_g * gunit, lh = (double)s.left_h * hunit;
     double rg = (double)(s.total_g - s.left_g) * gunit, rh = (double)(s.total_h - s.left_h) * hunit;
-    double lv = leaf_output(lg, lh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
-    double rv = leaf_output(rg, rh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+    const bool set_split = s.default_left == kCategoricalSetTask;
+    const double l2 = sp.lambda_l2 + (set_split ? cfg_.cat_l2 : 0.0);
+    double lv = leaf_output(lg, lh, sp.lambda_l1, l2, sp.max_delta_step);
+    double rv = leaf_output(rg, rh, sp.lambda_l1, l2, sp.max_delta_step);
     if (node_info) {
       // the outputs the split was valued with (smoothed / clamped), kept inside the children's own ranges
       lv = clamp_output(nodes[(size_t)n.left].out, nodes[(size_t)n.left].lo, nodes[(size_t)n.left].hi);
@@ -391,7 +396,15 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     double real_thr = bm.bin_to_threshold(s.threshold);
     if (std::isinf(real_thr)) real_thr = 1e300;
     int right_leaf;
-    if (bm.categorical)
+    if (set_split) {
+      uint64_t bins[kCatSetWords];
+      be.node_cat_set(id, bins);
+      std::vector<int64_t> categories;
+      for (int b = 0; b < (int)bm.upper.size() && b < kMaxBins; ++b)
+        if ((bins[b >> 6] >> (b & 63)) & 1ull) categories.push_back((int64_t)bm.upper[(size_t)b]);
+      right_leaf = tree.split_categorical_set(leaf, ds_->real_feature(s.feature), s.feature, bins, categories, s.gain, lv, rv,
+                                              lc, rc, lh, rh);
+    } else if (bm.categorical)
       right_leaf = tree.split_categorical(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
                                           (int64_t)bm.upper[(size_t)s.threshold], s.gain, lv, rv, lc, rc, lh, rh);
     else

@@ -4,6 +4,7 @@
 #include "hip_engine.hpp"
 #include "kernels.hpp"
 #include "../metric.hpp"
+#include "../cat_search.hpp"
 #include "../percentile.hpp"
 #include "sort.hpp"
 #include <algorithm>
@@ -167,6 +168,10 @@ class HipBackend : public TreeBackend {
     results_dev_.resize((size_t)(2 * max_batch_ + 2));
     // Two rounds may be in flight when results travel through the mapped block (fused scan) and no
     // per-phase event timing is requested; the second context owns a stream of its own.
+    cat_.cat_smooth = cfg.cat_smooth;
+    cat_.cat_l2 = cfg.cat_l2;
+    cat_.max_cat_threshold = cfg.max_cat_threshold;
+    cat_.min_data_per_group = cfg.min_data_per_group;
     prof.on = cfg.profile;
     if (cfg.profile || std::getenv("LGA_ROCTX")) trace_enable(true);
     const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
@@ -227,6 +232,9 @@ class HipBackend : public TreeBackend {
     double* b = reinterpret_cast<double*>(bounds_host_.get()) + (size_t)kNodeInfoStride * (size_t)node;
     b[0] = lo; b[1] = hi; b[2] = out;
   }
+  void node_cat_set(int node, uint64_t* words) const override {
+    for (int w = 0; w < kCatSetWords; ++w) words[w] = cat_sets_host_.get()[(size_t)node * kCatSetWords + (size_t)w];
+  }
   // Interaction constraints: masks live in a device array like the ranges (SplitParams::node_masks).
   void set_node_mask(int node, const uint64_t* words) override {
     const size_t W = (size_t)((F_ + 63) / 64);
@@ -248,6 +256,14 @@ class HipBackend : public TreeBackend {
     // Monotone constraints: node output ranges live in a device array the scan reads (SplitParams::
     // node_bounds); the grower announces them per node, every round uploads the entries of its children.
     masked_ = false;
+    sorted_cat_.clear();
+    for (int f = 0; f < (int)meta.size(); ++f)
+      if (meta[(size_t)f].enabled && meta[(size_t)f].categorical == kCategoricalSorted) sorted_cat_.push_back(f);
+    if (!sorted_cat_.empty() && cat_sets_dev_.size() == 0) {
+      const size_t n_nodes = (size_t)(2 * capacity_splits_ + 2);
+      cat_sets_host_.resize(n_nodes * kCatSetWords);
+      cat_sets_dev_.resize(n_nodes * kCatSetWords);
+    }
     ranged_ = params.path_smooth > 0.0;
     for (const FeatureMeta& m : meta) ranged_ = ranged_ || (m.enabled && m.monotone != 0);
     if (ranged_) {
@@ -446,11 +462,22 @@ class HipBackend : public TreeBackend {
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
     prof.mark(PhaseProfile::kPartition, st_);
     trace_push(root ? "lga.root_round" : "lga.split_round");
-    if (!root)
+    if (!root) {
+      k::BagParams part{};
+      if (!sorted_cat_.empty()) {
+        // splits on category sets: the sets of this round's parents go up before the partition reads them
+        part.cat_sets = cat_sets_dev_.get();
+        for (const auto& t : tasks)
+          if (t.default_left == kCategoricalSetTask)
+            LGA_HIP_CHECK(hipMemcpyAsync(cat_sets_dev_.get() + (size_t)t.parent_node * kCatSetWords,
+                                         cat_sets_host_.get() + (size_t)t.parent_node * kCatSetWords,
+                                         sizeof(uint64_t) * kCatSetWords, hipMemcpyHostToDevice, st_));
+      }
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
-                   k::BagParams{}, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
+                   part, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
                    (int64_t)slot_words_ * B, st_);
+    }
     prof.mark(PhaseProfile::kHist, st_);
     {
       int tile_first = 0, tile_step = 1, tile_count = T_;
@@ -559,11 +586,76 @@ class HipBackend : public TreeBackend {
         ranges_host_[(size_t)t.right_node] = NodeRange{p.begin + tl[i], p.count - tl[i], 1 - p.buf, 0};
       }
     }
+    if (!sorted_cat_.empty()) category_set_pass(x, infos, n_scan);
     x.busy = false;
     prof.last_end = std::chrono::steady_clock::now();
     if (k::device_checks_enabled()) {   // debug build: a kernel of this round may have refused an index
       const std::string failure = k::take_check_failure(x.stream);
       if (!failure.empty()) throw std::runtime_error(failure);
+    }
+  }
+
+  // Features searched over category sets (cat_search.hpp): the finished histogram rows of those features
+  // come back for every node the round scanned, the search runs on the host - the same code the host
+  // engine runs - and a set that beats the device scan's winner replaces it in `infos`.
+  void category_set_pass(RoundCtx& x, SplitInfo* infos, int n_scan) {
+    const int nf = (int)sorted_cat_.size();
+    cat_items_host_.resize((size_t)n_scan * (size_t)nf * 2);
+    cat_items_dev_.resize((size_t)n_scan * (size_t)nf * 2);
+    cat_hist_dev_.resize((size_t)n_scan * (size_t)nf * 2 * kMaxBins);
+    cat_hist_host_.resize((size_t)n_scan * (size_t)nf * 2 * kMaxBins);
+    std::vector<int> node_of((size_t)n_scan);
+    std::vector<uint32_t> key_of((size_t)n_scan);
+    for (int s = 0; s < n_scan; ++s) {
+      int slot = 0;
+      if (x.root) { node_of[(size_t)s] = 0; key_of[(size_t)s] = kRootNodeKey; }
+      else {
+        const SplitTask& t = x.tasks[(size_t)(s >> 1)];
+        const int side = s & 1;
+        node_of[(size_t)s] = side == 0 ? t.left_node : t.right_node;
+        key_of[(size_t)s] = child_node_key((uint32_t)t.parent_key, side);
+        slot = side == t.hist_child ? t.new_slot : t.parent_slot;
+      }
+      for (int j = 0; j < nf; ++j) {
+        cat_items_host_.get()[((size_t)s * (size_t)nf + (size_t)j) * 2] = slot;
+        cat_items_host_.get()[((size_t)s * (size_t)nf + (size_t)j) * 2 + 1] = sorted_cat_[(size_t)j];
+      }
+    }
+    const int n_items = n_scan * nf;
+    LGA_HIP_CHECK(hipMemcpyAsync(cat_items_dev_.get(), cat_items_host_.get(), sizeof(int32_t) * 2 * (size_t)n_items,
+                                 hipMemcpyHostToDevice, x.stream));
+    k::gather_feature_hist(pool_.get(), slot_words_, plane_, cat_items_dev_.get(), n_items, cat_hist_dev_.get(), x.stream);
+    LGA_HIP_CHECK(hipMemcpyAsync(cat_hist_host_.get(), cat_hist_dev_.get(), sizeof(int64_t) * 2 * kMaxBins * (size_t)n_items,
+                                 hipMemcpyDeviceToHost, x.stream));
+    LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
+    const double gunit = unit_of(qs_host_.kg), hunit = unit_of(qs_host_.kh);
+    const double kInf = std::numeric_limits<double>::infinity();
+    SplitParams sp_host = sp_;          // the node tables of sp_ are device pointers: the host reads its own copies
+    sp_host.node_bounds = nullptr;
+    sp_host.node_masks = masked_ ? masks_host_.get() : nullptr;
+    for (int s = 0; s < n_scan; ++s) {
+      SplitInfo& o = infos[s];
+      const int node = node_of[(size_t)s];
+      const double* nb = ranged_ ? bounds_host_.get() + (size_t)kNodeInfoStride * (size_t)node : nullptr;
+      const LeafScanCtx ctx = make_scan_ctx(o.total_g, o.total_h, o.total_cnt, gunit, hunit, sp_host, nb ? nb[0] : -kInf,
+                                            nb ? nb[1] : kInf, nb ? nb[2] : std::numeric_limits<double>::quiet_NaN());
+      CatSetSplit cs;
+      cs.gain = o.feature >= 0 ? o.gain : -kInf;
+      for (int j = 0; j < nf; ++j) {
+        const int f = sorted_cat_[(size_t)j];
+        if (!node_feature_on(sp_host, key_of[(size_t)s], f, F_) || !node_allows(sp_host, node, f)) continue;
+        const FeatureMeta& m = meta_host_[(size_t)f];
+        const int64_t* g = cat_hist_host_.get() + ((size_t)s * (size_t)nf + (size_t)j) * 2 * kMaxBins;
+        categorical_set_search(g, g + kMaxBins, m.missing_bin >= 0 ? m.num_bin - 1 : m.num_bin, f, ctx, sp_host, cat_, &cs);
+      }
+      if (cs.feature < 0) continue;
+      o.gain = cs.gain;
+      o.feature = cs.feature;
+      o.threshold = cs.num_cat;
+      o.default_left = kCategoricalSetTask;
+      o.left_g = cs.lg; o.left_h = cs.lh;
+      o.left_cnt = est_count(cs.lh, ctx);
+      for (int w = 0; w < kCatSetWords; ++w) cat_sets_host_.get()[(size_t)node * kCatSetWords + (size_t)w] = cs.bins[w];
     }
   }
 
@@ -613,6 +705,14 @@ class HipBackend : public TreeBackend {
   bool ranged_ = false;                 // monotone constraints or path smoothing: node_bounds is in use
   PinnedBuffer<double> bounds_host_;    // [node][lo, hi, out]
   DeviceBuffer<double> bounds_dev_;
+  std::vector<int> sorted_cat_;         // features of the current tree searched over category sets
+  CatParams cat_;
+  PinnedBuffer<uint64_t> cat_sets_host_;   // [node][kCatSetWords]
+  DeviceBuffer<uint64_t> cat_sets_dev_;
+  PinnedBuffer<int32_t> cat_items_host_;
+  DeviceBuffer<int32_t> cat_items_dev_;
+  PinnedBuffer<int64_t> cat_hist_host_;
+  DeviceBuffer<int64_t> cat_hist_dev_;
   bool masked_ = false;                 // interaction constraints are active for the current tree
   PinnedBuffer<uint64_t> masks_host_;   // [node][words]
   DeviceBuffer<uint64_t> masks_dev_;
@@ -1144,22 +1244,34 @@ class HipEngine : public Engine {
   struct TreeOnDevice {
     const k::TreeNodeDev* nodes;
     const double* leaf_value;
+    const uint64_t* node_sets;   // null unless a node splits on a set of categories
     int n_internal, num_leaves;
   };
   TreeOnDevice upload_tree(const Tree& tree) {
     const int L = tree.num_leaves, ni = L - 1;
+    bool has_sets = false;
+    for (int i = 0; i < ni; ++i)
+      has_sets = has_sets || ((tree.decision_type[(size_t)i] & kCategoricalMask) && tree.threshold_bin[(size_t)i] < 0);
     const size_t doff = sizeof(k::TreeNodeDev) * (size_t)std::max(ni, 1);
-    const size_t bytes = doff + sizeof(double) * (size_t)L;
-    tree_pack_.resize(bytes);
+    const size_t soff = doff + sizeof(double) * (size_t)L;
+    const size_t bytes = soff + (has_sets ? sizeof(uint64_t) * kCatSetWords * (size_t)ni : 0);
+    tree_pack_.assign(bytes, 0);
     k::TreeNodeDev* np = reinterpret_cast<k::TreeNodeDev*>(tree_pack_.data());
+    uint64_t* sets = reinterpret_cast<uint64_t*>(tree_pack_.data() + soff);
     for (int i = 0; i < ni; ++i) {
       const int f = tree.split_feature_inner[(size_t)i];
       const int mb = train_->inner_mapper(f).missing_bin;
+      const bool cat = (tree.decision_type[(size_t)i] & kCategoricalMask) != 0;
+      const bool set = cat && tree.threshold_bin[(size_t)i] < 0;
       np[i].feature = f;
-      np[i].meta = (tree.threshold_bin[(size_t)i] & 255) | ((tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 256 : 0) |
-                   ((tree.decision_type[(size_t)i] & kCategoricalMask) ? 512 : 0) | ((mb + 1) << 16);
+      np[i].meta = (set ? 0 : (tree.threshold_bin[(size_t)i] & 255)) | ((tree.decision_type[(size_t)i] & kDefaultLeftMask) ? 256 : 0) |
+                   (cat && !set ? 512 : 0) | (set ? 1024 : 0) | ((mb + 1) << 16);
       np[i].left = tree.left_child[(size_t)i];
       np[i].right = tree.right_child[(size_t)i];
+      if (set) {
+        const size_t k = (size_t)tree.threshold[(size_t)i];
+        for (int w = 0; w < kCatSetWords; ++w) sets[(size_t)i * kCatSetWords + (size_t)w] = tree.cat_bins[kCatSetWords * k + (size_t)w];
+      }
     }
     std::memcpy(tree_pack_.data() + doff, tree.leaf_value.data(), sizeof(double) * (size_t)L);
     if (tree_pack_ != tree_uploaded_) {
@@ -1174,6 +1286,7 @@ class HipEngine : public Engine {
     TreeOnDevice td;
     td.nodes = reinterpret_cast<const k::TreeNodeDev*>(tree_dev_.get());
     td.leaf_value = reinterpret_cast<const double*>(tree_dev_.get() + doff);
+    td.node_sets = has_sets ? reinterpret_cast<const uint64_t*>(tree_dev_.get() + soff) : nullptr;
     td.n_internal = ni;
     td.num_leaves = L;
     return td;
@@ -1181,7 +1294,7 @@ class HipEngine : public Engine {
   void traverse(const TreeOnDevice& td, const DeviceMirror* m, int64_t N, const int32_t* rows, int64_t n, double sign,
                 double* scores) {
     k::traverse_add(td.nodes, td.n_internal, td.leaf_value, td.num_leaves, m->bins_fm.get(), N, rows, n, sign, scores,
-                    stream_);
+                    td.node_sets, stream_);
   }
 
   std::shared_ptr<Dataset> train_;

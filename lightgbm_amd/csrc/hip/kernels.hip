@@ -281,6 +281,8 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
   }
   int b = bins_fm[(int64_t)t.feature * N + row];
   if (t.default_left == kCategoricalTask) return b == t.threshold;
+  if (t.default_left == kCategoricalSetTask)
+    return (bag.cat_sets[(int64_t)t.parent_node * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull;
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F) && node_allows(sp, t.node, f), t.key);
+  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F) && node_allows(sp, t.node, f) && m.categorical != kCategoricalSorted, t.key);
   if (lane == 0) *out = Cand{bg, bkey, blg, blh};
 }
 
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
   for (int f = wave; f < F; f += kFusedWaves) {
     const FeatureMeta m = meta[f];
     if (!m.enabled) continue;
-    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F) && node_allows(sp, node, f), key);
+    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F) && node_allows(sp, node, f) && m.categorical != kCategoricalSorted, key);
   }
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();
@@ -1006,7 +1008,8 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
                                                            const double* __restrict__ leaf_value, int num_leaves,
                                                            const uint8_t* __restrict__ bins_fm, int64_t N,
                                                            const int32_t* __restrict__ rows, int64_t n, double sign,
-                                                           double* __restrict__ scores) {
+                                                           double* __restrict__ scores,
+                                                           const uint64_t* __restrict__ node_sets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const TreeNodeDev* tn = nodes;
   const double* lv = leaf_value;
@@ -1028,7 +1031,8 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
       const TreeNodeDev t = tn[node];
       const int b = bins_fm[(int64_t)t.feature * N + r];
       const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
-      const bool left = (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
+      const bool left = (t.meta & 1024) ? ((node_sets[(int64_t)node * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull) != 0
+                        : (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
       node = left ? t.left : t.right;
       if (!LGA_DEV_CHECK(node < n_internal && ~node < num_leaves, kCheckWalkNode, node, n_internal)) break;
     }
@@ -1400,16 +1404,35 @@ void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double
 }
 
 void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
-                  const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
+                  const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores, const uint64_t* node_sets,
                   hipStream_t s) {
   if (n <= 0) return;
   const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)num_leaves * sizeof(double);
   if (sm <= 48 * 1024)
     hipLaunchKernelGGL(traverse_add_kernel<true>, dim3(grid_for(n, 256)), dim3(256), sm, s, nodes, n_internal,
-                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores);
+                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores, node_sets);
   else
     hipLaunchKernelGGL(traverse_add_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, nodes, n_internal,
-                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores);
+                       leaf_value, num_leaves, bins_fm, N, rows, n, sign, scores, node_sets);
+  LGA_LAUNCH_CHECK();
+}
+
+namespace {
+// One workgroup per (slot, feature) item: the feature's gradient and hessian histogram rows, next to each other.
+__global__ __launch_bounds__(kMaxBins) void gather_feature_hist_kernel(const int64_t* __restrict__ pool, int64_t slot_words,
+                                                                       int64_t plane, const int32_t* __restrict__ items,
+                                                                       int64_t* __restrict__ out) {
+  const int slot = items[2 * blockIdx.x], f = items[2 * blockIdx.x + 1];
+  const int64_t* base = pool + (int64_t)slot * slot_words + (int64_t)f * kMaxBins;
+  out[(int64_t)blockIdx.x * 2 * kMaxBins + threadIdx.x] = base[threadIdx.x];
+  out[(int64_t)blockIdx.x * 2 * kMaxBins + kMaxBins + threadIdx.x] = base[plane + threadIdx.x];
+}
+}  // namespace
+
+void gather_feature_hist(const int64_t* pool, int64_t slot_words, int64_t plane, const int32_t* items, int n_items,
+                         int64_t* out, hipStream_t s) {
+  if (n_items <= 0) return;
+  hipLaunchKernelGGL(gather_feature_hist_kernel, dim3(n_items), dim3(kMaxBins), 0, s, pool, slot_words, plane, items, out);
   LGA_LAUNCH_CHECK();
 }
 

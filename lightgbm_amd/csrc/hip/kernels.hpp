@@ -43,7 +43,8 @@ struct ScanTaskDev {
 
 struct TreeNodeDev {       // internal node of a tree for binned traversal (16 bytes, one LDS read)
   int32_t feature;         // inner feature
-  int32_t meta;            // threshold bin | default_left << 8 | categorical (bin == threshold) << 9 | (missing_bin + 1) << 16
+  int32_t meta;            // threshold bin | default_left << 8 | categorical (bin == threshold) << 9 |
+                           // category set (node_sets) << 10 | (missing_bin + 1) << 16
   int32_t left, right;     // >= 0 internal node, < 0: ~leaf
 };
 
@@ -94,6 +95,7 @@ struct BagParams {
   const float* threshold = nullptr;
   int num_class = 1;
   int64_t stride = 0;
+  const uint64_t* cat_sets = nullptr;   // growth rounds: kCatSetWords words per node, read for kCategoricalSetTask
 };
 // tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.
 // zero_ptr/zero_words: int64 range the partition workgroups clear on the way (the round's new histogram slots).
@@ -144,7 +146,12 @@ void residual_items(const LeafSpan* spans, int n_spans, const int32_t* a0, const
                     int32_t* leaf_out, float* value_out, float* weight_out, hipStream_t s);
 void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
                   const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
-                  hipStream_t s);
+                  const uint64_t* node_sets, hipStream_t s);
+// node_sets: kCatSetWords words per internal node, read for nodes whose meta has bit 10 set (a categorical
+// split on a set of bins); may be null when the tree has none.
+// items: n_items x (slot, feature); out: n_items x 2 x kMaxBins (gradient row, hessian row).
+void gather_feature_hist(const int64_t* pool, int64_t slot_words, int64_t plane, const int32_t* items, int n_items,
+                         int64_t* out, hipStream_t s);
 void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s);
 void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s);
 // Reduction outputs need kReduceDoubles doubles: results first, then per-workgroup partials.

@@ -30,9 +30,18 @@ constexpr int kPredThreads = 256;
 constexpr size_t kTileBytes = 36 * 1024;      // four 255-leaf trees; four workgroups (16 waves) share a CU's LDS
 constexpr size_t kMaxTileBytes = 120 * 1024;  // a single larger tree may claim up to this much
 
-// Categorical nodes reach the device with their single category in `threshold` (trees grown here send one
-// category left; models with larger sets predict on the host).
-__device__ __forceinline__ bool go_left_dev(double v, double thr, int dtype) {
+// Categorical nodes: a single category sits in `threshold` itself; a larger set (dtype bit 6) is a bitset
+// over category values in `cat_words`, `threshold` packing its first word (low 32 bits) and its length.
+constexpr int kSetNodeBit = 64;
+__device__ __forceinline__ bool go_left_dev(double v, double thr, int dtype, const uint32_t* __restrict__ cat_words) {
+  if (dtype & kSetNodeBit) {
+    if (!(v >= 0.0)) return false;
+    const long long c = (long long)v;
+    const unsigned long long enc = (unsigned long long)thr;
+    const unsigned long long first = enc & 0xffffffffull, words = enc >> 32;
+    if ((unsigned long long)(c >> 5) >= words) return false;
+    return (cat_words[first + (unsigned long long)(c >> 5)] >> (c & 31)) & 1u;
+  }
   if (dtype & 1) return v >= 0.0 && (double)(long long)v == thr;
   const int mt = (dtype >> 2) & 3;
   if (v != v && mt != 2) v = 0.0;
@@ -48,7 +57,8 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const T* __restri
                                                                const int32_t* __restrict__ leaf_off,   // [trees+1]
                                                                const int32_t* __restrict__ tile_begin, // [tiles+1]
                                                                int n_tiles, int n_trees, int average, int obj_kind,
-                                                               double sigmoid, int raw, double* __restrict__ out) {
+                                                               double sigmoid, int raw, double* __restrict__ out,
+                                                               const uint32_t* __restrict__ cat_words) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int64_t r0 = (int64_t)blockIdx.x * (kPredThreads * kRowsPerLane) + threadIdx.x;
   double sum[kRowsPerLane];
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const T* __restri
         for (int j = 0; j < kRowsPerLane; ++j) {
           if (node[j] >= 0) {
             const PNode nd = sn[nb + node[j]];
-            node[j] = go_left_dev((double)x[j][nd.feature], nd.threshold, nd.dtype) ? nd.left : nd.right;
+            node[j] = go_left_dev((double)x[j][nd.feature], nd.threshold, nd.dtype, cat_words) ? nd.left : nd.right;
             any = any || node[j] >= 0;
           }
         }
@@ -137,7 +147,8 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
                                                                    const int32_t* __restrict__ leaf_off,
                                                                    const int32_t* __restrict__ tile_begin,
                                                                    int n_tiles, int n_trees, int average, int obj_kind,
-                                                                   double sigmoid, int raw, double* __restrict__ out) {
+                                                                   double sigmoid, int raw, double* __restrict__ out,
+                                                                   const uint32_t* __restrict__ cat_words) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kRows = kPredThreads * R;
   T* xs = reinterpret_cast<T*>(smem);                                   // [nfeat][kRows]
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
           if (node[j] >= 0) {
             const QNode nd = sn[nb + node[j]];
             const double v = (double)xs[(int)nd.feature * kRows + j * kPredThreads + threadIdx.x];
-            node[j] = go_left_dev(v, nd.threshold, nd.dtype) ? (int)nd.left : (int)nd.right;
+            node[j] = go_left_dev(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
             any = any || node[j] >= 0;
           }
         }
@@ -210,13 +221,20 @@ size_t lds_kernel_bytes(int nfeat, size_t tile_limit) {
   return (((size_t)nfeat * kPredThreads * R * sizeof(T) + 15) & ~(size_t)15) + tile_limit;
 }
 
-// Numerical node: its threshold; categorical node: the one category that goes left.
-double node_threshold(const Tree& tr, int i) {
+// Numerical node: its threshold; categorical node: the one category that goes left, or - for a larger set -
+// the place of its bitset in `cat_words` (appended here), flagged in *dtype.
+double node_threshold(const Tree& tr, int i, std::vector<uint32_t>* cat_words, int* dtype) {
+  *dtype = tr.decision_type[(size_t)i];
   if (!(tr.decision_type[(size_t)i] & kCategoricalMask)) return tr.threshold[(size_t)i];
   const std::vector<int64_t> cats = tr.node_categories(i);
-  if (cats.size() != 1)
-    throw std::runtime_error("the device predictor handles categorical splits on a single category; this model predicts on the host");
-  return (double)cats[0];
+  if (cats.size() == 1) return (double)cats[0];
+  const size_t k = (size_t)tr.threshold[(size_t)i];
+  const size_t first = cat_words->size(), words = (size_t)(tr.cat_boundaries[k + 1] - tr.cat_boundaries[k]);
+  if (first + words >= (1ull << 32) || words >= (1ull << 21))
+    throw std::runtime_error("the model's category sets are too large for the device predictor; predict on the host");
+  cat_words->insert(cat_words->end(), tr.cat_threshold.begin() + tr.cat_boundaries[k], tr.cat_threshold.begin() + tr.cat_boundaries[k + 1]);
+  *dtype |= kSetNodeBit;
+  return (double)(((unsigned long long)words << 32) | (unsigned long long)first);
 }
 
 }  // namespace
@@ -300,6 +318,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
                 : (size_t)nfeat * kPredThreads * esz <= row_budget     ? 1 : 0;
     if (R > 0 && max_leaves <= 32768 && nfeat <= 32767 && q_limit <= 40 * 1024 && n_it > 0) {
       std::vector<QNode> nodes;
+      std::vector<uint32_t> cat_words;
       std::vector<double> leaves;
       std::vector<int32_t> node_off(1, 0), leaf_off(1, 0), tile_begin(1, 0);
       size_t tile_bytes = 0;
@@ -311,11 +330,12 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
         tile_bytes += bytes;
         for (int i = 0; i < ni; ++i) {
           QNode n;
-          n.threshold = node_threshold(tr, i);
+          int dt;
+          n.threshold = node_threshold(tr, i, &cat_words, &dt);
           n.feature = (int16_t)tr.split_feature[(size_t)i];
           n.left = (int16_t)tr.left_child[(size_t)i];
           n.right = (int16_t)tr.right_child[(size_t)i];
-          n.dtype = (int16_t)tr.decision_type[(size_t)i];
+          n.dtype = (int16_t)dt;
           nodes.push_back(n);
         }
         for (int l = 0; l < tr.num_leaves; ++l) leaves.push_back(tr.leaf_value[(size_t)l]);
@@ -332,6 +352,8 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
       d_noff.upload(node_off.data(), node_off.size(), s);
       d_loff.upload(leaf_off.data(), leaf_off.size(), s);
       d_tb.upload(tile_begin.data(), tile_begin.size(), s);
+      DeviceBuffer<uint32_t> d_cat(std::max<size_t>(cat_words.size(), 1));
+      if (!cat_words.empty()) d_cat.upload(cat_words.data(), cat_words.size(), s);
       const int avg = b.average_output() ? 1 : 0, raw = type == kPredictRaw ? 1 : 0;
       auto run = [&](auto kernel, size_t lds) {
         LGA_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -341,7 +363,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
           using XT = typename std::remove_pointer<decltype(kernel_arg0(kernel))>::type;
           hipLaunchKernelGGL(kernel, grid, dim3(kPredThreads), lds, s, (XT*)x, n, ncol, nfeat, d_nodes.get(),
                              d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it, avg, obj.kind,
-                             obj.sigmoid, raw, o);
+                             obj.sigmoid, raw, o, d_cat.get());
         });
       };
       if (dtype == 0 && R == 2) run(predict_lds_kernel<float, 2>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
@@ -354,6 +376,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
 
   // ---- wide matrices: trees in LDS, feature values through the vector cache
   std::vector<PNode> nodes;
+  std::vector<uint32_t> cat_words;
   std::vector<double> leaves;
   std::vector<int32_t> node_off(1, 0), leaf_off(1, 0), tile_begin(1, 0);
   size_t tile_bytes = 0, tile_limit = kTileBytes;
@@ -370,11 +393,12 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
     tile_bytes += bytes;
     for (int i = 0; i < ni; ++i) {
       PNode n;
-      n.threshold = node_threshold(tr, i);
+      int dt;
+      n.threshold = node_threshold(tr, i, &cat_words, &dt);
       n.feature = tr.split_feature[(size_t)i];
       n.left = tr.left_child[(size_t)i];
       n.right = tr.right_child[(size_t)i];
-      n.dtype = tr.decision_type[(size_t)i];
+      n.dtype = dt;
       nodes.push_back(n);
     }
     for (int l = 0; l < tr.num_leaves; ++l) leaves.push_back(tr.leaf_value[(size_t)l]);
@@ -392,6 +416,8 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
   d_noff.upload(node_off.data(), node_off.size(), s);
   d_loff.upload(leaf_off.data(), leaf_off.size(), s);
   d_tb.upload(tile_begin.data(), tile_begin.size(), s);
+  DeviceBuffer<uint32_t> d_cat(std::max<size_t>(cat_words.size(), 1));
+  if (!cat_words.empty()) d_cat.upload(cat_words.data(), cat_words.size(), s);
   static bool attr_set[2] = {false, false};
   if (!attr_set[dtype]) {
     if (dtype == 0) LGA_HIP_CHECK(hipFuncSetAttribute((const void*)predict_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxTileBytes));
@@ -403,11 +429,11 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
     if (dtype == 0)
       hipLaunchKernelGGL(predict_kernel<float>, grid, dim3(kPredThreads), tile_limit, s, (const float*)x, n, ncol,
                          d_nodes.get(), d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it,
-                         b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
+                         b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o, d_cat.get());
     else
       hipLaunchKernelGGL(predict_kernel<double>, grid, dim3(kPredThreads), tile_limit, s, (const double*)x, n, ncol,
                          d_nodes.get(), d_leaves.get(), d_noff.get(), d_loff.get(), d_tb.get(), n_tiles, n_it,
-                         b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o);
+                         b.average_output() ? 1 : 0, obj.kind, obj.sigmoid, type == kPredictRaw ? 1 : 0, o, d_cat.get());
   });
 }
 

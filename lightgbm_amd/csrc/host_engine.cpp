@@ -1,5 +1,6 @@
 #include "host_engine.hpp"
 #include "metric.hpp"
+#include "cat_search.hpp"
 #include "percentile.hpp"
 #include <algorithm>
 #include <functional>
@@ -54,6 +55,11 @@ class HostBackend : public TreeBackend {
     capacity_splits_ = 2 * (L - 1) + 1;
     pool_.assign((size_t)(capacity_splits_ + 1) * slot_words_, 0);
     ranges_.resize((size_t)(2 * capacity_splits_ + 1));
+    cat_sets_.assign(ranges_.size() * kCatSetWords, 0ull);
+    cat_.cat_smooth = cfg.cat_smooth;
+    cat_.cat_l2 = cfg.cat_l2;
+    cat_.max_cat_threshold = cfg.max_cat_threshold;
+    cat_.min_data_per_group = cfg.min_data_per_group;
     if (comm_ && comm_->size() > 1 && mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
     if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
   }
@@ -71,6 +77,9 @@ class HostBackend : public TreeBackend {
     }
     double* b = &bounds_[(size_t)kNodeInfoStride * (size_t)node];
     b[0] = lo; b[1] = hi; b[2] = out;
+  }
+  void node_cat_set(int node, uint64_t* words) const override {
+    for (int w = 0; w < kCatSetWords; ++w) words[w] = cat_sets_[(size_t)node * kCatSetWords + (size_t)w];
   }
   void set_node_mask(int node, const uint64_t* words) override {
     const size_t W = (size_t)((F_ + 63) / 64);
@@ -157,20 +166,18 @@ class HostBackend : public TreeBackend {
     const int32_t* src = arena_[p.buf].data() + p.begin;
     int32_t* dst = arena_[1 - p.buf].data() + p.begin;
     const uint8_t* col = root_->bins_fm() + (size_t)t.feature * (size_t)N_;
+    const uint64_t* set = t.default_left == kCategoricalSetTask ? &cat_sets_[(size_t)t.parent_node * kCatSetWords] : nullptr;
+    auto goes_left = [&](int b) {
+      if (set) return ((set[b >> 6] >> (b & 63)) & 1ull) != 0;
+      if (t.default_left == kCategoricalTask) return b == t.threshold;
+      return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+    };
     int32_t nl = 0;
-    for (int32_t i = 0; i < p.count; ++i) {
-      int b = col[src[i]];
-      bool left = t.default_left == kCategoricalTask ? (b == t.threshold)
-                                                       : ((b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold));
-      nl += left ? 1 : 0;
-    }
+    for (int32_t i = 0; i < p.count; ++i) nl += goes_left(col[src[i]]) ? 1 : 0;
     int32_t li = 0, ri = nl;
     for (int32_t i = 0; i < p.count; ++i) {
       int32_t row = src[i];
-      int b = col[row];
-      bool left = t.default_left == kCategoricalTask ? (b == t.threshold)
-                                                       : ((b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold));
-      if (left) dst[li++] = row; else dst[ri++] = row;
+      if (goes_left(col[row])) dst[li++] = row; else dst[ri++] = row;
     }
     ranges_[(size_t)t.left_node] = NodeRange{p.begin, nl, 1 - p.buf, 0};
     ranges_[(size_t)t.right_node] = NodeRange{p.begin + nl, p.count - nl, 1 - p.buf, 0};
@@ -258,6 +265,7 @@ class HostBackend : public TreeBackend {
     const double ninf = -std::numeric_limits<double>::infinity();
     const uint64_t worst_key = ~0ull;
     std::vector<Cand> local((size_t)n);
+    std::vector<CatSetSplit> sets((size_t)n);
 #pragma omp parallel for schedule(dynamic) if (n * F_ >= 512)
     for (int i = 0; i < n; ++i) {
       const ScanTask& s = st[i];
@@ -276,11 +284,22 @@ class HostBackend : public TreeBackend {
       Cand best{ninf, worst_key, 0, 0};
       for (int f = 0; f < F_; ++f) {
         if (!meta_[(size_t)f].enabled || !owns_feature(f) || !node_feature_on(sp_, s.key, f, F_) ||
-            !node_allows(sp_, s.node, f))
+            !node_allows(sp_, s.node, f) || meta_[(size_t)f].categorical == kCategoricalSorted)
           continue;
         scan_feature(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, s.key, &best);
       }
       local[(size_t)i] = best;
+      // features searched over category sets: a set must beat the best split found above
+      CatSetSplit& cs = sets[(size_t)i];
+      cs.gain = best.gain;
+      for (int f = 0; f < F_; ++f) {
+        const FeatureMeta& m = meta_[(size_t)f];
+        if (m.categorical != kCategoricalSorted || !m.enabled || !node_feature_on(sp_, s.key, f, F_) ||
+            !node_allows(sp_, s.node, f))
+          continue;
+        categorical_set_search(self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins,
+                               m.missing_bin >= 0 ? m.num_bin - 1 : m.num_bin, f, ctx, sp_, cat_, &cs);
+      }
       SplitInfo& o = out[i];
       o.total_g = tg; o.total_h = th; o.total_cnt = tc;
     }
@@ -302,7 +321,16 @@ class HostBackend : public TreeBackend {
       const Cand& b = local[(size_t)i];
       SplitInfo& o = out[i];
       o.pad0 = 0;
-      if (b.gain == ninf) {
+      if (sets[(size_t)i].feature >= 0) {
+        const CatSetSplit& cs = sets[(size_t)i];
+        o.gain = cs.gain;
+        o.feature = cs.feature;
+        o.threshold = cs.num_cat;
+        o.default_left = kCategoricalSetTask;
+        o.left_g = cs.lg; o.left_h = cs.lh;
+        o.left_cnt = est_count(cs.lh, make_scan_ctx(o.total_g, o.total_h, o.total_cnt, gunit, hunit, sp_));
+        for (int w = 0; w < kCatSetWords; ++w) cat_sets_[(size_t)st[i].node * kCatSetWords + (size_t)w] = cs.bins[w];
+      } else if (b.gain == ninf) {
         o.gain = ninf; o.feature = -1; o.threshold = 0; o.default_left = 0; o.left_g = o.left_h = 0; o.left_cnt = 0;
       } else {
         o.gain = b.gain;
@@ -318,6 +346,8 @@ class HostBackend : public TreeBackend {
   static constexpr double kInf = std::numeric_limits<double>::infinity();
   std::vector<double> bounds_;   // [node][lo, hi, out]; empty unless monotone constraints / path smoothing are active
   std::vector<uint64_t> masks_;  // [node][words]; empty unless interaction constraints are active
+  std::vector<uint64_t> cat_sets_;   // [node][kCatSetWords]: bins going left in the node's best split, when it is a set split
+  CatParams cat_;
   const Dataset* root_;
   Comm* comm_;
   ParallelMode mode_;

@@ -17,25 +17,42 @@ void Tree::reset(int max_leaves) {
   rs(internal_count, m);
   leaf_value.assign(1, 0.0); leaf_weight.assign(1, 0.0); leaf_count.assign(1, 0);
   leaf_depth.assign(1, 0); leaf_parent.assign(1, -1);
-  cat_boundaries.clear(); cat_threshold.clear();
+  cat_boundaries.clear(); cat_threshold.clear(); cat_bins.clear();
   shrinkage = 1.0;
 }
 
 int Tree::split_categorical(int leaf, int feature_real, int feature_inner, int category_bin, int64_t category, double gain,
                             double left_value, double right_value, int64_t left_cnt, int64_t right_cnt,
                             double left_weight, double right_weight) {
-  if (category < 0) throw std::runtime_error("categorical split on a negative category");
+  uint64_t bins[4] = {0, 0, 0, 0};
+  bins[category_bin >> 6] |= 1ull << (category_bin & 63);
+  const int right = split_categorical_set(leaf, feature_real, feature_inner, bins, std::vector<int64_t>(1, category), gain,
+                                          left_value, right_value, left_cnt, right_cnt, left_weight, right_weight);
+  threshold_bin[(size_t)(num_leaves - 2)] = category_bin;   // the node just created
+  return right;
+}
+
+int Tree::split_categorical_set(int leaf, int feature_real, int feature_inner, const uint64_t* bins,
+                                const std::vector<int64_t>& categories, double gain, double left_value, double right_value,
+                                int64_t left_cnt, int64_t right_cnt, double left_weight, double right_weight) {
+  if (categories.empty()) throw std::runtime_error("categorical split on an empty set");
+  int64_t largest = 0;
+  for (int64_t c : categories) {
+    if (c < 0) throw std::runtime_error("categorical split on a negative category");
+    largest = std::max(largest, c);
+  }
   if (cat_boundaries.empty()) cat_boundaries.push_back(0);
   const int k = (int)cat_boundaries.size() - 1;
-  const size_t words = (size_t)(category >> 5) + 1;
+  const size_t words = (size_t)(largest >> 5) + 1;
   const size_t base = cat_threshold.size();
   cat_threshold.resize(base + words, 0u);
-  cat_threshold[base + (size_t)(category >> 5)] |= 1u << (category & 31);
+  for (int64_t c : categories) cat_threshold[base + (size_t)(c >> 5)] |= 1u << (c & 31);
   cat_boundaries.push_back((int32_t)cat_threshold.size());
+  cat_bins.insert(cat_bins.end(), bins, bins + 4);
   // missing type NaN: unknown values fall to the right, like every value outside the set
-  int right = split(leaf, feature_real, feature_inner, category_bin, (double)k, false, 2, gain, left_value, right_value,
+  int right = split(leaf, feature_real, feature_inner, -1, (double)k, false, 2, gain, left_value, right_value,
                     left_cnt, right_cnt, left_weight, right_weight);
-  decision_type.back() |= kCategoricalMask;
+  decision_type[(size_t)(num_leaves - 2)] |= kCategoricalMask;
   return right;
 }
 

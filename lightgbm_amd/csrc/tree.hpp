@@ -38,6 +38,13 @@ struct Tree {
   std::vector<int32_t> cat_boundaries;   // starts with 0 once a categorical split exists
   std::vector<uint32_t> cat_threshold;
   int num_cat() const { return cat_boundaries.empty() ? 0 : (int)cat_boundaries.size() - 1; }
+  // The same sets over the feature's BINS, 4 words per categorical split k (training-time traversal; not
+  // serialised).  A split on a set of several categories has threshold_bin -1.
+  std::vector<uint64_t> cat_bins;
+  bool bin_in_set(int node, int b) const {
+    const size_t k = (size_t)threshold[(size_t)node];
+    return (cat_bins[4 * k + (size_t)(b >> 6)] >> (b & 63)) & 1ull;
+  }
 
   Tree() { reset(1); }
   void reset(int max_leaves);
@@ -51,6 +58,11 @@ struct Tree {
   int split_categorical(int leaf, int feature_real, int feature_inner, int category_bin, int64_t category, double gain,
                         double left_value, double right_value, int64_t left_cnt, int64_t right_cnt, double left_weight,
                         double right_weight);
+
+  // Rows whose bin is in `bins` (256 bits; their values are `categories`) go left.
+  int split_categorical_set(int leaf, int feature_real, int feature_inner, const uint64_t* bins,
+                            const std::vector<int64_t>& categories, double gain, double left_value, double right_value,
+                            int64_t left_cnt, int64_t right_cnt, double left_weight, double right_weight);
 
   void apply_shrinkage(double rate);
   void add_bias(double v);
@@ -95,7 +107,7 @@ struct Tree {
       int f = split_feature_inner[(size_t)node];
       int b = bins(f);
       bool left;
-      if (decision_type[(size_t)node] & kCategoricalMask) left = b == threshold_bin[(size_t)node];
+      if (decision_type[(size_t)node] & kCategoricalMask) left = bin_in_set(node, b);
       else if (b == missing_bin_of_inner[f]) left = (decision_type[(size_t)node] & kDefaultLeftMask) != 0;
       else left = b <= threshold_bin[(size_t)node];
       node = left ? left_child[(size_t)node] : right_child[(size_t)node];

@@ -1,7 +1,7 @@
-"""Categorical features: category codes get one bin each (by frequency), a split sends ONE category left
-(LightGBM's one-against-the-rest search, i.e. its behaviour with max_cat_to_onehot above the cardinality);
-the model file uses upstream's cat_boundaries / cat_threshold bitsets, so larger sets written by upstream
-still parse and predict."""
+"""Categorical features: category codes get one bin each (by frequency).  Up to max_cat_to_onehot categories
+a split sends ONE category left (one against the rest); above it the categories are sorted by their gradient
+statistics and a split sends a SET of them left (cat_smooth / cat_l2 / max_cat_threshold /
+min_data_per_group).  The model file uses upstream's cat_boundaries / cat_threshold bitsets."""
 import numpy as np
 import pytest
 
@@ -21,9 +21,53 @@ def make_data(n=6000, seed=0):
     return X, y, city, effect
 
 
+def test_category_set_splits_beat_one_against_the_rest_on_many_categories():
+    rng = np.random.RandomState(0)
+    n = 20000
+    codes = rng.randint(0, 60, size=n)
+    effect = rng.randn(60) * 2
+    X = np.column_stack([codes, rng.randn(n, 3)])
+    y = effect[codes] + 0.5 * X[:, 1] + 0.3 * rng.randn(n)
+    base = {**CPU, "num_leaves": 15, "min_data_in_leaf": 20}
+    l2 = lambda m: float(np.mean((m.predict(X) - y) ** 2))
+    sets = lgb.train(base, lgb.Dataset(X, label=y, categorical_feature=[0]), 20)
+    single = lgb.train({**base, "max_cat_to_onehot": 256}, lgb.Dataset(X, label=y, categorical_feature=[0]), 20)
+    assert l2(sets) < 0.5 * l2(single)
+    size = lambda m: [len(str(t).split("||")) for t in m.trees_to_dataframe().query("decision_type == '=='")["threshold"]]
+    assert max(size(single)) == 1
+    assert max(size(sets)) > 5 and max(size(sets)) <= 30              # (60 + 1) / 2 caps a set at 30 categories
+    assert max(size(lgb.train({**base, "max_cat_threshold": 4}, lgb.Dataset(X, label=y, categorical_feature=[0]), 5))) <= 4
+    # the sets survive the model file, the NumPy reader and the binned traversal of the training scores
+    text = sets.model_to_string()
+    np.testing.assert_array_equal(lgb.Booster(model_str=text).predict(X), sets.predict(X))
+    np.testing.assert_allclose(TreeEnsemble.from_string(text).predict(X), sets.predict(X), atol=1e-12)
+    kept = lgb.Booster(base, lgb.Dataset(X, label=y, categorical_feature=[0]))
+    ev = lgb.Dataset(X[:3000], label=y[:3000], reference=kept.train_set)
+    kept.add_valid(ev, "v")
+    for _ in range(6):
+        kept.update()
+    np.testing.assert_allclose(kept._inner_predict(-1, raw=True), kept.predict(X, raw_score=True), atol=1e-9)
+    np.testing.assert_allclose(kept._inner_predict(0, raw=True), kept.predict(X[:3000], raw_score=True), atol=1e-9)
+    kept.rollback_one_iter()
+    np.testing.assert_allclose(kept._inner_predict(-1, raw=True), kept.predict(X, raw_score=True), atol=1e-9)
+    # a tiny category never decides a split on its own: with huge min_data_per_group no set qualifies
+    none = lgb.train({**base, "min_data_per_group": 15000}, lgb.Dataset(X, label=y, categorical_feature=[0]), 3)
+    assert "==" not in set(none.trees_to_dataframe()["decision_type"].dropna())
+    # data-parallel ranks agree on the sets
+    from test_parallel import run_ranks, trees_of
+    serial = lgb.train({**base, "boost_from_average": False}, lgb.Dataset(X, label=y, categorical_feature=[0], bin_sample=X), 5)
+
+    def rank(r, comm):
+        sl = slice(r * n // 2, (r + 1) * n // 2)
+        d = lgb.Dataset(X[sl], label=y[sl], categorical_feature=[0], bin_sample=X)
+        return lgb.train({**base, "boost_from_average": False, "tree_learner": "data"}, d, 5, comm=comm).model_to_string()
+    for s in run_ranks(2, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
 def test_categorical_splits_isolate_categories_and_beat_the_ordinal_reading():
     X, y, city, effect = make_data()
-    p = {**CPU, "num_leaves": 31, "min_data_in_leaf": 5, "learning_rate": 0.2}
+    p = {**CPU, "num_leaves": 31, "min_data_in_leaf": 5, "learning_rate": 0.2, "max_cat_to_onehot": 12}
     cat = lgb.train(p, lgb.Dataset(X, label=y, categorical_feature=[1], params=CPU), 30)
     num = lgb.train(p, lgb.Dataset(X, label=y, params=CPU), 30)
     rm = lambda b: float(np.sqrt(np.mean((b.predict(X) - y) ** 2)))

@@ -232,7 +232,11 @@ def test_randomised_parity_sweep(first):
         assert same, f"seed {seed}: {case}"
 
 
-def test_gpu_categorical_features_match_the_cpu_and_the_device_predictor_agrees():
+@pytest.mark.parametrize("onehot", [4, 64])
+def test_gpu_categorical_features_match_the_cpu_and_the_device_predictor_agrees(onehot):
+    """onehot=4: the 40-category column is split on category SETS (histogram rows come back, the sorted search
+    runs on the host, the partition and the tree walk read the sets); 64: one category against the rest, all
+    on the device.  Either way the trees are the CPU engine's and the device predictor agrees with the host's."""
     rng = np.random.RandomState(3)
     n = 50000
     city = rng.randint(0, 40, size=n)
@@ -240,10 +244,12 @@ def test_gpu_categorical_features_match_the_cpu_and_the_device_predictor_agrees(
     X = np.c_[rng.randn(n), city.astype(float), rng.randn(n), rng.randint(0, 5, size=n).astype(float)]
     X[::19, 1] = np.nan
     y = np.where(np.isnan(X[:, 1]), 0.0, effect[city]) + 0.5 * X[:, 0] + 0.3 * (X[:, 3] == 2) + 0.2 * rng.randn(n)
-    p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.8, "bagging_freq": 1}
+    p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.8, "bagging_freq": 1, "max_cat_to_onehot": onehot}
     a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, categorical_feature=[1, 3], params=CPU), 10)
     b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, categorical_feature=[1, 3], params=GPU), 10, keep_training_booster=True)
     assert trees_of(a) == trees_of(b) and "cat_threshold=" in trees_of(b)
+    set_sizes = [len(str(t).split("||")) for t in b.trees_to_dataframe().query("decision_type == '=='")["threshold"]]
+    assert (max(set_sizes) > 3) == (onehot == 4)
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
     np.testing.assert_allclose(b.predict(X, device="gpu"), b.predict(X, device="cpu"), atol=1e-12)
     Xf = X.astype(np.float32)

@@ -72,6 +72,8 @@ def draw_case(seed: int, max_rows: int):
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
             "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25,
             "categorical": rng.rand() < 0.3}
+    if opts["categorical"] and rng.rand() < 0.3:
+        p["max_cat_to_onehot"] = 64            # one category against the rest, on the device
     if opts["categorical"] and "monotone_constraints" in p:
         p["monotone_constraints"][F - 2 if F > 1 else 0] = 0
     return n, F, p, opts
@@ -86,9 +88,10 @@ def make_data(seed, n, F, opts):
     y = X[:, 0] * 1.5 + np.abs(X[:, 1 % F]) - 0.7 * X[:, 2 % F] * (X[:, 0] > 0) + 0.1 * rng.randn(n)
     if opts.get("categorical"):
         c = F - 2 if F > 1 else 0
-        codes = rng.randint(0, 9, size=n)
+        ncat = 9 if seed % 2 else 40            # 9: still above max_cat_to_onehot; 40: long sorted searches
+        codes = rng.randint(0, ncat, size=n)
         X[:, c] = codes
-        y = y + np.array([2.0, -1.0, 0.5, 3.0, -2.5, 0.0, 1.0, -0.5, 1.5])[codes]
+        y = y + np.random.RandomState(7).randn(40)[codes] * 1.5
     if opts["nan"]:
         X[rng.rand(n) < 0.07, 1 % F] = np.nan
         X[rng.rand(n) < 0.01, F - 1] = np.nan
