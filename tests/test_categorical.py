@@ -53,16 +53,6 @@ def test_category_set_splits_beat_one_against_the_rest_on_many_categories():
     # a tiny category never decides a split on its own: with huge min_data_per_group no set qualifies
     none = lgb.train({**base, "min_data_per_group": 15000}, lgb.Dataset(X, label=y, categorical_feature=[0]), 3)
     assert "==" not in set(none.trees_to_dataframe()["decision_type"].dropna())
-    # data-parallel ranks agree on the sets
-    from test_parallel import run_ranks, trees_of
-    serial = lgb.train({**base, "boost_from_average": False}, lgb.Dataset(X, label=y, categorical_feature=[0], bin_sample=X), 5)
-
-    def rank(r, comm):
-        sl = slice(r * n // 2, (r + 1) * n // 2)
-        d = lgb.Dataset(X[sl], label=y[sl], categorical_feature=[0], bin_sample=X)
-        return lgb.train({**base, "boost_from_average": False, "tree_learner": "data"}, d, 5, comm=comm).model_to_string()
-    for s in run_ranks(2, rank):
-        assert trees_of(s) == trees_of(serial)
 
 
 def test_categorical_splits_isolate_categories_and_beat_the_ordinal_reading():

@@ -147,6 +147,25 @@ def test_feature_parallel_with_fewer_tiles_than_ranks():
     assert trees_of(res[0]) == trees_of(res[1]) == trees_of(serial)
 
 
+def test_data_parallel_ranks_agree_on_category_sets():
+    """The sorted category search runs on every rank from the reduced histograms: same sets, same trees."""
+    rng = np.random.RandomState(0)
+    n = 20000
+    codes = rng.randint(0, 60, size=n)
+    X = np.column_stack([codes, rng.randn(n, 3)])
+    y = (rng.randn(60) * 2)[codes] + 0.5 * X[:, 1] + 0.3 * rng.randn(n)
+    params = {**CPU, "num_leaves": 15, "min_data_in_leaf": 20, "boost_from_average": False}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, categorical_feature=[0], bin_sample=X), 5)
+    assert "||" in "".join(str(t) for t in serial.trees_to_dataframe()["threshold"])
+
+    def rank(r, comm):
+        sl = slice(r * n // 2, (r + 1) * n // 2)
+        d = lgb.Dataset(X[sl], label=y[sl], categorical_feature=[0], bin_sample=X)
+        return lgb.train({**params, "tree_learner": "data"}, d, 5, comm=comm).model_to_string()
+    for s in run_ranks(2, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
