@@ -33,8 +33,9 @@ constexpr size_t kMaxTileBytes = 120 * 1024;  // a single larger tree may claim 
 // Categorical nodes: a single category sits in `threshold` itself; a larger set (dtype bit 6) is a bitset
 // over category values in `cat_words`, `threshold` packing its first word (low 32 bits) and its length.
 constexpr int kSetNodeBit = 64;
+template <bool SETS = true>
 __device__ __forceinline__ bool go_left_dev(double v, double thr, int dtype, const uint32_t* __restrict__ cat_words) {
-  if (dtype & kSetNodeBit) {
+  if (SETS && (dtype & kSetNodeBit)) {
     if (!(v >= 0.0)) return false;
     const long long c = (long long)v;
     const unsigned long long enc = (unsigned long long)thr;
@@ -138,7 +139,8 @@ struct QNode {
 static_assert(sizeof(QNode) == 16, "QNode layout");
 constexpr size_t kQTileBytes = 20 * 1024;   // three 255-leaf trees
 
-template <typename T, int R>
+// SETS: the model has category-set nodes (the common case without them compiles the lookup away)
+template <typename T, int R, bool SETS>
 __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __restrict__ X, int64_t nrow, int ncol,
                                                                    int nfeat,   // columns the model reads (<= ncol)
                                                                    const QNode* __restrict__ nodes,
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
           if (node[j] >= 0) {
             const QNode nd = sn[nb + node[j]];
             const double v = (double)xs[(int)nd.feature * kRows + j * kPredThreads + threadIdx.x];
-            node[j] = go_left_dev(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
+            node[j] = go_left_dev<SETS>(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
             any = any || node[j] >= 0;
           }
         }
@@ -366,10 +368,20 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
                              obj.sigmoid, raw, o, d_cat.get());
         });
       };
-      if (dtype == 0 && R == 2) run(predict_lds_kernel<float, 2>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
-      else if (dtype == 0) run(predict_lds_kernel<float, 1>, lds_kernel_bytes<float, 1>(nfeat, q_limit));
-      else if (R == 2) run(predict_lds_kernel<double, 2>, lds_kernel_bytes<double, 2>(nfeat, q_limit));
-      else run(predict_lds_kernel<double, 1>, lds_kernel_bytes<double, 1>(nfeat, q_limit));
+      const bool sets = !cat_words.empty();
+      if (dtype == 0 && R == 2) {
+        if (sets) run(predict_lds_kernel<float, 2, true>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
+        else run(predict_lds_kernel<float, 2, false>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
+      } else if (dtype == 0) {
+        if (sets) run(predict_lds_kernel<float, 1, true>, lds_kernel_bytes<float, 1>(nfeat, q_limit));
+        else run(predict_lds_kernel<float, 1, false>, lds_kernel_bytes<float, 1>(nfeat, q_limit));
+      } else if (R == 2) {
+        if (sets) run(predict_lds_kernel<double, 2, true>, lds_kernel_bytes<double, 2>(nfeat, q_limit));
+        else run(predict_lds_kernel<double, 2, false>, lds_kernel_bytes<double, 2>(nfeat, q_limit));
+      } else {
+        if (sets) run(predict_lds_kernel<double, 1, true>, lds_kernel_bytes<double, 1>(nfeat, q_limit));
+        else run(predict_lds_kernel<double, 1, false>, lds_kernel_bytes<double, 1>(nfeat, q_limit));
+      }
       return;
     }
   }
