@@ -66,25 +66,33 @@ class _CallbackComm:
 
 
 class TorchComm(_CallbackComm):
-    """Host-buffer collectives through a ``torch.distributed`` process group (gloo)."""
+    """Host-buffer collectives through a ``torch.distributed`` process group (gloo; under an ``nccl`` group
+    the buffers take a detour through device tensors)."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
         self._dist = dist
         self._group = group
+        self._on_device = dist.get_backend(group) == "nccl"
         super().__init__(dist.get_rank(group), dist.get_world_size(group))
 
     def allreduce(self, view, op):
         import torch
         t = torch.from_numpy(view)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM,
-                              group=self._group)
+        red = self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM
+        if self._on_device:
+            d = t.cuda()
+            self._dist.all_reduce(d, op=red, group=self._group)
+            t.copy_(d)
+        else:
+            self._dist.all_reduce(t, op=red, group=self._group)
 
     def allgather(self, a, out):
         import torch
-        outs = [torch.empty(len(a), dtype=torch.uint8) for _ in range(self.size)]
-        self._dist.all_gather(outs, torch.from_numpy(a.copy()), group=self._group)
-        out[:] = torch.cat(outs).numpy()
+        dev = "cuda" if self._on_device else "cpu"
+        outs = [torch.empty(len(a), dtype=torch.uint8, device=dev) for _ in range(self.size)]
+        self._dist.all_gather(outs, torch.from_numpy(a.copy()).to(dev), group=self._group)
+        out[:] = torch.cat(outs).cpu().numpy()
 
 
 class _ThreadHub:
@@ -189,5 +197,22 @@ def default_comm(group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return None
     if _lib.is_hip() and dist.get_backend(group) == "nccl":
-        return RcclComm(group)
+        # The native communicator is created from an id the process group hands round.  Should that fail on
+        # any rank, every rank falls back to the group's own collectives (slower: buffers are staged through
+        # host memory) instead of leaving the job without a communicator.
+        import torch
+        comm, err = None, None
+        try:
+            comm = RcclComm(group)
+        except Exception as e:      # noqa: BLE001 - any failure takes the fallback
+            err = e
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
+        import warnings
+        warnings.warn(f"native RCCL communicator unavailable ({err}); using torch.distributed collectives")
+        return TorchComm(group)
     return TorchComm(group)

@@ -597,6 +597,36 @@ def test_rccl_single_rank_communicator(tmp_path):
         dist.destroy_process_group()
 
 
+def test_fallback_communicator_works_under_an_nccl_group(tmp_path):
+    """default_comm() falls back to the process group's own collectives when the native RCCL communicator
+    cannot be created; under an nccl group those take device tensors, so host buffers make a detour."""
+    import os, socket, subprocess, sys, textwrap
+    script = tmp_path / "fallback.py"
+    script.write_text(textwrap.dedent("""
+        import sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r)
+        from lightgbm_amd.parallel.comm import TorchComm
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        c = TorchComm()
+        v = np.arange(10, dtype=np.int64)
+        c.allreduce(v, "sum")
+        f = np.array([1.5, -2.0], dtype=np.float32)
+        c.allreduce(f, "max")
+        out = np.zeros(4, dtype=np.uint8)
+        c.allgather(np.array([1, 2, 3, 4], dtype=np.uint8), out)
+        assert v.tolist() == list(range(10)) and f.tolist() == [1.5, -2.0] and out.tolist() == [1, 2, 3, 4]
+        c.close()
+        dist.destroy_process_group()
+        print("FALLBACK_OK")
+    """) % os.path.join(os.path.dirname(__file__), ".."))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {**os.environ, "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1"}
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "FALLBACK_OK" in r.stdout, r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("P", [2, 4, 8])
 def test_rccl_data_parallel_over_several_gpus(P, tmp_path):
     """One process per GPU, histograms summed by RCCL: every rank ends with the serial learner's trees.
