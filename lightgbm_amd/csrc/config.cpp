@@ -44,6 +44,8 @@ const ParamDef kParams[] = {
     P(min_data_in_leaf, "min_data_per_leaf,min_data,min_child_samples,min_samples_leaf", Int, 0, kNone),
     P(min_sum_hessian_in_leaf, "min_sum_hessian_per_leaf,min_sum_hessian,min_hessian,min_child_weight", Double, 0, kNone),
     P(bagging_fraction, "sub_row,subsample,bagging", Double, 1e-300, 1.0),
+    P(pos_bagging_fraction, "pos_sub_row,pos_subsample,pos_bagging", Double, 1e-300, 1.0),
+    P(neg_bagging_fraction, "neg_sub_row,neg_subsample,neg_bagging", Double, 1e-300, 1.0),
     P(bagging_freq, "subsample_freq", Int, 0, kNone),
     P(bagging_seed, "bagging_fraction_seed", Int, kNone, kNone),
     P(categorical_feature, "cat_feature,categorical_column,cat_column,categorical_features", IntList, 0, kNone),
@@ -414,7 +416,7 @@ void Config::check() {
   // accepted names whose behaviour is not implemented: refuse instead of training something else silently
   if (zero_as_missing) throw std::runtime_error("zero_as_missing=true is not supported (NaN is the missing value)");
   if (boosting == "rf") {
-    bool row_sub = bagging_freq > 0 && bagging_fraction < 1.0;
+    bool row_sub = bagging_freq > 0 && (bagging_fraction < 1.0 || pos_bagging_fraction < 1.0 || neg_bagging_fraction < 1.0);
     bool col_sub = feature_fraction < 1.0 || feature_fraction_bynode < 1.0;
     if (!row_sub && !col_sub)
       throw std::runtime_error(

@@ -28,6 +28,8 @@ struct Config {
   int min_data_in_leaf = 20;
   double min_sum_hessian_in_leaf = 1e-3;
   double bagging_fraction = 1.0;
+  double pos_bagging_fraction = 1.0;   // balanced bagging (binary): share of the positive / negative rows kept
+  double neg_bagging_fraction = 1.0;
   int bagging_freq = 0;
   int bagging_seed = 3;
   std::vector<int> categorical_feature;    // column indices holding integer category codes

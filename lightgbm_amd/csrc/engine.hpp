@@ -56,8 +56,9 @@ class Engine {
   }
   // Gradients supplied by the caller, ordered like the training dataset's rows.
   virtual void set_gradients(const float* g, const float* h, int64_t n) = 0;
-  // Draw a new bag (every row when fraction >= 1).
-  virtual void resample(double fraction, uint64_t seed, uint64_t iter) = 0;
+  // Draw a new bag (every row when fraction >= 1).  neg_fraction >= 0: balanced bagging - rows with a
+  // positive label stay with probability `fraction`, the others with `neg_fraction`.
+  virtual void resample(double fraction, uint64_t seed, uint64_t iter, double neg_fraction = -1.0) = 0;
 
   // Gradient-based one-side sampling on the gradients just computed: a row's weight is the sum over classes
   // of |g * h|; the top_k heaviest rows stay (ties with the k-th included), every other row stays with

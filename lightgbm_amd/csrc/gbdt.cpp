@@ -384,7 +384,10 @@ void Booster::sample_rows() {
     engine_->goss_sample(cfg_.top_rate, cfg_.other_rate, (uint64_t)cfg_.bagging_seed, (uint64_t)iter_);
     return;
   }
-  if (cfg_.bagging_freq > 0 && cfg_.bagging_fraction < 1.0) draw_bag();
+  const bool balanced = cfg_.pos_bagging_fraction < 1.0 || cfg_.neg_bagging_fraction < 1.0;
+  if (balanced && obj_.kind != kObjBinary)
+    throw std::runtime_error("pos_bagging_fraction / neg_bagging_fraction need objective=binary");
+  if (cfg_.bagging_freq > 0 && (cfg_.bagging_fraction < 1.0 || balanced)) draw_bag();
 }
 
 // The bag of iteration k is drawn at the last multiple of bagging_freq <= k, also when training starts
@@ -392,7 +395,10 @@ void Booster::sample_rows() {
 void Booster::draw_bag() {
   const int period_start = iter_ - iter_ % cfg_.bagging_freq;
   if (bag_drawn_ && period_start != iter_) return;
-  engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)period_start);
+  if (cfg_.pos_bagging_fraction < 1.0 || cfg_.neg_bagging_fraction < 1.0)
+    engine_->resample(cfg_.pos_bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)period_start, cfg_.neg_bagging_fraction);
+  else
+    engine_->resample(cfg_.bagging_fraction, (uint64_t)cfg_.bagging_seed, (uint64_t)period_start);
   bag_drawn_ = true;
 }
 

@@ -326,7 +326,7 @@ class HipBackend : public TreeBackend {
     return sample_partition(base_rows, n, out, -1, bp);
   }
 
-  // feature: -1 bagging, -2 gradient-based one-side sampling (kernels.hpp: BagParams)
+  // feature: -1 bagging, -2 gradient-based one-side sampling, -3 bagging by label (kernels.hpp: BagParams)
   int64_t sample_partition(const int32_t* base_rows, int64_t n, int32_t* out, int feature, const k::BagParams& bp) {
     if (n == 0) return 0;
     SplitTask t{};
@@ -982,9 +982,16 @@ class HipEngine : public Engine {
     }
   }
 
-  void resample(double fraction, uint64_t seed, uint64_t iter) override {
-    if (fraction >= 1.0) { bag_ptr_ = base_rows_.get(); bag_n_ = n_base_; oob_n_ = 0; return; }
+  void resample(double fraction, uint64_t seed, uint64_t iter, double neg_fraction) override {
+    if (fraction >= 1.0 && (neg_fraction < 0.0 || neg_fraction >= 1.0)) { bag_ptr_ = base_rows_.get(); bag_n_ = n_base_; oob_n_ = 0; return; }
     uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
+    if (neg_fraction >= 0.0) {
+      k::BagParams bp{};
+      bp.seed = seed; bp.iter = iter; bp.salt = salt; bp.fraction = (float)fraction;
+      bp.label = mir_->label.get();
+      bp.neg_fraction = (float)neg_fraction;
+      bag_n_ = backend_->sample_partition(base_rows_.get(), n_base_, bag_rows_.get(), -3, bp);
+    } else
     bag_n_ = backend_->bag_partition(base_rows_.get(), n_base_, bag_rows_.get(), fraction, seed, iter, salt);
     bag_ptr_ = bag_rows_.get();
     oob_n_ = n_base_ - bag_n_;

@@ -277,7 +277,8 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
                                           int32_t row, const BagParams& bag) {
   if (t.feature < 0) {
     if (t.feature == -2 && goss_weight(bag.g, bag.h, row, bag.num_class, bag.stride) >= *bag.threshold) return true;
-    return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < bag.fraction;
+    const float keep = (t.feature == -3 && !(bag.label[row] > 0.0f)) ? bag.neg_fraction : bag.fraction;
+    return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < keep;
   }
   int b = bins_fm[(int64_t)t.feature * N + row];
   if (t.default_left == kCategoricalTask) return b == t.threshold;

@@ -95,6 +95,8 @@ struct BagParams {
   const float* threshold = nullptr;
   int num_class = 1;
   int64_t stride = 0;
+  const float* label = nullptr;         // feature -3 (balanced bagging): rows with label > 0 stay with probability
+  float neg_fraction = 0.0f;            // `fraction`, the others with `neg_fraction`
   const uint64_t* cat_sets = nullptr;   // growth rounds: kCatSetWords words per node, read for kCategoricalSetTask
 };
 // tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.

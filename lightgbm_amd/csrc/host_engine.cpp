@@ -511,13 +511,15 @@ class HostEngine : public Engine {
       }
   }
 
-  void resample(double fraction, uint64_t seed, uint64_t iter) override {
-    if (fraction >= 1.0) { bag_ = base_; oob_.clear(); return; }
+  void resample(double fraction, uint64_t seed, uint64_t iter, double neg_fraction) override {
+    if (fraction >= 1.0 && (neg_fraction < 0.0 || neg_fraction >= 1.0)) { bag_ = base_; oob_.clear(); return; }
     bag_.clear(); oob_.clear();
     uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
-    float fr = (float)fraction;
+    const float fr = (float)fraction, nfr = (float)(neg_fraction < 0.0 ? fraction : neg_fraction);
+    const auto& y = train_->root_label();
     for (int32_t r : base_) {
-      if (rng_uniform(seed, iter, salt + (uint64_t)r) < fr) bag_.push_back(r); else oob_.push_back(r);
+      const float keep = y[(size_t)r] > 0.0f ? fr : nfr;
+      if (rng_uniform(seed, iter, salt + (uint64_t)r) < keep) bag_.push_back(r); else oob_.push_back(r);
     }
   }
 

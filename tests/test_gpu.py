@@ -308,6 +308,18 @@ def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     assert trees_of(a) == trees_of(b)
 
 
+def test_gpu_balanced_bagging_draws_the_cpu_bag():
+    X, y = make_higgs_like(80000, seed=5, device="numpy")
+    y = (y > 0) & (X[:, 0] > 0.3)
+    p = {"objective": "binary", "num_leaves": 31, "bagging_freq": 1, "pos_bagging_fraction": 0.9, "neg_bagging_fraction": 0.2,
+         "boost_from_average": False}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y.astype(float), params=CPU), 5)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y.astype(float), params=GPU), 5, keep_training_booster=True)
+    sa, sb = a.model_to_string(), b.model_to_string()
+    assert sa[sa.index("Tree=0"):sa.index("Tree=1")] == sb[sb.index("Tree=0"):sb.index("Tree=1")]
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
+
+
 def test_gpu_binary_matches_cpu_quality_and_first_tree():
     X, y = make_higgs_like(60000, seed=2, device="numpy")
     p = {"objective": "binary", "num_leaves": 63, "metric": ["auc", "binary_logloss"], "min_sum_hessian_in_leaf": 10.0}

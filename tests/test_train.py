@@ -527,3 +527,23 @@ def test_scipy_sparse_input_is_accepted_for_training_and_prediction():
         b = lgb.train(CPU, lgb.Dataset(S, label=y), 5)
         assert b.model_to_string() == dense.model_to_string()
         np.testing.assert_array_equal(b.predict(S), dense.predict(X))
+
+
+def test_balanced_bagging_keeps_different_shares_of_the_classes():
+    rng = np.random.RandomState(0)
+    X = rng.randn(20000, 5)
+    y = (X[:, 0] + rng.randn(20000) > 1.6).astype(float)            # about 13 % positives
+    base = {**CPU, "objective": "binary", "num_leaves": 15, "bagging_freq": 1, "boost_from_average": False}
+    plain = lgb.train(base, lgb.Dataset(X, label=y), 20)
+    bal = lgb.train({**base, "pos_bagging_fraction": 1.0, "neg_bagging_fraction": 0.15}, lgb.Dataset(X, label=y), 20)
+    # the trees see about as many negatives as positives: predicted probabilities move up
+    assert bal.predict(X).mean() > plain.predict(X).mean() + 0.1
+    from sklearn.metrics import roc_auc_score
+    assert roc_auc_score(y, bal.predict(X)) > 0.85
+    # out-of-bag rows still get their scores: training scores equal predictions
+    kept = lgb.Booster({**base, "pos_bagging_fraction": 0.8, "neg_bagging_fraction": 0.3}, lgb.Dataset(X, label=y))
+    for _ in range(4):
+        kept.update()
+    np.testing.assert_allclose(kept._inner_predict(-1, raw=True), kept.predict(X, raw_score=True), atol=1e-9)
+    with pytest.raises(lgb.LightGBMError, match="binary"):
+        lgb.train({**CPU, "neg_bagging_fraction": 0.5, "bagging_freq": 1}, lgb.Dataset(X, label=y), 2)
