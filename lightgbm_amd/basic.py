@@ -252,12 +252,33 @@ class Dataset:
         if self.data is None:
             raise LightGBMError("Cannot construct a Dataset whose raw data was freed")
         if isinstance(self.data, (str, os.PathLike)):
-            # a binary cache written by save_binary(): boundaries, bins and fields come from the file
-            h = ctypes.c_void_p()
-            check(lib.lga_dataset_load_binary(c_str(os.fspath(self.data)), ctypes.byref(h)))
-            self._handle = h
-            self._set_fields()
-            return self
+            path = os.fspath(self.data)
+            with open(path, "rb") as f:
+                is_cache = f.read(6) == b"LGABIN"
+            if is_cache:
+                # a binary cache written by save_binary(): boundaries, bins and fields come from the file
+                h = ctypes.c_void_p()
+                check(lib.lga_dataset_load_binary(c_str(path), ctypes.byref(h)))
+                self._handle = h
+                self._set_fields()
+                return self
+            # a text file (CSV / TSV / LibSVM) with the application's conventions: label_column / header
+            # parameters, <file>.weight / <file>.query / <file>.init side files
+            from .cli import _load_table, _side_file
+            label_column = get_param(self.params, "label_column", 0)
+            if isinstance(label_column, str) and label_column.startswith("name:"):
+                raise LightGBMError("label_column=name:... is not supported; give the column index")
+            ref_cols = self.reference.construct().num_feature() if self.reference is not None else 0
+            X, y = _load_table(path, int(label_column), str(get_param(self.params, "header", False)).lower() in ("true", "1"),
+                               ref_cols)
+            if ref_cols and X.shape[1] < ref_cols:
+                X = np.hstack([X, np.zeros((X.shape[0], ref_cols - X.shape[1]))])
+            self.data = X
+            if self.label is None:
+                self.label = y
+            for attr, suffix in (("weight", ".weight"), ("group", ".query"), ("init_score", ".init")):
+                if getattr(self, attr) is None:
+                    setattr(self, attr, _side_file(path, suffix))
         if self.reference is not None:
             self.reference.construct()   # bin boundaries come from the reference
         raw, auto_cat, self.pandas_categorical = _encode_pandas_categories(

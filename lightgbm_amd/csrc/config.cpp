@@ -104,6 +104,8 @@ const ParamDef kParams[] = {
     P(snapshot_freq, "save_period", Int, kNone, kNone),
     P(output_model, "model_output,model_out", String, kNone, kNone),
     P(input_model, "model_input,model_in", String, kNone, kNone),
+    P(label_column, "label", String, kNone, kNone),
+    P(header, "has_header", Bool, kNone, kNone),
     P(num_machines, "num_machine", Int, 1, kNone),
     P(gpu_device_id, "", Int, kNone, kNone),
     P(max_batch_leaves, "", Int, 0, kNone),

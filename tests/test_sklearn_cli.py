@@ -131,3 +131,17 @@ def test_cli_libsvm_ranking_side_files_refit_and_binary_cache(tmp_path):
     r = run("task=train", f"data={reg}.bin", f"output_model={m1}", "num_trees=15", "verbose=-1")
     assert r.returncode == 0, r.stderr
     assert open(m1).read().split("parameters:")[0] == open(m3).read().split("parameters:")[0]
+
+
+def test_dataset_from_a_text_file_path(tmp_path):
+    import lightgbm_amd as lgb
+    rng = np.random.RandomState(0)
+    X = rng.randn(500, 4)
+    y = X[:, 0] + 0.1 * rng.randn(500)
+    path = str(tmp_path / "t.csv")
+    np.savetxt(path, np.column_stack([X[:, :2], y, X[:, 2:]]), delimiter=",", header="a,b,target,c,d", comments="")
+    np.savetxt(path + ".weight", np.full(500, 2.0))
+    p = {"device_type": "cpu", "verbose": -1}
+    from_file = lgb.train(p, lgb.Dataset(path, params={**p, "label_column": 2, "header": True}), 5)
+    in_memory = lgb.train(p, lgb.Dataset(X, label=y, weight=np.full(500, 2.0)), 5)
+    assert from_file.model_to_string().split("parameters:")[0] == in_memory.model_to_string().split("parameters:")[0]
