@@ -43,6 +43,12 @@ def main():
                                                 "reported config then names them)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the result: whatever libraries print on the way (RCCL announces its
+    # version on stdout when a communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,7 +150,8 @@ def main():
         out["config"]["profile"] = booster.profile()
         out["config"]["last_tree"] = booster.grow_stats()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()
     if distributed:
