@@ -380,6 +380,19 @@ std::vector<std::string> Config::resolved_metrics() const {
 }
 
 void Config::check() {
+  // an explicit master seed settles every random stream that was not given a seed of its own
+  if (std::find(explicit_keys.begin(), explicit_keys.end(), "seed") != explicit_keys.end()) {
+    struct Derived { const char* name; int* value; };
+    const Derived streams[] = {{"data_random_seed", &data_random_seed}, {"bagging_seed", &bagging_seed},
+                               {"drop_seed", &drop_seed}, {"feature_fraction_seed", &feature_fraction_seed},
+                               {"objective_seed", &objective_seed}, {"extra_seed", &extra_seed}};
+    uint64_t x = (uint64_t)(uint32_t)seed * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;
+    for (const Derived& d : streams) {
+      x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; x ^= x >> 31;
+      if (std::find(explicit_keys.begin(), explicit_keys.end(), d.name) == explicit_keys.end())
+        *d.value = (int)(x & 0x7fffffffull);
+    }
+  }
   std::string b = lower(boosting);
   if (b == "gbrt" || b == "gbdt") boosting = "gbdt";
   else if (b == "rf" || b == "random_forest") boosting = "rf";

@@ -62,3 +62,17 @@ def test_parameters_block_in_model():
     b = lgb.train({"learning_rate": 0.07, "num_leaves": 5, "verbose": -1, "min_data_in_leaf": 5}, lgb.Dataset(X, label=y), 2)
     s = b.model_to_string()
     assert "[learning_rate: 0.07" in s and "[num_leaves: 5]" in s and "[boosting: gbdt]" in s
+
+
+def test_master_seed_settles_the_other_random_streams():
+    import numpy as np
+    import lightgbm_amd as lgb
+    rng = np.random.RandomState(0)
+    X = rng.randn(3000, 6)
+    y = X[:, 0] + 0.5 * rng.randn(3000)
+    p = {"device_type": "cpu", "verbose": -1, "bagging_fraction": 0.5, "bagging_freq": 1, "feature_fraction": 0.5}
+    fit = lambda **kw: lgb.train({**p, **kw}, lgb.Dataset(X, label=y), 5).predict(X)
+    assert np.array_equal(fit(seed=1), fit(seed=1))
+    assert not np.array_equal(fit(seed=1), fit(seed=2))                       # bag and feature subsets follow the seed
+    assert np.array_equal(fit(seed=1, bagging_seed=9, feature_fraction_seed=9),
+                          fit(seed=2, bagging_seed=9, feature_fraction_seed=9))   # explicit stream seeds win
