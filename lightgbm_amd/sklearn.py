@@ -84,27 +84,40 @@ class LGBMModel(BaseEstimator):
         return p
 
     def fit(self, X, y, sample_weight=None, init_score=None, eval_set=None, eval_names=None, eval_metric=None,
-            early_stopping_rounds=None, callbacks=None, init_model=None, group=None, eval_group=None):
+            early_stopping_rounds=None, callbacks=None, init_model=None, group=None, eval_group=None,
+            eval_sample_weight=None, eval_init_score=None, feature_name="auto", categorical_feature="auto"):
         params = self._params()
-        if eval_metric is not None:
+        feval = None
+        if callable(eval_metric):
+            # sklearn-style metric f(y_true, y_pred) -> (name, value, is_higher_better)
+            user = eval_metric
+            feval = lambda preds, data: user(data.get_label(), preds)   # noqa: E731
+        elif eval_metric is not None:
             params["metric"] = eval_metric
         dtrain = Dataset(X, label=self._encode_label(y), weight=sample_weight, init_score=init_score, params=params,
-                         free_raw_data=init_model is None, group=group)
+                         free_raw_data=init_model is None, group=group, feature_name=feature_name,
+                         categorical_feature=categorical_feature)
         valid_sets, valid_names = [], []
+        pick = lambda seq, i: None if seq is None else (seq.get(i) if isinstance(seq, dict) else seq[i])   # noqa: E731
         for i, (vx, vy) in enumerate(eval_set or []):
             if vx is X and vy is y:
                 valid_sets.append(dtrain)
             else:
-                valid_sets.append(dtrain.create_valid(vx, label=self._encode_label(vy),
-                                                      group=eval_group[i] if eval_group is not None else None))
+                valid_sets.append(dtrain.create_valid(vx, label=self._encode_label(vy), weight=pick(eval_sample_weight, i),
+                                                      init_score=pick(eval_init_score, i), group=pick(eval_group, i)))
             valid_names.append(eval_names[i] if eval_names else f"valid_{i}")
         self.evals_result_ = {}
         self._Booster = train(params, dtrain, num_boost_round=self.n_estimators, valid_sets=valid_sets or None,
                               valid_names=valid_names or None, early_stopping_rounds=early_stopping_rounds,
                               evals_result=self.evals_result_ if valid_sets else None, callbacks=callbacks,
-                              init_model=init_model)
+                              init_model=init_model, feval=feval)
         self.best_iteration_ = self._Booster.best_iteration
-        self.n_features_in_ = self._Booster.num_feature()
+        self.best_score_ = getattr(self._Booster, "best_score", {})
+        self.n_features_in_ = self.n_features_ = self._Booster.num_feature()
+        self.feature_name_ = self._Booster.feature_name()
+        self.objective_ = params["objective"]
+        self.n_iter_ = self._Booster.current_iteration()
+        self.fitted_ = True
         return self
 
     def _encode_label(self, y):

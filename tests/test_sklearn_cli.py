@@ -145,3 +145,16 @@ def test_dataset_from_a_text_file_path(tmp_path):
     from_file = lgb.train(p, lgb.Dataset(path, params={**p, "label_column": 2, "header": True}), 5)
     in_memory = lgb.train(p, lgb.Dataset(X, label=y, weight=np.full(500, 2.0)), 5)
     assert from_file.model_to_string().split("parameters:")[0] == in_memory.model_to_string().split("parameters:")[0]
+
+
+def test_estimator_fit_arguments_and_fitted_attributes():
+    rng = np.random.RandomState(0)
+    X = rng.randn(1000, 4)
+    y = X[:, 0] + 0.1 * rng.randn(1000)
+    m = LGBMRegressor(n_estimators=20, device_type="cpu").fit(
+        X[:800], y[:800], eval_set=[(X[800:], y[800:])], eval_sample_weight=[np.ones(200)],
+        eval_metric=lambda yt, yp: ("mad", float(np.median(np.abs(yt - yp))), False),
+        feature_name=["a", "b", "c", "d"], early_stopping_rounds=5)
+    assert m.feature_name_ == ["a", "b", "c", "d"] and m.n_features_ == 4 and m.objective_ == "regression"
+    assert list(m.evals_result_["valid_0"]) == ["l2", "mad"] and m.n_iter_ == 20
+    assert set(m.best_score_["valid_0"]) == {"l2", "mad"}
