@@ -289,7 +289,8 @@ class Dataset:
         if self.reference is not None:
             self._has_categorical = self.reference._has_categorical
         else:
-            self._has_categorical = bool(cat_idx)
+            # host binning: category lookup, and zeros that count as missing values
+            self._has_categorical = bool(cat_idx) or str(get_param(params, "zero_as_missing", False)).lower() in ("true", "1")
             if cat_idx:
                 params["categorical_feature"] = cat_idx
             else:

@@ -16,11 +16,14 @@ std::vector<double> greedy_find_bounds(const std::vector<double>& distinct, cons
   return out;
 }
 
-void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing) {
-  // strip NaN
+void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing,
+                          bool zero_as_missing) {
+  // strip NaN (and zeros when they count as missing)
+  const bool zeros_missing = use_missing && zero_as_missing;
   size_t n_all = values.size();
   size_t w = 0;
-  for (size_t i = 0; i < n_all; ++i) if (values[i] == values[i]) values[w++] = values[i];
+  for (size_t i = 0; i < n_all; ++i)
+    if (values[i] == values[i] && !(zeros_missing && values[i] > -1e-35 && values[i] < 1e-35)) values[w++] = values[i];
   size_t n_nan = n_all - w;
   values.resize(w);
   std::sort(values.begin(), values.end());
@@ -30,12 +33,12 @@ void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data
     if (i == 0 || values[i] != values[i - 1]) { distinct.push_back(values[i]); counts.push_back(1); }
     else counts.back()++;
   }
-  missing = (use_missing && n_nan > 0) ? MissingType::NaN : MissingType::None;
-  int value_bins = max_bin - (missing == MissingType::NaN ? 1 : 0);
+  missing = (use_missing && n_nan > 0) ? (zeros_missing ? MissingType::Zero : MissingType::NaN) : MissingType::None;
+  int value_bins = max_bin - (missing != MissingType::None ? 1 : 0);
   if (value_bins < 1) value_bins = 1;
   upper = greedy_find_bounds(distinct, counts, value_bins, (int64_t)values.size(), min_data_in_bin);
   int nv = (int)upper.size();
-  if (missing == MissingType::NaN) { missing_bin = nv; num_bin = nv + 1; }
+  if (missing != MissingType::None) { missing_bin = nv; num_bin = nv + 1; }
   else { missing_bin = -1; num_bin = nv; }
   if (!distinct.empty()) { min_val = distinct.front(); max_val = distinct.back(); }
   else { min_val = max_val = 0.0; }

@@ -16,7 +16,7 @@ struct BinMapper {
   std::vector<double> upper;   // upper[i]: inclusive upper bound of value bin i; last is +inf
   int32_t num_bin = 1;         // value bins + (1 if a NaN bin exists)
   MissingType missing = MissingType::None;
-  int32_t missing_bin = -1;    // == num_bin-1 when missing == NaN
+  int32_t missing_bin = -1;    // == num_bin-1 when a missing bin exists (NaN, or zero and NaN)
   double min_val = 0.0, max_val = 0.0;
   bool trivial = true;         // a single bin: the feature cannot split
   // Categorical feature: values are non-negative integer codes.  `upper` then holds the kept category
@@ -27,7 +27,9 @@ struct BinMapper {
 
   // Build from a sample of one feature.  `values` may contain NaN; it is
   // modified (sorted).  total_sample_cnt is the number of sampled rows.
-  void find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing);
+  // zero_as_missing: zeros (|v| <= 1e-35) share the missing bin with NaN (MissingType::Zero).
+  void find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing,
+                 bool zero_as_missing = false);
   // Categorical form: the (max_bin - 1) most frequent categories that occur at least min_data_in_bin times
   // (ties: smaller category first) get a bin each.
   void find_bins_categorical(const std::vector<double>& values, int max_bin, int min_data_in_bin);
@@ -46,6 +48,7 @@ struct BinMapper {
       }
       return (lo < cat_lookup.size() && cat_lookup[lo].first == c) ? cat_lookup[lo].second : missing_bin;
     }
+    if (missing == MissingType::Zero && (v != v || (v > -1e-35 && v < 1e-35))) return missing_bin;
     if (v != v) {
       if (missing == MissingType::NaN) return missing_bin;
       v = 0.0;

@@ -428,8 +428,6 @@ void Config::check() {
   if (d == "cpu") device_type = "cpu";
   else if (d == "gpu" || d == "hip" || d == "cuda" || d == "rocm") device_type = "gpu";
   else throw std::runtime_error("unknown device_type \"" + device_type + "\"");
-  // accepted names whose behaviour is not implemented: refuse instead of training something else silently
-  if (zero_as_missing) throw std::runtime_error("zero_as_missing=true is not supported (NaN is the missing value)");
   if (boosting == "rf") {
     bool row_sub = bagging_freq > 0 && (bagging_fraction < 1.0 || pos_bagging_fraction < 1.0 || neg_bagging_fraction < 1.0);
     bool col_sub = feature_fraction < 1.0 || feature_fraction_bynode < 1.0;

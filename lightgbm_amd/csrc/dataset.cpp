@@ -43,7 +43,7 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
     for (int64_t i = 0; i < nsample; ++i) col[(size_t)i] = sample[i * ncol + f];
     const bool cat = std::find(cfg.categorical_feature.begin(), cfg.categorical_feature.end(), f) != cfg.categorical_feature.end();
     if (cat) ds->mappers_[f].find_bins_categorical(col, cfg.max_bin, cfg.min_data_in_bin);
-    else ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing);
+    else ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing, cfg.zero_as_missing);
   }
   ds->finish_mappers();
   return ds;

@@ -398,11 +398,27 @@ def test_snapshots_allow_resuming_a_killed_run(tmp_path):
     np.testing.assert_allclose(resumed.predict(X), full.predict(X), rtol=1e-9, atol=1e-9)
 
 
-def test_unimplemented_parameters_are_refused():
-    X, y = make_regression(500, 4, seed=1)
-    for bad in ({"zero_as_missing": True},):
-        with pytest.raises(lgb.LightGBMError):
-            lgb.train({**CPU, **bad}, lgb.Dataset(X, label=y, params=CPU), 2)
+def test_zero_as_missing_sends_zeros_with_the_nans():
+    rng = np.random.RandomState(0)
+    X = rng.randn(6000, 3)
+    absent = rng.rand(6000) < 0.3
+    X[absent, 0] = 0.0                       # "not recorded" is written as 0
+    X[rng.rand(6000) < 0.05, 0] = np.nan
+    y = np.where(absent | np.isnan(X[:, 0]), 2.0, X[:, 0]) + 0.1 * rng.randn(6000)
+    p = {**CPU, "num_leaves": 15, "zero_as_missing": True}
+    d = lgb.Dataset(X, label=y, params=p)
+    b = lgb.train(p, d, 30, keep_training_booster=True)
+    assert d.bin_info(0)["missing_bin"] == d.bin_info(0)["num_bin"] - 1
+    df = b.trees_to_dataframe()
+    assert set(df[df.split_feature == "Column_0"]["missing_type"]) == {"Zero"}
+    assert float(np.mean((b.predict(X) - y) ** 2)) < 0.03
+    # zeros and NaNs take the same branch everywhere; the binned training scores agree with the raw-value predictor
+    probe = np.tile(X[:1], (2, 1))
+    probe[:, 0] = [0.0, np.nan]
+    assert b.predict(probe)[0] == b.predict(probe)[1]
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
+    from lightgbm_amd.models import TreeEnsemble
+    np.testing.assert_allclose(TreeEnsemble.from_string(b.model_to_string()).predict(X), b.predict(X), atol=1e-12)
 
 
 def _internal_nodes(node):

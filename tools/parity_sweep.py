@@ -69,6 +69,8 @@ def draw_case(seed: int, max_rows: int):
     if rng.rand() < 0.2 and F >= 6:
         cut = int(rng.randint(2, F - 2))
         p["interaction_constraints"] = [list(range(0, cut)), list(range(cut - 1, F - 1))]   # last column in no group
+    if rng.rand() < 0.15:
+        p["zero_as_missing"] = True
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
             "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25,
             "categorical": rng.rand() < 0.3}
@@ -107,7 +109,8 @@ def run_case(seed: int, max_rows: int):
     for dev in ("cpu", "gpu"):
         base = {"device_type": dev, "verbose": -1}
         cats = [F - 2 if F > 1 else 0] if opts.get("categorical") else "auto"
-        d = lgb.Dataset(X, label=y, weight=w, params={**base, "max_bin": p["max_bin"]}, categorical_feature=cats)
+        dp = {**base, "max_bin": p["max_bin"], "zero_as_missing": p.get("zero_as_missing", False)}
+        d = lgb.Dataset(X, label=y, weight=w, params=dp, categorical_feature=cats)
         if opts["subset"]:
             d = d.construct().subset(np.arange(0, n, 2))
         b = lgb.train({**base, **p}, d, opts["rounds"])
