@@ -65,7 +65,7 @@ def test_text_round_trip_is_stable_and_counts_are_consistent(tmp_path):
 def test_random_forest_family_averages_and_stages():
     X, y = _data(5000, 8, seed=3, nan=False)
     Xt, yt = _data(2000, 8, seed=4, nan=False)
-    rf = RandomForest(n_estimators=40, device_type="cpu", seed=1).fit(X, y)
+    rf = RandomForest(n_estimators=40, device_type="cpu", bagging_seed=77, feature_fraction_seed=5).fit(X, y)
     gb = GBDT(n_estimators=40, device_type="cpu", learning_rate=0.2).fit(X, y)
     ens = TreeEnsemble.from_booster(rf.booster_)
     assert ens.average_output
