@@ -347,7 +347,7 @@ std::string Config::canonical_metric(const std::string& name0) {
       {"ndcg", "ndcg"}, {"lambdarank", "ndcg"}, {"rank_xendcg", "ndcg"}, {"xendcg", "ndcg"}, {"xe_ndcg", "ndcg"},
       {"xe_ndcg_mart", "ndcg"}, {"xendcg_mart", "ndcg"},
       {"map", "map"}, {"mean_average_precision", "map"},
-      {"average_precision", "average_precision"},
+      {"average_precision", "average_precision"}, {"auc_mu", "auc_mu"},
       {"none", "none"}, {"null", "none"}, {"custom", "none"}, {"na", "none"}, {"", "none"},
   };
   auto it = m.find(name);

@@ -26,6 +26,8 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
       for (int k : at) rank_metrics_.push_back(RankMetric{m == "ndcg", k});
     } else if (m == "average_precision") {
       eval_average_precision_ = true;
+    } else if (m == "auc_mu") {
+      eval_auc_mu_ = true;
     } else {
       metrics_.push_back(metric_kind_from_name(m));
     }
@@ -237,6 +239,31 @@ void Booster::eval_ranking(int which, std::vector<EvalResult>* out) {
     double b[2] = {ap * pos, pos};
     engine_->sum_over_ranks(b, 2);
     out->push_back(EvalResult{"average_precision", b[1] > 0.0 ? b[0] / b[1] : 1.0, true});
+  }
+  if (eval_auc_mu_) {
+    if (num_class_ < 2) throw std::runtime_error("auc_mu needs a multiclass objective");
+    const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
+    const int64_t n = engine_->num_rows(which);
+    const int K = num_class_;
+    std::vector<double> score((size_t)n * (size_t)K);      // [class][row]
+    engine_->get_scores(which, score.data());
+    const std::vector<float> label = ds->local_label(), weight = ds->local_weight();
+    // for every pair of classes: the AUC of telling them apart by the difference of their two raw scores
+    double sum = 0.0;
+    for (int i = 0; i < K; ++i)
+      for (int j = i + 1; j < K; ++j) {
+        std::vector<std::pair<double, std::pair<float, float>>> items;
+        for (int64_t r = 0; r < n; ++r) {
+          const int c = (int)label[(size_t)r];
+          if (c != i && c != j) continue;
+          items.push_back({score[(size_t)j * (size_t)n + (size_t)r] - score[(size_t)i * (size_t)n + (size_t)r],
+                           {c == j ? 1.0f : 0.0f, weight.empty() ? 1.0f : weight[(size_t)r]}});
+        }
+        sum += auc_host(items);
+      }
+    double b[2] = {sum * 2.0 / ((double)K * (double)(K - 1)), 1.0};   // distributed: the mean of the ranks' values
+    engine_->sum_over_ranks(b, 2);
+    out->push_back(EvalResult{"auc_mu", b[0] / b[1], true});
   }
   if (rank_metrics_.empty()) return;
   const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
@@ -618,6 +645,7 @@ std::vector<std::pair<std::string, bool>> Booster::eval_names() const {
   std::vector<std::pair<std::string, bool>> out;
   for (int32_t m : metrics_) out.emplace_back(metric_name(m), metric_higher_better(m));
   if (eval_average_precision_) out.emplace_back("average_precision", true);
+  if (eval_auc_mu_) out.emplace_back("auc_mu", true);
   for (int pass = 0; pass < 2; ++pass)
     for (const auto& m : rank_metrics_)
       if (m.ndcg == (pass == 0)) out.emplace_back(std::string(m.ndcg ? "ndcg@" : "map@") + std::to_string(m.at), true);

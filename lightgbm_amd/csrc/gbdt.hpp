@@ -132,6 +132,7 @@ class Booster {
   void setup_ranking();
   void compute_gradients();
   void eval_ranking(int which, std::vector<EvalResult>* out);
+  bool eval_auc_mu_ = false;              // multiclass AUC (Kleiman & Page): mean pairwise class separability
   bool eval_average_precision_ = false;   // evaluated here from the engine's scores, like the ranking metrics
   RankingSpec rank_;
   std::vector<RankMetric> rank_metrics_;

@@ -158,3 +158,20 @@ def test_data_parallel_multiclass_equals_serial():
     [c.close() for c in comms]
     cut = lambda s: s[s.index("Tree=0"):s.index("end of trees")]
     assert out[0] is not None and cut(out[0]) == cut(out[1]) == cut(serial.model_to_string())
+
+
+def test_auc_mu_is_the_mean_pairwise_auc():
+    from sklearn.metrics import roc_auc_score
+    X, y = make_classes(4000, K=4, seed=6)
+    d = lgb.Dataset(X, label=y, params=CPU)
+    ev = {}
+    b = lgb.train({**CPU, "objective": "multiclass", "num_class": 4, "num_leaves": 7, "metric": ["multi_logloss", "auc_mu"]}, d, 8,
+                  valid_sets=[d], evals_result=ev)
+    raw = b.predict(X, raw_score=True)
+    pairs = []
+    for i in range(4):
+        for j in range(i + 1, 4):
+            m = (y == i) | (y == j)
+            pairs.append(roc_auc_score(y[m] == j, raw[m, j] - raw[m, i]))
+    assert list(ev["training"]) == ["multi_logloss", "auc_mu"]
+    assert ev["training"]["auc_mu"][-1] == pytest.approx(np.mean(pairs), abs=1e-9)
