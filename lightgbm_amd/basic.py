@@ -289,8 +289,9 @@ class Dataset:
         if self.reference is not None:
             self._has_categorical = self.reference._has_categorical
         else:
-            # host binning: category lookup, and zeros that count as missing values
-            self._has_categorical = bool(cat_idx) or str(get_param(params, "zero_as_missing", False)).lower() in ("true", "1")
+            # host binning: category lookup, zeros that count as missing values, per-feature bin counts
+            self._has_categorical = (bool(cat_idx) or str(get_param(params, "zero_as_missing", False)).lower() in ("true", "1")
+                                     or get_param(params, "max_bin_by_feature", None) not in (None, "", []))
             if cat_idx:
                 params["categorical_feature"] = cat_idx
             else:

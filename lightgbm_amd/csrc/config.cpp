@@ -79,6 +79,7 @@ const ParamDef kParams[] = {
     P(interaction_constraints, "", String, kNone, kNone),
     P(verbosity, "verbose", Int, kNone, kNone),
     P(max_bin, "max_bins", Int, 2, 255),
+    P(max_bin_by_feature, "", IntList, 2, 255),
     P(min_data_in_bin, "", Int, 1, kNone),
     P(bin_construct_sample_cnt, "subsample_for_bin", Int, 1, kNone),
     P(data_random_seed, "data_seed", Int, kNone, kNone),

@@ -66,6 +66,7 @@ struct Config {
   int verbosity = 1;
   // dataset
   int max_bin = 255;
+  std::vector<int> max_bin_by_feature;   // per column of the raw matrix; empty: max_bin everywhere
   int min_data_in_bin = 3;
   int bin_construct_sample_cnt = 200000;
   int data_random_seed = 1;

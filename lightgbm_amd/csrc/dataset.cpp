@@ -37,13 +37,17 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
   auto ds = std::make_shared<Dataset>();
   ds->root_rows_ = nrow;
   ds->mappers_.resize(ncol);
+  if (!cfg.max_bin_by_feature.empty() && (int)cfg.max_bin_by_feature.size() != ncol)
+    throw std::runtime_error("max_bin_by_feature lists " + std::to_string(cfg.max_bin_by_feature.size()) +
+                             " values, the data has " + std::to_string(ncol) + " columns");
 #pragma omp parallel for schedule(dynamic)
   for (int f = 0; f < ncol; ++f) {
     std::vector<double> col((size_t)nsample);
     for (int64_t i = 0; i < nsample; ++i) col[(size_t)i] = sample[i * ncol + f];
     const bool cat = std::find(cfg.categorical_feature.begin(), cfg.categorical_feature.end(), f) != cfg.categorical_feature.end();
-    if (cat) ds->mappers_[f].find_bins_categorical(col, cfg.max_bin, cfg.min_data_in_bin);
-    else ds->mappers_[f].find_bins(col, cfg.max_bin, cfg.min_data_in_bin, cfg.use_missing, cfg.zero_as_missing);
+    const int bins = cfg.max_bin_by_feature.empty() ? cfg.max_bin : cfg.max_bin_by_feature[(size_t)f];
+    if (cat) ds->mappers_[f].find_bins_categorical(col, bins, cfg.min_data_in_bin);
+    else ds->mappers_[f].find_bins(col, bins, cfg.min_data_in_bin, cfg.use_missing, cfg.zero_as_missing);
   }
   ds->finish_mappers();
   return ds;

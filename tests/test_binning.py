@@ -105,3 +105,14 @@ def test_binary_cache_round_trip(tmp_path):
         fh.truncate(1000)
     with pytest.raises(lgb.LightGBMError):
         lgb.Dataset(str(path), params=CPU).construct()
+
+
+def test_max_bin_by_feature():
+    import lightgbm_amd as lgb
+    rng = np.random.RandomState(0)
+    X = rng.randn(5000, 3)
+    d = lgb.Dataset(X, label=X[:, 0], params={"device_type": "cpu", "verbose": -1, "max_bin_by_feature": [4, 255, 16]}).construct()
+    assert [d.feature_num_bin(f) for f in range(3)] == [4, 255, 16]
+    import pytest
+    with pytest.raises(lgb.LightGBMError, match="max_bin_by_feature"):
+        lgb.Dataset(X, label=X[:, 0], params={"device_type": "cpu", "max_bin_by_feature": [4, 255]}).construct()
