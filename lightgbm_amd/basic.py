@@ -8,6 +8,7 @@ matrix)`` (r/gridsearchCV.R:63) and staged prediction with the first k trees
 from __future__ import annotations
 
 import ctypes
+import weakref
 import json
 import os
 import warnings
@@ -195,6 +196,39 @@ def _mat_args(arr: np.ndarray):
 
 
 # ----------------------------------------------------------------------------
+# Native handles and interpreter shutdown.  Objects still alive when the interpreter exits (module-level
+# boosters and datasets of a script) are released by an exit hook while the runtime underneath - the HIP
+# runtime, torch's allocator and streams - is still whole; destructors that run later, during module
+# teardown, leave the native side alone.
+# ----------------------------------------------------------------------------
+_live_objects: "weakref.WeakSet" = weakref.WeakSet()
+_shutting_down = False
+_exit_hook_installed = False
+
+
+def _release_all_at_exit():
+    global _shutting_down
+    objs = list(_live_objects)
+    for o in sorted(objs, key=lambda o: isinstance(o, Dataset)):     # boosters first: they hold their datasets
+        try:
+            o._free()
+        except Exception:
+            pass
+    _shutting_down = True
+
+
+def _track(obj):
+    """Called when an object takes ownership of a native handle.  The hook is registered then - after torch
+    has been imported on the GPU path - so that it runs before torch's own exit handlers."""
+    global _exit_hook_installed
+    _live_objects.add(obj)
+    if not _exit_hook_installed:
+        import atexit
+        atexit.register(_release_all_at_exit)
+        _exit_hook_installed = True
+
+
+# ----------------------------------------------------------------------------
 # Dataset
 # ----------------------------------------------------------------------------
 class Dataset:
@@ -245,6 +279,7 @@ class Dataset:
             check(lib.lga_dataset_subset(self._parent._handle, idx.ctypes.data_as(ctypes.c_void_p), len(idx),
                                          ctypes.byref(h)))
             self._handle = h
+            _track(self)
             self._has_categorical = self._parent._has_categorical
             self.pandas_categorical = self._parent.pandas_categorical
             self._set_fields()
@@ -260,6 +295,7 @@ class Dataset:
                 h = ctypes.c_void_p()
                 check(lib.lga_dataset_load_binary(c_str(path), ctypes.byref(h)))
                 self._handle = h
+                _track(self)
                 self._set_fields()
                 return self
             # a text file (CSV / TSV / LibSVM) with the application's conventions: label_column / header
@@ -348,6 +384,7 @@ class Dataset:
             import torch
             torch.cuda.synchronize()
         self._handle = h
+        _track(self)
         self._num_total_features = mat.shape[1]
         if isinstance(self.feature_name, (list, tuple)):
             names = [str(n) for n in self.feature_name]
@@ -620,12 +657,16 @@ class Dataset:
         check(lib.lga_dataset_get_bins(self._handle, out.ctypes.data_as(ctypes.c_void_p), None))
         return out
 
+    def _free(self):
+        if getattr(self, "_handle", None) is not None:
+            lib, _ = _lib.load()
+            h, self._handle = self._handle, None
+            lib.lga_dataset_free(h)
+
     def __del__(self):
         try:
-            if self._handle is not None:
-                lib, _ = _lib.load()
-                lib.lga_dataset_free(self._handle)
-                self._handle = None
+            if not _shutting_down:
+                self._free()
         except Exception:
             pass
 
@@ -640,6 +681,7 @@ class Booster:
                  model_file: Optional[str] = None, model_str: Optional[str] = None, comm=None):
         lib, hip = _lib.load()
         self._handle = ctypes.c_void_p()
+        _track(self)
         self.params = dict(params or {})
         self.best_iteration = 0
         self.best_score: Dict[str, Dict[str, float]] = {}
@@ -686,12 +728,16 @@ class Booster:
                 self.pandas_categorical = None
         check(lib.lga_booster_from_string(c_str(text), ctypes.byref(self._handle)))
 
+    def _free(self):
+        if getattr(self, "_handle", None):
+            lib, _ = _lib.load()
+            h, self._handle = self._handle, None
+            lib.lga_booster_free(h)
+
     def __del__(self):
         try:
-            if self._handle:
-                lib, _ = _lib.load()
-                lib.lga_booster_free(self._handle)
-                self._handle = None
+            if not _shutting_down:
+                self._free()
         except Exception:
             pass
 
@@ -928,6 +974,7 @@ class Booster:
         if self._handle:
             lib.lga_booster_free(self._handle)
         self._handle = ctypes.c_void_p()
+        _track(self)
         self._load(model_str)
         self.train_set = None
         self.valid_sets, self.name_valid_sets = [], []

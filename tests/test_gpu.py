@@ -609,6 +609,28 @@ def test_rccl_single_rank_communicator(tmp_path):
         dist.destroy_process_group()
 
 
+def test_module_level_objects_do_not_crash_the_interpreter_at_exit(tmp_path):
+    """A script's global boosters / datasets are still alive when the interpreter shuts down; their device
+    memory is released by an exit hook while the HIP runtime is whole (a destructor running during module
+    teardown used to end the process with a segmentation fault)."""
+    import os, subprocess, sys, textwrap
+    script = tmp_path / "globals.py"
+    script.write_text(textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np, lightgbm_amd as lgb
+        rng = np.random.RandomState(0)
+        X = rng.randn(3000, 5); y = X[:, 0] + 0.1 * rng.randn(3000)
+        p = {"device_type": "gpu", "verbose": -1}
+        d = lgb.Dataset(X, label=y, params=p)
+        b = lgb.train(p, d, 3, valid_sets=[d], verbose_eval=False, keep_training_booster=True)
+        cvb = lgb.cv(p, lgb.Dataset(X, label=y, params=p), 3, nfold=2, return_cvbooster=True)
+        print("END_OF_SCRIPT", flush=True)
+    """) % os.path.join(os.path.dirname(__file__), ".."))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    assert "END_OF_SCRIPT" in r.stdout and r.returncode == 0, (r.returncode, r.stderr[-1500:])
+
+
 def test_fallback_communicator_works_under_an_nccl_group(tmp_path):
     """default_comm() falls back to the process group's own collectives when the native RCCL communicator
     cannot be created; under an nccl group those take device tensors, so host buffers make a detour."""
