@@ -1,6 +1,6 @@
 """Learning-to-rank timing on an MSLR-WEB30K-shaped synthetic set (queries of ~120 documents, 136 features,
 grades 0-4): seconds per boosting iteration with the per-query gradients taken on the device and - for
-comparison - on the host (LGA_RANK_ON_HOST=1).
+comparison - on the host (LGA_RANK_ON_HOST=1); likewise one evaluation of ndcg@10 over the training queries.
 
     python bench/rank_bench.py [rows] [trees]
 """
@@ -41,8 +41,13 @@ def main():
         dt = (time.time() - t0) / trees
         b._train_data_name = "training"
         ndcg = b.eval_train()[0][2]
+        t0 = time.time()
+        for _ in range(10):
+            b.eval_train()
+        te = (time.time() - t0) / 10
         out[mode] = dt
-        print(f"{mode:6s} gradients: {n} rows, {len(sizes)} queries: {dt * 1e3:.2f} ms per iteration, train ndcg@10 {ndcg:.4f}", flush=True)
+        print(f"{mode:6s} gradients: {n} rows, {len(sizes)} queries: {dt * 1e3:.2f} ms per iteration, train ndcg@10 {ndcg:.4f}; "
+              f"one ndcg@10 evaluation ({mode}) {te * 1e3:.2f} ms", flush=True)
     print(f"speed-up of the device gradients: {out['host'] / out['device']:.1f}x")
 
 

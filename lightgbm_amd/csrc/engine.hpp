@@ -54,6 +54,14 @@ class Engine {
     (void)spec; (void)bounds; (void)inv_max_dcg; (void)iter;
     return false;
   }
+  // ndcg@k and map@k of every query of a dataset (which: -1 training, >= 0 validation) at the engine's current
+  // scores: values[q * 2 * at.size() + k] = ndcg@at[k], values[... + at.size() + k] = map@at[k].  false: the
+  // engine leaves the metrics to the caller (ranking.cpp on the host).
+  virtual bool ranking_metric_values(int which, const RankingSpec& spec, const std::vector<int64_t>& bounds,
+                                     const std::vector<int>& at, std::vector<double>* values) {
+    (void)which; (void)spec; (void)bounds; (void)at; (void)values;
+    return false;
+  }
   // Gradients supplied by the caller, ordered like the training dataset's rows.
   virtual void set_gradients(const float* g, const float* h, int64_t n) = 0;
   // Draw a new bag (every row when fraction >= 1).  neg_fraction >= 0: balanced bagging - rows with a

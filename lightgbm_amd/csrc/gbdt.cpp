@@ -269,19 +269,41 @@ void Booster::eval_ranking(int which, std::vector<EvalResult>* out) {
   const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
   if (ds->query_boundaries().empty())
     throw std::runtime_error("the ndcg / map metrics need query information (Dataset group=) on every evaluated dataset");
-  const int64_t n = engine_->num_rows(which);
-  std::vector<double> score((size_t)n * (size_t)num_class_);
-  engine_->get_scores(which, score.data());
-  const std::vector<float> label = ds->local_label(), weight = ds->local_weight();
-  check_rank_labels(label.data(), (int64_t)label.size(), rank_.label_gain);
+  const std::vector<float> weight = ds->local_weight();
+  if (!rank_labels_checked_.count(which)) {     // once per dataset: grades must be integers inside the gain table
+    const std::vector<float> all_labels = ds->local_label();
+    check_rank_labels(all_labels.data(), (int64_t)all_labels.size(), rank_.label_gain);
+    rank_labels_checked_.insert(which);
+  }
+  // every cut-off either metric asks for; the engine may hand back both metrics per query in one go
+  std::vector<int> all_at;
+  for (const auto& m : rank_metrics_)
+    if (std::find(all_at.begin(), all_at.end(), m.at) == all_at.end()) all_at.push_back(m.at);
+  std::vector<double> per_query;
+  const bool from_engine = engine_->ranking_metric_values(which, rank_, ds->query_boundaries(), all_at, &per_query);
+  std::vector<double> score;
+  std::vector<float> label;
+  if (!from_engine) {
+    const int64_t n = engine_->num_rows(which);
+    score.resize((size_t)n * (size_t)num_class_);
+    engine_->get_scores(which, score.data());
+    label = ds->local_label();
+  }
   for (int pass = 0; pass < 2; ++pass) {
     const bool ndcg = pass == 0;
     std::vector<int> at;
     for (const auto& m : rank_metrics_) if (m.ndcg == ndcg) at.push_back(m.at);
     if (at.empty()) continue;
     std::vector<double> sums;
-    if (ndcg) ndcg_sums(score.data(), label.data(), weight.empty() ? nullptr : weight.data(), ds->query_boundaries(),
-                        rank_.label_gain, at, &sums);
+    if (from_engine) {
+      // pick this metric's cut-offs out of the engine's [ndcg x all_at | map x all_at] rows
+      std::vector<double> all_sums;
+      weighted_query_sums(per_query.data(), 2 * all_at.size(), ndcg ? 0 : all_at.size(), all_at.size(),
+                          weight.empty() ? nullptr : weight.data(), ds->query_boundaries(), &all_sums);
+      for (int k : at) sums.push_back(all_sums[(size_t)(std::find(all_at.begin(), all_at.end(), k) - all_at.begin())]);
+      sums.push_back(all_sums.back());
+    } else if (ndcg) ndcg_sums(score.data(), label.data(), weight.empty() ? nullptr : weight.data(), ds->query_boundaries(),
+                               rank_.label_gain, at, &sums);
     else map_sums(score.data(), label.data(), weight.empty() ? nullptr : weight.data(), ds->query_boundaries(), at, &sums);
     engine_->sum_over_ranks(sums.data(), sums.size());
     for (size_t k = 0; k < at.size(); ++k)

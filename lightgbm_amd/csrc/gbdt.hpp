@@ -10,6 +10,7 @@
 #include "tree.hpp"
 #include <functional>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -136,6 +137,7 @@ class Booster {
   bool eval_average_precision_ = false;   // evaluated here from the engine's scores, like the ranking metrics
   RankingSpec rank_;
   std::vector<RankMetric> rank_metrics_;
+  std::set<int> rank_labels_checked_;
   std::vector<double> inv_max_dcg_;
   std::vector<float> rank_label_, rank_weight_;   // training rows, local order
   std::vector<Tree> trees_;

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <memory>
 #include <numeric>
 #include <sstream>
 
@@ -961,6 +963,55 @@ class HipEngine : public Engine {
     have_max_ = false;
     return true;
   }
+  bool ranking_metric_values(int which, const RankingSpec& spec, const std::vector<int64_t>& bounds,
+                             const std::vector<int>& at, std::vector<double>* values) override {
+    const int nq = (int)bounds.size() - 1;
+    if (nq <= 0 || at.empty() || (int)at.size() > k::kMaxRankCutoffs || std::getenv("LGA_RANK_ON_HOST")) return false;
+    if (spec.label_gain.size() > 64) return false;
+    int64_t longest = 1;
+    for (int q = 0; q < nq; ++q) longest = std::max(longest, bounds[(size_t)q + 1] - bounds[(size_t)q]);
+    if (longest > k::kMaxDeviceQuery) return false;
+    // per-dataset query offsets go up once; the gain and discount tables are shared and only ever grow
+    auto& db = metric_bounds_[which];
+    if (!db) {
+      db.reset(new DeviceBuffer<int64_t>());
+      db->upload(bounds.data(), bounds.size(), stream_);
+      LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    }
+    if ((int64_t)metric_disc_len_ < longest) {
+      std::vector<double> disc((size_t)longest);
+      for (int64_t r = 0; r < longest; ++r) disc[(size_t)r] = rank_discount((int)r);
+      metric_disc_.upload(disc.data(), disc.size(), stream_);
+      std::vector<double> gain(64, 0.0);
+      for (size_t g = 0; g < spec.label_gain.size(); ++g) gain[g] = spec.label_gain[g];
+      metric_gain_.upload(gain.data(), gain.size(), stream_);
+      LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+      metric_disc_len_ = (size_t)longest;
+    }
+    k::RankArgs a{};
+    if (which < 0) { a.score = scores_.get(); a.label = mir_->label.get(); a.to_root = base_or_null(); }
+    else {
+      Valid& v = *valid_[(size_t)which];
+      a.score = all_scores(v);
+      a.label = v.mir->label.get();
+      a.to_root = v.ds->used_indices() ? v.rows.get() : nullptr;
+    }
+    a.bounds = db->get();
+    a.label_gain = metric_gain_.get();
+    a.discount = metric_disc_.get();
+    a.nq = nq;
+    a.max_query = (int)longest;
+    k::RankCutoffs cut{};
+    cut.n = (int)at.size();
+    for (int k = 0; k < cut.n; ++k) cut.k[k] = at[(size_t)k];
+    const size_t n_out = (size_t)nq * 2 * at.size();
+    tmp_f64_.resize(n_out);
+    k::rank_metrics(a, cut, tmp_f64_.get(), stream_);
+    values->resize(n_out);
+    LGA_HIP_CHECK(hipMemcpyAsync(values->data(), tmp_f64_.get(), sizeof(double) * n_out, hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    return true;
+  }
   void set_gradients(const float* g, const float* h, int64_t n) override {
     if (n != n_base_) throw std::runtime_error("custom gradients: wrong length");
     tmp_f32_.resize((size_t)n * 2);
@@ -1330,6 +1381,9 @@ class HipEngine : public Engine {
   int rank_max_query_ = 0;
   DeviceBuffer<int64_t> rank_bounds_;
   DeviceBuffer<double> rank_imd_, rank_gain_, rank_disc_;
+  std::map<int, std::unique_ptr<DeviceBuffer<int64_t>>> metric_bounds_;   // per dataset (which)
+  DeviceBuffer<double> metric_gain_, metric_disc_;
+  size_t metric_disc_len_ = 0;
   DeviceBuffer<int64_t> packed_;
   DeviceBuffer<uint32_t> maxbits_, select_scratch_;
   DeviceBuffer<k::LeafSpan> span_dev_;

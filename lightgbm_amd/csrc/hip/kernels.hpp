@@ -184,6 +184,14 @@ struct RankArgs {
   int norm, trunc;
   uint64_t seed, iter;        // rank_xendcg noise stream
 };
+constexpr int kMaxRankCutoffs = 8;
+struct RankCutoffs {
+  int n;
+  int k[kMaxRankCutoffs];
+};
+// ndcg@k / map@k per query (score, label, to_root, bounds, label_gain, discount of `a` are read);
+// out: nq x [ndcg x at.n | map x at.n].  Labels are grades below 64 with a label_gain entry each.
+void rank_metrics(const RankArgs& a, const RankCutoffs& at, double* out, hipStream_t s);
 void lambdarank_gradients(const RankArgs& a, hipStream_t s);
 void xendcg_gradients(const RankArgs& a, hipStream_t s);
 

@@ -233,6 +233,75 @@ __global__ __launch_bounds__(kRankThreads) void xendcg_kernel(RankArgs a, int P)
   }
 }
 
+
+// ndcg@k and map@k of every query for up to kMaxRankCutoffs cut-offs: the same LDS sort as the lambdarank
+// kernel, then one lane walks the top of the ranking - the additions run in the host's order
+// (ranking.cpp: ndcg_sums / map_sums), so the values are the host's bit for bit.
+// out: per query [ndcg x n_at | map x n_at].
+__global__ __launch_bounds__(kRankThreads) void rank_metrics_kernel(RankArgs a, int P, RankCutoffs at, double* __restrict__ out) {
+  extern __shared__ unsigned char smem[];
+  uint64_t* key = reinterpret_cast<uint64_t*>(smem);
+  int32_t* idx = reinterpret_cast<int32_t*>(key + P);
+  int32_t* grade = idx + P;
+  __shared__ int grade_count[64];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x;
+  const int64_t s0 = a.bounds[q];
+  const int cnt = (int)(a.bounds[q + 1] - s0);
+  double* o = out + (int64_t)q * 2 * at.n;
+  if (tid < 64) grade_count[tid] = 0;
+  if (cnt <= 0 || cnt > P) {
+    if (tid == 0)
+      for (int k = 0; k < 2 * at.n; ++k) o[k] = 1.0;
+    return;
+  }
+  int n2 = 1;
+  while (n2 < cnt) n2 <<= 1;
+  for (int i = tid; i < n2; i += kRankThreads) {
+    if (i < cnt) { key[i] = ~ordered_bits(a.score[root_row(a, s0 + i)] + 0.0); idx[i] = i; }
+    else { key[i] = ~0ull; idx[i] = 0x7fffffff; }
+  }
+  __syncthreads();
+  for (int k2 = 2; k2 <= n2; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += kRankThreads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const uint64_t ka = key[i], kb = key[p];
+          const int ia = idx[i], ib = idx[p];
+          const bool a_after_b = ka > kb || (ka == kb && ia > ib);
+          if (a_after_b == ((i & k2) == 0)) { key[i] = kb; key[p] = ka; idx[i] = ib; idx[p] = ia; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < cnt; r += kRankThreads) {
+    const int g = (int)a.label[root_row(a, s0 + idx[r])];
+    grade[r] = g;
+    atomicAdd(&grade_count[g < 63 ? g : 63], 1);
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  int relevant = 0;
+  for (int g = 1; g < 64; ++g) relevant += grade_count[g];
+  for (int k = 0; k < at.n; ++k) {
+    const int top = cnt < at.k[k] ? cnt : at.k[k];
+    // the ranking's DCG and, from the grade counts walked downwards, the best possible one
+    double dcg = 0.0, best = 0.0, ap = 0.0;
+    int hits = 0, g = 63, left = grade_count[63];
+    for (int i = 0; i < top; ++i) {
+      dcg += a.label_gain[grade[i]] * a.discount[i];
+      while (left == 0 && g > 0) { --g; left = grade_count[g]; }
+      best += a.label_gain[g] * a.discount[i];
+      --left;
+      if (grade[i] > 0) { ++hits; ap += (double)hits / (double)(i + 1); }
+    }
+    o[k] = best > 0.0 ? dcg / best : 1.0;
+    o[at.n + k] = relevant > 0 ? ap / (double)(relevant < top ? relevant : top) : 1.0;
+  }
+}
+
 // The LDS budget of every instantiation is raised once, to what the largest supported query needs
 // (boosters on several host threads launch these kernels concurrently).
 template <typename Kernel>
@@ -257,6 +326,21 @@ void lambdarank_gradients(const RankArgs& a, hipStream_t s) {
   if (a.max_query <= kRankThreads) launch_rank(lambdarank_kernel<1>, once[0], a, per_doc, s);
   else if (a.max_query <= 4 * kRankThreads) launch_rank(lambdarank_kernel<4>, once[1], a, per_doc, s);
   else launch_rank(lambdarank_kernel<kMaxDeviceQuery / kRankThreads>, once[2], a, per_doc, s);
+}
+
+void rank_metrics(const RankArgs& a, const RankCutoffs& at, double* out, hipStream_t s) {
+  if (a.nq <= 0) return;
+  if (a.max_query > kMaxDeviceQuery) throw std::runtime_error("rank_metrics: query larger than the device kernel holds");
+  constexpr size_t per_doc = sizeof(uint64_t) + 2 * sizeof(int32_t);
+  static std::once_flag once;
+  std::call_once(once, [&] {
+    LGA_HIP_CHECK(hipFuncSetAttribute((const void*)rank_metrics_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)(per_doc * (size_t)kMaxDeviceQuery)));
+  });
+  int P = 1;
+  while (P < a.max_query) P <<= 1;
+  hipLaunchKernelGGL(rank_metrics_kernel, dim3((unsigned)a.nq), dim3(kRankThreads), per_doc * (size_t)P, s, a, P, at, out);
+  LGA_LAUNCH_CHECK();
 }
 
 void xendcg_gradients(const RankArgs& a, hipStream_t s) {

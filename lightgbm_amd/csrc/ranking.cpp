@@ -203,6 +203,17 @@ void ndcg_sums(const double* score, const float* label, const float* weight, con
     for (size_t k = 0; k <= K; ++k) (*sums)[k] += per_query[(size_t)q * (K + 1) + k];
 }
 
+void weighted_query_sums(const double* values, size_t stride, size_t offset, size_t n_at, const float* weight,
+                         const std::vector<int64_t>& bounds, std::vector<double>* sums) {
+  const int64_t nq = (int64_t)bounds.size() - 1;
+  sums->assign(n_at + 1, 0.0);
+  for (int64_t q = 0; q < nq; ++q) {
+    const double w = query_weight(weight, bounds[(size_t)q], bounds[(size_t)q + 1]);
+    for (size_t k = 0; k < n_at; ++k) (*sums)[k] += w * values[(size_t)q * stride + offset + k];
+    (*sums)[n_at] += w;
+  }
+}
+
 void map_sums(const double* score, const float* label, const float* weight, const std::vector<int64_t>& bounds,
               const std::vector<int>& at, std::vector<double>* sums) {
   const int64_t nq = (int64_t)bounds.size() - 1;

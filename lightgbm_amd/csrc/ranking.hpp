@@ -65,6 +65,10 @@ void ranking_gradients(const RankingSpec& spec, const double* score, const float
 // as 1.  The query weight is the mean row weight of the query (1 without weights).
 void ndcg_sums(const double* score, const float* label, const float* weight, const std::vector<int64_t>& bounds,
                const std::vector<double>& label_gain, const std::vector<int>& at, std::vector<double>* sums);
+// The same sums from per-query values computed elsewhere (Engine::ranking_metric_values):
+// values[q * stride + offset + k] is query q's metric at cut-off k.
+void weighted_query_sums(const double* values, size_t stride, size_t offset, size_t n_at, const float* weight,
+                         const std::vector<int64_t>& bounds, std::vector<double>* sums);
 void map_sums(const double* score, const float* label, const float* weight, const std::vector<int64_t>& bounds,
               const std::vector<int>& at, std::vector<double>* sums);
 

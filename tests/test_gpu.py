@@ -398,12 +398,17 @@ def test_device_ranking_gradients_match_the_host(objective, lo, hi, nq):
     bounds = np.concatenate([[0], np.cumsum(sizes)])
     rows = np.concatenate([np.arange(bounds[q], bounds[q + 1]) for q in np.flatnonzero(keep_q)])
     p = {"objective": objective, "min_data_in_leaf": 1, "lambdarank_truncation_level": 20, "sigmoid": 1.2}
-    grads = []
+    p.update({"metric": ["ndcg", "map"], "eval_at": [1, 3, 10, 50]})
+    grads, metrics = [], []
     for dev in (CPU, GPU):
         d = lgb.Dataset(X, label=y, weight=w, group=sizes, init_score=init, params=dev).construct().subset(rows)
         b = lgb.Booster({**dev, **p}, d)
+        b._train_data_name = "training"
+        metrics.append(b.eval_train())         # at the initial scores, which both engines hold exactly
         b.update()
         grads.append(b.get_gradients())
+    # the metric kernel (same sort, additions in the host's order) reproduces the host's values bit for bit
+    assert len(metrics[0]) == 8 and metrics[0] == metrics[1]
     for host, device in zip(*grads):
         assert np.abs(host).max() > 0
         np.testing.assert_allclose(device, host, rtol=2e-5, atol=1e-9)
