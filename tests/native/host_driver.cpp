@@ -254,6 +254,71 @@ int main() {
     OK(lga_booster_free(s2));
   }
 
+  // the later additions under the sanitizers: ranking (gradients per query, ndcg / map), category-set
+  // splits with constraints and path smoothing, multiclass with GOSS, leaf refit
+  {
+    const int64_t m = 4000;
+    const int fc = 6;
+    std::vector<double> Xc((size_t)m * fc);
+    std::vector<float> rel((size_t)m), cls((size_t)m), reg((size_t)m);
+    std::vector<double> groups;
+    for (int64_t i = 0; i < m; ++i) {
+      for (int j = 0; j < fc; ++j) Xc[(size_t)(i * fc + j)] = gauss();
+      const int cat = (int)(uni() * 40);
+      Xc[(size_t)(i * fc + 4)] = (double)cat;
+      if (i % 11 == 0) Xc[(size_t)(i * fc + 1)] = 0.0;
+      const double s = Xc[(size_t)(i * fc)] + std::sin((double)cat) + 0.3 * gauss();
+      reg[(size_t)i] = (float)s;
+      rel[(size_t)i] = (float)std::min(4, std::max(0, (int)std::lround(s + 1.5)));
+      cls[(size_t)i] = (float)std::min(2, std::max(0, (int)std::lround(s + 1.0)));
+    }
+    for (int64_t left = m; left > 0;) { int64_t q = std::min<int64_t>(left, 7 + (int64_t)(uni() * 60)); groups.push_back((double)q); left -= q; }
+    const char* dp = "max_bin=63 verbose=-1 device_type=cpu categorical_feature=4 zero_as_missing=true";
+    LgaDataset dc = nullptr;
+    OK(lga_dataset_from_mat(Xc.data(), 1, m, fc, 1, dp, nullptr, 1, &dc));
+    OK(lga_dataset_set_field(dc, "label", rel.data(), m, 0));
+    OK(lga_dataset_set_field(dc, "group", groups.data(), (int64_t)groups.size(), 1));
+    for (const char* obj : {"lambdarank", "rank_xendcg"}) {
+      LgaBooster rb = nullptr;
+      std::string ps = std::string("objective=") + obj + " num_leaves=15 min_data_in_leaf=5 metric=ndcg,map eval_at=1,5 "
+                       "bagging_fraction=0.7 bagging_freq=1 verbose=-1 device_type=cpu categorical_feature=4 zero_as_missing=true";
+      OK(lga_booster_create(dc, ps.c_str(), nullptr, &rb));
+      double ev[8];
+      int ne = 0;
+      for (int it = 0; it < 4; ++it) { int fin = 0; OK(lga_booster_update(rb, &fin)); }
+      OK(lga_booster_eval(rb, -1, ev, 8, &ne));
+      REQUIRE(ne == 4 && ev[1] > 0.5 && ev[1] <= 1.0);
+      OK(lga_booster_free(rb));
+    }
+    OK(lga_dataset_set_field(dc, "group", nullptr, 0, 1));
+    OK(lga_dataset_set_field(dc, "label", reg.data(), m, 0));
+    LgaBooster cb = nullptr;
+    OK(lga_booster_create(dc, "objective=regression num_leaves=31 min_data_in_leaf=5 path_smooth=5 min_data_per_group=20 "
+                              "monotone_constraints=1,0,0,0,0,0 interaction_constraints=[0,1,4],[2,3,5] "
+                              "verbose=-1 device_type=cpu categorical_feature=4 zero_as_missing=true", nullptr, &cb));
+    for (int it = 0; it < 6; ++it) { int fin = 0; OK(lga_booster_update(cb, &fin)); }
+    std::string cm = model_text(cb);
+    REQUIRE(cm.find("cat_threshold=") != std::string::npos);
+    std::vector<double> sc2((size_t)m), pr2((size_t)m);
+    OK(lga_booster_inner_predict(cb, -1, 1, sc2.data()));
+    OK(lga_booster_predict(cb, Xc.data(), 1, m, fc, 1, 0, -1, 1, pr2.data()));
+    for (int64_t i = 0; i < m; ++i) REQUIRE(std::fabs(sc2[(size_t)i] - pr2[(size_t)i]) < 1e-9);
+    OK(lga_booster_refit(cb, Xc.data(), 1, m, fc, 1, reg.data(), nullptr, 0.5, ""));
+    OK(lga_booster_free(cb));
+    OK(lga_dataset_set_field(dc, "label", cls.data(), m, 0));
+    LgaBooster mb = nullptr;
+    OK(lga_booster_create(dc, "objective=multiclass num_class=3 num_leaves=15 data_sample_strategy=goss learning_rate=0.5 "
+                              "metric=multi_logloss,auc_mu verbose=-1 device_type=cpu categorical_feature=4 zero_as_missing=true",
+                          nullptr, &mb));
+    for (int it = 0; it < 5; ++it) { int fin = 0; OK(lga_booster_update(mb, &fin)); }
+    double ev[4];
+    int ne = 0;
+    OK(lga_booster_eval(mb, -1, ev, 4, &ne));
+    REQUIRE(ne == 2 && ev[1] > 0.6);
+    OK(lga_booster_free(mb));
+    OK(lga_dataset_free(dc));
+  }
+
   // error path: message, no crash
   LgaBooster bad = nullptr;
   REQUIRE(lga_booster_create(full, "boosting=rf verbose=-1 device_type=cpu", nullptr, &bad) != 0);
