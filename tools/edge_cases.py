@@ -58,13 +58,40 @@ def cases():
     yield "quantile 0.999", X, y, {"objective": "quantile", "alpha": 0.999}, 3, {}
     yield "monotone on every feature", X, y, {"monotone_constraints": [1, -1, 1, -1, 1]}, 3, {}
 
+    # ranking and categorical corner cases (dk carries group / categorical_feature)
+    Xr = rng.randn(400, 4)
+    rel = np.clip(np.round(Xr[:, 0] + 1.5), 0, 4)
+    yield "ranking: queries of one document", Xr, rel, {"objective": "lambdarank", **tiny}, 3, {"group": np.ones(400, dtype=int)}
+    yield "ranking: a single query", Xr, rel, {"objective": "lambdarank", **tiny}, 3, {"group": [400]}
+    yield "ranking: no relevant document anywhere", Xr, np.zeros(400), {"objective": "lambdarank", **tiny}, 3, {"group": [100] * 4}
+    yield "ranking: every label equal", Xr, np.full(400, 2.0), {"objective": "rank_xendcg", **tiny}, 3, {"group": [50] * 8}
+    big = rng.randn(6000, 3)
+    yield ("ranking: a query beyond the device kernels' LDS budget (regression objective: host metrics only)", big,
+           np.clip(np.round(big[:, 0] + 1.5), 0, 4), {"objective": "regression", "metric": "ndcg", "eval_at": [5]}, 2,
+           {"group": [5000, 1000]})
+    Xc = rng.randn(600, 3)
+    Xc[:, 1] = 7.0
+    yield "categorical: one category", Xc, Xc[:, 0], {**tiny}, 3, {"categorical_feature": [1]}
+    Xc2 = rng.randn(600, 3)
+    Xc2[:, 1] = np.arange(600)
+    yield "categorical: every row its own category", Xc2, Xc2[:, 0], {**tiny}, 3, {"categorical_feature": [1]}
+    Xc3 = rng.randn(600, 3)
+    Xc3[:, 1] = rng.randint(-3, 4, size=600)
+    yield "categorical: negative codes", Xc3, Xc3[:, 0] + (Xc3[:, 1] == 2), {**tiny}, 3, {"categorical_feature": [1]}
+    Xc4 = rng.randn(3000, 2)
+    Xc4[:, 1] = rng.randint(0, 200, size=3000)
+    yield ("categorical: 200 categories, tiny groups", Xc4, Xc4[:, 0] + np.sin(Xc4[:, 1]),
+           {"min_data_in_leaf": 1, "min_data_per_group": 1, "cat_smooth": 0, "cat_l2": 0, "max_cat_threshold": 128}, 3,
+           {"categorical_feature": [1]})
+
 
 def train_case(case, device: str):
     import lightgbm_amd as lgb
     name, X, y, p, rounds, dk = case
     base = {"device_type": device, "verbose": -1}
     dparams = {**base, **{k: v for k, v in p.items() if k in ("max_bin", "min_data_in_bin")}}
-    b = lgb.train({**base, **p}, lgb.Dataset(X, label=y, params=dparams, **dk), rounds)
+    d = lgb.Dataset(X, label=y, params=dparams, **dk)
+    b = lgb.train({**base, **p}, d, rounds, valid_sets=[d] if "group" in dk else None, verbose_eval=False)
     pred = b.predict(np.asarray(X, dtype=np.float64))
     assert np.all(np.isfinite(pred)), f"{name}: non-finite prediction"
     text = b.model_to_string()
