@@ -476,6 +476,8 @@ class Dataset:
         return self
 
     def get_group(self) -> Optional[np.ndarray]:
+        if self._handle is None and isinstance(self.data, (str, os.PathLike)):
+            self.construct()       # fields of a file-backed dataset live in the file
         if self._handle is None:
             return None if self.group is None else _to_1d(self.group, np.int64)
         g = self._get_field("group")
@@ -494,16 +496,22 @@ class Dataset:
         return out
 
     def get_label(self) -> Optional[np.ndarray]:
+        if self._handle is None and isinstance(self.data, (str, os.PathLike)):
+            self.construct()       # fields of a file-backed dataset live in the file
         if self._handle is None:
             return None if self.label is None else _to_1d(self.label, np.float64)
         return self._get_field("label")
 
     def get_weight(self) -> Optional[np.ndarray]:
+        if self._handle is None and isinstance(self.data, (str, os.PathLike)):
+            self.construct()       # fields of a file-backed dataset live in the file
         if self._handle is None:
             return None if self.weight is None else _to_1d(self.weight, np.float64)
         return self._get_field("weight")
 
     def get_init_score(self) -> Optional[np.ndarray]:
+        if self._handle is None and isinstance(self.data, (str, os.PathLike)):
+            self.construct()       # fields of a file-backed dataset live in the file
         if self._handle is None:
             return None if self.init_score is None else _to_1d(self.init_score, np.float64)
         return self._get_field("init_score")

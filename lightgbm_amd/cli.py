@@ -84,8 +84,7 @@ def _dataset(path: str, label_column: int, header: bool, params, reference=None)
     """A Dataset from a data file (+ its .weight / .query / .init side files), or from a binned cache."""
     from . import Dataset
     if path.endswith(".bin"):
-        # the cache holds label / weight / init_score; query sizes still come from the text file's side file
-        return Dataset(path, params=params, group=_side_file(path[:-4], ".query")), None
+        return Dataset(path, params=params), None      # the cache holds label / weight / init_score / query sizes
     X, y = _load_table(path, label_column, header, reference.num_feature() if reference is not None else 0)
     if reference is not None and X.shape[1] < reference.num_feature():      # LibSVM rows without the last columns
         X = np.hstack([X, np.zeros((X.shape[0], reference.num_feature() - X.shape[1]))])

@@ -289,6 +289,7 @@ void Dataset::save_binary(const std::string& path) const {
     w.vec(label_);
     w.vec(weight_);
     w.vec(init_score_);
+    w.vec(query_bounds_);   // trailing section (files written before it existed simply end here)
     if (std::fflush(fc.f) != 0) throw std::runtime_error("save_binary: flush failed");
   }
   if (std::rename(tmp.c_str(), path.c_str()) != 0) throw std::runtime_error("save_binary: cannot move the file into place");
@@ -331,6 +332,15 @@ std::shared_ptr<Dataset> Dataset::load_binary(const std::string& path) {
   r.vec(ds->label_, n);
   r.vec(ds->weight_, n);
   r.vec(ds->init_score_, n);
+  {
+    const int c = std::fgetc(r.f);
+    if (c != EOF) {
+      std::ungetc(c, r.f);
+      r.vec(ds->query_bounds_, n + 1);
+      if (!ds->query_bounds_.empty() && (ds->query_bounds_.front() != 0 || ds->query_bounds_.back() != (int64_t)n))
+        throw std::runtime_error("load_binary: query boundaries do not cover the rows");
+    }
+  }
   // the row-tile-major copy is derived
   const int T = ds->num_tiles();
   ds->bins_rt_.assign((size_t)T * n * kTileFeatures, 0);

@@ -38,7 +38,7 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   static std::shared_ptr<Dataset> from_mappers(std::vector<BinMapper>&& mappers, int64_t nrow);
   std::shared_ptr<Dataset> subset(const int32_t* indices, int64_t n) const;
   // Binary cache of a ROOT dataset: bin boundaries, feature names, the feature-major bin matrix and the
-  // label / weight / init-score vectors.  Loading skips sampling, bin finding and binning.
+  // label / weight / init-score vectors and the query boundaries.  Loading skips sampling, bin finding and binning.
   void save_binary(const std::string& path) const;
   static std::shared_ptr<Dataset> load_binary(const std::string& path);
 

@@ -187,3 +187,16 @@ def test_data_parallel_ranking_equals_serial():
     for s, m in run_ranks(2, rank):
         assert trees_of(s) == trees_of(serial)
         assert m == pytest.approx(ev0["training"]["ndcg@3"][-1], abs=1e-12)
+
+
+def test_binary_cache_keeps_the_queries(tmp_path):
+    X, y, sizes = make_rank_data(nq=40, seed=8)
+    p = {**CPU, "objective": "lambdarank", "min_data_in_leaf": 5}
+    d = lgb.Dataset(X, label=y, group=sizes, params=p)
+    path = str(tmp_path / "rank.bin")
+    d.save_binary(path)
+    again = lgb.Dataset(path, params=p)
+    np.testing.assert_array_equal(again.get_group(), sizes)
+    a = lgb.train(p, d, 4).model_to_string()
+    b = lgb.train(p, again, 4).model_to_string()
+    assert a.split("parameters:")[0] == b.split("parameters:")[0]
