@@ -187,6 +187,10 @@ class HipBackend : public TreeBackend {
       RoundCtx& x = ctx_[c];
       if (c == 0) x.stream = stream_;
       else { LGA_HIP_CHECK(hipStreamCreateWithFlags(&x.stream, hipStreamNonBlocking)); x.owns_stream = true; }
+      if (n_ctx_ > 1 && mode_ != ParallelMode::Serial) {
+        LGA_HIP_CHECK(hipEventCreateWithFlags(&x.ev_ready, hipEventDisableTiming));
+        LGA_HIP_CHECK(hipEventCreateWithFlags(&x.ev_reduced, hipEventDisableTiming));
+      }
       x.mask.resize((size_t)max_pchunks_ * (k::kPartChunk / 64));
       x.chunk_left.resize((size_t)max_pchunks_);
       x.task_left.resize((size_t)max_batch_ + 1);
@@ -199,6 +203,11 @@ class HipBackend : public TreeBackend {
       x.done_counter.resize(4);
       x.done_counter.zero(stream_);
     }
+    // Distributed learners with two rounds in flight: every collective goes through ONE stream of its own,
+    // in submission order (the same on every rank), tied to the rounds' streams by events - a communicator
+    // never sees calls from two streams.
+    if (n_ctx_ > 1 && mode_ != ParallelMode::Serial)
+      LGA_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     meta_dev_.resize((size_t)std::max(F_, 1));
     qs_dev_.resize(1);
@@ -211,6 +220,11 @@ class HipBackend : public TreeBackend {
   ~HipBackend() override {
     for (int c = 0; c < n_ctx_; ++c)
       if (ctx_[c].owns_stream) { (void)hipStreamSynchronize(ctx_[c].stream); (void)hipStreamDestroy(ctx_[c].stream); }
+    for (int c = 0; c < n_ctx_; ++c) {
+      if (ctx_[c].ev_ready) (void)hipEventDestroy(ctx_[c].ev_ready);
+      if (ctx_[c].ev_reduced) (void)hipEventDestroy(ctx_[c].ev_reduced);
+    }
+    if (comm_stream_) { (void)hipStreamSynchronize(comm_stream_); (void)hipStreamDestroy(comm_stream_); }
   }
 
   void set_bag(const int32_t* rows_dev, int64_t n) { bag_ = rows_dev; bag_n_ = n; }
@@ -376,6 +390,7 @@ class HipBackend : public TreeBackend {
   struct RoundCtx {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    hipEvent_t ev_ready = nullptr, ev_reduced = nullptr;   // hand-over to / from the collectives' stream
     DeviceBuffer<uint64_t> mask;
     DeviceBuffer<int32_t> chunk_left, task_left;
     DeviceBuffer<char> stage_dev;
@@ -494,9 +509,19 @@ class HipBackend : public TreeBackend {
                    root ? &root_quant_ : nullptr, st_);
     }
     prof.mark(PhaseProfile::kComm, st_);
-    if (mode_ == ParallelMode::Data)
-      comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true,
-                               st_);
+    if (mode_ == ParallelMode::Data) {
+      hipStream_t cs = st_;
+      if (comm_stream_) {
+        LGA_HIP_CHECK(hipEventRecord(x.ev_ready, st_));
+        LGA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, x.ev_ready, 0));
+        cs = comm_stream_;
+      }
+      comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true, cs);
+      if (comm_stream_) {
+        LGA_HIP_CHECK(hipEventRecord(x.ev_reduced, comm_stream_));
+        LGA_HIP_CHECK(hipStreamWaitEvent(st_, x.ev_reduced, 0));
+      }
+    }
     prof.mark(PhaseProfile::kScan, st_);
     if (ranged_ && !root) {
       // the children of a round's tasks have consecutive node ids
@@ -687,6 +712,7 @@ class HipBackend : public TreeBackend {
   Comm* comm_;
   ParallelMode mode_;
   hipStream_t stream_ = nullptr;
+  hipStream_t comm_stream_ = nullptr;   // distributed, two rounds in flight: the one stream collectives run on
   int F_ = 0, T_ = 0;
   int64_t N_ = 0, plane_ = 0, slot_words_ = 0;
   int capacity_splits_ = 0, max_batch_ = 0, max_pchunks_ = 0, max_hchunks_ = 0;
