@@ -224,7 +224,7 @@ void Booster::compute_gradients() {
   engine_->set_gradients(g.data(), h.data(), n);
 }
 
-void Booster::eval_ranking(int which, std::vector<EvalResult>* out) {
+void Booster::eval_host_metrics(int which, std::vector<EvalResult>* out) {
   if (eval_average_precision_) {
     const Dataset* ds = which < 0 ? train_.get() : valid_sets_[(size_t)which].get();
     const int64_t n = engine_->num_rows(which);
@@ -659,7 +659,7 @@ std::vector<EvalResult> Booster::eval(int which) {
   if (!engine_) throw std::runtime_error("eval on a prediction-only booster");
   ensure_scores();
   std::vector<EvalResult> out = engine_->eval(which, metrics_, obj_);
-  eval_ranking(which, &out);
+  eval_host_metrics(which, &out);
   return out;
 }
 

@@ -127,12 +127,13 @@ class Booster {
   double sum_tree_weight_ = 0.0;
   double dart_shrinkage_ = 1.0;         // learning rate of the iteration in progress
   void renew_leaf_outputs(Tree& tree);
-  // ranking (ranking.hpp): per-query gradients and ndcg / map evaluation on the host
+  // ranking (ranking.hpp): per-query gradients; eval_host_metrics adds the metrics the engines do not compute
+  // themselves (ndcg / map per query, average_precision, auc_mu) from the engine's scores
   struct RankMetric { bool ndcg; int at; };
   bool is_ranking() const { return obj_.kind == kObjLambdarank || obj_.kind == kObjXendcg; }
   void setup_ranking();
   void compute_gradients();
-  void eval_ranking(int which, std::vector<EvalResult>* out);
+  void eval_host_metrics(int which, std::vector<EvalResult>* out);
   bool eval_auc_mu_ = false;              // multiclass AUC (Kleiman & Page): mean pairwise class separability
   bool eval_average_precision_ = false;   // evaluated here from the engine's scores, like the ranking metrics
   RankingSpec rank_;

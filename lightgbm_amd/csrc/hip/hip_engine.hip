@@ -1068,8 +1068,9 @@ class HipEngine : public Engine {
       bp.label = mir_->label.get();
       bp.neg_fraction = (float)neg_fraction;
       bag_n_ = backend_->sample_partition(base_rows_.get(), n_base_, bag_rows_.get(), -3, bp);
-    } else
-    bag_n_ = backend_->bag_partition(base_rows_.get(), n_base_, bag_rows_.get(), fraction, seed, iter, salt);
+    } else {
+      bag_n_ = backend_->bag_partition(base_rows_.get(), n_base_, bag_rows_.get(), fraction, seed, iter, salt);
+    }
     bag_ptr_ = bag_rows_.get();
     oob_n_ = n_base_ - bag_n_;
   }
