@@ -61,7 +61,7 @@ inline void categorical_set_search(const int64_t* g, const int64_t* h, int value
       if ((double)(ctx.total_h - lh) * ctx.hunit < sp.min_sum_hessian_in_leaf) break;
       if (group_cnt < cp.min_data_per_group) continue;
       group_cnt = 0;
-      const double gain = split_gain(lg, lh, ctx, sp_cat, 0);
+      const double gain = adjust_feature_gain(split_gain(lg, lh, ctx, sp_cat, 0), feature, ctx.total_cnt, sp);
       if (!(gain > best->gain)) continue;
       best->gain = gain;
       best->feature = feature;

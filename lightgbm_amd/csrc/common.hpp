@@ -54,6 +54,12 @@ struct SplitParams {
   // the node; nullptr when there are none.
   const uint64_t* node_masks;
   double path_smooth;       // > 0: child outputs are pulled towards the parent's, less so the more rows they hold
+  // Per-feature gain adjustment (feature_contri, cost-effective gradient boosting), in the backend's memory
+  // space, indexed by inner feature; nullptr when unused.  A candidate's gain becomes
+  // gain * feature_scale[f] - feature_offset[f] - split_penalty * rows_in_leaf.
+  const double* feature_scale;
+  const double* feature_offset;
+  double split_penalty;
 };
 constexpr int kNodeInfoStride = 3;
 
@@ -285,6 +291,17 @@ LGA_HD double split_gain(int64_t lg, int64_t lh, const LeafScanCtx& c, const Spl
   }
   if (!(gain > p.min_gain_to_split)) return ninf;
   return gain;
+}
+
+// The gain a candidate on feature f competes with (see SplitParams::feature_scale); -inf stays -inf, and a
+// candidate whose adjusted gain does not clear min_gain_to_split is no candidate.  Monotone in `gain` for a
+// fixed feature and leaf, so it may be applied to a feature's best candidate instead of to every one.
+LGA_HD double adjust_feature_gain(double gain, int f, int64_t leaf_rows, const SplitParams& sp) {
+  if (!sp.feature_scale || !(gain > -std::numeric_limits<double>::infinity())) return gain;
+  const double scale = sp.feature_scale[f];
+  if (!(scale > 0.0)) return -std::numeric_limits<double>::infinity();
+  const double g = gain * scale - sp.feature_offset[f] - sp.split_penalty * (double)leaf_rows;
+  return g > sp.min_gain_to_split ? g : -std::numeric_limits<double>::infinity();
 }
 
 // Counter-based RNG (splitmix64 finaliser over a (seed, stream, index) triple):

@@ -75,6 +75,11 @@ const ParamDef kParams[] = {
     P(lambda_l1, "reg_alpha,l1_regularization", Double, 0, kNone),
     P(lambda_l2, "reg_lambda,lambda,l2_regularization", Double, 0, kNone),
     P(min_gain_to_split, "min_split_gain", Double, 0, kNone),
+    P(feature_contri, "feature_contrib,fc,fp,feature_penalty", DoubleList, 0, kNone),
+    P(cegb_tradeoff, "", Double, 0, kNone),
+    P(cegb_penalty_split, "", Double, 0, kNone),
+    P(cegb_penalty_feature_coupled, "", DoubleList, 0, kNone),
+    P(cegb_penalty_feature_lazy, "", DoubleList, 0, kNone),
     P(path_smooth, "", Double, 0, kNone),
     P(interaction_constraints, "", String, kNone, kNone),
     P(verbosity, "verbose", Int, kNone, kNone),
@@ -418,6 +423,8 @@ void Config::check() {
     if (!multi && o != "custom" && num_class != 1)
       throw std::runtime_error("num_class must be 1 for objective=" + o);
   }
+  for (double v : cegb_penalty_feature_lazy)
+    if (v != 0.0) throw std::runtime_error("cegb_penalty_feature_lazy is not supported (split and coupled feature penalties are)");
   for (const auto& m : metric) (void)canonical_metric(m);
   std::string t = lower(tree_learner);
   if (t == "serial") tree_learner = "serial";

@@ -61,6 +61,11 @@ struct Config {
   double lambda_l1 = 0.0;
   double lambda_l2 = 0.0;
   double min_gain_to_split = 0.0;
+  std::vector<double> feature_contri;                 // per column: factor on the gains of splits on it
+  double cegb_tradeoff = 1.0;                         // cost-effective gradient boosting: weight of the penalties
+  double cegb_penalty_split = 0.0;                    // ... per row of a leaf that is split
+  std::vector<double> cegb_penalty_feature_coupled;   // ... per column, paid once, when the model first uses it
+  std::vector<double> cegb_penalty_feature_lazy;      // accepted for its name; per-row lazy costs are not implemented
   double path_smooth = 0.0;                // > 0: pull a child's output towards its parent's (less with more rows)
   std::string interaction_constraints;     // "[0,1,2],[2,3]": features that may appear together on a branch
   int verbosity = 1;

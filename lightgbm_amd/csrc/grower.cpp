@@ -11,6 +11,27 @@ namespace lga {
 
 TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds) {
   if (const char* e = std::getenv("LGA_SPEC_FLOOR")) spec_floor_ = std::atof(e);
+  {
+    const int F = ds_->num_features(), total = ds_->num_total_features();
+    auto sized = [&](const std::vector<double>& v, const char* name) {
+      if (!v.empty() && (int)v.size() != total)
+        throw std::runtime_error(std::string(name) + " lists " + std::to_string(v.size()) + " values, the data has " +
+                                 std::to_string(total) + " features");
+      return !v.empty();
+    };
+    const bool contri = sized(cfg_.feature_contri, "feature_contri");
+    const bool coupled = sized(cfg_.cegb_penalty_feature_coupled, "cegb_penalty_feature_coupled");
+    if (contri || coupled || cfg_.cegb_penalty_split > 0.0) {
+      gain_scale_.assign((size_t)std::max(F, 1), 1.0);
+      gain_offset_.assign((size_t)std::max(F, 1), 0.0);
+      coupled_penalty_.assign((size_t)std::max(F, 1), 0.0);
+      for (int f = 0; f < F; ++f) {
+        if (contri) gain_scale_[(size_t)f] = cfg_.feature_contri[(size_t)ds_->real_feature(f)];
+        if (coupled) coupled_penalty_[(size_t)f] = cfg_.cegb_penalty_feature_coupled[(size_t)ds_->real_feature(f)];
+      }
+      refresh_gain_adjustment();
+    }
+  }
   // interaction_constraints = "[0,1,2],[2,3]": groups of raw-matrix columns; columns without a usable
   // feature (constant ones) drop out
   const std::string& ic = cfg_.interaction_constraints;
@@ -50,8 +71,15 @@ TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds
   }
 }
 
+void TreeGrower::refresh_gain_adjustment() {
+  for (size_t f = 0; f < gain_offset_.size(); ++f) gain_offset_[f] = cfg_.cegb_tradeoff * coupled_penalty_[f];
+}
+
 SplitParams TreeGrower::split_params() const {
   SplitParams p;
+  p.feature_scale = gain_scale_.empty() ? nullptr : gain_scale_.data();
+  p.feature_offset = gain_scale_.empty() ? nullptr : gain_offset_.data();
+  p.split_penalty = cfg_.cegb_tradeoff * cfg_.cegb_penalty_split;
   p.lambda_l1 = cfg_.lambda_l1;
   p.lambda_l2 = cfg_.lambda_l2;
   p.min_gain_to_split = cfg_.min_gain_to_split;
@@ -415,6 +443,11 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     leaf_of_node[(size_t)n.right] = right_leaf;
     leaf_nodes[(size_t)leaf] = n.left;
     leaf_nodes.push_back(n.right);
+  }
+  if (!coupled_penalty_.empty()) {
+    // a feature's coupled cost is paid by the first tree that uses it
+    for (int id : chosen) coupled_penalty_[(size_t)nodes[(size_t)id].best.feature] = 0.0;
+    refresh_gain_adjustment();
   }
   // Rows of a final leaf: a leaf that was partitioned speculatively (its split never got its turn)
   // has its rows in the ranges of its deepest partitioned descendants.

@@ -45,7 +45,7 @@ class TreeGrower {
   const GrowStats& last_stats() const { return stats_; }
   // Index of the tree about to be grown: seeds its per-node feature sampling.
   void set_tree_index(int64_t i) { tree_index_ = i; }
-  SplitParams split_params() const;
+  SplitParams split_params() const;   // pointers inside stay valid until the next grow()
 
  private:
   struct Node {
@@ -60,6 +60,11 @@ class TreeGrower {
     double out = std::numeric_limits<double>::quiet_NaN();   // the node's own output (monotone / path smoothing)
     SplitInfo best;
   };
+  // per-feature gain adjustment (feature_contri, CEGB): SplitParams points into these; offsets follow the
+  // features the model has used so far
+  std::vector<double> gain_scale_, gain_offset_;
+  std::vector<double> coupled_penalty_;   // per inner feature, 0 once the feature has been used
+  void refresh_gain_adjustment();
   // interaction constraints as bit sets over inner features (empty: none)
   std::vector<std::vector<uint64_t>> groups_;
   int mask_words_ = 0;

@@ -271,6 +271,19 @@ class HipBackend : public TreeBackend {
     sp_ = params;
     // Monotone constraints: node output ranges live in a device array the scan reads (SplitParams::
     // node_bounds); the grower announces them per node, every round uploads the entries of its children.
+    // per-feature gain adjustment: the grower's host tables go to the device; the host keeps its pointers
+    // for the category-set pass
+    gain_scale_host_ = params.feature_scale;
+    gain_offset_host_ = params.feature_offset;
+    if (params.feature_scale) {
+      gain_dev_.resize((size_t)2 * (size_t)std::max(F_, 1));
+      gain_pinned_.resize((size_t)2 * (size_t)std::max(F_, 1));
+      std::memcpy(gain_pinned_.get(), params.feature_scale, sizeof(double) * (size_t)F_);
+      std::memcpy(gain_pinned_.get() + F_, params.feature_offset, sizeof(double) * (size_t)F_);
+      LGA_HIP_CHECK(hipMemcpyAsync(gain_dev_.get(), gain_pinned_.get(), sizeof(double) * 2 * (size_t)F_, hipMemcpyHostToDevice, stream_));
+      sp_.feature_scale = gain_dev_.get();
+      sp_.feature_offset = gain_dev_.get() + F_;
+    }
     masked_ = false;
     sorted_cat_.clear();
     for (int f = 0; f < (int)meta.size(); ++f)
@@ -660,6 +673,8 @@ class HipBackend : public TreeBackend {
     SplitParams sp_host = sp_;          // the node tables of sp_ are device pointers: the host reads its own copies
     sp_host.node_bounds = nullptr;
     sp_host.node_masks = masked_ ? masks_host_.get() : nullptr;
+    sp_host.feature_scale = gain_scale_host_;
+    sp_host.feature_offset = gain_offset_host_;
     for (int s = 0; s < n_scan; ++s) {
       SplitInfo& o = infos[s];
       const int node = node_of[(size_t)s];
@@ -733,6 +748,10 @@ class HipBackend : public TreeBackend {
   bool ranged_ = false;                 // monotone constraints or path smoothing: node_bounds is in use
   PinnedBuffer<double> bounds_host_;    // [node][lo, hi, out]
   DeviceBuffer<double> bounds_dev_;
+  const double* gain_scale_host_ = nullptr;   // the grower's tables behind SplitParams::feature_scale / _offset
+  const double* gain_offset_host_ = nullptr;
+  DeviceBuffer<double> gain_dev_;
+  PinnedBuffer<double> gain_pinned_;
   std::vector<int> sorted_cat_;         // features of the current tree searched over category sets
   CatParams cat_;
   PinnedBuffer<uint64_t> cat_sets_host_;   // [node][kCatSetWords]

@@ -661,7 +661,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
       int64_t lg2 = shfl_xor_i64(clg, msk), lh2 = shfl_xor_i64(clh, msk);
       take_better(cbg, ckey, clg, clh, g2, k2, lg2, lh2);
     }
-    take_better(bg, bkey, blg, blh, cbg, ckey, clg, clh);
+    take_better(bg, bkey, blg, blh, adjust_feature_gain(cbg, f, ctx.total_cnt, sp), ckey, clg, clh);
     return;
   }
   // stats of the missing-value bin, broadcast from the lane that holds it
@@ -706,7 +706,7 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
     int64_t lg2 = shfl_xor_i64(llg, msk), lh2 = shfl_xor_i64(llh, msk);
     take_better(lbg, lkey, llg, llh, g2, k2, lg2, lh2);
   }
-  take_better(bg, bkey, blg, blh, lbg, lkey, llg, llh);
+  take_better(bg, bkey, blg, blh, adjust_feature_gain(lbg, f, ctx.total_cnt, sp), lkey, llg, llh);
 }
 
 __global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict__ tasks,

@@ -239,7 +239,7 @@ class HostBackend : public TreeBackend {
       // one category against the rest: the left child is a single value bin
       for (int t = 0; t < vb; ++t) {
         if (only >= 0 && t != only) continue;
-        double ga = split_gain(g[t], h[t], ctx, sp_, 0);
+        double ga = adjust_feature_gain(split_gain(g[t], h[t], ctx, sp_, 0), f, ctx.total_cnt, sp_);
         uint64_t ka = cand_key(f, t, 0);
         if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, g[t], h[t]};
       }
@@ -249,11 +249,11 @@ class HostBackend : public TreeBackend {
       lg += g[t];
       lh += h[t];
       if (only >= 0 && t != only) continue;
-      double ga = split_gain(lg, lh, ctx, sp_, m.monotone);
+      double ga = adjust_feature_gain(split_gain(lg, lh, ctx, sp_, m.monotone), f, ctx.total_cnt, sp_);
       uint64_t ka = cand_key(f, t, 0);
       if (cand_better(ga, ka, best->gain, best->key)) *best = Cand{ga, ka, lg, lh};
       if (mb >= 0 && t <= vb - 2) {
-        double gb = split_gain(lg + mg, lh + mh, ctx, sp_, m.monotone);
+        double gb = adjust_feature_gain(split_gain(lg + mg, lh + mh, ctx, sp_, m.monotone), f, ctx.total_cnt, sp_);
         uint64_t kb = cand_key(f, t, 1);
         if (cand_better(gb, kb, best->gain, best->key)) *best = Cand{gb, kb, lg + mg, lh + mh};
       }

@@ -127,7 +127,8 @@ class _SplitParams(ctypes.Structure):
                 ("min_data_in_leaf", ctypes.c_int32), ("max_depth", ctypes.c_int32),
                 ("bynode_fraction", ctypes.c_double), ("bynode_seed", ctypes.c_uint64),
                 ("extra_trees", ctypes.c_int32), ("mask_words", ctypes.c_int32), ("extra_seed", ctypes.c_uint64),
-                ("node_bounds", ctypes.c_void_p), ("node_masks", ctypes.c_void_p), ("path_smooth", ctypes.c_double)]
+                ("node_bounds", ctypes.c_void_p), ("node_masks", ctypes.c_void_p), ("path_smooth", ctypes.c_double),
+                ("feature_scale", ctypes.c_void_p), ("feature_offset", ctypes.c_void_p), ("split_penalty", ctypes.c_double)]
 
 
 def split_scan(g, h, count: int, total_g: int, total_h: int, num_bins, missing_bins, kg: int, kh: int,
@@ -149,7 +150,7 @@ def split_scan(g, h, count: int, total_g: int, total_h: int, num_bins, missing_b
     st = _i32([0, 0, -1, -1, -1, 0])
     totals = torch.zeros(4, dtype=torch.int64, device="cuda")
     qs = _i32([kg, kh])
-    sp = _SplitParams(lambda_l1, lambda_l2, min_gain_to_split, min_sum_hessian_in_leaf, 0.0, min_data_in_leaf, -1, 1.0, 0, 0, 0, 0, None, None, 0.0)
+    sp = _SplitParams(lambda_l1, lambda_l2, min_gain_to_split, min_sum_hessian_in_leaf, 0.0, min_data_in_leaf, -1, 1.0, 0, 0, 0, 0, None, None, 0.0, None, None, 0.0)
     cands = torch.zeros(F * 4, dtype=torch.int64, device="cuda")
     out = torch.zeros(9, dtype=torch.int64, device="cuda")
     _op(lib, "scan", [st.data_ptr(), meta_t.data_ptr(), pool.data_ptr(), totals.data_ptr(), qs.data_ptr(),

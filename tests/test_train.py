@@ -563,3 +563,34 @@ def test_balanced_bagging_keeps_different_shares_of_the_classes():
     np.testing.assert_allclose(kept._inner_predict(-1, raw=True), kept.predict(X, raw_score=True), atol=1e-9)
     with pytest.raises(lgb.LightGBMError, match="binary"):
         lgb.train({**CPU, "neg_bagging_fraction": 0.5, "bagging_freq": 1}, lgb.Dataset(X, label=y), 2)
+
+
+def test_feature_contri_and_cost_effective_penalties():
+    rng = np.random.RandomState(0)
+    X = rng.randn(6000, 4)
+    X[:, 1] = X[:, 0] + 0.05 * rng.randn(6000)               # column 1 is nearly a copy of column 0
+    y = X[:, 0] + 0.5 * X[:, 2] + 0.1 * rng.randn(6000)
+    base = {**CPU, "num_leaves": 15, "min_data_in_leaf": 20}
+    used = lambda b: b.feature_importance().tolist()
+    plain = lgb.train(base, lgb.Dataset(X, label=y), 10)
+    assert used(plain)[0] > used(plain)[1]
+    # a small factor on column 0's gains hands its splits to the copy; a zero switches a column off
+    tilted = lgb.train({**base, "feature_contri": [0.05, 1.0, 1.0, 1.0]}, lgb.Dataset(X, label=y), 10)
+    assert used(tilted)[1] > used(tilted)[0]
+    off = lgb.train({**base, "feature_contri": [0.0, 1.0, 1.0, 1.0]}, lgb.Dataset(X, label=y), 10)
+    assert used(off)[0] == 0 and used(off)[1] > 0
+    # coupled cost: a feature is only bought when its gain pays for it - the noise column never is, and a
+    # feature that was bought once is free afterwards
+    gains = plain.feature_importance(importance_type="gain")
+    costly = lgb.train({**base, "cegb_penalty_feature_coupled": [0.0, 0.0, 0.0, 10 * float(gains[3] + 1.0)]},
+                       lgb.Dataset(X, label=y), 10)
+    assert used(costly)[3] == 0 and used(costly)[2] > 0
+    bought = lgb.train({**base, "cegb_penalty_feature_coupled": [0.0, 0.0, 0.3 * float(gains[2]) / 10, 0.0]}, lgb.Dataset(X, label=y), 10)
+    assert used(bought)[2] > 0
+    # a cost per row of every split leaf makes trees smaller
+    nodes = lambda b: len(b.trees_to_dataframe())
+    assert nodes(lgb.train({**base, "cegb_penalty_split": 0.05}, lgb.Dataset(X, label=y), 10)) < nodes(plain)
+    with pytest.raises(lgb.LightGBMError, match="feature_contri"):
+        lgb.train({**base, "feature_contri": [1.0, 1.0]}, lgb.Dataset(X, label=y), 2)
+    with pytest.raises(lgb.LightGBMError, match="lazy"):
+        lgb.train({**base, "cegb_penalty_feature_lazy": [1.0, 0, 0, 0]}, lgb.Dataset(X, label=y), 2)

@@ -71,6 +71,11 @@ def draw_case(seed: int, max_rows: int):
         p["interaction_constraints"] = [list(range(0, cut)), list(range(cut - 1, F - 1))]   # last column in no group
     if rng.rand() < 0.15:
         p["zero_as_missing"] = True
+    if rng.rand() < 0.15:
+        p["feature_contri"] = [float(v) for v in np.round(0.2 + rng.rand(F) * 1.5, 2)]
+    if rng.rand() < 0.15:
+        p["cegb_penalty_split"] = 1e-5
+        p["cegb_penalty_feature_coupled"] = [float(v) for v in np.round(rng.rand(F) * 0.5, 2)]
     opts = {"nan": rng.rand() < 0.4, "weight": rng.rand() < 0.3, "lowcard": rng.rand() < 0.4,
             "rounds": int(rng.randint(3, 7)) + (4 if p.get("boosting") == "dart" else 0), "subset": rng.rand() < 0.25,
             "categorical": rng.rand() < 0.3}
