@@ -6,7 +6,7 @@ CV, a resumable parameter-grid CV search, and the LightGBM text model format.
 The compute path is hand-written HIP for gfx950 (``csrc/hip``) driven by a C++
 core; a same-numerics OpenMP engine serves CPU runs and as the test oracle.
 """
-from .basic import Booster, Dataset, LightGBMError, default_device, params_to_string, resolve_alias
+from .basic import Booster, Dataset, LightGBMError, default_device, params_to_string, register_logger, resolve_alias
 from .callback import EarlyStopException, early_stopping, log_evaluation, print_evaluation, record_evaluation, reset_parameter
 from .engine import CVBooster, cv, make_folds, train
 
@@ -30,5 +30,5 @@ def __getattr__(name):
 __all__ = [
     "Dataset", "Booster", "CVBooster", "LightGBMError", "train", "cv", "make_folds",
     "early_stopping", "log_evaluation", "print_evaluation", "record_evaluation", "reset_parameter",
-    "EarlyStopException", "default_device", "params_to_string", "resolve_alias",
+    "EarlyStopException", "default_device", "params_to_string", "resolve_alias", "register_logger",
 ]

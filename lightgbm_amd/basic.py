@@ -25,6 +25,38 @@ __all__ = ["Dataset", "Booster", "LightGBMError", "params_to_string", "resolve_a
 # ----------------------------------------------------------------------------
 # parameters
 # ----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------
+# Messages: printed by default, or handed to a logger registered with register_logger().
+# ----------------------------------------------------------------------------
+_logger = None
+_info_method, _warning_method = "info", "warning"
+
+
+def register_logger(logger, info_method_name: str = "info", warning_method_name: str = "warning") -> None:
+    """Routes the package's messages (evaluation lines, early-stopping notes, warnings) to ``logger``, any
+    object with the two named methods - e.g. a ``logging.Logger``.  ``None`` restores printing."""
+    global _logger, _info_method, _warning_method
+    if logger is not None:
+        for name in (info_method_name, warning_method_name):
+            if not callable(getattr(logger, name, None)):
+                raise TypeError(f"Logger must provide '{name}' method")
+    _logger, _info_method, _warning_method = logger, info_method_name, warning_method_name
+
+
+def _log_info(msg: str) -> None:
+    if _logger is not None:
+        getattr(_logger, _info_method)(msg)
+    else:
+        print(msg)
+
+
+def _log_warning(msg: str, stacklevel: int = 3) -> None:
+    if _logger is not None:
+        getattr(_logger, _warning_method)(msg)
+    else:
+        warnings.warn(msg, stacklevel=stacklevel + 1)
+
+
 def _fmt_value(v: Any) -> str:
     if isinstance(v, bool) or isinstance(v, np.bool_):
         return "true" if v else "false"
@@ -119,7 +151,7 @@ def _with_device(params: Optional[Dict[str, Any]]) -> Dict[str, Any]:
 def _warn_unknown(params: Dict[str, Any]):
     unknown = [k for k in params if resolve_alias(k) is None and not callable(params[k])]
     if unknown:
-        warnings.warn("Unknown parameter(s) ignored: " + ", ".join(sorted(unknown)), stacklevel=3)
+        _log_warning("Unknown parameter(s) ignored: " + ", ".join(sorted(unknown)), stacklevel=3)
 
 
 # ----------------------------------------------------------------------------

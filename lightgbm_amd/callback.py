@@ -9,6 +9,8 @@ import collections
 import logging
 from typing import Any, Callable, Dict, List, Union
 
+from .basic import _log_info
+
 logger = logging.getLogger("lightgbm_amd")
 
 CallbackEnv = collections.namedtuple(
@@ -41,7 +43,7 @@ def log_evaluation(period: int = 1, show_stdv: bool = True) -> Callable:
         if period > 0 and env.evaluation_result_list and (env.iteration + 1) % period == 0:
             result = "\t".join(_format_eval_result(x, show_stdv) for x in env.evaluation_result_list)
             logger.info("[%d]\t%s", env.iteration + 1, result)
-            print(f"[{env.iteration + 1}]\t{result}")
+            _log_info(f"[{env.iteration + 1}]\t{result}")
 
     _callback.order = 10
     return _callback
@@ -122,7 +124,7 @@ def early_stopping(stopping_rounds: int, first_metric_only: bool = False, verbos
             logger.warning("Early stopping is not available without validation data")
             return
         if verbose:
-            print(f"Training until validation scores don't improve for {stopping_rounds} rounds")
+            _log_info(f"Training until validation scores don't improve for {stopping_rounds} rounds")
         first_metric[0] = env.evaluation_result_list[0][1].split(" ")[-1]
         best_score.clear(); best_iter.clear(); best_score_list.clear(); cmp_op.clear()
         for item in env.evaluation_result_list:
@@ -138,7 +140,7 @@ def early_stopping(stopping_rounds: int, first_metric_only: bool = False, verbos
     def _final_iteration_check(env: CallbackEnv, i: int) -> None:
         if env.iteration == env.end_iteration - 1:
             if verbose:
-                print("Did not meet early stopping. Best iteration is:\n[%d]\t%s" % (
+                _log_info("Did not meet early stopping. Best iteration is:\n[%d]\t%s" % (
                     best_iter[i] + 1, "\t".join(_format_eval_result(x) for x in best_score_list[i])))
             raise EarlyStopException(best_iter[i], best_score_list[i])
 
@@ -162,7 +164,7 @@ def early_stopping(stopping_rounds: int, first_metric_only: bool = False, verbos
                 continue
             if env.iteration - best_iter[i] >= stopping_rounds:
                 if verbose:
-                    print("Early stopping, best iteration is:\n[%d]\t%s" % (
+                    _log_info("Early stopping, best iteration is:\n[%d]\t%s" % (
                         best_iter[i] + 1, "\t".join(_format_eval_result(x) for x in best_score_list[i])))
                 raise EarlyStopException(best_iter[i], best_score_list[i])
             _final_iteration_check(env, i)

@@ -101,3 +101,33 @@ def test_r_style_train_accepts_dataframe_row():
     fit = lgb_train(row, d, nrounds=20, objective="regression", verbose=0)
     assert fit.num_trees() == 20
     assert np.sqrt(np.mean((predict(fit, X) - y) ** 2)) < 0.3
+
+
+def test_register_logger_receives_the_messages():
+    import lightgbm_amd as lgb
+
+    class Sink:
+        def __init__(self):
+            self.info_lines, self.warn_lines = [], []
+
+        def info(self, msg):
+            self.info_lines.append(msg)
+
+        def warning(self, msg):
+            self.warn_lines.append(msg)
+    sink = Sink()
+    lgb.register_logger(sink)
+    try:
+        rng = np.random.RandomState(0)
+        X = rng.randn(600, 3)
+        y = X[:, 0] + 0.1 * rng.randn(600)
+        d = lgb.Dataset(X, label=y, params={"device_type": "cpu", "verbose": -1})
+        lgb.train({"device_type": "cpu", "verbose": 1, "no_such_parameter": 1}, d, 30, valid_sets=[d], early_stopping_rounds=3,
+                  verbose_eval=10)
+    finally:
+        lgb.register_logger(None)
+    assert any("no_such_parameter" in m for m in sink.warn_lines)
+    assert any(m.startswith("[10]") for m in sink.info_lines)
+    import pytest
+    with pytest.raises(TypeError):
+        lgb.register_logger(object())
