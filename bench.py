@@ -49,6 +49,9 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver of this pool shares device memory between processes through dmabuf only; RCCL needs
+    # this before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
