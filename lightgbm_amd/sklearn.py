@@ -61,6 +61,21 @@ class LGBMModel(BaseEstimator):
         self.best_iteration_ = 0
         self.evals_result_: Dict[str, Any] = {}
 
+    # extra keyword parameters (any training parameter) are part of the estimator's parameter set, so that
+    # clone() / GridSearchCV / set_params see them like the named ones
+    def get_params(self, deep: bool = True) -> Dict[str, Any]:
+        params = super().get_params(deep=deep)
+        params.update(self._other_params)
+        return params
+
+    def set_params(self, **params) -> "LGBMModel":
+        for key, value in params.items():
+            if hasattr(self, key) and key in super().get_params(deep=False):
+                setattr(self, key, value)
+            else:
+                self._other_params[key] = value
+        return self
+
     def _default_objective(self) -> str:
         return "regression"
 
@@ -81,6 +96,7 @@ class LGBMModel(BaseEstimator):
         if self.device_type is not None:
             p["device_type"] = self.device_type
         p.update(self._other_params)
+        p.pop("class_weight", None)      # an estimator-level setting (turned into row weights), not a training parameter
         return p
 
     def fit(self, X, y, sample_weight=None, init_score=None, eval_set=None, eval_names=None, eval_metric=None,
@@ -194,8 +210,7 @@ class LGBMClassifier(ClassifierMixin, LGBMModel):
         self.n_classes_ = len(self.classes_)
         if self.n_classes_ < 2:
             raise ValueError("LGBMClassifier needs at least two classes")
-        cw = self._other_params.pop("class_weight", getattr(self, "class_weight", None))
-        self.class_weight = cw
+        cw = self._other_params.get("class_weight")
         if cw is not None:
             # "balanced": n / (n_classes * count(class)); a dict: weight per class label (missing labels: 1)
             ya = np.asarray(y)

@@ -158,3 +158,13 @@ def test_estimator_fit_arguments_and_fitted_attributes():
     assert m.feature_name_ == ["a", "b", "c", "d"] and m.n_features_ == 4 and m.objective_ == "regression"
     assert list(m.evals_result_["valid_0"]) == ["l2", "mad"] and m.n_iter_ == 20
     assert set(m.best_score_["valid_0"]) == {"l2", "mad"}
+
+
+def test_extra_keyword_parameters_survive_clone_and_set_params():
+    from sklearn.base import clone
+    est = LGBMRegressor(n_estimators=5, device_type="cpu", min_data_per_group=7, path_smooth=2.0)
+    assert est.get_params()["min_data_per_group"] == 7
+    twin = clone(est)
+    assert twin.get_params()["path_smooth"] == 2.0 and twin._params()["min_data_per_group"] == 7
+    twin.set_params(path_smooth=0.0, num_leaves=9, cat_l2=1.0)
+    assert twin.num_leaves == 9 and twin._params()["path_smooth"] == 0.0 and twin._params()["cat_l2"] == 1.0
