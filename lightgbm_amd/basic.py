@@ -495,6 +495,9 @@ class Dataset:
         return self
 
     def set_init_score(self, init_score) -> "Dataset":
+        """One initial score per row; multiclass: ``[rows, num_class]`` (or the flat ``[class][row]`` layout)."""
+        if init_score is not None and not _is_torch(init_score) and np.ndim(init_score) == 2:
+            init_score = np.ascontiguousarray(np.asarray(init_score, dtype=np.float64).T).reshape(-1)
         self.init_score = init_score
         if self._handle is not None:
             self._set_field("init_score", init_score, np.float64)

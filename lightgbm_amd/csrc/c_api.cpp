@@ -143,8 +143,11 @@ int lga_dataset_get_field(LgaDataset ds, const char* name, double* out, int64_t 
     else if (f == "init_score") {
       const auto& is = d->root_init_score();
       if (!is.empty()) {
-        if (d->used_indices()) for (int32_t r : *d->used_indices()) v.push_back(is[(size_t)r]);
-        else v = is;
+        if (d->used_indices()) {
+          const size_t classes = is.size() / (size_t)d->root_rows();
+          for (size_t k = 0; k < classes; ++k)
+            for (int32_t r : *d->used_indices()) v.push_back(is[k * (size_t)d->root_rows() + (size_t)r]);
+        } else v = is;
       }
     } else if (f == "group") {
       const auto& b = d->query_boundaries();

@@ -199,8 +199,22 @@ void Dataset::set_weight(const float* v, int64_t n) {
     if (!(v[i] >= 0.0f)) throw std::runtime_error("weights must be non-negative");
   scatter_field(root_mut()->weight_, root_rows_, used_indices_.get(), v, n, num_data(), "weight");
 }
+// n == num_data(), or num_class * num_data() values laid out [class][row] (multiclass); the root then holds
+// [class][root row].
 void Dataset::set_init_score(const double* v, int64_t n) {
-  scatter_field(root_mut()->init_score_, root_rows_, used_indices_.get(), v, n, num_data(), "init_score");
+  const int64_t local = num_data();
+  if (n == 0 || n == local || local == 0 || n % local != 0) {
+    scatter_field(root_mut()->init_score_, root_rows_, used_indices_.get(), v, n, local, "init_score");
+    return;
+  }
+  const int64_t K = n / local;
+  std::vector<double>& dst = root_mut()->init_score_;
+  if ((int64_t)dst.size() != K * root_rows_) dst.assign((size_t)(K * root_rows_), 0.0);
+  for (int64_t k = 0; k < K; ++k)
+    for (int64_t i = 0; i < local; ++i) {
+      const int64_t r = used_indices_ ? (int64_t)(*used_indices_)[(size_t)i] : i;
+      dst[(size_t)(k * root_rows_ + r)] = v[k * local + i];
+    }
 }
 
 void Dataset::set_group(const int32_t* sizes, int64_t n) {

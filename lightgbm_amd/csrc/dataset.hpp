@@ -71,8 +71,8 @@ class Dataset : public std::enable_shared_from_this<Dataset> {
   // ---- metadata (indexed by LOCAL row of this dataset; subsets read through to the root) ----
   void set_label(const float* v, int64_t n);
   void set_weight(const float* v, int64_t n);      // n == 0 clears
-  void set_init_score(const double* v, int64_t n); // n == 0 clears
-  // Root-indexed storage (length root_rows); empty when unset.
+  void set_init_score(const double* v, int64_t n); // n == 0 clears; num_class * num_data values are [class][row]
+  // Root-indexed storage (length root_rows; init_score: root_rows per class); empty when unset.
   const std::vector<float>& root_label() const { return root()->label_; }
   const std::vector<float>& root_weight() const { return root()->weight_; }
   const std::vector<double>& root_init_score() const { return root()->init_score_; }

@@ -851,8 +851,9 @@ class HipEngine : public Engine {
     red_dev_.resize(k::kReduceDoubles);
     red_host_.resize(8);
     if (!train_->root_init_score().empty()) {
-      init_score_dev_.upload(train_->root_init_score().data(), (size_t)N_, stream_);
+      init_score_dev_.upload(train_->root_init_score().data(), train_->root_init_score().size(), stream_);
       has_init_ = true;
+      init_per_class_ = (int64_t)train_->root_init_score().size() == (int64_t)K_ * N_ && K_ > 1;
     }
     backend_.reset(new HipBackend(train_.get(), mir_, cfg, comm, mode, n_base_));
     bag_ptr_ = base_rows_.get();
@@ -895,8 +896,9 @@ class HipEngine : public Engine {
     v->shared_scores = false;
     if (!v->shared_scores) v->scores.resize((size_t)v->N * (size_t)K_);
     if (!ds->root_init_score().empty() && !v->shared_scores) {
-      v->init.upload(ds->root_init_score().data(), (size_t)v->N, stream_);
+      v->init.upload(ds->root_init_score().data(), ds->root_init_score().size(), stream_);
       v->has_init = true;
+      v->init_per_class = (int64_t)ds->root_init_score().size() == (int64_t)K_ * v->N && K_ > 1;
     }
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     valid_.push_back(std::move(v));
@@ -915,10 +917,14 @@ class HipEngine : public Engine {
   }
 
   void reset_scores(double v) override {
-    k::init_scores(sc(), has_init_ ? init_score_dev_.get() : nullptr, base_or_null(), n_base_, v, stream_);
-    for (auto& vs : valid_)
-      k::init_scores(score_ptr(*vs), (vs->has_init ? vs->init.get() : (vs->shared_scores && has_init_ ? init_score_dev_.get() : nullptr)),
-                     vs->rows.get(), vs->n, v, stream_);
+    // initial scores: one vector for every class, or one per class ([class][root row])
+    const double* own = has_init_ ? init_score_dev_.get() + (init_per_class_ ? (size_t)cls_ * (size_t)N_ : 0) : nullptr;
+    k::init_scores(sc(), own, base_or_null(), n_base_, v, stream_);
+    for (auto& vs : valid_) {
+      const double* vi = vs->has_init ? vs->init.get() + (vs->init_per_class ? (size_t)cls_ * (size_t)vs->N : 0)
+                                      : (vs->shared_scores ? own : nullptr);
+      k::init_scores(score_ptr(*vs), vi, vs->rows.get(), vs->n, v, stream_);
+    }
   }
   void scale_scores(int which, double f) override {
     if (which < 0) k::scale_add(sc(), base_or_null(), n_base_, f, 0.0, stream_);
@@ -1286,7 +1292,7 @@ class HipEngine : public Engine {
     int64_t n = 0, N = 0;
     DeviceBuffer<int32_t> rows;
     DeviceBuffer<double> scores, init;
-    bool shared_scores = false, has_init = false;
+    bool shared_scores = false, has_init = false, init_per_class = false;
   };
   bool dist() const { return comm_ && comm_->size() > 1; }
   // the selected class's vectors
@@ -1420,6 +1426,7 @@ class HipEngine : public Engine {
   bool use_lines_ = false;
   DeviceBuffer<uint8_t> lines_;
   int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)
+  bool init_per_class_ = false;
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;
   // ranking: per-query tables of the training data (ranking_gradients)

@@ -437,13 +437,19 @@ class HostEngine : public Engine {
   }
 
   void reset_scores(double v) override {
+    // initial scores: one vector for every class, or one per class ([class][root row])
+    auto class_offset = [&](const std::vector<double>& is, int64_t rows) {
+      return (int64_t)is.size() >= (int64_t)(cls_ + 1) * rows && (int64_t)is.size() > rows ? (size_t)cls_ * (size_t)rows : (size_t)0;
+    };
     const auto& is = train_->root_init_score();
+    const size_t off = class_offset(is, N_);
     double* s = sc();
-    for (int32_t r : base_) s[r] = v + (is.empty() ? 0.0 : is[(size_t)r]);
+    for (int32_t r : base_) s[r] = v + (is.empty() ? 0.0 : is[off + (size_t)r]);
     for (auto& vs : valid_) {
       const auto& vis = vs.ds->root_init_score();
+      const size_t voff = class_offset(vis, vs.stride);
       double* t = vsc(vs);
-      for (int32_t r : vs.rows) t[r] = v + (vis.empty() ? 0.0 : vis[(size_t)r]);
+      for (int32_t r : vs.rows) t[r] = v + (vis.empty() ? 0.0 : vis[voff + (size_t)r]);
     }
   }
   void scale_scores(int which, double f) override {

@@ -66,8 +66,6 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
         predictor = Booster(model_file=init_model)
     elif isinstance(init_model, Booster):
         predictor = init_model
-    if predictor is not None and predictor.num_model_per_iteration() > 1:
-        raise LightGBMError("continued training (init_model) of a multiclass model is not supported")
     if predictor is not None:
         # continue training: the old model's raw predictions become the data's initial scores
         raw = train_set.data

@@ -357,6 +357,28 @@ def test_gpu_multiclass_matches_cpu(objective):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
 
 
+def test_gpu_multiclass_per_class_initial_scores():
+    """[rows, classes] initial scores (continued training): the device adds class k's slice to class k's
+    scores, for the training data and for a validation set of its own."""
+    rng = np.random.RandomState(8)
+    X = rng.randn(20000, 6)
+    y = (X @ rng.randn(6, 3)).argmax(axis=1).astype(np.float64)
+    p = {"objective": "multiclass", "num_class": 3, "num_leaves": 15, "metric": "multi_logloss"}
+    first = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 3)
+    out = {}
+    for name, dev in (("cpu", CPU), ("gpu", GPU)):
+        d = lgb.Dataset(X, label=y, params=dev, free_raw_data=False)
+        dv = lgb.Dataset(X[:5000], label=y[:5000], reference=d, params=dev, free_raw_data=False)
+        ev = {}
+        b = lgb.train({**dev, **p}, d, 3, init_model=first, valid_sets=[d, dv], evals_result=ev, keep_training_booster=True)
+        assert b.num_trees() == 18
+        np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True), atol=1e-9)
+        np.testing.assert_allclose(b._inner_predict(0, raw=True), b.predict(X[:5000], raw_score=True), atol=1e-9)
+        out[name] = ev
+    for k in ("training", "valid_1"):
+        assert abs(out["cpu"][k]["multi_logloss"][-1] - out["gpu"][k]["multi_logloss"][-1]) < 1e-3
+
+
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
 def test_device_predictor_serves_multiclass_models(objective):
     """One pass per class over device-resident rows plus the softmax / sigmoid kernel, against the host predictor:

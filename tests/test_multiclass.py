@@ -175,3 +175,29 @@ def test_auc_mu_is_the_mean_pairwise_auc():
             pairs.append(roc_auc_score(y[m] == j, raw[m, j] - raw[m, i]))
     assert list(ev["training"]) == ["multi_logloss", "auc_mu"]
     assert ev["training"]["auc_mu"][-1] == pytest.approx(np.mean(pairs), abs=1e-9)
+
+
+def test_continued_training_of_a_multiclass_model():
+    # 4 + 4 rounds through init_model equal 8 rounds in one go (no bagging, nothing random in between)
+    rng = np.random.RandomState(11)
+    X = rng.randn(900, 6)
+    y = (np.digitize(X[:, 0] + 0.5 * X[:, 1], [-0.6, 0.6])).astype(float)
+    p = {"device_type": "cpu", "verbose": -1, "objective": "multiclass", "num_class": 3, "min_data_in_leaf": 10,
+         "num_leaves": 7}
+    whole = lgb.train(p, lgb.Dataset(X, label=y), 8)
+    first = lgb.train(p, lgb.Dataset(X, label=y), 4)
+    d = lgb.Dataset(X, label=y, free_raw_data=False)
+    dv = lgb.Dataset(X[:300], label=y[:300], reference=d, free_raw_data=False)
+    ev = {}
+    more = lgb.train(p, d, 4, init_model=first, valid_sets=[dv], evals_result=ev)
+    assert more.num_trees() == 24
+    np.testing.assert_allclose(more.predict(X), whole.predict(X), rtol=1e-6, atol=1e-9)
+    pr = more.predict(X[:300])
+    ll = -np.mean(np.log(pr[np.arange(300), y[:300].astype(int)]))
+    assert ev["valid_0"]["multi_logloss"][-1] == pytest.approx(ll, rel=1e-9)
+    # per-class initial scores given directly: [rows, classes]
+    init = first.predict(X, raw_score=True)
+    d2 = lgb.Dataset(X, label=y, init_score=init)
+    b2 = lgb.train(p, d2, 4)
+    np.testing.assert_allclose(b2.predict(X, raw_score=True) + init, more.predict(X, raw_score=True), rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(d2.get_init_score().reshape(3, -1).T, init)
