@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import pytest
 
+import lightgbm_amd as lgb
 from lightgbm_amd.sklearn import LGBMClassifier, LGBMRandomForestRegressor, LGBMRegressor
 from lightgbm_amd.utils.datasets import make_curve_1d, make_regression
 
@@ -52,6 +53,29 @@ def test_cli_train_predict_convert(tmp_path):
     assert np.corrcoef(p, y)[0, 1] > 0.9
     r = run("task=convert_model", f"input_model={model}", f"convert_model={js}")
     assert r.returncode == 0 and len(json.load(open(js))["tree_info"]) == 20
+
+
+def test_cli_continues_a_multiclass_model(tmp_path):
+    # input_model on task=train: 4 + 4 iterations of a 3-class model equal 8 in one go
+    rng = np.random.RandomState(0)
+    X = rng.randn(600, 5)
+    y = np.digitize(X[:, 0] + 0.5 * X[:, 1], [-0.6, 0.6])
+    data = str(tmp_path / "train.csv")
+    np.savetxt(data, np.column_stack([y, X]), delimiter=",", fmt="%.6f")
+    env = {**os.environ, "LGA_FORCE_HOST": "1", "PYTHONPATH": ROOT}
+    common = ["task=train", f"data={data}", "objective=multiclass", "num_class=3", "device_type=cpu", "verbose=-1",
+              "min_data_in_leaf=10", "num_leaves=7"]
+    run = lambda *a: subprocess.run([sys.executable, "-m", "lightgbm_amd.cli", *common, *a], cwd=ROOT, env=env,
+                                    capture_output=True, text=True, timeout=300)
+    m4, m8, w8 = (str(tmp_path / n) for n in ("m4.txt", "m8.txt", "w8.txt"))
+    for args in (["num_iterations=4", f"output_model={m4}"], ["num_iterations=4", f"input_model={m4}", f"output_model={m8}"],
+                 ["num_iterations=8", f"output_model={w8}"]):
+        r = run(*args)
+        assert r.returncode == 0, r.stderr
+    Xr = np.loadtxt(data, delimiter=",")[:, 1:]
+    a, b = lgb.Booster(model_file=m8), lgb.Booster(model_file=w8)
+    assert a.num_trees() == b.num_trees() == 24
+    np.testing.assert_allclose(a.predict(Xr), b.predict(Xr), rtol=1e-6, atol=1e-9)
 
 
 def test_estimators_work_inside_sklearn_grid_search():
