@@ -10,7 +10,12 @@
 namespace lga {
 
 TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds) {
-  if (const char* e = std::getenv("LGA_SPEC_FLOOR")) spec_floor_ = std::atof(e);
+  if (const char* e = std::getenv("LGA_SPEC_FLOOR")) spec_lo_ = spec_hi_ = std::atof(e);
+  if (const char* e = std::getenv("LGA_SPEC_LO")) spec_lo_ = std::atof(e);
+  if (const char* e = std::getenv("LGA_SPEC_HI")) spec_hi_ = std::atof(e);
+  if (const char* e = std::getenv("LGA_SPEC_RATIO")) spec_ratio_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LGA_SPEC_ROWS_LO")) spec_rows_lo_ = std::max(1.0, std::atof(e));
+  if (const char* e = std::getenv("LGA_SPEC_ROWS_HI")) spec_rows_hi_ = std::max(spec_rows_lo_ * 2.0, std::atof(e));
   {
     const int F = ds_->num_features(), total = ds_->num_total_features();
     auto sized = [&](const std::vector<double>& v, const char* name) {
@@ -119,15 +124,17 @@ struct GrowTrace {
   bool on = std::getenv("LGA_GROW_TRACE") != nullptr;
   double total_us = 0, backend_us = 0, tail_us = 0;
   double rows_split = 0, rows_used = 0;   // rows of all partitioned leaves / of the leaves whose split was used
+  double rounds = 0, tasks = 0, est_ratio = 0;   // est_ratio: the tree's real cutoff gain over the estimate it started with
   int trees = 0;
   using clock = std::chrono::steady_clock;
   static double us(clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); }
   void report() {
     if (++trees % 100 == 0) {
       std::fprintf(stderr, "[grow trace] per tree: total %.1f us, in backend %.1f us, host %.1f us (of which after the last round %.1f us); "
-                   "rows partitioned %.0f, of used splits %.0f\n",
-                   total_us / 100, backend_us / 100, (total_us - backend_us) / 100, tail_us / 100, rows_split / 100, rows_used / 100);
-      total_us = backend_us = tail_us = rows_split = rows_used = 0;
+                   "rows partitioned %.0f, of used splits %.0f; rounds %.1f, splits computed %.0f, cutoff / estimate %.3f\n",
+                   total_us / 100, backend_us / 100, (total_us - backend_us) / 100, tail_us / 100, rows_split / 100, rows_used / 100,
+                   rounds / 100, tasks / 100, est_ratio / 100);
+      total_us = backend_us = tail_us = rows_split = rows_used = rounds = tasks = est_ratio = 0;
     }
   }
 };
@@ -220,9 +227,30 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   };
   std::vector<Flight> flights;           // oldest first
   std::vector<SplitInfo> infos;
-  // Leaves whose gain is far below the smallest gain the previous tree still used are unlikely to get
-  // their turn: they wait until the real replay asks for them (the stalled leaf itself always goes).
-  const double floor_gain = spec_floor_ * prev_cutoff_;
+  // Which leaves are worth splitting before the replay asks for them?  A leaf that enters the frontier after k
+  // splits have been chosen gets its turn iff its gain exceeds the smallest frontier maximum of the remaining
+  // choices.  The previous tree's sequence of chosen gains gives that bar as a function of k (its suffix
+  // minima, prev_bar_); residuals - and with them all gains - shrink from tree to tree, fast in the first
+  // iterations, so the bar is carried over in proportion to the root's best gain, the one gain of this tree
+  // that is known from the start.  What a wrong guess costs depends on the leaf: partitioning a leaf of a
+  // million rows for nothing costs about as much device time as a whole extra round, a leaf of a few thousand
+  // rows next to nothing, so the bar is scaled by a factor that rises with the row count, spec_lo_ .. spec_hi_.
+  double bar_scale = 1.0;
+  const double root_gain = splittable(nodes[0].best) ? nodes[0].best.gain : 0.0;
+  if (spec_ratio_ && prev_root_gain_ > 0.0 && root_gain > 0.0) {
+    bar_scale = root_gain / prev_root_gain_;
+    bar_scale = bar_scale < 0.25 ? 0.25 : (bar_scale > 1.5 ? 1.5 : bar_scale);
+  }
+  prev_root_gain_ = root_gain;
+  const double log_lo = std::log(spec_rows_lo_), log_span = std::log(spec_rows_hi_) - log_lo;
+  // n_chosen: splits chosen (really or virtually) before the leaf is considered
+  auto floor_gain_for = [&](int64_t rows, int n_chosen) {
+    if (prev_bar_.empty()) return 0.0;
+    const double bar = prev_bar_[(size_t)std::min<int>(std::max(n_chosen, 0), (int)prev_bar_.size() - 1)] * bar_scale;
+    double t = rows <= 1 ? 0.0 : (std::log((double)rows) - log_lo) / log_span;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+    return (spec_lo_ + (spec_hi_ - spec_lo_) * t) * bar;
+  };
 
   auto submit = [&](std::vector<SplitTask>&& tasks) {
     Flight f;
@@ -297,7 +325,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
           continue;
         }
         const bool is_stall_leaf = e.node == frontier.top().node;
-        if (!is_stall_leaf && e.gain < floor_gain) continue;
+        if (!is_stall_leaf && e.gain < floor_gain_for(c.best.total_cnt, budget_total - vbudget - 1)) continue;
         SplitTask t{};
         t.parent_node = e.node;
         t.left_node = (int)nodes.size();
@@ -381,14 +409,18 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   while (!flights.empty()) wait_oldest();
   stats_.materialized_splits = materialized;
   stats_.used_splits = (int)chosen.size();
-  // smallest gain that made it into this tree (0 when the tree ran out of splittable leaves first)
-  prev_cutoff_ = 0.0;
+  // the bar for the next tree: suffix minima of this tree's chosen gains (empty when the tree ran out of
+  // splittable leaves before its budget: then nothing is held back)
+  const double bar_used = prev_bar_.empty() ? 0.0 : prev_bar_.back() * bar_scale;
+  prev_bar_.clear();
   if ((int)chosen.size() == budget_total && !chosen.empty()) {
-    double m = nodes[(size_t)chosen[0]].best.gain;
-    for (int id : chosen) m = std::min(m, nodes[(size_t)id].best.gain);
-    prev_cutoff_ = m;
+    prev_bar_.resize(chosen.size());
+    double m = std::numeric_limits<double>::infinity();
+    for (size_t i = chosen.size(); i-- > 0;) {
+      m = std::min(m, nodes[(size_t)chosen[i]].best.gain);
+      prev_bar_[i] = m;
+    }
   }
-
   // Assemble the tree in LightGBM numbering by replaying the final order.
   Tree tree;
   tree.reset(cfg_.num_leaves);
@@ -463,9 +495,25 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
       else { stack.push_back(n.right); stack.push_back(n.left); }
     }
   }
+  if (g_trace.on && std::getenv("LGA_GROW_DUMP") && tree_index_ == std::atoll(std::getenv("LGA_GROW_DUMP"))) {
+    std::vector<char> is_chosen(nodes.size(), 0);
+    for (int id : chosen) is_chosen[(size_t)id] = 1;
+    const double prev_cutoff_ = prev_bar_.empty() ? 0.0 : prev_bar_.back();
+    std::fprintf(stderr, "[grow dump] tree %lld last chosen gain %.6g estimate %.6g\n", (long long)tree_index_, prev_cutoff_, bar_used);
+    for (size_t i = 0; i < nodes.size(); ++i) {
+      const Node& n = nodes[i];
+      if (n.left < 0) continue;
+      std::fprintf(stderr, "[grow dump] node %zu parent %d depth %d rows %lld gain %.6g rel %.3f chosen %d parent_chosen %d\n", i, n.parent,
+                   n.depth, (long long)n.best.total_cnt, n.best.gain, prev_cutoff_ > 0 ? n.best.gain / prev_cutoff_ : 0.0,
+                   (int)is_chosen[i], n.parent >= 0 ? (int)is_chosen[(size_t)n.parent] : 1);
+    }
+  }
   if (g_trace.on) {
     for (const Node& n : nodes) if (n.left >= 0) g_trace.rows_split += (double)n.best.total_cnt;
     for (int id : chosen) g_trace.rows_used += (double)nodes[(size_t)id].best.total_cnt;
+    g_trace.rounds += stats_.rounds;
+    g_trace.tasks += materialized;
+    g_trace.est_ratio += bar_used > 0.0 && !prev_bar_.empty() ? prev_bar_.back() / bar_used : 1.0;
     const auto t_exit = GrowTrace::clock::now();
     g_trace.total_us += GrowTrace::us(t_enter, t_exit);
     g_trace.backend_us += backend_us;

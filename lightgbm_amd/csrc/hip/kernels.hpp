@@ -14,7 +14,7 @@ constexpr int kPartThreads = 256;
 constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
 
 // Small rounds carry their task descriptors inside the kernel arguments.
-constexpr int kInlineTasks = 56;   // 56 x 64 B: the largest struct that still fits the 4 KiB kernel-argument block
+constexpr int kInlineTasks = 48;   // 48 x 64 B: leaves room for the round's other arguments in the 4 KiB kernel-argument block
 struct InlineTasks {
   SplitTask t[kInlineTasks];
   int32_t count;
@@ -24,21 +24,32 @@ struct InlineTasks {
 constexpr int kHostDataOffset = 64;
 constexpr int kFusedScanMaxFeatures = 512;
 
+// Histogram pool addressing.  A slot holds, per feature, 256 gradient words followed by 256 hessian words.
+// The slots a round creates form one contiguous region that is laid out rank-chunk-major: for each of the
+// `ranks` feature owners the chunk [slot of the round][feature of that owner][512] followed by a copy of the
+// slot header (rows, sum g, sum h), so that ONE in-place reduce-scatter over the region leaves every rank with
+// the reduced histograms of the features it scans plus the reduced totals.  ranks == 1: a slot is one
+// contiguous block.  slot_table[slot] = {word offset of the slot's rank-0 chunk, word stride between the
+// rank chunks}; the kernel that creates a slot writes its entry.
+struct PoolLayout {
+  int64_t* pool;
+  int64_t* slot_table;
+  int64_t slot_words;    // ranks * chunk_words
+  int64_t chunk_words;   // fpr * 512 + kSlotHeader
+  int32_t fpr;           // features per rank chunk
+  int32_t ranks;
+};
+// The slots created by one round: [first_slot, first_slot + n_slots).
+struct RoundSlots {
+  int32_t first_slot;
+  int32_t n_slots;
+};
+
 // Best candidate of one (leaf, feature) pair.
 struct Cand {
   double gain;
   uint64_t key;
   int64_t lg, lh;
-};
-
-// Device scan task: ScanTask + the parent's node id (for its totals).
-struct ScanTaskDev {
-  int32_t node;
-  int32_t slot;
-  int32_t parent_slot;    // -1: histogram already in `slot`
-  int32_t sibling_slot;
-  int32_t parent_node;
-  uint32_t key;           // position key of the node (per-node feature sampling)
 };
 
 struct TreeNodeDev {       // internal node of a tree for binned traversal (16 bytes, one LDS read)
@@ -114,24 +125,95 @@ struct FusedQuant {
   const uint32_t* maxbits = nullptr;
   QuantScale* qs_out = nullptr;
 };
+// Feature-tile records + separate gradient array (data with more than one feature tile, feature-parallel).
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks, int rows_per_chunk,
                const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
-               const int64_t* packed, int64_t* pool, int64_t slot_words, int64_t plane, int F, int tile_first,
-               int tile_step, int tile_count, const FusedQuant* quant, hipStream_t s);
+               const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F, int tile_first,
+               int tile_step, int tile_count, hipStream_t s);
 
-void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F, int f_first_tile, int tile_step,
-          int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
-          const SplitParams& sp, Cand* cands, hipStream_t s);
-void select(const ScanTaskDev* tasks, int n_tasks, int F, const Cand* cands, const int64_t* node_totals,
-            const QuantScale* qs, const SplitParams& sp, SplitInfo* out, Cand* best_out, hipStream_t s);
-// Fused scan + select writing into host-mapped memory and raising the completion flag `seq`.
-void scan_fused(const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks, const FeatureMeta* meta, int F,
-                int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
-                const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned* done_counter, unsigned seq,
-                hipStream_t s);
-// Feature-parallel: merge P ranks' winners (gathered [rank][task]) into SplitInfo.
-void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskDev* tasks, const int64_t* node_totals,
-                   const QuantScale* qs, const SplitParams& sp, SplitInfo* out, hipStream_t s);
+// ---- fused growth round over row lines (single feature tile) ----
+// One launch partitions the round's leaves, builds the smaller children's histograms from the same row lines
+// and - with `tail` - searches both children's best splits and hands the results to the host.  A leaf of up
+// to kSoloMaxRows rows is handled by ONE workgroup from start to finish (no atomics on global memory, no
+// second launch).  A larger leaf is cut into units of `unit_rows` rows; its units flush their LDS histograms
+// into the (zeroed) slot, the unit that finishes last runs the split search, and grow_scatter moves the rows.
+constexpr int kGrowThreads = 512;
+constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
+constexpr int kSoloMaxRows = 16384;   // upper bound of the solo limit (LDS mask words)
+struct GrowArgs {
+  NodeRange* nodes;
+  const int32_t* a0;        // row arenas a parent's `buf` selects (a0 is the bag itself for node 0)
+  const int32_t* a1;
+  int32_t* a0_dst;          // children go to the OTHER arena
+  int32_t* a1_dst;
+  uint8_t* lines;
+  int64_t N;
+  PoolLayout pool;
+  RoundSlots round;
+  int32_t F;
+  int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows, <= kMaxRowsPerPass)
+  int32_t task0;            // index of inl.t[0] among the round's tasks (rounds above kInlineTasks leaves take several launches)
+  int32_t n_tasks;          // tasks of the whole round
+  uint64_t* mask;           // [mask block][32]: go-left bits of multi-unit leaves, read by grow_scatter
+  int32_t* chunk_left;      // [mask block]
+  int32_t* task_left;       // [task of the round]: rows that went left (device copy; the tail also tells the host)
+  unsigned* tickets;        // [task of the round]: arrival counter of a multi-unit leaf's units (zero between rounds)
+  const uint64_t* cat_sets;
+  // tail (split search + hand-over)
+  int32_t tail;
+  const FeatureMeta* meta;
+  int64_t* node_totals;
+  const QuantScale* qs;
+  SplitParams sp;
+  char* host_out;
+  unsigned* done_counter;
+  unsigned seq;
+  FusedQuant quant;         // root pass: quantise the float gradients on the way (g != nullptr)
+};
+// root: the single task's "leaf" is node 0 and nothing is partitioned.  total_units = sum of the tasks' units.
+void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s);
+// Moves the rows of the multi-unit leaves of a grow_round launch (total_chunks mask blocks).
+void grow_scatter(const InlineTasks& inl, int total_chunks, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src,
+                  int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask, const int32_t* chunk_left, int32_t* task_left,
+                  hipStream_t s);
+
+// ---- split search as its own launch (distributed learners, data with several feature tiles) ----
+// Which features a rank searches: block b covers features
+//   [f_begin + (group_first + b * group_step) * group_size, + group_size)  cut at f_end.
+struct ScanRange {
+  int32_t f_begin, f_end;
+  int32_t group_size, group_first, group_step;
+  int32_t n_blocks;
+};
+struct ScanArgs {
+  const SplitTask* tasks;   // staged descriptors, or null: inl
+  int32_t n_scan;           // 2 x tasks, or 1 (root)
+  int32_t n_tasks;
+  int32_t root;
+  const FeatureMeta* meta;
+  int32_t F;
+  PoolLayout pool;
+  RoundSlots round;
+  ScanRange range;
+  int32_t my_rank;          // whose header copy holds this rank's (reduced) totals
+  int64_t* node_totals;
+  const QuantScale* qs;
+  SplitParams sp;
+  Cand* block_best;         // [n_scan][n_blocks]
+  unsigned* tickets;        // [n_scan], zero between launches
+  Cand* best_out;           // distributed: [n_scan] winners of this rank (then all-gather + merge_winners); else null
+  const int32_t* task_left;
+  char* host_out;           // not distributed: results + flag go straight to the host
+  unsigned* done_counter;
+  unsigned seq;
+};
+void scan_blocks(const InlineTasks& inl, const ScanArgs& a, hipStream_t s);
+
+// Distributed learners: merge the ranks' winners (gathered [rank][scan task]) into SplitInfo, written to the
+// host-mapped result block together with the left counts and the completion flag.
+void merge_winners(const Cand* gathered, int ranks, const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks,
+                   int root, const int64_t* node_totals, const QuantScale* qs, const SplitParams& sp,
+                   const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s);
 
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
@@ -152,8 +234,7 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 // node_sets: kCatSetWords words per internal node, read for nodes whose meta has bit 10 set (a categorical
 // split on a set of bins); may be null when the tree has none.
 // items: n_items x (slot, feature); out: n_items x 2 x kMaxBins (gradient row, hessian row).
-void gather_feature_hist(const int64_t* pool, int64_t slot_words, int64_t plane, const int32_t* items, int n_items,
-                         int64_t* out, hipStream_t s);
+void gather_feature_hist(const PoolLayout& pool, const int32_t* items, int n_items, int64_t* out, hipStream_t s);
 void scale_add(double* scores, const int32_t* rows, int64_t n, double scale, double add, hipStream_t s);
 void init_scores(double* scores, const double* init, const int32_t* rows, int64_t n, double v, hipStream_t s);
 // Reduction outputs need kReduceDoubles doubles: results first, then per-workgroup partials.
