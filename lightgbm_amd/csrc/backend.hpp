@@ -26,6 +26,11 @@ class Comm {
   virtual void allreduce_sum_i64(int64_t* buf, size_t n, bool device, void* stream) = 0;
   virtual void allreduce_sum_f64(double* buf, size_t n, bool device, void* stream) = 0;
   virtual void allreduce_max_f32(float* buf, size_t n, bool device, void* stream) = 0;
+  // In-place reduce-scatter of size() blocks of `block` words each: on return rank r's block
+  // (buf + r * block) holds the sum over ranks; the other blocks are unspecified.  The default sums everything.
+  virtual void reduce_scatter_sum_i64(int64_t* buf, size_t block, bool device, void* stream) {
+    allreduce_sum_i64(buf, block * (size_t)size(), device, stream);
+  }
   // out must hold size()*nbytes; rank r's block lands at out + r*nbytes.
   virtual void allgather_bytes(const void* in, void* out, size_t nbytes, bool device, void* stream) = 0;
 };

@@ -18,6 +18,7 @@
 #include <memory>
 #include <numeric>
 #include <sstream>
+#include <thread>
 
 namespace lga {
 
@@ -139,18 +140,26 @@ class HipBackend : public TreeBackend {
     F_ = root_->num_features();
     T_ = root_->num_tiles();
     N_ = root_->root_rows();
-    plane_ = (int64_t)T_ * kTileFeatures * kMaxBins;
-    slot_words_ = 2 * plane_ + kSlotHeader;
+    if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
+    else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
+    // Histogram pool layout (kernels.hpp: PoolLayout): the data-parallel learner splits every slot into one
+    // chunk per rank, so that one in-place reduce-scatter per round hands each rank the features it searches.
+    lay_.ranks = mode_ == ParallelMode::Data ? comm_->size() : 1;
+    lay_.fpr = lay_.ranks > 1 ? std::max(1, (F_ + lay_.ranks - 1) / lay_.ranks) : std::max(1, T_ * kTileFeatures);
+    lay_.chunk_words = (int64_t)lay_.fpr * 2 * kMaxBins + kSlotHeader;
+    lay_.slot_words = lay_.chunk_words * lay_.ranks;
+    slot_words_ = lay_.slot_words;
     int L = std::max(cfg.num_leaves, 2);
     max_batch_ = L - 1;
     capacity_splits_ = 3 * (L - 1) + 1;
     // keep the histogram pool below ~24 GiB
     while (capacity_splits_ > (L - 1) + 1 && (double)(capacity_splits_ + 1) * slot_words_ * 8.0 > 24.0 * (1u << 30))
       capacity_splits_ -= 1;
-    if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
-    else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
     stream_ = current_stream();
     pool_.resize((size_t)(capacity_splits_ + 1) * slot_words_);
+    slot_table_.resize((size_t)2 * (size_t)(capacity_splits_ + 1));
+    lay_.pool = pool_.get();
+    lay_.slot_table = slot_table_.get();
     int n_nodes = 2 * capacity_splits_ + 2;
     nodes_.resize((size_t)n_nodes + 2);   // + the bagging partition's scratch entries
     node_totals_.resize((size_t)n_nodes * 4);
@@ -159,30 +168,41 @@ class HipBackend : public TreeBackend {
     arena_[1].resize((size_t)std::max<int64_t>(max_rows, 1));
     max_pchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), k::kPartChunk) + max_batch_ + 1;
     max_hchunks_ = ceil_div(std::max<int64_t>(max_rows, 1), 1024) + max_batch_ + 1;
-    // one staging block per round context: [tasks | scan tasks | pchunk table | hchunk table]
+    // one staging block per round context: [tasks | pchunk table | hchunk table]
     off_tasks_ = 64;   // the first 64 bytes stage one NodeRange
-    off_scan_ = off_tasks_ + sizeof(SplitTask) * (size_t)(max_batch_ + 1);
-    off_pch_ = off_scan_ + sizeof(k::ScanTaskDev) * (size_t)(2 * max_batch_ + 2);
+    off_pch_ = off_tasks_ + sizeof(SplitTask) * (size_t)(max_batch_ + 1);
     off_hch_ = off_pch_ + sizeof(int32_t) * (size_t)max_pchunks_;
     stage_bytes_ = off_hch_ + sizeof(int32_t) * (size_t)max_hchunks_;
     stage_bytes_ = (stage_bytes_ + 255) & ~(size_t)255;
-    cands_.resize((size_t)(2 * max_batch_ + 2) * (size_t)std::max(F_, 1));
-    results_dev_.resize((size_t)(2 * max_batch_ + 2));
-    // Two rounds may be in flight when results travel through the mapped block (fused scan) and no
-    // per-phase event timing is requested; the second context owns a stream of its own.
     cat_.cat_smooth = cfg.cat_smooth;
     cat_.cat_l2 = cfg.cat_l2;
     cat_.max_cat_threshold = cfg.max_cat_threshold;
     cat_.min_data_per_group = cfg.min_data_per_group;
     prof.on = cfg.profile;
     if (cfg.profile || std::getenv("LGA_ROCTX")) trace_enable(true);
-    const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
-    // Small data gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on
-    // their own streams) already fill the hardware queues.
-    // Distributed learners keep one round in flight unless asked otherwise: two would put collectives of
-    // one communicator on two streams.
-    n_ctx_ = (fused && !prof.on && mode_ == ParallelMode::Serial && max_rows >= (int64_t)1 << 19) ? 2 : 1;
-    if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = (fused && !prof.on) ? std::max(1, std::min(2, std::atoi(e))) : 1;
+    // Which features this rank searches (kernels.hpp: ScanRange).
+    scan_range_ = k::ScanRange{0, F_, 64, 0, 1, std::max(1, (F_ + 63) / 64)};
+    if (mode_ == ParallelMode::Data) {
+      const int r = comm_->rank();
+      const int f0 = std::min(F_, r * lay_.fpr), f1 = std::min(F_, (r + 1) * lay_.fpr);
+      scan_range_ = k::ScanRange{f0, f1, 64, 0, 1, std::max(1, (f1 - f0 + 63) / 64)};
+    } else if (mode_ == ParallelMode::Feature) {
+      // feature tiles are dealt round-robin: rank r owns tiles r, r + P, ...
+      const int P = comm_->size(), r = comm_->rank();
+      const int owned = r < T_ ? (T_ - r + P - 1) / P : 0;
+      scan_range_ = k::ScanRange{0, F_, kTileFeatures, r, P, std::max(1, owned)};
+      if (owned == 0) scan_range_.f_end = 0;   // nothing to search: one empty block keeps the hand-over alive
+    }
+    // Two rounds may be in flight unless per-phase event timing is requested: one round's latency-bound tail
+    // (split search, result hand-over, host replay) overlaps with the other's row-level work.  Small data
+    // gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on their own
+    // streams) already fill the hardware queues.
+    n_ctx_ = (!prof.on && max_rows >= (int64_t)1 << 19) ? 2 : 1;
+    if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(2, std::atoi(e)));
+    if (const char* e = std::getenv("LGA_SOLO_ROWS"))
+      solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
+    if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
+    const size_t n_scan_max = (size_t)(2 * max_batch_ + 2);
     for (int c = 0; c < n_ctx_; ++c) {
       RoundCtx& x = ctx_[c];
       if (c == 0) x.stream = stream_;
@@ -197,11 +217,17 @@ class HipBackend : public TreeBackend {
       x.stage_host.resize(stage_bytes_);
       x.stage_dev.resize(stage_bytes_);
       // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
-      x.host_block.resize(k::kHostDataOffset + sizeof(SplitInfo) * (size_t)(2 * max_batch_ + 2) +
-                          sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+      x.host_block.resize(k::kHostDataOffset + sizeof(SplitInfo) * n_scan_max + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
       std::memset(x.host_block.get(), 0, x.host_block.size());
-      x.done_counter.resize(4);
-      x.done_counter.zero(stream_);
+      // counters the kernels leave at zero: [round completion | per-task unit tickets | per-scan-task block tickets]
+      x.counters.resize(4 + (size_t)(max_batch_ + 1) + n_scan_max);
+      x.counters.zero(stream_);
+      x.block_best.resize(n_scan_max * (size_t)scan_range_.n_blocks);
+      x.scan_totals.resize(n_scan_max * 4);
+      if (mode_ != ParallelMode::Serial) {
+        x.best_local.resize(n_scan_max);
+        x.best_all.resize(n_scan_max * (size_t)comm_->size());
+      }
     }
     // Distributed learners with two rounds in flight: every collective goes through ONE stream of its own,
     // in submission order (the same on every rank), tied to the rounds' streams by events - a communicator
@@ -211,10 +237,6 @@ class HipBackend : public TreeBackend {
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     meta_dev_.resize((size_t)std::max(F_, 1));
     qs_dev_.resize(1);
-    if (mode_ == ParallelMode::Feature) {
-      best_local_.resize((size_t)(2 * max_batch_ + 2));
-      best_all_.resize((size_t)(2 * max_batch_ + 2) * (size_t)comm_->size());
-    }
     prof.init();
   }
   ~HipBackend() override {
@@ -228,8 +250,10 @@ class HipBackend : public TreeBackend {
   }
 
   void set_bag(const int32_t* rows_dev, int64_t n) { bag_ = rows_dev; bag_n_ = n; }
-  // packed_dev == nullptr: `rows_src` are row lines that carry the gradients (kernels.hpp: build_row_lines)
-  void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) { packed_ = packed_dev; hist_src_ = rows_src; }
+  // Row lines (kernels.hpp: build_row_lines) carry the gradients themselves and take the fused growth rounds.
+  void set_lines(uint8_t* lines) { lines_ = lines; packed_ = nullptr; hist_src_ = nullptr; }
+  // Feature-tile records + a separate array of packed gradients.
+  void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) { packed_ = packed_dev; hist_src_ = rows_src; lines_ = nullptr; }
   // Row lines only: the root pass quantises these float gradients itself (no separate quantisation kernel).
   void set_root_quant(const float* g, const float* h, const uint32_t* maxbits) {
     root_quant_ = k::FusedQuant{g, h, maxbits, qs_dev_.get()};
@@ -409,31 +433,166 @@ class HipBackend : public TreeBackend {
     DeviceBuffer<char> stage_dev;
     PinnedBuffer<char> stage_host;
     MappedBuffer host_block;
-    DeviceBuffer<unsigned> done_counter;
+    DeviceBuffer<unsigned> counters;
+    DeviceBuffer<k::Cand> block_best, best_local, best_all;
+    DeviceBuffer<int64_t> scan_totals;
     unsigned seq = 0;
     // the round in flight
-    bool busy = false, root = false, fused = false;
+    bool busy = false, root = false;
     std::vector<SplitTask> tasks;
     std::chrono::steady_clock::time_point t_begin, t_launched;
+    unsigned* done_counter() const { return counters.get(); }
+    unsigned* unit_tickets() const { return counters.get() + 4; }
+    unsigned* scan_tickets(int max_batch) const { return counters.get() + 4 + (size_t)(max_batch + 1); }
   };
 
   void upload_stage(RoundCtx& x, size_t bytes) {
     LGA_HIP_CHECK(hipMemcpyAsync(x.stage_dev.get(), x.stage_host.get(), bytes, hipMemcpyHostToDevice, x.stream));
   }
 
-  // Enqueues one growth round on the context's stream.  root: no partition, a single scan task.  Rounds
-  // of <= kInlineTasks leaves carry their descriptors in the kernel arguments; results come back through
-  // host-mapped memory and a completion flag, so such a round costs 4 kernel launches and no copy.
+  // Node tables the split search reads (monotone ranges / path smoothing, interaction masks): the entries of
+  // this round's children go up before the round's first kernel.
+  void upload_node_tables(const std::vector<SplitTask>& tasks, hipStream_t st_) {
+    if (!ranged_ && !masked_) return;
+    int first = tasks[0].left_node, last = tasks[0].right_node;   // the children of a round's tasks have consecutive node ids
+    for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
+    if (ranged_)
+      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get() + kNodeInfoStride * (size_t)first,
+                                   bounds_host_.get() + kNodeInfoStride * (size_t)first,
+                                   kNodeInfoStride * sizeof(double) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    if (masked_) {
+      const size_t W = (size_t)sp_.mask_words;
+      LGA_HIP_CHECK(hipMemcpyAsync(masks_dev_.get() + W * (size_t)first, masks_host_.get() + W * (size_t)first,
+                                   W * sizeof(uint64_t) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    }
+  }
+  void upload_cat_sets(const std::vector<SplitTask>& tasks, hipStream_t st_) {
+    // splits on category sets: the sets of this round's parents go up before the partition reads them
+    if (sorted_cat_.empty()) return;
+    for (const auto& t : tasks)
+      if (t.default_left == kCategoricalSetTask)
+        LGA_HIP_CHECK(hipMemcpyAsync(cat_sets_dev_.get() + (size_t)t.parent_node * kCatSetWords,
+                                     cat_sets_host_.get() + (size_t)t.parent_node * kCatSetWords,
+                                     sizeof(uint64_t) * kCatSetWords, hipMemcpyHostToDevice, st_));
+  }
+
+  // Enqueues one growth round on the context's stream; results come back through host-mapped memory and a
+  // completion flag.  root: no partition, a single scan task.
   void launch_round(RoundCtx& x, std::vector<SplitTask>& tasks, bool root) {
     if (x.busy) throw std::runtime_error("round context is still in flight");
     const int B = (int)tasks.size();
     if (B > max_batch_) throw std::runtime_error("split batch exceeds backend capacity");
-    const int n_scan = root ? 1 : 2 * B;
-    hipStream_t st_ = x.stream;
     x.t_begin = std::chrono::steady_clock::now();
     if (!root) prof.host_between_ms += std::chrono::duration<double, std::milli>(x.t_begin - prof.last_end).count();
-    const bool fused = mode_ != ParallelMode::Feature && F_ <= k::kFusedScanMaxFeatures;
-    const bool inline_tasks = fused && B <= k::kInlineTasks;
+    if (++x.seq == 0) ++x.seq;   // never 0
+    prof.mark(PhaseProfile::kUpload, x.stream);
+    trace_push(root ? "lga.root_round" : "lga.split_round");
+    if (!root) {
+      upload_cat_sets(tasks, x.stream);
+      upload_node_tables(tasks, x.stream);
+    }
+    const k::RoundSlots round{tasks[0].new_slot, root ? 1 : B};
+    // a round's new slots are consecutive (the grower hands them out in task order)
+    for (int i = 0; i < B; ++i)
+      if (tasks[(size_t)i].new_slot != round.first_slot + i) throw std::runtime_error("round slots are not consecutive");
+    if (lines_) launch_lines(x, tasks, root, round);
+    else launch_tiles(x, tasks, root, round);
+    trace_pop();
+    x.busy = true;
+    x.root = root;
+    x.tasks = tasks;
+    x.t_launched = std::chrono::steady_clock::now();
+    prof.host_launch_ms += std::chrono::duration<double, std::milli>(x.t_launched - x.t_begin).count();
+  }
+
+  bool distributed() const { return mode_ != ParallelMode::Serial; }
+
+  // ---- fused rounds over row lines (one feature tile; serial and data-parallel) ----
+  void launch_lines(RoundCtx& x, std::vector<SplitTask>& tasks, bool root, k::RoundSlots round) {
+    const int B = (int)tasks.size();
+    hipStream_t st_ = x.stream;
+    const bool tail = !distributed();
+    // units: a leaf of up to solo_rows_ rows is one workgroup's; larger ones are cut into units of unit_rows
+    int64_t multi_rows = 0;
+    int n_multi = 0;
+    for (const auto& t : tasks) {
+      const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
+      if (root || cnt > solo_rows_) { multi_rows += cnt; ++n_multi; }
+    }
+    int64_t ur = (multi_rows + target_units_ - 1) / target_units_;
+    ur = ((ur + k::kSubRows - 1) / k::kSubRows) * k::kSubRows;
+    ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, std::min(kMaxRowsPerPass, k::kSoloMaxRows)));
+    const int unit_rows = (int)ur;
+    int np = 0;
+    for (auto& t : tasks) {
+      const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
+      const bool multi = root || cnt > solo_rows_;
+      t.first_pchunk = np;
+      t.num_pchunk = (multi && !root) ? ceil_div(cnt, k::kPartChunk) : 0;
+      t.num_hchunk = multi ? std::max(1, ceil_div(cnt, unit_rows)) : 1;
+      np += t.num_pchunk;
+      if (np > max_pchunks_) throw std::runtime_error("chunk table overflow");
+    }
+    // multi-unit leaves add their histograms with atomics: their slots start at zero
+    if (n_multi > 0 && !root) {
+      int lo = B, hi = -1;
+      for (int i = 0; i < B; ++i)
+        if (tasks[(size_t)i].num_pchunk > 0) { lo = std::min(lo, i); hi = std::max(hi, i); }
+      if (lay_.ranks > 1) { lo = 0; hi = B - 1; }   // a slot's rank chunks are spread over the round's region
+      LGA_HIP_CHECK(hipMemsetAsync(pool_.get() + (size_t)(round.first_slot + lo) * slot_words_, 0,
+                                   sizeof(int64_t) * (size_t)slot_words_ * (size_t)(hi - lo + 1), st_));
+    }
+    const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
+    prof.mark(PhaseProfile::kPartition, st_);
+    k::GrowArgs a{};
+    a.nodes = nodes_.get();
+    a.a0 = src0; a.a1 = arena_[1].get();
+    a.a0_dst = arena_[0].get(); a.a1_dst = arena_[1].get();
+    a.lines = lines_; a.N = N_;
+    a.pool = lay_; a.round = round;
+    a.F = F_; a.unit_rows = unit_rows;
+    a.n_tasks = root ? 1 : B;
+    a.mask = x.mask.get(); a.chunk_left = x.chunk_left.get(); a.task_left = x.task_left.get();
+    a.tickets = x.unit_tickets();
+    a.cat_sets = cat_sets_dev_.get();
+    a.tail = tail ? 1 : 0;
+    a.meta = meta_dev_.get(); a.node_totals = node_totals_.get(); a.qs = qs_dev_.get(); a.sp = sp_;
+    a.host_out = x.host_block.device_ptr(); a.done_counter = x.done_counter(); a.seq = x.seq;
+    if (root) a.quant = root_quant_;
+    for (int g0 = 0; g0 < B; g0 += k::kInlineTasks) {
+      const int gn = std::min(k::kInlineTasks, B - g0);
+      k::InlineTasks inl{};
+      inl.count = gn;
+      int units = 0, chunks = 0;
+      for (int i = 0; i < gn; ++i) {
+        SplitTask& t = tasks[(size_t)(g0 + i)];
+        t.first_hchunk = units;
+        units += t.num_hchunk;
+        chunks += t.num_pchunk;
+        inl.t[i] = t;
+      }
+      a.task0 = g0;
+      k::grow_round(inl, a, units, root, st_);
+      if (chunks > 0)
+        k::grow_scatter(inl, tasks[(size_t)g0].first_pchunk, chunks, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
+                        arena_[1].get(), x.mask.get(), x.chunk_left.get(), x.task_left.get() + g0, st_);
+    }
+    prof.mark(PhaseProfile::kHist, st_);
+    if (tail) {
+      prof.mark(PhaseProfile::kComm, st_);
+      prof.mark(PhaseProfile::kScan, st_);
+      prof.mark(PhaseProfile::kFetch, st_);
+      prof.mark(PhaseProfile::kCount, st_);
+      return;
+    }
+    finish_distributed(x, tasks, root, round, /*staged=*/nullptr);
+  }
+
+  // ---- rounds over feature-tile records (several tiles, or feature-parallel) ----
+  void launch_tiles(RoundCtx& x, std::vector<SplitTask>& tasks, bool root, k::RoundSlots round) {
+    const int B = (int)tasks.size();
+    hipStream_t st_ = x.stream;
+    const bool inline_tasks = B <= k::kInlineTasks;
     int64_t total_rows = 0;
     for (const auto& t : tasks) total_rows += root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
     const int hch = pick_hist_chunk(total_rows);
@@ -463,25 +622,11 @@ class HipBackend : public TreeBackend {
     const SplitTask* dt = nullptr;
     const int32_t* dpc = nullptr;
     const int32_t* dhc = nullptr;
-    prof.mark(PhaseProfile::kUpload, st_);
     if (inline_tasks) {
       inl.count = B;
       std::memcpy(inl.t, tasks.data(), sizeof(SplitTask) * (size_t)B);
     } else {
       std::memcpy(st + off_tasks_, tasks.data(), sizeof(SplitTask) * (size_t)B);
-      if (!fused) {
-        k::ScanTaskDev* sd = reinterpret_cast<k::ScanTaskDev*>(st + off_scan_);
-        for (int i = 0; i < n_scan; ++i) {
-          const SplitTask& t = tasks[(size_t)(i >> 1)];
-          const int side = i & 1;
-          k::ScanTaskDev& sdt = sd[i];
-          sdt.node = side == 0 ? t.left_node : t.right_node;
-          sdt.parent_node = t.parent_node;
-          sdt.key = root ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
-          if (side == t.hist_child) { sdt.slot = t.new_slot; sdt.parent_slot = -1; sdt.sibling_slot = -1; }
-          else { sdt.slot = t.parent_slot; sdt.parent_slot = t.parent_slot; sdt.sibling_slot = t.new_slot; }
-        }
-      }
       upload_stage(x, off_hch_ + sizeof(int32_t) * (size_t)nh);
       dt = reinterpret_cast<const SplitTask*>(x.stage_dev.get() + off_tasks_);
       dpc = reinterpret_cast<const int32_t*>(x.stage_dev.get() + off_pch_);
@@ -491,22 +636,12 @@ class HipBackend : public TreeBackend {
     // copying the row list.  Only the root round and the round that splits the root ever touch node 0.
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
     prof.mark(PhaseProfile::kPartition, st_);
-    trace_push(root ? "lga.root_round" : "lga.split_round");
     if (!root) {
       k::BagParams part{};
-      if (!sorted_cat_.empty()) {
-        // splits on category sets: the sets of this round's parents go up before the partition reads them
-        part.cat_sets = cat_sets_dev_.get();
-        for (const auto& t : tasks)
-          if (t.default_left == kCategoricalSetTask)
-            LGA_HIP_CHECK(hipMemcpyAsync(cat_sets_dev_.get() + (size_t)t.parent_node * kCatSetWords,
-                                         cat_sets_host_.get() + (size_t)t.parent_node * kCatSetWords,
-                                         sizeof(uint64_t) * kCatSetWords, hipMemcpyHostToDevice, st_));
-      }
+      part.cat_sets = cat_sets_dev_.get();
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
-                   part, pool_.get() + (size_t)tasks[0].new_slot * slot_words_,
-                   (int64_t)slot_words_ * B, st_);
+                   part, pool_.get() + (size_t)round.first_slot * slot_words_, (int64_t)slot_words_ * B, st_);
     }
     prof.mark(PhaseProfile::kHist, st_);
     {
@@ -517,80 +652,96 @@ class HipBackend : public TreeBackend {
         if (owned > 0) { tile_first = r; tile_step = P; tile_count = owned; }
         else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
       }
-      k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_,
-                   packed_, pool_.get(), slot_words_, plane_, F_, tile_first, tile_step, tile_count,
-                   root ? &root_quant_ : nullptr, st_);
+      k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_, packed_, lay_, round, F_,
+                   tile_first, tile_step, tile_count, st_);
     }
+    if (distributed()) { finish_distributed(x, tasks, root, round, dt); return; }
     prof.mark(PhaseProfile::kComm, st_);
-    if (mode_ == ParallelMode::Data) {
-      hipStream_t cs = st_;
-      if (comm_stream_) {
-        LGA_HIP_CHECK(hipEventRecord(x.ev_ready, st_));
-        LGA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, x.ev_ready, 0));
-        cs = comm_stream_;
-      }
-      comm_->allreduce_sum_i64(pool_.get() + (size_t)tasks[0].new_slot * slot_words_, (size_t)B * slot_words_, true, cs);
-      if (comm_stream_) {
-        LGA_HIP_CHECK(hipEventRecord(x.ev_reduced, comm_stream_));
-        LGA_HIP_CHECK(hipStreamWaitEvent(st_, x.ev_reduced, 0));
-      }
-    }
     prof.mark(PhaseProfile::kScan, st_);
-    if (ranged_ && !root) {
-      // the children of a round's tasks have consecutive node ids
-      int first = tasks[0].left_node, last = tasks[0].right_node;
-      for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
-      LGA_HIP_CHECK(hipMemcpyAsync(bounds_dev_.get() + kNodeInfoStride * (size_t)first,
-                                   bounds_host_.get() + kNodeInfoStride * (size_t)first,
-                                   kNodeInfoStride * sizeof(double) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    k::ScanArgs sa = scan_args(x, root, B, round);
+    sa.tasks = dt;
+    sa.host_out = x.host_block.device_ptr();
+    k::scan_blocks(inl, sa, root ? 1 : 2 * B, st_);
+    prof.mark(PhaseProfile::kFetch, st_);
+    prof.mark(PhaseProfile::kCount, st_);
+  }
+
+  k::ScanArgs scan_args(RoundCtx& x, bool root, int B, k::RoundSlots round) {
+    k::ScanArgs sa{};
+    sa.task0 = 0;
+    sa.n_scan = root ? 1 : 2 * B;
+    sa.n_tasks = root ? 0 : B;
+    sa.root = root ? 1 : 0;
+    sa.meta = meta_dev_.get();
+    sa.F = F_;
+    sa.pool = lay_;
+    sa.round = round;
+    sa.range = scan_range_;
+    sa.my_rank = lay_.ranks > 1 ? comm_->rank() : 0;
+    sa.node_totals = node_totals_.get();
+    sa.scan_totals = x.scan_totals.get();
+    sa.qs = qs_dev_.get();
+    sa.sp = sp_;
+    sa.block_best = x.block_best.get();
+    sa.tickets = x.scan_tickets(max_batch_);
+    sa.task_left = x.task_left.get();
+    sa.done_counter = x.done_counter();
+    sa.seq = x.seq;
+    return sa;
+  }
+
+  // Distributed tail of a round.  Data-parallel: ONE in-place reduce-scatter over the round's slots leaves
+  // this rank with the summed histograms of the features it owns (and the summed totals); it searches those,
+  // the ranks' winners (32 bytes per child) are all-gathered and every rank merges them the same way.
+  // Feature-parallel: every rank already holds the full rows of its tiles; only the winners travel.
+  // With two rounds in flight the collectives (and what sits between them) run on the one stream that
+  // carries every collective, in submission order.
+  void finish_distributed(RoundCtx& x, const std::vector<SplitTask>& tasks, bool root, k::RoundSlots round,
+                          const SplitTask* staged) {
+    const int B = (int)tasks.size();
+    hipStream_t st_ = x.stream;
+    prof.mark(PhaseProfile::kComm, st_);
+    hipStream_t cs = st_;
+    if (comm_stream_) {
+      LGA_HIP_CHECK(hipEventRecord(x.ev_ready, st_));
+      LGA_HIP_CHECK(hipStreamWaitEvent(comm_stream_, x.ev_ready, 0));
+      cs = comm_stream_;
     }
-    if (masked_ && !root) {
-      int first = tasks[0].left_node, last = tasks[0].right_node;
-      for (const auto& t : tasks) { first = std::min(first, t.left_node); last = std::max(last, t.right_node); }
-      const size_t W = (size_t)sp_.mask_words;
-      LGA_HIP_CHECK(hipMemcpyAsync(masks_dev_.get() + W * (size_t)first, masks_host_.get() + W * (size_t)first,
-                                   W * sizeof(uint64_t) * (size_t)(last - first + 1), hipMemcpyHostToDevice, st_));
+    if (mode_ == ParallelMode::Data) {
+      int64_t* region = pool_.get() + (size_t)round.first_slot * slot_words_;
+      const size_t block = (size_t)round.n_slots * (size_t)lay_.chunk_words;
+      // features searched over category sets need their full rows on every rank: sum everything then
+      if (sorted_cat_.empty()) comm_->reduce_scatter_sum_i64(region, block, true, cs);
+      else comm_->allreduce_sum_i64(region, block * (size_t)lay_.ranks, true, cs);
     }
-    char* hres = x.host_block.get() + k::kHostDataOffset;
-    if (fused) {
-      if (++x.seq == 0) ++x.seq;   // never 0
-      k::scan_fused(dt, inl, n_scan, root ? 0 : B, meta_dev_.get(), F_, pool_.get(), slot_words_, plane_,
-                    node_totals_.get(), qs_dev_.get(), sp_, x.task_left.get(), x.host_block.device_ptr(),
-                    x.done_counter.get(), x.seq, st_);
-      prof.mark(PhaseProfile::kFetch, st_);
-      prof.mark(PhaseProfile::kCount, st_);
+    prof.mark(PhaseProfile::kScan, cs);
+    const int n_scan = root ? 1 : 2 * B;
+    k::ScanArgs sa = scan_args(x, root, B, round);
+    sa.best_out = x.best_local.get();
+    if (staged || root) {
+      k::InlineTasks inl{};
+      if (root) { inl.count = 1; inl.t[0] = tasks[0]; }
+      sa.tasks = root ? nullptr : staged;
+      k::scan_blocks(inl, sa, n_scan, cs);
     } else {
-      const k::ScanTaskDev* ds = reinterpret_cast<const k::ScanTaskDev*>(x.stage_dev.get() + off_scan_);
-      int first = 0, step = 1;
-      if (mode_ == ParallelMode::Feature) { first = comm_->rank(); step = comm_->size(); }
-      k::scan(ds, n_scan, meta_dev_.get(), F_, first, step, pool_.get(), slot_words_, plane_, node_totals_.get(),
-              qs_dev_.get(), sp_, cands_.get(), st_);
-      if (mode_ == ParallelMode::Feature) {
-        k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(),
-                  best_local_.get(), st_);
-        comm_->allgather_bytes(best_local_.get(), best_all_.get(), sizeof(k::Cand) * (size_t)n_scan, true, st_);
-        k::merge_winners(best_all_.get(), comm_->size(), n_scan, ds, node_totals_.get(), qs_dev_.get(), sp_,
-                         results_dev_.get(), st_);
-      } else {
-        k::select(ds, n_scan, F_, cands_.get(), node_totals_.get(), qs_dev_.get(), sp_, results_dev_.get(), nullptr,
-                  st_);
+      for (int g0 = 0; g0 < B; g0 += k::kInlineTasks) {
+        const int gn = std::min(k::kInlineTasks, B - g0);
+        k::InlineTasks inl{};
+        inl.count = gn;
+        for (int i = 0; i < gn; ++i) inl.t[i] = tasks[(size_t)(g0 + i)];
+        sa.task0 = g0;
+        k::scan_blocks(inl, sa, 2 * gn, cs);
       }
-      prof.mark(PhaseProfile::kFetch, st_);
-      size_t off = sizeof(SplitInfo) * (size_t)n_scan;
-      LGA_HIP_CHECK(hipMemcpyAsync(hres, results_dev_.get(), off, hipMemcpyDeviceToHost, st_));
-      if (!root)
-        LGA_HIP_CHECK(hipMemcpyAsync(hres + off, x.task_left.get(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, st_));
-      LGA_HIP_CHECK(hipMemcpyAsync(hres + off + sizeof(int32_t) * (size_t)(root ? 0 : B), qs_dev_.get(),
-                                   sizeof(QuantScale), hipMemcpyDeviceToHost, st_));
-      prof.mark(PhaseProfile::kCount, st_);
     }
-    trace_pop();
-    x.busy = true;
-    x.root = root;
-    x.fused = fused;
-    x.tasks = tasks;
-    x.t_launched = std::chrono::steady_clock::now();
-    prof.host_launch_ms += std::chrono::duration<double, std::milli>(x.t_launched - x.t_begin).count();
+    comm_->allgather_bytes(x.best_local.get(), x.best_all.get(), sizeof(k::Cand) * (size_t)n_scan, true, cs);
+    k::merge_winners(x.best_all.get(), comm_->size(), n_scan, root ? 0 : B, x.scan_totals.get(), qs_dev_.get(), sp_,
+                     x.task_left.get(), x.host_block.device_ptr(), x.seq, cs);
+    if (comm_stream_) {
+      LGA_HIP_CHECK(hipEventRecord(x.ev_reduced, comm_stream_));
+      LGA_HIP_CHECK(hipStreamWaitEvent(st_, x.ev_reduced, 0));
+    }
+    prof.mark(PhaseProfile::kFetch, st_);
+    prof.mark(PhaseProfile::kCount, st_);
   }
 
   // Waits for the round of this context and hands its results over.
@@ -598,11 +749,10 @@ class HipBackend : public TreeBackend {
     if (!x.busy) throw std::runtime_error("no round in flight on this context");
     const auto t_wait = std::chrono::steady_clock::now();
     TraceRange wait_range("lga.wait_round");
-    if (x.fused) {
-      wait_flag(x);
-      if (prof.on) LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
-    } else {
+    wait_flag(x);
+    if (prof.on) {
       LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
+      if (comm_stream_) LGA_HIP_CHECK(hipStreamSynchronize(comm_stream_));
     }
     prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_wait).count();
     prof.collect(PhaseProfile::kCount);
@@ -664,7 +814,7 @@ class HipBackend : public TreeBackend {
     const int n_items = n_scan * nf;
     LGA_HIP_CHECK(hipMemcpyAsync(cat_items_dev_.get(), cat_items_host_.get(), sizeof(int32_t) * 2 * (size_t)n_items,
                                  hipMemcpyHostToDevice, x.stream));
-    k::gather_feature_hist(pool_.get(), slot_words_, plane_, cat_items_dev_.get(), n_items, cat_hist_dev_.get(), x.stream);
+    k::gather_feature_hist(lay_, cat_items_dev_.get(), n_items, cat_hist_dev_.get(), x.stream);
     LGA_HIP_CHECK(hipMemcpyAsync(cat_hist_host_.get(), cat_hist_dev_.get(), sizeof(int64_t) * 2 * kMaxBins * (size_t)n_items,
                                  hipMemcpyDeviceToHost, x.stream));
     LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
@@ -701,14 +851,18 @@ class HipBackend : public TreeBackend {
     }
   }
 
-  // Polls the completion flag the last scan workgroup writes into host-mapped memory.  The stream is
+  // Waits for the completion flag the round's last workgroup writes into host-mapped memory.  A short spin
+  // catches the common case (a round takes tens of microseconds); after that the thread yields its core between
+  // polls, so many boosters - cross-validation folds, grid rows - can wait on few cores.  The stream is
   // queried now and then so that a failed launch surfaces as an error instead of an endless wait.
   void wait_flag(RoundCtx& x) {
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(x.host_block.get());
     const unsigned seq = x.seq;
     unsigned spins = 0;
     while (*flag != seq) {
-      if ((++spins & 4095u) == 0) {
+      ++spins;
+      if (spins > kSpinBeforeYield) std::this_thread::yield();
+      if ((spins & 4095u) == 0) {
         hipError_t q = hipStreamQuery(x.stream);
         if (q == hipSuccess) {
           if (*flag == seq) break;
@@ -721,6 +875,7 @@ class HipBackend : public TreeBackend {
 #endif
     }
   }
+  static constexpr unsigned kSpinBeforeYield = 2000;   // ~20-40 us of pause-spinning
 
   const Dataset* root_;
   DeviceMirror* mir_;
@@ -729,21 +884,23 @@ class HipBackend : public TreeBackend {
   hipStream_t stream_ = nullptr;
   hipStream_t comm_stream_ = nullptr;   // distributed, two rounds in flight: the one stream collectives run on
   int F_ = 0, T_ = 0;
-  int64_t N_ = 0, plane_ = 0, slot_words_ = 0;
+  int64_t N_ = 0, slot_words_ = 0;
   int capacity_splits_ = 0, max_batch_ = 0, max_pchunks_ = 0, max_hchunks_ = 0;
-  DeviceBuffer<int64_t> pool_;
+  int solo_rows_ = 8192;      // leaves up to this many rows are one workgroup's (LGA_SOLO_ROWS)
+  int target_units_ = 640;    // units a round's multi-unit leaves are cut into (LGA_TARGET_UNITS)
+  k::PoolLayout lay_{};
+  k::ScanRange scan_range_{};
+  DeviceBuffer<int64_t> pool_, slot_table_;
   DeviceBuffer<NodeRange> nodes_;
   DeviceBuffer<int64_t> node_totals_;
   DeviceBuffer<int32_t> arena_[2];
   RoundCtx ctx_[2];
   int n_ctx_ = 1;
-  DeviceBuffer<k::Cand> cands_, best_local_, best_all_;
-  DeviceBuffer<SplitInfo> results_dev_;
   DeviceBuffer<FeatureMeta> meta_dev_;
   DeviceBuffer<QuantScale> qs_dev_;
   std::vector<FeatureMeta> meta_host_;
   std::vector<NodeRange> ranges_host_;
-  size_t off_tasks_ = 0, off_scan_ = 0, off_pch_ = 0, off_hch_ = 0, stage_bytes_ = 0;
+  size_t off_tasks_ = 0, off_pch_ = 0, off_hch_ = 0, stage_bytes_ = 0;
   SplitParams sp_{};
   bool ranged_ = false;                 // monotone constraints or path smoothing: node_bounds is in use
   PinnedBuffer<double> bounds_host_;    // [node][lo, hi, out]
@@ -768,6 +925,7 @@ class HipBackend : public TreeBackend {
   int64_t bag_n_ = 0;
   const int64_t* packed_ = nullptr;
   const uint8_t* hist_src_ = nullptr;
+  uint8_t* lines_ = nullptr;
   k::FusedQuant root_quant_{};
 };
 
@@ -862,7 +1020,7 @@ class HipEngine : public Engine {
     // Large single-tile datasets get a private copy of the bin records interleaved with the packed
     // gradients (one 128-byte line per three rows); everything else keeps the separate gradient array.
     const bool lines_possible = train_->num_tiles() == 1 && backend_->mode() != ParallelMode::Feature;
-    use_lines_ = lines_possible && N_ >= kLinesMinRows;
+    use_lines_ = lines_possible;
     if (const char* e = std::getenv("LGA_ROW_LINES")) use_lines_ = lines_possible && std::string(e) != "0";   // 0 / 1 override the size rule
     if (use_lines_) {
       lines_.resize((size_t)k::row_line_bytes(N_));
@@ -1128,7 +1286,7 @@ class HipEngine : public Engine {
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
     if (use_lines_) {
-      backend_->set_packed(nullptr, lines_.get());
+      backend_->set_lines(lines_.get());
       backend_->set_root_quant(gr(), he(), maxbits_.get());
     } else {
       k::quantize(gr(), he(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
@@ -1422,7 +1580,6 @@ class HipEngine : public Engine {
   const int32_t* bag_ptr_ = nullptr;
   DeviceBuffer<int32_t> base_rows_, bag_rows_;
   static constexpr int64_t kWalkMinRows = 1 << 20;
-  static constexpr int64_t kLinesMinRows = 1 << 18;
   bool use_lines_ = false;
   DeviceBuffer<uint8_t> lines_;
   int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)

@@ -393,11 +393,11 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl,
     NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src,
     int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask,
-    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left) {
+    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, int chunk0) {
   constexpr int kWords = kPartChunk / kWave;   // 32 mask words per chunk
   __shared__ int red_before[kPartThreads / kWave], red_all[kPartThreads / kWave];
   __shared__ int word_prefix[kWords];
-  const int wg = blockIdx.x;
+  const int wg = blockIdx.x + chunk0;
   const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
   const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   if (t.num_pchunk == 1) return;   // finished by pass 1
@@ -458,16 +458,64 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// histogram
+// histogram pool addressing (kernels.hpp: PoolLayout)
 // ---------------------------------------------------------------------------
-// LINES: the rows come from the engine's 128-byte row lines (three rows per line: 3 x 32 bin bytes, then
-// their 3 packed gradient words), so a sparse leaf pays ONE line per row instead of one for the bin
-// record and another for the gradient word.  Single-tile datasets only; bins_rt then points at the lines.
+struct SlotRef {
+  int64_t* base;     // the slot's chunk of rank 0
+  int64_t rstride;   // words between the chunks of consecutive ranks
+};
+// A slot created by the round `r`.
+__device__ __forceinline__ SlotRef new_slot_ref(const PoolLayout& L, const RoundSlots& r, int slot) {
+  return SlotRef{L.pool + (int64_t)r.first_slot * L.slot_words + (int64_t)(slot - r.first_slot) * L.chunk_words,
+                 (int64_t)r.n_slots * L.chunk_words};
+}
+// A slot created by an earlier launch.
+__device__ __forceinline__ SlotRef old_slot_ref(const PoolLayout& L, int slot) {
+  return SlotRef{L.pool + L.slot_table[2 * slot], L.slot_table[2 * slot + 1]};
+}
+__device__ __forceinline__ void publish_slot(const PoolLayout& L, int slot, const SlotRef& s) {
+  L.slot_table[2 * slot] = (int64_t)(s.base - L.pool);
+  L.slot_table[2 * slot + 1] = s.rstride;
+}
+// Feature f's block: 256 gradient words, then 256 hessian words.
+__device__ __forceinline__ int64_t* feat_block(const PoolLayout& L, const SlotRef& s, int f) {
+  const int r = L.ranks > 1 ? f / L.fpr : 0;
+  return s.base + (int64_t)r * s.rstride + (int64_t)(f - r * L.fpr) * (2 * kMaxBins);
+}
+// Rank r's copy of the slot header (rows, sum g, sum h).
+__device__ __forceinline__ int64_t* slot_header(const PoolLayout& L, const SlotRef& s, int r) {
+  return s.base + (int64_t)r * s.rstride + (int64_t)L.fpr * (2 * kMaxBins);
+}
+
+// Adds a workgroup's LDS histogram (packed g:int32 | h:uint32 cells, features f0 .. f0 + nf - 1) to a slot.
+// ROTATED: cell (f, bin) sits at f * 256 + ((bin + 8 f) & 255) (row-line kernels).
+template <bool ROTATED>
+__device__ __forceinline__ void flush_lds_hist(const unsigned long long* lds, int nf, int f0, const PoolLayout& L,
+                                               const SlotRef& s, int nthreads) {
+  for (int e = threadIdx.x; e < nf * kMaxBins; e += nthreads) {
+    const int fe = e >> 8, b = e & 255;
+    const unsigned long long v = ROTATED ? lds[(fe << 8) + ((b + 8 * fe) & 255)] : lds[e];
+    if (v != 0ull) {
+      unsigned long long* blk = reinterpret_cast<unsigned long long*>(feat_block(L, s, f0 + fe));
+      atomicAdd(&blk[b], (unsigned long long)(long long)(int32_t)(v >> 32));
+      atomicAdd(&blk[kMaxBins + b], v & 0xffffffffull);
+    }
+  }
+}
+__device__ __forceinline__ void add_slot_header(const PoolLayout& L, const SlotRef& s, long long rows, long long tg, long long th) {
+  for (int r = 0; r < L.ranks; ++r) {
+    unsigned long long* hd = reinterpret_cast<unsigned long long*>(slot_header(L, s, r));
+    atomicAdd(&hd[0], (unsigned long long)rows);
+    atomicAdd(&hd[1], (unsigned long long)tg);
+    atomicAdd(&hd[2], (unsigned long long)th);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// histogram (feature-tile records + separate gradient array)
+// ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned div3(unsigned r) { return (unsigned)(((unsigned long long)r * 0xAAAAAAABull) >> 33); }
 
-// QUANT (root pass over row lines): the gradients arrive as floats, are quantised here and written into
-// the rows' lines on the way - the lines are in flight anyway, so the separate quantisation pass (a
-// scattered 8-byte write per row) disappears.
 struct QuantSource {
   const float* g;
   const float* h;
@@ -475,14 +523,13 @@ struct QuantSource {
   QuantScale* qs_out;
 };
 
-template <bool LINES, bool QUANT>
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl, int rows_per_chunk,
     const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
-    const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, int64_t* __restrict__ pool,
-    int64_t slot_words, int64_t plane, int F, int tile_first, int tile_step, QuantSource qsrc) {
+    const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, PoolLayout L, RoundSlots round,
+    int F, int tile_first, int tile_step) {
   __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
-  __shared__ long long red[3][kHistThreads / kWave];
+  __shared__ long long red[2][kHistThreads / kWave];
   const int x = blockIdx.x;
   const int tile = tile_first + (int)blockIdx.y * tile_step;
   const int ti = tasks ? chunk_task[x] : find_task<false>(inl, x);
@@ -490,21 +537,17 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   const int c = x - t.first_hchunk;
   const int node = t.hist_child ? t.right_node : t.left_node;
   const NodeRange r = nodes[node];
+  const SlotRef slot = new_slot_ref(L, round, t.new_slot);
+  if (c == 0 && blockIdx.y == 0 && threadIdx.x == 0) publish_slot(L, t.new_slot, slot);
   const int lo = c * rows_per_chunk;
   if (lo >= r.count) return;   // the child turned out smaller than the grid was sized for
   const int hi = min(lo + rows_per_chunk, r.count);
-  for (int i = threadIdx.x; i < kTileFeatures * kMaxBins; i += kHistThreads) lds[i] = 0ull;
+  const int nf = min(kTileFeatures, F - tile * kTileFeatures);
+  for (int i = threadIdx.x; i < nf * kMaxBins; i += kHistThreads) lds[i] = 0ull;
   __syncthreads();
   const int32_t* rows = (r.buf ? a1 : a0) + r.begin;
   const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
-  const int nf = min(kTileFeatures, F - tile * kTileFeatures);
   long long sg = 0, sh = 0;
-  int kg = 0, kh = 0;
-  if (QUANT) {
-    kg = quant_exponent(__uint_as_float(qsrc.maxbits[0]));
-    kh = quant_exponent(__uint_as_float(qsrc.maxbits[1]));
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { qsrc.qs_out->kg = kg; qsrc.qs_out->kh = kh; }
-  }
   // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
   // SIMD keep ~U x 3 memory requests per lane in flight.
   constexpr int U = 4;
@@ -521,22 +564,9 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] >= 0) {
-        if (LINES) {
-          const unsigned line = div3((unsigned)row[u]), slot = (unsigned)row[u] - line * 3u;
-          const uint4* L = recs + (int64_t)line * 8;
-          ra[u] = L[slot * 2];
-          rb[u] = L[slot * 2 + 1];
-          if (QUANT) {
-            p[u] = (unsigned long long)pack_gh(lga::quantize(qsrc.g[row[u]], kg), lga::quantize(qsrc.h[row[u]], kh));
-            reinterpret_cast<unsigned long long*>(const_cast<uint4*>(L))[12 + slot] = p[u];
-          } else {
-            p[u] = reinterpret_cast<const unsigned long long*>(L)[12 + slot];
-          }
-        } else {
-          p[u] = (unsigned long long)packed[row[u]];
-          ra[u] = recs[(int64_t)row[u] * 2];
-          rb[u] = recs[(int64_t)row[u] * 2 + 1];
-        }
+        p[u] = (unsigned long long)packed[row[u]];
+        ra[u] = recs[(int64_t)row[u] * 2];
+        rb[u] = recs[(int64_t)row[u] * 2 + 1];
       }
     }
 #pragma unroll
@@ -545,46 +575,20 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
         sg += (long long)(int32_t)(p[u] >> 32);
         sh += (long long)(p[u] & 0xffffffffull);
         const unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
-        if (LINES) {
-          // byte k of the row's record holds feature (k + row) mod 32: the lanes of a wave work on
-          // different features at any moment, so a feature with three distinct values no longer makes
-          // 64 lanes queue on three LDS words; the (bin + 8 f) rotation keeps equal bins of different
-          // features in different banks.
-          const unsigned rot = (unsigned)row[u];
 #pragma unroll
-          for (int k = 0; k < kTileFeatures; ++k) {
-            const unsigned f = (k + rot) & 31u;
-            if (f < (unsigned)nf) {
-              const unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-              atomicAdd(&lds[f * kMaxBins + ((bin + 8u * f) & 255u)], p[u]);
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < kTileFeatures; ++k) {
-            if (k < nf) {
-              unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-              atomicAdd(&lds[k * kMaxBins + bin], p[u]);
-            }
+        for (int k = 0; k < kTileFeatures; ++k) {
+          if (k < nf) {
+            unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+            atomicAdd(&lds[k * kMaxBins + bin], p[u]);
           }
         }
       }
     }
   }
   __syncthreads();
-  int64_t* slot = pool + (int64_t)t.new_slot * slot_words;
-  unsigned long long* gp = reinterpret_cast<unsigned long long*>(slot + (int64_t)tile * kTileFeatures * kMaxBins);
-  unsigned long long* hp = reinterpret_cast<unsigned long long*>(slot + plane + (int64_t)tile * kTileFeatures * kMaxBins);
-  for (int e = threadIdx.x; e < nf * kMaxBins; e += kHistThreads) {
-    const int fe = e >> 8;
-    unsigned long long v = LINES ? lds[(fe << 8) + ((e + 8 * fe) & 255)] : lds[e];
-    if (v != 0ull) {
-      atomicAdd(&gp[e], (unsigned long long)(long long)(int32_t)(v >> 32));
-      atomicAdd(&hp[e], v & 0xffffffffull);
-    }
-  }
+  flush_lds_hist<false>(lds, nf, tile * kTileFeatures, L, slot, kHistThreads);
   if (blockIdx.y == 0) {
-    // header: rows, sum g, sum h of this child (tile 0's workgroups see every row once)
+    // header: rows, sum g, sum h of this child (the first tile's workgroups see every row once)
     sg = wave_sum_i64(sg);
     sh = wave_sum_i64(sh);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -594,10 +598,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
       long long tg = 0, th = 0;
 #pragma unroll
       for (int w = 0; w < kHistThreads / kWave; ++w) { tg += red[0][w]; th += red[1][w]; }
-      unsigned long long* hd = reinterpret_cast<unsigned long long*>(slot + 2 * plane);
-      atomicAdd(&hd[0], (unsigned long long)(hi - lo));
-      atomicAdd(&hd[1], (unsigned long long)tg);
-      atomicAdd(&hd[2], (unsigned long long)th);
+      add_slot_header(L, slot, hi - lo, tg, th);
     }
   }
 }
@@ -610,35 +611,26 @@ __device__ __forceinline__ void take_better(double& g, uint64_t& key, int64_t& l
   if (cand_better(g2, k2, g, key)) { g = g2; key = k2; lg = lg2; lh = lh2; }
 }
 
-// Best split of ONE feature of one leaf, computed by one wave (4 bins per lane).  When `sib` is
-// given the leaf's histogram is first derived in place: self = self(parent) - sibling.
-// On return every lane holds the running best updated with this feature's winner.
-__device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __restrict__ self,
-                                                  const int64_t* __restrict__ sib, int64_t plane,
-                                                  const FeatureMeta m, const LeafScanCtx& ctx, const SplitParams& sp,
-                                                  double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh,
-                                                  bool evaluate = true, uint32_t key = kRootNodeKey) {
-  const int64_t e = (int64_t)f * kMaxBins + lane * 4;
-  int64_t g[4], h[4];
-  {
-    const longlong2* gs = reinterpret_cast<const longlong2*>(self + e);
-    const longlong2* hs = reinterpret_cast<const longlong2*>(self + plane + e);
-    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
-    g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
-    h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
-  }
-  if (sib) {
-    const longlong2* gs = reinterpret_cast<const longlong2*>(sib + e);
-    const longlong2* hs = reinterpret_cast<const longlong2*>(sib + plane + e);
-    longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
-    g[0] -= g01.x; g[1] -= g01.y; g[2] -= g23.x; g[3] -= g23.y;
-    h[0] -= h01.x; h[1] -= h01.y; h[2] -= h23.x; h[3] -= h23.y;
-    longlong2* go = reinterpret_cast<longlong2*>(self + e);
-    longlong2* ho = reinterpret_cast<longlong2*>(self + plane + e);
-    go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
-    ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
-  }
-  if (!evaluate) return;   // feature not offered at this node: only its histogram had to be derived
+// Lane l of a wave holds bins 4 l .. 4 l + 3 of one feature.
+__device__ __forceinline__ void load_feat_cells(const int64_t* __restrict__ blk, int lane, int64_t (&g)[4], int64_t (&h)[4]) {
+  const longlong2* gs = reinterpret_cast<const longlong2*>(blk + lane * 4);
+  const longlong2* hs = reinterpret_cast<const longlong2*>(blk + kMaxBins + lane * 4);
+  const longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+  g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
+  h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
+}
+__device__ __forceinline__ void store_feat_cells(int64_t* __restrict__ blk, int lane, const int64_t (&g)[4], const int64_t (&h)[4]) {
+  longlong2* go = reinterpret_cast<longlong2*>(blk + lane * 4);
+  longlong2* ho = reinterpret_cast<longlong2*>(blk + kMaxBins + lane * 4);
+  go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
+  ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
+}
+
+// Best split of ONE feature of one leaf from the feature's histogram held by one wave (g, h: 4 bins per
+// lane; overwritten).  On return every lane holds the running best updated with this feature's winner.
+__device__ __forceinline__ void scan_cells_wave(int f, int lane, int64_t (&g)[4], int64_t (&h)[4], const FeatureMeta m,
+                                                const LeafScanCtx& ctx, const SplitParams& sp, double& bg, uint64_t& bkey,
+                                                int64_t& blg, int64_t& blh, uint32_t key) {
   const int nb = m.num_bin, mb = m.missing_bin;
   const int vb = mb >= 0 ? nb - 1 : nb;
   if (m.categorical) {
@@ -709,56 +701,6 @@ __device__ __forceinline__ void scan_feature_wave(int f, int lane, int64_t* __re
   take_better(bg, bkey, blg, blh, adjust_feature_gain(lbg, f, ctx.total_cnt, sp), lkey, llg, llh);
 }
 
-__global__ __launch_bounds__(256) void scan_kernel(const ScanTaskDev* __restrict__ tasks,
-                                                   const FeatureMeta* __restrict__ meta, int F, int f_first_tile,
-                                                   int tile_step, int64_t* __restrict__ pool, int64_t slot_words,
-                                                   int64_t plane, int64_t* __restrict__ node_totals,
-                                                   const QuantScale* __restrict__ qs, SplitParams sp,
-                                                   Cand* __restrict__ cands) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int f = blockIdx.x * 4 + wave;
-  const int s = blockIdx.y;
-  if (f >= F) return;
-  const ScanTaskDev t = tasks[s];
-  const double ninf = -std::numeric_limits<double>::infinity();
-  int64_t* self = pool + (int64_t)t.slot * slot_words;
-  // leaf totals
-  int64_t tc, tg, th;
-  if (t.parent_slot < 0) {
-    const int64_t* hd = self + 2 * plane;
-    tc = hd[0]; tg = hd[1]; th = hd[2];
-  } else {
-    const int64_t* sib = pool + (int64_t)t.sibling_slot * slot_words + 2 * plane;
-    const int64_t* pt = node_totals + (int64_t)t.parent_node * 4;
-    tc = pt[0] - sib[0]; tg = pt[1] - sib[1]; th = pt[2] - sib[2];
-  }
-  if (f == 0 && lane == 0) {
-    int64_t* nt = node_totals + (int64_t)t.node * 4;
-    nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
-  }
-  Cand* out = cands + (int64_t)s * F + f;
-  const FeatureMeta m = meta[f];
-  const int my_tile = f / kTileFeatures;
-  const bool owned = tile_step <= 1 || (my_tile % tile_step) == f_first_tile;
-  if (!m.enabled || !owned) {
-    if (lane == 0) *out = Cand{ninf, ~0ull, 0, 0};
-    return;
-  }
-  const QuantScale q = *qs;
-  const double kInf = std::numeric_limits<double>::infinity();
-  const double kNaN = std::numeric_limits<double>::quiet_NaN();
-  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node] : -kInf,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node + 1] : kInf,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * t.node + 2] : kNaN);
-  const int64_t* sb = t.parent_slot >= 0 ? pool + (int64_t)t.sibling_slot * slot_words : nullptr;
-  double bg = ninf;
-  uint64_t bkey = ~0ull;
-  int64_t blg = 0, blh = 0;
-  scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, t.key, f, F) && node_allows(sp, t.node, f) && m.categorical != kCategoricalSorted, t.key);
-  if (lane == 0) *out = Cand{bg, bkey, blg, blh};
-}
-
 __device__ __forceinline__ void write_split(SplitInfo* o, double bg, uint64_t bkey, int64_t blg, int64_t blh, int64_t tc,
                                             int64_t tg, int64_t th, const QuantScale& q, const SplitParams& sp) {
   const double ninf = -std::numeric_limits<double>::infinity();
@@ -775,117 +717,479 @@ __device__ __forceinline__ void write_split(SplitInfo* o, double bg, uint64_t bk
   }
 }
 
-__global__ __launch_bounds__(64) void select_kernel(const ScanTaskDev* __restrict__ tasks, int F,
-                                                    const Cand* __restrict__ cands,
-                                                    const int64_t* __restrict__ node_totals,
-                                                    const QuantScale* __restrict__ qs, SplitParams sp,
-                                                    SplitInfo* __restrict__ out, Cand* __restrict__ best_out) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const double ninf = -std::numeric_limits<double>::infinity();
-  double bg = ninf;
-  uint64_t bkey = ~0ull;
-  int64_t blg = 0, blh = 0;
-  for (int f = lane; f < F; f += kWave) {
-    const Cand c = cands[(int64_t)s * F + f];
-    take_better(bg, bkey, blg, blh, c.gain, c.key, c.lg, c.lh);
-  }
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    double g2 = shfl_xor_f64(bg, msk);
-    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
-    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
-    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
-  }
-  if (lane == 0) {
-    const int64_t* nt = node_totals + (int64_t)tasks[s].node * 4;
-    if (best_out) best_out[s] = Cand{bg, bkey, blg, blh};
-    write_split(&out[s], bg, bkey, blg, blh, nt[0], nt[1], nt[2], *qs, sp);
+__device__ __forceinline__ LeafScanCtx node_scan_ctx(int64_t tg, int64_t th, int64_t tc, const QuantScale& q,
+                                                     const SplitParams& sp, int node) {
+  const double kInf = std::numeric_limits<double>::infinity();
+  const double kNaN = std::numeric_limits<double>::quiet_NaN();
+  return make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
+                       sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node] : -kInf,
+                       sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 1] : kInf,
+                       sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 2] : kNaN);
+}
+
+// Completion of a round whose results go straight to host-mapped memory: the `n_done`-th caller writes the
+// quantisation scales behind the left counts and raises the flag the host polls.
+__device__ __forceinline__ void finish_to_host(char* host_out, int n_scan, int n_left, int n_done, unsigned* done_counter,
+                                               unsigned seq, const QuantScale& q) {
+  __threadfence_system();
+  const unsigned old = atomicAdd(done_counter, 1u);
+  if (old == (unsigned)(n_done - 1)) {
+    int32_t* tl = reinterpret_cast<int32_t*>(host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
+    QuantScale* qo = reinterpret_cast<QuantScale*>(tl + n_left);
+    *qo = q;
+    *done_counter = 0u;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned*>(host_out) = seq;
   }
 }
 
-// Fused scan + select for rounds handled without a host copy: one 16-wave workgroup per leaf walks
-// all features (wave w takes features w, w+16, ...), reduces the waves' winners through LDS and
-// writes the SplitInfo straight into host-mapped memory.  The workgroup that finishes last also
-// hands over the children's row counts and raises the round's completion flag, which the host polls.
-constexpr int kFusedWaves = 16;
-__global__ __launch_bounds__(kFusedWaves * kWave) void scan_fused_kernel(
-    const SplitTask* __restrict__ tasks, InlineTasks inl, int n_scan, int n_tasks,
-    const FeatureMeta* __restrict__ meta, int F, int64_t* __restrict__ pool, int64_t slot_words, int64_t plane,
-    int64_t* __restrict__ node_totals, const QuantScale* __restrict__ qs, SplitParams sp,
-    const int32_t* __restrict__ task_left, char* __restrict__ host_out, unsigned* __restrict__ done_counter,
-    unsigned seq) {
-  __shared__ Cand wbest[kFusedWaves];
+// Hand-over between the workgroups of one launch.  Every wave has drained its own stores / atomics
+// (s_waitcnt) before the barrier; one lane then releases at agent scope and draws a ticket.
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned release_and_ticket(unsigned* counter) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void acquire_after_ticket() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Split search as its own launch: workgroup (s, b) searches feature block b of scan task s (one wave per
+// feature at a time), the workgroup that finishes a task last merges the blocks' winners.
+__global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanArgs a) {
+  __shared__ Cand wbest[8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int s = blockIdx.x;
-  const int ti = s >> 1, side = s & 1;
-  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
-  const bool direct = side == t.hist_child;
-  const int node = side == 0 ? t.left_node : t.right_node;
-  const uint32_t key = t.parent_node < 0 ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
-  const int slot = direct ? t.new_slot : t.parent_slot;
-  const double ninf = -std::numeric_limits<double>::infinity();
-  int64_t* self = pool + (int64_t)slot * slot_words;
-  const int64_t* sb = direct ? nullptr : pool + (int64_t)t.new_slot * slot_words;
+  const int b = blockIdx.y;
+  const int ti = blockIdx.x >> 1, side = blockIdx.x & 1;
+  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const int s = 2 * a.task0 + blockIdx.x;   // index among the round's scan tasks
+  const bool direct = a.root || side == t.hist_child;
+  const int node = a.root ? 0 : (side == 0 ? t.left_node : t.right_node);
+  const uint32_t key = a.root ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
+  const SlotRef fresh = new_slot_ref(a.pool, a.round, t.new_slot);
+  const SlotRef self = direct ? fresh : old_slot_ref(a.pool, t.parent_slot);
   int64_t tc, tg, th;
-  if (direct) {
-    const int64_t* hd = self + 2 * plane;
+  {
+    const int64_t* hd = slot_header(a.pool, fresh, a.my_rank);
     tc = hd[0]; tg = hd[1]; th = hd[2];
-  } else {
-    const int64_t* sh = sb + 2 * plane;
-    const int64_t* pt = node_totals + (int64_t)t.parent_node * 4;
-    tc = pt[0] - sh[0]; tg = pt[1] - sh[1]; th = pt[2] - sh[2];
+    if (!direct) {
+      const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
+      tc = pt[0] - tc; tg = pt[1] - tg; th = pt[2] - th;
+    }
   }
-  const QuantScale q = *qs;
-  const double kInf = std::numeric_limits<double>::infinity();
-  const double kNaN = std::numeric_limits<double>::quiet_NaN();
-  const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, unit_of(q.kg), unit_of(q.kh), sp,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node] : -kInf,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 1] : kInf,
-                                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 2] : kNaN);
+  const QuantScale q = *a.qs;
+  const LeafScanCtx ctx = node_scan_ctx(tg, th, tc, q, a.sp, node);
+  const double ninf = -std::numeric_limits<double>::infinity();
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  for (int f = wave; f < F; f += kFusedWaves) {
-    const FeatureMeta m = meta[f];
+  const int group = a.range.group_first + b * a.range.group_step;
+  const int f0 = a.range.f_begin + group * a.range.group_size;
+  const int f1 = min(f0 + a.range.group_size, a.range.f_end);
+  for (int f = f0 + wave; f < f1; f += 8) {
+    const FeatureMeta m = a.meta[f];
     if (!m.enabled) continue;
-    scan_feature_wave(f, lane, self, sb, plane, m, ctx, sp, bg, bkey, blg, blh, node_feature_on(sp, key, f, F) && node_allows(sp, node, f) && m.categorical != kCategoricalSorted, key);
+    int64_t g[4], h[4];
+    int64_t* blk = feat_block(a.pool, self, f);
+    load_feat_cells(blk, lane, g, h);
+    if (!direct) {
+      int64_t cg[4], ch[4];
+      load_feat_cells(feat_block(a.pool, fresh, f), lane, cg, ch);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
+      store_feat_cells(blk, lane, g, h);
+    }
+    if (node_feature_on(a.sp, key, f, a.F) && node_allows(a.sp, node, f) && m.categorical != kCategoricalSorted)
+      scan_cells_wave(f, lane, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
   }
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < kFusedWaves; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
-    int64_t* nt = node_totals + (int64_t)node * 4;
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 8; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
+  const int nb = a.range.n_blocks;
+  if (b == 0) {
+    int64_t* nt = a.node_totals + (int64_t)node * 4;
     nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
-    SplitInfo* out = reinterpret_cast<SplitInfo*>(host_out + kHostDataOffset);
-    write_split(&out[s], bg, bkey, blg, blh, tc, tg, th, q, sp);
-    __threadfence_system();
-    const unsigned old = atomicAdd(done_counter, 1u);
-    if (old == (unsigned)(n_scan - 1)) {
-      int32_t* tl = reinterpret_cast<int32_t*>(host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
-      for (int i = 0; i < n_tasks; ++i) tl[i] = task_left[i];
-      QuantScale* qo = reinterpret_cast<QuantScale*>(tl + n_tasks);
-      *qo = q;
-      *done_counter = 0u;
-      __threadfence_system();
-      *reinterpret_cast<volatile unsigned*>(host_out) = seq;
+    int64_t* st = a.scan_totals + (int64_t)s * 4;
+    st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
+  }
+  if (nb > 1) {
+    a.block_best[(int64_t)s * nb + b] = Cand{bg, bkey, blg, blh};
+    if (release_and_ticket(&a.tickets[s]) != (unsigned)(nb - 1)) return;
+    acquire_after_ticket();
+    a.tickets[s] = 0u;
+    bg = ninf; bkey = ~0ull; blg = 0; blh = 0;
+    for (int i = 0; i < nb; ++i) {
+      const Cand c = a.block_best[(int64_t)s * nb + i];
+      take_better(bg, bkey, blg, blh, c.gain, c.key, c.lg, c.lh);
     }
+  }
+  if (a.best_out) {
+    a.best_out[s] = Cand{bg, bkey, blg, blh};
+    return;
+  }
+  SplitInfo* out = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
+  write_split(&out[s], bg, bkey, blg, blh, tc, tg, th, q, a.sp);
+  if (!a.root && side == 0) {
+    int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
+    tl[a.task0 + ti] = a.task_left[a.task0 + ti];
+  }
+  finish_to_host(a.host_out, a.n_scan, a.root ? 0 : a.n_tasks, a.n_scan, a.done_counter, a.seq, q);
+}
+
+// Distributed learners: every rank's winners have been gathered ([rank][scan task]); each rank merges them the
+// same way and hands the results to its host.  One workgroup.
+__global__ __launch_bounds__(256) void merge_winners_kernel(const Cand* __restrict__ gathered, int ranks, int n_scan,
+                                                            int n_left, const int64_t* __restrict__ scan_totals,
+                                                            const QuantScale* __restrict__ qs, SplitParams sp,
+                                                            const int32_t* __restrict__ task_left, char* host_out,
+                                                            unsigned seq) {
+  const QuantScale q = *qs;
+  SplitInfo* out = reinterpret_cast<SplitInfo*>(host_out + kHostDataOffset);
+  int32_t* tl = reinterpret_cast<int32_t*>(host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
+  for (int s = threadIdx.x; s < n_scan; s += blockDim.x) {
+    Cand b = gathered[s];
+    for (int r = 1; r < ranks; ++r) {
+      const Cand c = gathered[(int64_t)r * n_scan + s];
+      if (cand_better(c.gain, c.key, b.gain, b.key)) b = c;
+    }
+    const int64_t* st = scan_totals + (int64_t)s * 4;
+    write_split(&out[s], b.gain, b.key, b.lg, b.lh, st[0], st[1], st[2], q, sp);
+  }
+  for (int i = threadIdx.x; i < n_left; i += blockDim.x) tl[i] = task_left[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    QuantScale* qo = reinterpret_cast<QuantScale*>(tl + n_left);
+    *qo = q;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned*>(host_out) = seq;
   }
 }
 
-__global__ __launch_bounds__(64) void merge_winners_kernel(const Cand* __restrict__ gathered, int ranks, int n_tasks,
-                                                           const ScanTaskDev* __restrict__ tasks,
-                                                           const int64_t* __restrict__ node_totals,
-                                                           const QuantScale* __restrict__ qs, SplitParams sp,
-                                                           SplitInfo* __restrict__ out) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_tasks) return;
-  Cand b = gathered[s];
-  for (int r = 1; r < ranks; ++r) {
-    const Cand c = gathered[(int64_t)r * n_tasks + s];
-    if (cand_better(c.gain, c.key, b.gain, b.key)) b = c;
+// ---------------------------------------------------------------------------
+// fused growth round over row lines (kernels.hpp: GrowArgs)
+// ---------------------------------------------------------------------------
+// Row r's line slot holds its 32 bin bytes rotated by r: byte j = feature (j + r) mod 32.
+__device__ __forceinline__ int line_bin(const unsigned (&w)[8], int feature, int32_t row) {
+  const unsigned j = ((unsigned)feature - (unsigned)row) & 31u;
+  const unsigned q = j >> 2;
+  unsigned d = w[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) d = q == (unsigned)i ? w[i] : d;
+  return (int)((d >> ((j & 3u) * 8)) & 255u);
+}
+__device__ __forceinline__ bool bin_goes_left(const SplitTask& t, int b, const uint64_t* __restrict__ cat_sets) {
+  if (t.default_left == kCategoricalTask) return b == t.threshold;
+  if (t.default_left == kCategoricalSetTask)
+    return (cat_sets[(int64_t)t.parent_node * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull;
+  return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
+}
+
+// One child of a task during the split search inside grow_kernel.
+struct ChildSearch {
+  int node;
+  uint32_t key;
+  int64_t tc, tg, th;
+  double bg;
+  uint64_t bkey;
+  int64_t blg, blh;
+};
+
+template <bool ROOT, bool QUANT>
+__global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
+  constexpr int kWaves = kGrowThreads / kWave;
+  constexpr int kMaskWords = kSoloMaxRows / kWave;
+  __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
+  __shared__ unsigned long long smask[kMaskWords];
+  __shared__ int word_prefix[kMaskWords + 1];
+  __shared__ int wave_tot[kWaves];
+  __shared__ long long red[2][kWaves];
+  __shared__ long long tot[3];
+  __shared__ Cand wbest[2][kWaves];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ti = find_task<false>(inl, blockIdx.x);
+  const SplitTask& t = inl.t[ti];
+  const int ridx = a.task0 + ti;                 // index among the round's tasks
+  const int u = blockIdx.x - t.first_hchunk;
+  const bool solo = !ROOT && t.num_pchunk == 0;  // the whole leaf is this workgroup's
+  const NodeRange p = a.nodes[ROOT ? 0 : t.parent_node];
+  const int32_t* src = (p.buf ? a.a1 : a.a0) + p.begin;
+  const int lo = solo ? 0 : u * a.unit_rows;
+  const int hi = solo ? p.count : min(lo + a.unit_rows, p.count);
+  const int nf = a.F;
+  const PoolLayout& L = a.pool;
+  const SlotRef fresh = new_slot_ref(L, a.round, t.new_slot);
+  if (u == 0 && tid == 0) publish_slot(L, t.new_slot, fresh);
+  for (int i = tid; i < nf * kMaxBins; i += kGrowThreads) lds[i] = 0ull;
+  __syncthreads();
+  int kg = 0, kh = 0;
+  if (QUANT) {
+    kg = quant_exponent(__uint_as_float(a.quant.maxbits[0]));
+    kh = quant_exponent(__uint_as_float(a.quant.maxbits[1]));
+    if (blockIdx.x == 0 && tid == 0) { a.quant.qs_out->kg = kg; a.quant.qs_out->kh = kh; }
   }
-  const int64_t* nt = node_totals + (int64_t)tasks[s].node * 4;
-  write_split(&out[s], b.gain, b.key, b.lg, b.lh, nt[0], nt[1], nt[2], *qs, sp);
+  const bool hist_left = t.hist_child == 0;
+  const uint4* lines = reinterpret_cast<const uint4*>(a.lines);
+  long long sg = 0, sh = 0;
+  // Four rows per lane and trip (one block of 32 mask words per trip): every load of a trip is issued
+  // before its LDS atomics.
+  for (int sub = lo; sub < hi; sub += kSubRows) {
+    const int wbase = ((sub - lo) / kSubRows) * (kSubRows / kWave);
+    int row[4];
+    unsigned long long pk[4];
+    uint4 ra[4], rb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int pos = sub + k * kGrowThreads + tid;
+      row[k] = pos < hi ? src[pos] : -1;
+      if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckHistRow, row[k], a.N)) row[k] = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (row[k] >= 0) {
+        const unsigned line = div3((unsigned)row[k]), slot = (unsigned)row[k] - line * 3u;
+        const uint4* Lp = lines + (int64_t)line * 8;
+        ra[k] = Lp[slot * 2];
+        rb[k] = Lp[slot * 2 + 1];
+        if (QUANT) {
+          pk[k] = (unsigned long long)pack_gh(lga::quantize(a.quant.g[row[k]], kg), lga::quantize(a.quant.h[row[k]], kh));
+          reinterpret_cast<unsigned long long*>(const_cast<uint4*>(Lp))[12 + slot] = pk[k];
+        } else {
+          pk[k] = reinterpret_cast<const unsigned long long*>(Lp)[12 + slot];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+      bool left = false;
+      if (!ROOT) {
+        if (row[k] >= 0) left = bin_goes_left(t, line_bin(w, t.feature, row[k]), a.cat_sets);
+        const unsigned long long m = __ballot(left);
+        if (lane == 0) smask[wbase + k * kWaves + wave] = m;
+      }
+      if (row[k] >= 0 && (ROOT || left == hist_left)) {
+        sg += (long long)(int32_t)(pk[k] >> 32);
+        sh += (long long)(pk[k] & 0xffffffffull);
+        // byte j of the record holds feature (j + row) mod 32: the lanes of a wave work on different
+        // features at any moment, so a feature with three distinct values does not make 64 lanes queue on
+        // three LDS words; the (bin + 8 f) rotation keeps equal bins of different features in different banks
+        const unsigned rot = (unsigned)row[k];
+#pragma unroll
+        for (int j = 0; j < kTileFeatures; ++j) {
+          const unsigned f = (j + rot) & 31u;
+          if (f < (unsigned)nf) {
+            const unsigned bin = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
+            atomicAdd(&lds[f * kMaxBins + ((bin + 8u * f) & 255u)], pk[k]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive prefix of the mask words' popcounts
+  int lefts = 0;
+  if (!ROOT) {
+    const int n_words = (hi - lo + kWave - 1) / kWave;
+    int pc = 0, incl = 0;
+    if (tid < kMaskWords) {
+      pc = tid < n_words ? __popcll(smask[tid]) : 0;
+      incl = pc;
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+      }
+      if (lane == kWave - 1) wave_tot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < kMaskWords) {
+      int off = 0;
+      for (int w = 0; w < wave; ++w) off += wave_tot[w];
+      word_prefix[tid] = off + incl - pc;
+      if (tid == kMaskWords - 1) word_prefix[kMaskWords] = off + incl;
+    }
+    __syncthreads();
+    lefts = word_prefix[kMaskWords];
+    if (solo) {
+      // the leaf fits this workgroup: move its rows right away - lefts to the front, rights behind, in order
+      int32_t* dst = (p.buf ? a.a0_dst : a.a1_dst) + p.begin;
+      for (int pos = tid; pos < p.count; pos += kGrowThreads) {
+        const int w = pos >> 6, l = pos & 63;
+        const unsigned long long m = smask[w];
+        const bool left = (m >> l) & 1ull;
+        const int lrank = word_prefix[w] + __popcll(m & ((1ull << l) - 1ull));
+        const int d = left ? lrank : lefts + (pos - lrank);
+        if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = src[pos];
+      }
+      if (tid == 0) {
+        a.nodes[t.left_node] = NodeRange{p.begin, lefts, 1 - p.buf, 0};
+        a.nodes[t.right_node] = NodeRange{p.begin + lefts, p.count - lefts, 1 - p.buf, 0};
+        a.task_left[ridx] = lefts;
+      }
+    } else {
+      // masks and left counts of this unit's blocks for grow_scatter
+      const int blocks = (hi - lo + kSubRows - 1) / kSubRows;
+      const int64_t gb = (int64_t)t.first_pchunk + (int64_t)u * (a.unit_rows / kSubRows);
+      for (int i = tid; i < blocks * (kSubRows / kWave); i += kGrowThreads) a.mask[gb * (kSubRows / kWave) + i] = smask[i];
+      if (tid < blocks) a.chunk_left[gb + tid] = word_prefix[(tid + 1) * (kSubRows / kWave)] - word_prefix[tid * (kSubRows / kWave)];
+    }
+  }
+  // rows, sum g, sum h of what this workgroup put into its histogram
+  sg = wave_sum_i64(sg);
+  sh = wave_sum_i64(sh);
+  if (lane == 0) { red[0][wave] = sg; red[1][wave] = sh; }
+  __syncthreads();
+  if (tid == 0) {
+    long long tg = 0, th = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { tg += red[0][w]; th += red[1][w]; }
+    tot[0] = ROOT ? (hi - lo) : (hist_left ? lefts : (hi - lo) - lefts);
+    tot[1] = tg;
+    tot[2] = th;
+  }
+  __syncthreads();
+
+  if (!solo) {
+    flush_lds_hist<true>(lds, nf, 0, L, fresh, kGrowThreads);
+    if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
+    if (!a.tail) return;
+    // the unit that arrives last searches the splits
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) {
+      const bool last = release_and_ticket(&a.tickets[ridx]) == (unsigned)(t.num_hchunk - 1);
+      if (last) { acquire_after_ticket(); a.tickets[ridx] = 0u; }
+      s_last = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (!ROOT) {
+      // rows that went left, over all units
+      int v = 0;
+      for (int i = tid; i < t.num_pchunk; i += kGrowThreads) v += a.chunk_left[t.first_pchunk + i];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+      if (lane == 0) wave_tot[wave] = v;
+      __syncthreads();
+      if (tid == 0) {
+        int all = 0;
+        for (int w = 0; w < kWaves; ++w) all += wave_tot[w];
+        lefts = all;
+        const int64_t* hd = slot_header(L, fresh, 0);
+        tot[0] = hd[0]; tot[1] = hd[1]; tot[2] = hd[2];
+      }
+    } else if (tid == 0) {
+      const int64_t* hd = slot_header(L, fresh, 0);
+      tot[0] = hd[0]; tot[1] = hd[1]; tot[2] = hd[2];
+    }
+    __syncthreads();
+  } else if (!a.tail) {
+    // solo leaf, split search elsewhere (distributed): the histogram goes to the slot as it is
+    for (int e = tid; e < nf * kMaxBins; e += kGrowThreads) {
+      const int fe = e >> 8, b = e & 255;
+      const unsigned long long v = lds[(fe << 8) + ((b + 8 * fe) & 255)];
+      int64_t* blk = feat_block(L, fresh, fe);
+      blk[b] = (int64_t)(int32_t)(v >> 32);
+      blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
+    }
+    if (tid == 0)
+      for (int r = 0; r < L.ranks; ++r) {
+        int64_t* hd = slot_header(L, fresh, r);
+        hd[0] = tot[0]; hd[1] = tot[1]; hd[2] = tot[2];
+      }
+    return;
+  }
+
+  // ---- split search: child A owns the fresh histogram, child B = parent - A (in the parent's slot) ----
+  const QuantScale q = *a.qs;
+  const SplitParams& sp = a.sp;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  const int sideA = ROOT ? 0 : t.hist_child;
+  ChildSearch A, B;
+  A.node = ROOT ? 0 : (sideA == 0 ? t.left_node : t.right_node);
+  A.key = ROOT ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, sideA);
+  A.tc = tot[0]; A.tg = tot[1]; A.th = tot[2];
+  A.bg = ninf; A.bkey = ~0ull; A.blg = 0; A.blh = 0;
+  B = A;
+  SlotRef parent = fresh;
+  if (!ROOT) {
+    B.node = sideA == 0 ? t.right_node : t.left_node;
+    B.key = child_node_key((uint32_t)t.parent_key, 1 - sideA);
+    const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
+    B.tc = pt[0] - A.tc; B.tg = pt[1] - A.tg; B.th = pt[2] - A.th;
+    parent = old_slot_ref(L, t.parent_slot);
+  }
+  // One child at a time (the second pass re-reads A's cells): the search keeps a leaf's context and a
+  // feature's cells in registers, and two of each would cost the whole kernel its second workgroup per CU.
+#pragma unroll 1
+  for (int pass = 0; pass < (ROOT ? 1 : 2); ++pass) {
+    ChildSearch& C = pass == 0 ? A : B;
+    const LeafScanCtx ctx = node_scan_ctx(C.tg, C.th, C.tc, q, sp, C.node);
+    for (int f = wave; f < nf; f += kWaves) {
+      const FeatureMeta m = a.meta[f];
+      if (!m.enabled) continue;
+      int64_t g[4], h[4];
+      int64_t* blkA = feat_block(L, fresh, f);
+      if (solo) {
+        // the finished histogram is still in LDS: unpack; the first pass keeps a copy in the slot for
+        // later subtractions
+        const unsigned long long* c = &lds[f * kMaxBins + ((lane * 4 + 8 * f) & 255)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned long long v = c[j];
+          g[j] = (int64_t)(int32_t)(v >> 32);
+          h[j] = (int64_t)(v & 0xffffffffull);
+        }
+        if (pass == 0) store_feat_cells(blkA, lane, g, h);
+      } else {
+        load_feat_cells(blkA, lane, g, h);
+      }
+      if (pass == 1) {
+        int64_t gp[4], hp[4];
+        int64_t* blkB = feat_block(L, parent, f);
+        load_feat_cells(blkB, lane, gp, hp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = gp[j] - g[j]; h[j] = hp[j] - h[j]; }
+        store_feat_cells(blkB, lane, g, h);
+      }
+      if (m.categorical != kCategoricalSorted && node_feature_on(sp, C.key, f, nf) && node_allows(sp, C.node, f))
+        scan_cells_wave(f, lane, g, h, m, ctx, sp, C.bg, C.bkey, C.blg, C.blh, C.key);
+    }
+  }
+  if (lane == 0) {
+    wbest[0][wave] = Cand{A.bg, A.bkey, A.blg, A.blh};
+    wbest[1][wave] = Cand{B.bg, B.bkey, B.blg, B.blh};
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  for (int w = 1; w < kWaves; ++w) {
+    take_better(A.bg, A.bkey, A.blg, A.blh, wbest[0][w].gain, wbest[0][w].key, wbest[0][w].lg, wbest[0][w].lh);
+    take_better(B.bg, B.bkey, B.blg, B.blh, wbest[1][w].gain, wbest[1][w].key, wbest[1][w].lg, wbest[1][w].lh);
+  }
+  if (solo) {
+    int64_t* hd = slot_header(L, fresh, 0);
+    hd[0] = A.tc; hd[1] = A.tg; hd[2] = A.th;
+  }
+  SplitInfo* out = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
+  int64_t* ntA = a.node_totals + (int64_t)A.node * 4;
+  ntA[0] = A.tc; ntA[1] = A.tg; ntA[2] = A.th; ntA[3] = 0;
+  if (ROOT) {
+    write_split(&out[0], A.bg, A.bkey, A.blg, A.blh, A.tc, A.tg, A.th, q, sp);
+    finish_to_host(a.host_out, 1, 0, 1, a.done_counter, a.seq, q);
+    return;
+  }
+  int64_t* ntB = a.node_totals + (int64_t)B.node * 4;
+  ntB[0] = B.tc; ntB[1] = B.tg; ntB[2] = B.th; ntB[3] = 0;
+  write_split(&out[2 * ridx + sideA], A.bg, A.bkey, A.blg, A.blh, A.tc, A.tg, A.th, q, sp);
+  write_split(&out[2 * ridx + 1 - sideA], B.bg, B.bkey, B.blg, B.blh, B.tc, B.tg, B.th, q, sp);
+  int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * 2 * (size_t)a.n_tasks);
+  tl[ridx] = lefts;
+  finish_to_host(a.host_out, 2 * a.n_tasks, a.n_tasks, a.n_tasks, a.done_counter, a.seq, q);
 }
 
 // ---------------------------------------------------------------------------
@@ -1272,33 +1576,44 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
   LGA_LAUNCH_CHECK();
   if (!any_multi_chunk) return;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
-                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left);
+                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0);
   LGA_LAUNCH_CHECK();
 }
 
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                int rows_per_chunk, const NodeRange* nodes, const int32_t* a0, const int32_t* a1,
-               const uint8_t* bins_rt, int64_t N, const int64_t* packed, int64_t* pool, int64_t slot_words,
-               int64_t plane, int F, int tile_first, int tile_step, int tile_count, const FusedQuant* quant,
-               hipStream_t s) {
+               const uint8_t* bins_rt, int64_t N, const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F,
+               int tile_first, int tile_step, int tile_count, hipStream_t s) {
   if (total_chunks <= 0 || tile_count <= 0) return;
   if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
-  const QuantSource none{nullptr, nullptr, nullptr, nullptr};
-  if (packed == nullptr) {
-    if (tile_count != 1 || tile_first != 0) throw std::runtime_error("row lines hold a single feature tile");
-    if (quant && quant->g)
-      hipLaunchKernelGGL((hist_kernel<true, true>), dim3(total_chunks, 1), dim3(kHistThreads), 0, s, tasks, chunk_task,
-                         inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, 0, 1,
-                         QuantSource{quant->g, quant->h, quant->maxbits, quant->qs_out});
+  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
+                     rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step);
+  LGA_LAUNCH_CHECK();
+}
+
+void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s) {
+  if (total_units <= 0) return;
+  if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > kMaxRowsPerPass || a.unit_rows > kSoloMaxRows)
+    throw std::runtime_error("growth round: bad unit size");
+  if (a.F > kTileFeatures) throw std::runtime_error("row lines hold a single feature tile");
+  if (root) {
+    if (a.quant.g)
+      hipLaunchKernelGGL((grow_kernel<true, true>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
     else
-      hipLaunchKernelGGL((hist_kernel<true, false>), dim3(total_chunks, 1), dim3(kHistThreads), 0, s, tasks, chunk_task,
-                         inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F, 0, 1, none);
+      hipLaunchKernelGGL((grow_kernel<true, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
   } else {
-    if (quant && quant->g) throw std::runtime_error("fused quantisation needs the row-line layout");
-    hipLaunchKernelGGL((hist_kernel<false, false>), dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks,
-                       chunk_task, inl, rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, slot_words, plane, F,
-                       tile_first, tile_step, none);
+    if (a.quant.g) throw std::runtime_error("fused quantisation belongs to the root pass");
+    hipLaunchKernelGGL((grow_kernel<false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
   }
+  LGA_LAUNCH_CHECK();
+}
+
+void grow_scatter(const InlineTasks& inl, int chunk0, int total_chunks, NodeRange* nodes, const int32_t* a0_src,
+                  const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask, const int32_t* chunk_left,
+                  int32_t* task_left, hipStream_t s) {
+  if (total_chunks <= 0) return;
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, (const SplitTask*)nullptr,
+                     (const int32_t*)nullptr, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, chunk0);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1326,6 +1641,21 @@ __global__ __launch_bounds__(256) void build_lines_kernel(const unsigned* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void store_line_gradients_kernel(unsigned long long* __restrict__ lines,
+                                                                   const int64_t* __restrict__ packed, int64_t N) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t line = r / 3;
+    lines[line * 16 + 12 + (r - line * 3)] = (unsigned long long)packed[r];
+  }
+}
+
+void store_line_gradients(uint8_t* lines, const int64_t* packed, int64_t N, hipStream_t s) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(store_line_gradients_kernel, dim3(grid_for(N, 256, 8192)), dim3(256), 0, s,
+                     reinterpret_cast<unsigned long long*>(lines), packed, N);
+  LGA_LAUNCH_CHECK();
+}
+
 void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hipStream_t s) {
   if (N <= 0) return;
   LGA_HIP_CHECK(hipMemsetAsync(lines, 0, (size_t)row_line_bytes(N), s));
@@ -1334,37 +1664,18 @@ void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hi
   LGA_LAUNCH_CHECK();
 }
 
-void scan_fused(const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks, const FeatureMeta* meta, int F,
-                int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
-                const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned* done_counter, unsigned seq,
-                hipStream_t s) {
+void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hipStream_t s) {
+  if (launch_scan <= 0) return;
+  if (a.range.n_blocks < 1) throw std::runtime_error("split search needs at least one feature block");
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(launch_scan, a.range.n_blocks), dim3(512), 0, s, inl, a);
+  LGA_LAUNCH_CHECK();
+}
+
+void merge_winners(const Cand* gathered, int ranks, int n_scan, int n_left, const int64_t* scan_totals, const QuantScale* qs,
+                   const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s) {
   if (n_scan <= 0) return;
-  hipLaunchKernelGGL(scan_fused_kernel, dim3(n_scan), dim3(kFusedWaves * kWave), 0, s, tasks, inl, n_scan, n_tasks, meta,
-                     F, pool, slot_words, plane, node_totals, qs, sp, task_left, host_out, done_counter, seq);
-  LGA_LAUNCH_CHECK();
-}
-
-void scan(const ScanTaskDev* tasks, int n_tasks, const FeatureMeta* meta, int F, int f_first_tile, int tile_step,
-          int64_t* pool, int64_t slot_words, int64_t plane, int64_t* node_totals, const QuantScale* qs,
-          const SplitParams& sp, Cand* cands, hipStream_t s) {
-  if (n_tasks <= 0) return;
-  hipLaunchKernelGGL(scan_kernel, dim3((F + 3) / 4, n_tasks), dim3(256), 0, s, tasks, meta, F, f_first_tile, tile_step,
-                     pool, slot_words, plane, node_totals, qs, sp, cands);
-  LGA_LAUNCH_CHECK();
-}
-
-void select(const ScanTaskDev* tasks, int n_tasks, int F, const Cand* cands, const int64_t* node_totals,
-            const QuantScale* qs, const SplitParams& sp, SplitInfo* out, Cand* best_out, hipStream_t s) {
-  if (n_tasks <= 0) return;
-  hipLaunchKernelGGL(select_kernel, dim3(n_tasks), dim3(64), 0, s, tasks, F, cands, node_totals, qs, sp, out, best_out);
-  LGA_LAUNCH_CHECK();
-}
-
-void merge_winners(const Cand* gathered, int ranks, int n_tasks, const ScanTaskDev* tasks, const int64_t* node_totals,
-                   const QuantScale* qs, const SplitParams& sp, SplitInfo* out, hipStream_t s) {
-  if (n_tasks <= 0) return;
-  hipLaunchKernelGGL(merge_winners_kernel, dim3((n_tasks + 63) / 64), dim3(64), 0, s, gathered, ranks, n_tasks, tasks,
-                     node_totals, qs, sp, out);
+  hipLaunchKernelGGL(merge_winners_kernel, dim3(1), dim3(256), 0, s, gathered, ranks, n_scan, n_left, scan_totals, qs, sp,
+                     task_left, host_out, seq);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1420,20 +1731,18 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 
 namespace {
 // One workgroup per (slot, feature) item: the feature's gradient and hessian histogram rows, next to each other.
-__global__ __launch_bounds__(kMaxBins) void gather_feature_hist_kernel(const int64_t* __restrict__ pool, int64_t slot_words,
-                                                                       int64_t plane, const int32_t* __restrict__ items,
+__global__ __launch_bounds__(kMaxBins) void gather_feature_hist_kernel(PoolLayout L, const int32_t* __restrict__ items,
                                                                        int64_t* __restrict__ out) {
   const int slot = items[2 * blockIdx.x], f = items[2 * blockIdx.x + 1];
-  const int64_t* base = pool + (int64_t)slot * slot_words + (int64_t)f * kMaxBins;
-  out[(int64_t)blockIdx.x * 2 * kMaxBins + threadIdx.x] = base[threadIdx.x];
-  out[(int64_t)blockIdx.x * 2 * kMaxBins + kMaxBins + threadIdx.x] = base[plane + threadIdx.x];
+  const int64_t* blk = feat_block(L, old_slot_ref(L, slot), f);
+  out[(int64_t)blockIdx.x * 2 * kMaxBins + threadIdx.x] = blk[threadIdx.x];
+  out[(int64_t)blockIdx.x * 2 * kMaxBins + kMaxBins + threadIdx.x] = blk[kMaxBins + threadIdx.x];
 }
 }  // namespace
 
-void gather_feature_hist(const int64_t* pool, int64_t slot_words, int64_t plane, const int32_t* items, int n_items,
-                         int64_t* out, hipStream_t s) {
+void gather_feature_hist(const PoolLayout& pool, const int32_t* items, int n_items, int64_t* out, hipStream_t s) {
   if (n_items <= 0) return;
-  hipLaunchKernelGGL(gather_feature_hist_kernel, dim3(n_items), dim3(kMaxBins), 0, s, pool, slot_words, plane, items, out);
+  hipLaunchKernelGGL(gather_feature_hist_kernel, dim3(n_items), dim3(kMaxBins), 0, s, pool, items, out);
   LGA_LAUNCH_CHECK();
 }
 

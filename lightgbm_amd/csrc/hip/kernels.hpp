@@ -93,6 +93,8 @@ void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, co
 // the 32 bin bytes of row r are rotated by r (byte j = feature (j + r) mod 32).
 inline int64_t row_line_bytes(int64_t N) { return ((N + 2) / 3) * 128; }
 void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hipStream_t s);
+// Writes already packed gradients into the lines (what the root pass does itself when it quantises on the way).
+void store_line_gradients(uint8_t* lines, const int64_t* packed, int64_t N, hipStream_t s);
 
 // Partition (or bagging when task.feature < 0): a0/a1 are the two row-index buffers a node's `buf` selects.
 // Row sampling predicate of a partition task with feature < 0.  feature == -1 (bagging): a row goes left
@@ -172,8 +174,9 @@ struct GrowArgs {
 };
 // root: the single task's "leaf" is node 0 and nothing is partitioned.  total_units = sum of the tasks' units.
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s);
-// Moves the rows of the multi-unit leaves of a grow_round launch (total_chunks mask blocks).
-void grow_scatter(const InlineTasks& inl, int total_chunks, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src,
+// Moves the rows of the multi-unit leaves of a grow_round launch: mask blocks chunk0 .. chunk0 + total_chunks - 1
+// of the round; task_left is the launch's first task's entry.
+void grow_scatter(const InlineTasks& inl, int chunk0, int total_chunks, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src,
                   int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask, const int32_t* chunk_left, int32_t* task_left,
                   hipStream_t s);
 
@@ -187,8 +190,9 @@ struct ScanRange {
 };
 struct ScanArgs {
   const SplitTask* tasks;   // staged descriptors, or null: inl
-  int32_t n_scan;           // 2 x tasks, or 1 (root)
-  int32_t n_tasks;
+  int32_t task0;            // index of the launch's first task among the round's tasks
+  int32_t n_scan;           // scan tasks of the whole round: 2 x tasks, or 1 (root)
+  int32_t n_tasks;          // tasks of the whole round
   int32_t root;
   const FeatureMeta* meta;
   int32_t F;
@@ -197,6 +201,7 @@ struct ScanArgs {
   ScanRange range;
   int32_t my_rank;          // whose header copy holds this rank's (reduced) totals
   int64_t* node_totals;
+  int64_t* scan_totals;     // [n_scan][4]: rows, sum g, sum h of every searched child (read by merge_winners)
   const QuantScale* qs;
   SplitParams sp;
   Cand* block_best;         // [n_scan][n_blocks]
@@ -207,13 +212,13 @@ struct ScanArgs {
   unsigned* done_counter;
   unsigned seq;
 };
-void scan_blocks(const InlineTasks& inl, const ScanArgs& a, hipStream_t s);
+// launch_scan: scan tasks of this launch (inl.count x 2, the staged tasks x 2, or 1 for the root)
+void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hipStream_t s);
 
 // Distributed learners: merge the ranks' winners (gathered [rank][scan task]) into SplitInfo, written to the
 // host-mapped result block together with the left counts and the completion flag.
-void merge_winners(const Cand* gathered, int ranks, const SplitTask* tasks, const InlineTasks& inl, int n_scan, int n_tasks,
-                   int root, const int64_t* node_totals, const QuantScale* qs, const SplitParams& sp,
-                   const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s);
+void merge_winners(const Cand* gathered, int ranks, int n_scan, int n_left, const int64_t* scan_totals, const QuantScale* qs,
+                   const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s);
 
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);

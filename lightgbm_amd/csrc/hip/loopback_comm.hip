@@ -54,6 +54,29 @@ class LoopbackComm : public Comm {
   void allreduce_sum_i64(int64_t* b, size_t n, bool dev, void* s) override { reduce<int64_t, false>(b, n, dev, (hipStream_t)s); }
   void allreduce_sum_f64(double* b, size_t n, bool dev, void* s) override { reduce<double, false>(b, n, dev, (hipStream_t)s); }
   void allreduce_max_f32(float* b, size_t n, bool dev, void* s) override { reduce<float, true>(b, n, dev, (hipStream_t)s); }
+  // A true reduce-scatter: only this rank's block is reduced, the others keep the local partial sums -
+  // what RCCL leaves behind as well, so a learner that reads a block it does not own shows up in the tests.
+  void reduce_scatter_sum_i64(int64_t* buf, size_t block, bool dev, void* stream) override {
+    if (block == 0) return;
+    if (!dev) { reduce<int64_t, false>(buf, block * (size_t)hub_->size, false, (hipStream_t)stream); return; }
+    hipStream_t s = (hipStream_t)stream;
+    const int P = hub_->size;
+    const size_t total = block * (size_t)P;
+    hub_->stage[(size_t)rank_].resize(total * sizeof(int64_t));
+    LGA_HIP_CHECK(hipMemcpyAsync(hub_->stage[(size_t)rank_].get(), buf, total * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    hub_->barrier();
+    std::vector<const int64_t*> parts((size_t)P);
+    for (int r = 0; r < P; ++r) parts[(size_t)r] = (const int64_t*)hub_->stage[(size_t)r].get() + (size_t)rank_ * block;
+    ptrs_.resize((size_t)P * sizeof(void*));
+    LGA_HIP_CHECK(hipMemcpyAsync(ptrs_.get(), parts.data(), (size_t)P * sizeof(void*), hipMemcpyHostToDevice, s));
+    int blocks = (int)std::min<size_t>((block + 255) / 256, 2048);
+    hipLaunchKernelGGL((reduce_kernel<int64_t, false>), dim3(blocks), dim3(256), 0, s, buf + (size_t)rank_ * block,
+                       (const int64_t* const*)ptrs_.get(), P, block);
+    LGA_HIP_CHECK(hipGetLastError());
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    hub_->barrier();
+  }
   void allgather_bytes(const void* in, void* out, size_t nbytes, bool dev, void* stream) override {
     hipStream_t s = (hipStream_t)stream;
     if (dev) {

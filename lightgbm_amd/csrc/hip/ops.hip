@@ -49,13 +49,58 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     return 0;
   }
   if (name == "histogram") {
-    // ptrs: tasks, chunk_task, nodes, a0, a1, bins_rt, packed, pool
-    // ints: total_chunks, rows_per_chunk, N, slot_words, plane, F, tile_first, tile_step, tile_count
-    if (nptr < 8 || nint < 9) return -1;
+    // ptrs: tasks, chunk_task, nodes, a0, a1, bins_rt, packed, pool, slot_table (2 words)
+    // ints: total_chunks, rows_per_chunk, N, F, tile_first, tile_step, tile_count, tiles
+    // pool: one slot of `tiles` x 32 feature blocks [g 256 | h 256] + header
+    if (nptr < 9 || nint < 8) return -1;
     k::InlineTasks none{};
+    k::PoolLayout L{};
+    L.pool = (int64_t*)p[7];
+    L.slot_table = (int64_t*)p[8];
+    L.fpr = (int32_t)a[7] * kTileFeatures;
+    L.ranks = 1;
+    L.chunk_words = (int64_t)L.fpr * 2 * kMaxBins + kSlotHeader;
+    L.slot_words = L.chunk_words;
     k::histogram((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], (int)a[1], (const NodeRange*)p[2],
-                 (const int32_t*)p[3], (const int32_t*)p[4], (const uint8_t*)p[5], a[2], (const int64_t*)p[6],
-                 (int64_t*)p[7], a[3], a[4], (int)a[5], (int)a[6], (int)a[7], (int)a[8], nullptr, s);
+                 (const int32_t*)p[3], (const int32_t*)p[4], (const uint8_t*)p[5], a[2], (const int64_t*)p[6], L,
+                 k::RoundSlots{0, 1}, (int)a[3], (int)a[4], (int)a[5], (int)a[6], s);
+    return 0;
+  }
+  if (name == "lines_histogram") {
+    // Root pass of the fused growth kernel over row lines, histogram only (no split search).
+    // ptrs: nodes (root range), rows, bins_rt (tile 0 records), packed, lines (scratch, row_line_bytes(N)), pool,
+    //       slot_table, tickets (1 word, zero), g (float, for the fused quantisation) or null, h, maxbits, qs out
+    // ints: n_rows, N, F, unit_rows
+    if (nptr < 12 || nint < 4) return -1;
+    const int64_t n = a[0], N = a[1];
+    k::build_row_lines((const uint8_t*)p[2], N, (uint8_t*)p[4], s);
+    k::InlineTasks inl{};
+    inl.count = 1;
+    SplitTask& t = inl.t[0];
+    t.parent_node = -1;
+    const int unit_rows = (int)a[3];
+    t.num_hchunk = (int)std::max<int64_t>(1, (n + unit_rows - 1) / unit_rows);
+    k::GrowArgs g{};
+    g.nodes = (NodeRange*)p[0];
+    g.a0 = (const int32_t*)p[1];
+    g.a1 = (const int32_t*)p[1];
+    g.lines = (uint8_t*)p[4];
+    g.N = N;
+    g.pool.pool = (int64_t*)p[5];
+    g.pool.slot_table = (int64_t*)p[6];
+    g.pool.fpr = kTileFeatures;
+    g.pool.ranks = 1;
+    g.pool.chunk_words = (int64_t)kTileFeatures * 2 * kMaxBins + kSlotHeader;
+    g.pool.slot_words = g.pool.chunk_words;
+    g.round = k::RoundSlots{0, 1};
+    g.F = (int)a[2];
+    g.unit_rows = unit_rows;
+    g.n_tasks = 1;
+    g.tickets = (unsigned*)p[7];
+    g.tail = 0;
+    if (p[8]) g.quant = k::FusedQuant{(const float*)p[8], (const float*)p[9], (const uint32_t*)p[10], (QuantScale*)p[11]};
+    else k::store_line_gradients((uint8_t*)p[4], (const int64_t*)p[3], N, s);
+    k::grow_round(inl, g, t.num_hchunk, true, s);
     return 0;
   }
   if (name == "partition") {
@@ -68,13 +113,37 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     return 0;
   }
   if (name == "scan") {
-    // ptrs: scan tasks, meta, pool, node_totals, qs, split params (host), cands, out ; ints: n_tasks, F, slot_words, plane
-    if (nptr < 8 || nint < 4) return -1;
+    // Split search of ONE leaf whose histogram sits in slot 0 of `pool` (feature blocks [g 256 | h 256] + header).
+    // ptrs: meta, pool, slot_table (filled: {0, chunk_words}), node_totals, qs, split params (host), block_best,
+    //       counters (>= 8 words, zero), scan_totals (4 words), out (device: 64-byte flag block + SplitInfo + QuantScale)
+    // ints: F, features per slot (multiple of 32)
+    if (nptr < 10 || nint < 2) return -1;
     const SplitParams sp = *(const SplitParams*)p[5];
-    k::scan((const k::ScanTaskDev*)p[0], (int)a[0], (const FeatureMeta*)p[1], (int)a[1], 0, 1, (int64_t*)p[2], a[2],
-            a[3], (int64_t*)p[3], (const QuantScale*)p[4], sp, (k::Cand*)p[6], s);
-    k::select((const k::ScanTaskDev*)p[0], (int)a[0], (int)a[1], (const k::Cand*)p[6], (const int64_t*)p[3],
-              (const QuantScale*)p[4], sp, (SplitInfo*)p[7], nullptr, s);
+    k::InlineTasks inl{};
+    inl.count = 1;
+    k::ScanArgs sa{};
+    sa.n_scan = 1;
+    sa.root = 1;
+    sa.meta = (const FeatureMeta*)p[0];
+    sa.F = (int)a[0];
+    sa.pool.pool = (int64_t*)p[1];
+    sa.pool.slot_table = (int64_t*)p[2];
+    sa.pool.fpr = (int32_t)a[1];
+    sa.pool.ranks = 1;
+    sa.pool.chunk_words = (int64_t)sa.pool.fpr * 2 * kMaxBins + kSlotHeader;
+    sa.pool.slot_words = sa.pool.chunk_words;
+    sa.round = k::RoundSlots{0, 1};
+    sa.range = k::ScanRange{0, (int)a[0], 64, 0, 1, std::max(1, ((int)a[0] + 63) / 64)};
+    sa.node_totals = (int64_t*)p[3];
+    sa.scan_totals = (int64_t*)p[8];
+    sa.qs = (const QuantScale*)p[4];
+    sa.sp = sp;
+    sa.block_best = (k::Cand*)p[6];
+    sa.tickets = (unsigned*)p[7] + 4;
+    sa.done_counter = (unsigned*)p[7];
+    sa.host_out = (char*)p[9];
+    sa.seq = 1;
+    k::scan_blocks(inl, sa, 1, s);
     return 0;
   }
   return -1;

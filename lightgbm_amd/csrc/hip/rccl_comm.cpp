@@ -74,6 +74,13 @@ class RcclComm : public Comm {
   void allreduce_max_f32(float* buf, size_t n, bool device, void* stream) override {
     reduce(buf, n, sizeof(float), ncclFloat32, ncclMax, device, (hipStream_t)stream);
   }
+  void reduce_scatter_sum_i64(int64_t* buf, size_t block, bool device, void* stream) override {
+    if (block == 0) return;
+    if (!device) { allreduce_sum_i64(buf, block * (size_t)size_, false, stream); return; }
+    // in place: the receive buffer is this rank's block of the send buffer
+    check(api().ReduceScatter(buf, buf + (size_t)rank_ * block, block, ncclInt64, ncclSum, comm_, (hipStream_t)stream),
+          "ReduceScatter");
+  }
   void allgather_bytes(const void* in, void* out, size_t nbytes, bool device, void* stream) override {
     hipStream_t s = (hipStream_t)stream;
     if (device) {

@@ -4,7 +4,8 @@ The training loop never goes through these - it drives the kernels from C++ -
 they exist so that every hot kernel can be checked against a plain NumPy /
 PyTorch reference in isolation:
 
-* :func:`hist_build`      - gradient histogram of a row list (LDS packed 64-bit atomics)
+* :func:`hist_build`      - gradient histogram of a row list (LDS packed 64-bit atomics), feature-tile records
+* :func:`lines_hist_build` - the same through the fused growth kernel's root pass over 128-byte row lines
 * :func:`partition_rows`  - stable split of a row list by ``bin <= threshold``
 * :func:`split_scan`      - best split of one leaf histogram (wave prefix scan + fp64 gain)
 * :func:`pack_gradients`  - the (g, h) -> packed int64 quantisation used by the histograms
@@ -68,14 +69,21 @@ def pack_gradients(g: np.ndarray, h: np.ndarray) -> Tuple[np.ndarray, int, int]:
     return packed, kg, kh
 
 
+def _slot_views(pool, fpad: int):
+    """Views of one histogram slot: feature blocks [g 256 | h 256], then the header (rows, sum g, sum h)."""
+    blocks = pool[:fpad * 2 * BINS].view(fpad, 2, BINS)
+    return blocks[:, 0, :], blocks[:, 1, :], pool[fpad * 2 * BINS:]
+
+
 def hist_build(bins_rt, rows, packed, num_features: int, rows_per_chunk: int = 4096):
-    """bins_rt uint8 [tiles, N, 32], rows int32 [n], packed int64 [N] -> (g int64 [tiles*32, 256], h, header[8])."""
+    """bins_rt uint8 [tiles, N, 32], rows int32 [n], packed int64 [N] -> (g int64 [tiles*32, 256], h, header[8]).
+    Runs the feature-tile histogram kernel (data with several tiles, feature-parallel)."""
     import torch
     lib = _need_hip()
     T, N = int(bins_rt.shape[0]), int(bins_rt.shape[1])
     n = int(rows.numel())
-    plane = T * TILE * BINS
-    slot_words = 2 * plane + SLOT_HEADER
+    fpad = T * TILE
+    slot_words = fpad * 2 * BINS + SLOT_HEADER
     nch = max(1, -(-n // rows_per_chunk))
     task = np.zeros(16, dtype=np.int32)
     task[13] = nch   # num_hchunk; left_node = 0, hist_child = 0, new_slot = 0, first_hchunk = 0
@@ -83,14 +91,47 @@ def hist_build(bins_rt, rows, packed, num_features: int, rows_per_chunk: int = 4
     chunk_task = torch.zeros(nch, dtype=torch.int32, device="cuda")
     nodes = _i32([0, n, 0, 0])
     pool = torch.zeros(slot_words, dtype=torch.int64, device="cuda")
+    table = torch.zeros(2, dtype=torch.int64, device="cuda")
     rows = rows.contiguous()
     _op(lib, "histogram",
         [tasks.data_ptr(), chunk_task.data_ptr(), nodes.data_ptr(), rows.data_ptr(), rows.data_ptr(),
-         bins_rt.data_ptr(), packed.data_ptr(), pool.data_ptr()],
-        [nch, rows_per_chunk, N, slot_words, plane, num_features, 0, 1, T])
-    g = pool[:plane].view(T * TILE, BINS)
-    h = pool[plane:2 * plane].view(T * TILE, BINS)
-    return g, h, pool[2 * plane:]
+         bins_rt.data_ptr(), packed.data_ptr(), pool.data_ptr(), table.data_ptr()],
+        [nch, rows_per_chunk, N, num_features, 0, 1, T, T])
+    return _slot_views(pool, fpad)
+
+
+def lines_hist_build(bins_rt, rows, num_features: int, packed=None, g=None, h=None, unit_rows: int = 4096):
+    """Root pass of the fused growth kernel over row lines (one feature tile), histogram only.
+
+    bins_rt uint8 [1, N, 32], rows int32 [n].  Either ``packed`` int64 [N] (quantised gradients) or float32
+    ``g`` / ``h`` [N], which the pass quantises itself (scales from their maxima over ``rows``).
+    Returns (g int64 [32, 256], h, header[8], (kg, kh) or None)."""
+    import torch
+    lib = _need_hip()
+    assert int(bins_rt.shape[0]) == 1 and num_features <= TILE
+    N = int(bins_rt.shape[1])
+    n = int(rows.numel())
+    slot_words = TILE * 2 * BINS + SLOT_HEADER
+    nodes = _i32([0, n, 0, 0])
+    pool = torch.zeros(slot_words, dtype=torch.int64, device="cuda")
+    table = torch.zeros(2, dtype=torch.int64, device="cuda")
+    tickets = torch.zeros(4, dtype=torch.int32, device="cuda")
+    lines = torch.zeros(((N + 2) // 3) * 128, dtype=torch.uint8, device="cuda")
+    rows = rows.contiguous()
+    qs = torch.zeros(2, dtype=torch.int32, device="cuda")
+    if packed is not None:
+        ptrs = [nodes.data_ptr(), rows.data_ptr(), bins_rt.data_ptr(), packed.data_ptr(), lines.data_ptr(),
+                pool.data_ptr(), table.data_ptr(), tickets.data_ptr(), 0, 0, 0, 0]
+    else:
+        gm = float(g[rows.long()].abs().max()) if n else 0.0
+        hm = float(h[rows.long()].max()) if n else 0.0
+        maxbits = torch.tensor(np.array([gm, hm], dtype=np.float32).view(np.int32), device="cuda")
+        ptrs = [nodes.data_ptr(), rows.data_ptr(), bins_rt.data_ptr(), 0, lines.data_ptr(), pool.data_ptr(),
+                table.data_ptr(), tickets.data_ptr(), g.data_ptr(), h.data_ptr(), maxbits.data_ptr(), qs.data_ptr()]
+    _op(lib, "lines_histogram", ptrs, [n, N, num_features, unit_rows])
+    G, H, hd = _slot_views(pool, TILE)
+    scales = None if packed is not None else tuple(int(v) for v in qs.cpu().numpy())
+    return G, H, hd, scales
 
 
 def partition_rows(rows, bins_fm, feature: int, threshold: int, missing_bin: int = -1, default_left: bool = False):
@@ -138,24 +179,32 @@ def split_scan(g, h, count: int, total_g: int, total_h: int, num_bins, missing_b
     import torch
     lib = _need_hip()
     F = len(num_bins)
-    plane = int(g.numel())
-    slot_words = 2 * plane + SLOT_HEADER
-    pool = torch.zeros(slot_words, dtype=torch.int64, device="cuda")
-    pool[:plane] = g.reshape(-1)
-    pool[plane:2 * plane] = h.reshape(-1)
-    pool[2 * plane + 0], pool[2 * plane + 1], pool[2 * plane + 2] = int(count), int(total_g), int(total_h)
+    fpad = int(g.shape[0])
+    chunk_words = fpad * 2 * BINS + SLOT_HEADER
+    pool = torch.zeros(chunk_words, dtype=torch.int64, device="cuda")
+    blocks = pool[:fpad * 2 * BINS].view(fpad, 2, BINS)
+    blocks[:, 0, :] = g
+    blocks[:, 1, :] = h
+    hd = fpad * 2 * BINS
+    pool[hd + 0], pool[hd + 1], pool[hd + 2] = int(count), int(total_g), int(total_h)
+    table = torch.tensor([0, chunk_words], dtype=torch.int64, device="cuda")
     meta = np.zeros((F, 4), dtype=np.int32)
     meta[:, 0], meta[:, 1], meta[:, 2] = num_bins, missing_bins, 1
     meta_t = _i32(meta.reshape(-1))
-    st = _i32([0, 0, -1, -1, -1, 0])
     totals = torch.zeros(4, dtype=torch.int64, device="cuda")
+    scan_totals = torch.zeros(4, dtype=torch.int64, device="cuda")
     qs = _i32([kg, kh])
     sp = _SplitParams(lambda_l1, lambda_l2, min_gain_to_split, min_sum_hessian_in_leaf, 0.0, min_data_in_leaf, -1, 1.0, 0, 0, 0, 0, None, None, 0.0, None, None, 0.0)
-    cands = torch.zeros(F * 4, dtype=torch.int64, device="cuda")
-    out = torch.zeros(9, dtype=torch.int64, device="cuda")
-    _op(lib, "scan", [st.data_ptr(), meta_t.data_ptr(), pool.data_ptr(), totals.data_ptr(), qs.data_ptr(),
-                      ctypes.addressof(sp), cands.data_ptr(), out.data_ptr()], [1, F, slot_words, plane])
+    n_blocks = max(1, (F + 63) // 64)
+    block_best = torch.zeros(n_blocks * 4, dtype=torch.int64, device="cuda")
+    counters = torch.zeros(16, dtype=torch.int32, device="cuda")
+    out = torch.zeros(8 + 9 + 2, dtype=torch.int64, device="cuda")    # flag block (64 B) | SplitInfo (72 B) | QuantScale
+    _op(lib, "scan", [meta_t.data_ptr(), pool.data_ptr(), table.data_ptr(), totals.data_ptr(), qs.data_ptr(),
+                      ctypes.addressof(sp), block_best.data_ptr(), counters.data_ptr(), scan_totals.data_ptr(),
+                      out.data_ptr()], [F, fpad])
     raw = out.cpu().numpy()
+    assert int(raw[:1].view(np.uint32)[0]) == 1, "the split search did not raise its completion flag"
+    raw = raw[8:17]
     ints = raw[1:3].view(np.int32)
     return {"gain": float(raw[:1].view(np.float64)[0]), "feature": int(ints[0]), "threshold": int(ints[1]),
             "default_left": int(ints[2]), "left_g": int(raw[3]), "left_h": int(raw[4]), "total_g": int(raw[5]),

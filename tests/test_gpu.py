@@ -65,6 +65,41 @@ def test_histogram_kernel_matches_numpy(n, F, chunk):
     assert hd[0] == n and hd[1] == gq[rows].sum() and hd[2] == hq[rows].sum()
 
 
+@pytest.mark.parametrize("n,F,unit,fused_quant", [(1000, 28, 2048, False), (70000, 28, 4096, True), (50000, 6, 16384, False),
+                                                  (3, 5, 2048, True), (40000, 32, 2048, True)])
+def test_row_line_histogram_kernel_matches_numpy(n, F, unit, fused_quant):
+    """Root pass of the fused growth kernel (row lines, rotated records, optional in-pass quantisation)."""
+    import torch
+    from lightgbm_amd import ops
+    N = n + 500
+    bins, rt = _random_bins(N, F, seed=n + 1, low_card=(1, 3))
+    rng = np.random.RandomState(2)
+    g = rng.randn(N).astype(np.float32)
+    h = rng.rand(N).astype(np.float32)
+    rows = np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32)
+    if fused_quant:
+        G, H, hd, scales = ops.lines_hist_build(torch.from_numpy(rt).cuda(), torch.from_numpy(rows).cuda(), F,
+                                                g=torch.from_numpy(g).cuda(), h=torch.from_numpy(h).cuda(), unit_rows=unit)
+        kg, kh = ops.quant_exponent(float(np.abs(g[rows]).max())), ops.quant_exponent(float(h[rows].max()))
+        assert scales == (kg, kh)
+        lim = float(1 << ops.QUANT_BITS)
+        gq = np.rint(np.clip(np.ldexp(g, kg), -lim, lim)).astype(np.int64)
+        hq = np.rint(np.clip(np.ldexp(h, kh), -lim, lim)).astype(np.int64)
+    else:
+        packed, kg, kh = ops.pack_gradients(g, h)
+        gq, hq = packed >> 32, packed & 0xffffffff
+        G, H, hd, _ = ops.lines_hist_build(torch.from_numpy(rt).cuda(), torch.from_numpy(rows).cuda(), F,
+                                           packed=torch.from_numpy(packed).cuda(), unit_rows=unit)
+    G, H, hd = G.cpu().numpy(), H.cpu().numpy(), hd.cpu().numpy()
+    for f in range(F):
+        eg = np.zeros(256, dtype=np.int64); eh = np.zeros(256, dtype=np.int64)
+        np.add.at(eg, bins[rows, f], gq[rows]); np.add.at(eh, bins[rows, f], hq[rows])
+        np.testing.assert_array_equal(G[f], eg)      # integer sums: exact
+        np.testing.assert_array_equal(H[f], eh)
+    assert G[F:].sum() == 0 and H[F:].sum() == 0     # padding features untouched
+    assert hd[0] == n and hd[1] == gq[rows].sum() and hd[2] == hq[rows].sum()
+
+
 @pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100000])
 def test_partition_kernel_is_a_stable_split(n):
     import torch
