@@ -75,8 +75,8 @@ class TreeGrower {
   // the previous tree's chosen gains as suffix minima: prev_bar_[k] = smallest gain chosen from the k-th choice on
   std::vector<double> prev_bar_;
   // speculate on a leaf only when its gain reaches a multiple of that bar which rises with its row count
-  double spec_lo_ = 0.5, spec_hi_ = 1.0;
-  double spec_rows_lo_ = 262144.0, spec_rows_hi_ = 4194304.0;
+  double spec_lo_ = 0.2, spec_hi_ = 0.95;
+  double spec_rows_lo_ = 131072.0, spec_rows_hi_ = 2097152.0;
   bool spec_ratio_ = true;        // scale the previous cutoff by the ratio of the roots' best gains
   double prev_root_gain_ = 0.0;
 };

@@ -157,6 +157,7 @@ class HipBackend : public TreeBackend {
       capacity_splits_ -= 1;
     stream_ = current_stream();
     pool_.resize((size_t)(capacity_splits_ + 1) * slot_words_);
+    slots_dirty_ = capacity_splits_ + 1;   // the first tree clears the whole pool
     slot_table_.resize((size_t)2 * (size_t)(capacity_splits_ + 1));
     lay_.pool = pool_.get();
     lay_.slot_table = slot_table_.get();
@@ -219,11 +220,12 @@ class HipBackend : public TreeBackend {
       // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
       x.host_block.resize(k::kHostDataOffset + sizeof(SplitInfo) * n_scan_max + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
       std::memset(x.host_block.get(), 0, x.host_block.size());
-      // counters the kernels leave at zero: [round completion | per-task unit tickets | per-scan-task block tickets]
-      x.counters.resize(4 + (size_t)(max_batch_ + 1) + n_scan_max);
+      // counters the kernels leave at zero: [round completion | per-scan-task block tickets]
+      x.counters.resize(4 + n_scan_max);
       x.counters.zero(stream_);
-      x.block_best.resize(n_scan_max * (size_t)scan_range_.n_blocks);
+      x.block_best.resize(n_scan_max * (size_t)std::max(scan_range_.n_blocks, (F_ + 7) / 8));
       x.scan_totals.resize(n_scan_max * 4);
+      x.results.resize(n_scan_max);
       if (mode_ != ParallelMode::Serial) {
         x.best_local.resize(n_scan_max);
         x.best_all.resize(n_scan_max * (size_t)comm_->size());
@@ -350,7 +352,10 @@ class HipBackend : public TreeBackend {
     RoundCtx& x = ctx_[0];
     std::memcpy(x.stage_host.get(), &ranges_host_[0], sizeof(NodeRange));
     LGA_HIP_CHECK(hipMemcpyAsync(nodes_.get(), x.stage_host.get(), sizeof(NodeRange), hipMemcpyHostToDevice, stream_));
-    LGA_HIP_CHECK(hipMemsetAsync(pool_.get(), 0, sizeof(int64_t) * (size_t)slot_words_, stream_));
+    // Large leaves ADD their histograms to their slots, so slots start a tree at zero: one clear per tree of
+    // what the previous tree used, instead of one per round.
+    LGA_HIP_CHECK(hipMemsetAsync(pool_.get(), 0, sizeof(int64_t) * (size_t)slot_words_ * (size_t)slots_dirty_, stream_));
+    slots_dirty_ = 1;
     launch_round(x, tasks, true);
     finish_round(x, out);
   }
@@ -436,14 +441,14 @@ class HipBackend : public TreeBackend {
     DeviceBuffer<unsigned> counters;
     DeviceBuffer<k::Cand> block_best, best_local, best_all;
     DeviceBuffer<int64_t> scan_totals;
+    DeviceBuffer<SplitInfo> results;
     unsigned seq = 0;
     // the round in flight
     bool busy = false, root = false;
     std::vector<SplitTask> tasks;
     std::chrono::steady_clock::time_point t_begin, t_launched;
     unsigned* done_counter() const { return counters.get(); }
-    unsigned* unit_tickets() const { return counters.get() + 4; }
-    unsigned* scan_tickets(int max_batch) const { return counters.get() + 4 + (size_t)(max_batch + 1); }
+    unsigned* scan_tickets() const { return counters.get() + 4; }
   };
 
   void upload_stage(RoundCtx& x, size_t bytes) {
@@ -495,6 +500,7 @@ class HipBackend : public TreeBackend {
     // a round's new slots are consecutive (the grower hands them out in task order)
     for (int i = 0; i < B; ++i)
       if (tasks[(size_t)i].new_slot != round.first_slot + i) throw std::runtime_error("round slots are not consecutive");
+    slots_dirty_ = std::max(slots_dirty_, round.first_slot + round.n_slots);
     if (lines_) launch_lines(x, tasks, root, round);
     else launch_tiles(x, tasks, root, round);
     trace_pop();
@@ -511,13 +517,11 @@ class HipBackend : public TreeBackend {
   void launch_lines(RoundCtx& x, std::vector<SplitTask>& tasks, bool root, k::RoundSlots round) {
     const int B = (int)tasks.size();
     hipStream_t st_ = x.stream;
-    const bool tail = !distributed();
     // units: a leaf of up to solo_rows_ rows is one workgroup's; larger ones are cut into units of unit_rows
     int64_t multi_rows = 0;
-    int n_multi = 0;
     for (const auto& t : tasks) {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
-      if (root || cnt > solo_rows_) { multi_rows += cnt; ++n_multi; }
+      if (root || cnt > solo_rows_) multi_rows += cnt;
     }
     int64_t ur = (multi_rows + target_units_ - 1) / target_units_;
     ur = ((ur + k::kSubRows - 1) / k::kSubRows) * k::kSubRows;
@@ -533,59 +537,46 @@ class HipBackend : public TreeBackend {
       np += t.num_pchunk;
       if (np > max_pchunks_) throw std::runtime_error("chunk table overflow");
     }
-    // multi-unit leaves add their histograms with atomics: their slots start at zero
-    if (n_multi > 0 && !root) {
-      int lo = B, hi = -1;
-      for (int i = 0; i < B; ++i)
-        if (tasks[(size_t)i].num_pchunk > 0) { lo = std::min(lo, i); hi = std::max(hi, i); }
-      if (lay_.ranks > 1) { lo = 0; hi = B - 1; }   // a slot's rank chunks are spread over the round's region
-      LGA_HIP_CHECK(hipMemsetAsync(pool_.get() + (size_t)(round.first_slot + lo) * slot_words_, 0,
-                                   sizeof(int64_t) * (size_t)slot_words_ * (size_t)(hi - lo + 1), st_));
-    }
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
+    int units = 0;
+    for (auto& t : tasks) { t.first_hchunk = units; units += t.num_hchunk; }
+    // descriptors: inline in the kernel arguments, or - rounds above kInlineTasks leaves - staged in device memory
+    k::InlineTasks inl{};
+    const SplitTask* staged = nullptr;
+    if (B <= k::kInlineTasks) {
+      inl.count = B;
+      std::memcpy(inl.t, tasks.data(), sizeof(SplitTask) * (size_t)B);
+    } else {
+      std::memcpy(x.stage_host.get() + off_tasks_, tasks.data(), sizeof(SplitTask) * (size_t)B);
+      LGA_HIP_CHECK(hipMemcpyAsync(x.stage_dev.get() + off_tasks_, x.stage_host.get() + off_tasks_, sizeof(SplitTask) * (size_t)B,
+                                   hipMemcpyHostToDevice, st_));
+      staged = reinterpret_cast<const SplitTask*>(x.stage_dev.get() + off_tasks_);
+    }
     prof.mark(PhaseProfile::kPartition, st_);
     k::GrowArgs a{};
+    a.tasks = staged; a.n_staged = staged ? B : 0;
     a.nodes = nodes_.get();
     a.a0 = src0; a.a1 = arena_[1].get();
     a.a0_dst = arena_[0].get(); a.a1_dst = arena_[1].get();
-    a.lines = lines_; a.N = N_;
+    a.lines = lines_; a.bins_fm = mir_->bins_fm.get(); a.N = N_;
     a.pool = lay_; a.round = round;
     a.F = F_; a.unit_rows = unit_rows;
-    a.n_tasks = root ? 1 : B;
     a.mask = x.mask.get(); a.chunk_left = x.chunk_left.get(); a.task_left = x.task_left.get();
-    a.tickets = x.unit_tickets();
     a.cat_sets = cat_sets_dev_.get();
-    a.tail = tail ? 1 : 0;
-    a.meta = meta_dev_.get(); a.node_totals = node_totals_.get(); a.qs = qs_dev_.get(); a.sp = sp_;
-    a.host_out = x.host_block.device_ptr(); a.done_counter = x.done_counter(); a.seq = x.seq;
     if (root) a.quant = root_quant_;
-    for (int g0 = 0; g0 < B; g0 += k::kInlineTasks) {
-      const int gn = std::min(k::kInlineTasks, B - g0);
-      k::InlineTasks inl{};
-      inl.count = gn;
-      int units = 0, chunks = 0;
-      for (int i = 0; i < gn; ++i) {
-        SplitTask& t = tasks[(size_t)(g0 + i)];
-        t.first_hchunk = units;
-        units += t.num_hchunk;
-        chunks += t.num_pchunk;
-        inl.t[i] = t;
-      }
-      a.task0 = g0;
-      k::grow_round(inl, a, units, root, st_);
-      if (chunks > 0)
-        k::grow_scatter(inl, tasks[(size_t)g0].first_pchunk, chunks, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
-                        arena_[1].get(), x.mask.get(), x.chunk_left.get(), x.task_left.get() + g0, st_);
-    }
+    k::grow_round(inl, a, units, root, st_);
+    if (np > 0)
+      k::grow_scatter(staged, a.n_staged, inl, np, nodes_.get(), src0, arena_[1].get(), arena_[0].get(), arena_[1].get(),
+                      x.mask.get(), x.chunk_left.get(), x.task_left.get(), st_);
     prof.mark(PhaseProfile::kHist, st_);
-    if (tail) {
-      prof.mark(PhaseProfile::kComm, st_);
-      prof.mark(PhaseProfile::kScan, st_);
-      prof.mark(PhaseProfile::kFetch, st_);
-      prof.mark(PhaseProfile::kCount, st_);
-      return;
-    }
-    finish_distributed(x, tasks, root, round, /*staged=*/nullptr);
+    if (distributed()) { finish_distributed(x, tasks, root, round, staged, inl); return; }
+    prof.mark(PhaseProfile::kComm, st_);
+    prof.mark(PhaseProfile::kScan, st_);
+    k::ScanArgs sa = scan_args(x, root, B, round);
+    sa.tasks = staged;
+    k::scan_blocks(inl, sa, root ? 1 : 2 * B, st_);
+    prof.mark(PhaseProfile::kFetch, st_);
+    prof.mark(PhaseProfile::kCount, st_);
   }
 
   // ---- rounds over feature-tile records (several tiles, or feature-parallel) ----
@@ -655,7 +646,7 @@ class HipBackend : public TreeBackend {
       k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_, packed_, lay_, round, F_,
                    tile_first, tile_step, tile_count, st_);
     }
-    if (distributed()) { finish_distributed(x, tasks, root, round, dt); return; }
+    if (distributed()) { finish_distributed(x, tasks, root, round, dt, inl); return; }
     prof.mark(PhaseProfile::kComm, st_);
     prof.mark(PhaseProfile::kScan, st_);
     k::ScanArgs sa = scan_args(x, root, B, round);
@@ -677,14 +668,26 @@ class HipBackend : public TreeBackend {
     sa.pool = lay_;
     sa.round = round;
     sa.range = scan_range_;
+    if (mode_ != ParallelMode::Feature) {
+      // feature blocks: one feature per wave (8 per workgroup) while the round is small - its search is pure
+      // latency - growing to keep the launch near a thousand workgroups when it has hundreds of leaves
+      const int owned = std::max(0, scan_range_.f_end - scan_range_.f_begin);
+      const int want_blocks = std::max(1, 1024 / std::max(1, sa.n_scan));
+      int g = (owned + want_blocks - 1) / want_blocks;
+      g = std::max(8, ((g + 7) / 8) * 8);
+      sa.range.group_size = g;
+      sa.range.n_blocks = std::max(1, (owned + g - 1) / g);
+    }
     sa.my_rank = lay_.ranks > 1 ? comm_->rank() : 0;
     sa.node_totals = node_totals_.get();
     sa.scan_totals = x.scan_totals.get();
     sa.qs = qs_dev_.get();
     sa.sp = sp_;
     sa.block_best = x.block_best.get();
-    sa.tickets = x.scan_tickets(max_batch_);
+    sa.tickets = x.scan_tickets();
     sa.task_left = x.task_left.get();
+    sa.results = x.results.get();
+    sa.host_out = x.host_block.device_ptr();
     sa.done_counter = x.done_counter();
     sa.seq = x.seq;
     return sa;
@@ -697,7 +700,7 @@ class HipBackend : public TreeBackend {
   // With two rounds in flight the collectives (and what sits between them) run on the one stream that
   // carries every collective, in submission order.
   void finish_distributed(RoundCtx& x, const std::vector<SplitTask>& tasks, bool root, k::RoundSlots round,
-                          const SplitTask* staged) {
+                          const SplitTask* staged, const k::InlineTasks& inl) {
     const int B = (int)tasks.size();
     hipStream_t st_ = x.stream;
     prof.mark(PhaseProfile::kComm, st_);
@@ -718,21 +721,8 @@ class HipBackend : public TreeBackend {
     const int n_scan = root ? 1 : 2 * B;
     k::ScanArgs sa = scan_args(x, root, B, round);
     sa.best_out = x.best_local.get();
-    if (staged || root) {
-      k::InlineTasks inl{};
-      if (root) { inl.count = 1; inl.t[0] = tasks[0]; }
-      sa.tasks = root ? nullptr : staged;
-      k::scan_blocks(inl, sa, n_scan, cs);
-    } else {
-      for (int g0 = 0; g0 < B; g0 += k::kInlineTasks) {
-        const int gn = std::min(k::kInlineTasks, B - g0);
-        k::InlineTasks inl{};
-        inl.count = gn;
-        for (int i = 0; i < gn; ++i) inl.t[i] = tasks[(size_t)(g0 + i)];
-        sa.task0 = g0;
-        k::scan_blocks(inl, sa, 2 * gn, cs);
-      }
-    }
+    sa.tasks = staged;
+    k::scan_blocks(inl, sa, n_scan, cs);
     comm_->allgather_bytes(x.best_local.get(), x.best_all.get(), sizeof(k::Cand) * (size_t)n_scan, true, cs);
     k::merge_winners(x.best_all.get(), comm_->size(), n_scan, root ? 0 : B, x.scan_totals.get(), qs_dev_.get(), sp_,
                      x.task_left.get(), x.host_block.device_ptr(), x.seq, cs);
@@ -886,7 +876,8 @@ class HipBackend : public TreeBackend {
   int F_ = 0, T_ = 0;
   int64_t N_ = 0, slot_words_ = 0;
   int capacity_splits_ = 0, max_batch_ = 0, max_pchunks_ = 0, max_hchunks_ = 0;
-  int solo_rows_ = 8192;      // leaves up to this many rows are one workgroup's (LGA_SOLO_ROWS)
+  int slots_dirty_ = 1;       // slots written since the pool was last cleared
+  int solo_rows_ = 2048;      // leaves up to this many rows are one workgroup's (LGA_SOLO_ROWS)
   int target_units_ = 640;    // units a round's multi-unit leaves are cut into (LGA_TARGET_UNITS)
   k::PoolLayout lay_{};
   k::ScanRange scan_range_{};

@@ -70,6 +70,29 @@ __device__ __forceinline__ int64_t shfl_xor_i64(int64_t v, int m) {
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
   return __longlong_as_double(shfl_xor_i64(__double_as_longlong(v), m));
 }
+// Inclusive prefix sum over the 64 lanes of a wave with data-parallel-primitive moves (no LDS round trip per
+// step): shifts by 1, 2, 4, 8 inside each row of 16 lanes, then the row totals are carried on with the row
+// broadcasts (lane 15 of rows 0 / 2 to rows 1 / 3, lane 31 to rows 2 and 3).  Lanes without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int64_t dpp_move_i64(int64_t v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v & 0xffffffffull), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)v >> 32), CTRL, ROW_MASK, 0xF, false);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
+__device__ __forceinline__ int64_t wave_prefix_sum_i64(int64_t v) {
+  v += dpp_move_i64<0x111, 0xF>(v);   // row_shr:1
+  v += dpp_move_i64<0x112, 0xF>(v);   // row_shr:2
+  v += dpp_move_i64<0x114, 0xF>(v);   // row_shr:4
+  v += dpp_move_i64<0x118, 0xF>(v);   // row_shr:8
+  v += dpp_move_i64<0x142, 0xA>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_move_i64<0x143, 0xC>(v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ int64_t read_lane_i64(int64_t v, int src_lane) {   // src_lane is wave-uniform
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v & 0xffffffffull), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src_lane);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+}
 __device__ __forceinline__ int64_t wave_sum_i64(int64_t v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_i64(v, m);
@@ -302,6 +325,18 @@ __device__ __forceinline__ int find_task(const InlineTasks& inl, int wg) {
   return lo;
 }
 
+template <bool PART>
+__device__ __forceinline__ int find_task_staged(const SplitTask* __restrict__ tasks, int count, int wg) {
+  int lo = 0, hi = count - 1;
+#pragma unroll 1
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    const int first = PART ? tasks[mid].first_pchunk : tasks[mid].first_hchunk;
+    if (wg >= first) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // Pass 1 of the partition: ballot masks + left counts per 2048-row chunk.  A task that fits ONE
 // chunk is finished right here (ranks from the masks in LDS, scatter, child ranges), so rounds made
 // of small leaves need no second launch.  The workgroups also clear the histogram slots of the round.
@@ -393,12 +428,12 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl,
     NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src,
     int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask,
-    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, int chunk0) {
+    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, int chunk0, int n_staged) {
   constexpr int kWords = kPartChunk / kWave;   // 32 mask words per chunk
   __shared__ int red_before[kPartThreads / kWave], red_all[kPartThreads / kWave];
   __shared__ int word_prefix[kWords];
   const int wg = blockIdx.x + chunk0;
-  const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
+  const int ti = tasks ? (chunk_task ? chunk_task[wg] : find_task_staged<true>(tasks, n_staged, wg)) : find_task<true>(inl, wg);
   const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
   if (t.num_pchunk == 1) return;   // finished by pass 1
   const int c = wg - t.first_pchunk;
@@ -626,81 +661,70 @@ __device__ __forceinline__ void store_feat_cells(int64_t* __restrict__ blk, int 
   ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
 }
 
+// Combines the lanes' running bests: on return every lane holds the wave's winner.
+__device__ __forceinline__ void wave_best(double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+#pragma unroll
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    double g2 = shfl_xor_f64(bg, msk);
+    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
+    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
+    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
+  }
+}
+
 // Best split of ONE feature of one leaf from the feature's histogram held by one wave (g, h: 4 bins per
-// lane; overwritten).  On return every lane holds the running best updated with this feature's winner.
+// lane; overwritten).  Every lane folds ITS candidates of this feature into its own running best; the lanes'
+// bests are combined once per leaf (wave_best), not once per feature.  The per-feature gain adjustment is
+// monotone in the gain, so it may be applied to a lane's best candidate of the feature.
 __device__ __forceinline__ void scan_cells_wave(int f, int lane, int64_t (&g)[4], int64_t (&h)[4], const FeatureMeta m,
                                                 const LeafScanCtx& ctx, const SplitParams& sp, double& bg, uint64_t& bkey,
                                                 int64_t& blg, int64_t& blh, uint32_t key) {
   const int nb = m.num_bin, mb = m.missing_bin;
   const int vb = mb >= 0 ? nb - 1 : nb;
-  if (m.categorical) {
-    // one category against the rest: the left child is a single value bin (no prefix sums)
-    const int only_c = extra_trees_threshold(sp, key, f, vb);
-    const double ninf_c = -std::numeric_limits<double>::infinity();
-    double cbg = ninf_c;
-    uint64_t ckey = ~0ull;
-    int64_t clg = 0, clh = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int thr = lane * 4 + j;
-      if (thr < vb && (only_c < 0 || thr == only_c))
-        take_better(cbg, ckey, clg, clh, split_gain(g[j], h[j], ctx, sp, 0), cand_key(f, thr, 0), g[j], h[j]);
-    }
-#pragma unroll
-    for (int msk = 32; msk >= 1; msk >>= 1) {
-      double g2 = shfl_xor_f64(cbg, msk);
-      uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)ckey, msk);
-      int64_t lg2 = shfl_xor_i64(clg, msk), lh2 = shfl_xor_i64(clh, msk);
-      take_better(cbg, ckey, clg, clh, g2, k2, lg2, lh2);
-    }
-    take_better(bg, bkey, blg, blh, adjust_feature_gain(cbg, f, ctx.total_cnt, sp), ckey, clg, clh);
-    return;
-  }
-  // stats of the missing-value bin, broadcast from the lane that holds it
-  int64_t mg = 0, mh = 0;
-  if (mb >= 0) {
-    const int j = mb & 3;
-    int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
-    int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
-    mg = shfl_i64(og, mb >> 2);
-    mh = shfl_i64(oh, mb >> 2);
-  }
-  // inclusive prefix inside the lane, exclusive prefix across lanes
-  g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
-  h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
-  int64_t ig = g[3], ih = h[3];
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    int64_t og = shfl_up_i64(ig, d), oh = shfl_up_i64(ih, d);
-    if (lane >= d) { ig += og; ih += oh; }
-  }
-  const int64_t eg = ig - g[3], eh = ih - h[3];
-  const int last = mb >= 0 ? vb - 1 : vb - 2;
-  const int only = extra_trees_threshold(sp, key, f, last + 1);
   const double ninf = -std::numeric_limits<double>::infinity();
   double lbg = ninf;
   uint64_t lkey = ~0ull;
   int64_t llg = 0, llh = 0;
+  if (m.categorical) {
+    // one category against the rest: the left child is a single value bin (no prefix sums)
+    const int only_c = extra_trees_threshold(sp, key, f, vb);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int thr = lane * 4 + j;
-    if (thr <= last && (only < 0 || thr == only)) {
-      const int64_t lg = eg + g[j], lh = eh + h[j];
-      take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp, m.monotone), cand_key(f, thr, 0), lg, lh);
-      if (mb >= 0 && thr <= vb - 2)
-        take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp, m.monotone), cand_key(f, thr, 1), lg + mg, lh + mh);
+    for (int j = 0; j < 4; ++j) {
+      const int thr = lane * 4 + j;
+      if (thr < vb && (only_c < 0 || thr == only_c))
+        take_better(lbg, lkey, llg, llh, split_gain(g[j], h[j], ctx, sp, 0), cand_key(f, thr, 0), g[j], h[j]);
+    }
+  } else {
+    // stats of the missing-value bin, broadcast from the lane that holds it
+    int64_t mg = 0, mh = 0;
+    if (mb >= 0) {
+      const int j = mb & 3;
+      int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
+      int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
+      mg = read_lane_i64(og, mb >> 2);
+      mh = read_lane_i64(oh, mb >> 2);
+    }
+    // inclusive prefix inside the lane, exclusive prefix across lanes
+    g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
+    h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
+    const int64_t eg = wave_prefix_sum_i64(g[3]) - g[3], eh = wave_prefix_sum_i64(h[3]) - h[3];
+    const int last = mb >= 0 ? vb - 1 : vb - 2;
+    const int only = extra_trees_threshold(sp, key, f, last + 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int thr = lane * 4 + j;
+      if (thr <= last && (only < 0 || thr == only)) {
+        const int64_t lg = eg + g[j], lh = eh + h[j];
+        take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp, m.monotone), cand_key(f, thr, 0), lg, lh);
+        if (mb >= 0 && thr <= vb - 2)
+          take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp, m.monotone), cand_key(f, thr, 1), lg + mg, lh + mh);
+      }
     }
   }
-#pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    double g2 = shfl_xor_f64(lbg, msk);
-    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)lkey, msk);
-    int64_t lg2 = shfl_xor_i64(llg, msk), lh2 = shfl_xor_i64(llh, msk);
-    take_better(lbg, lkey, llg, llh, g2, k2, lg2, lh2);
-  }
+  // with a gain adjustment the feature's winner is chosen on the raw gains first, as the host engine does
+  if (sp.feature_scale) wave_best(lbg, lkey, llg, llh);
   take_better(bg, bkey, blg, blh, adjust_feature_gain(lbg, f, ctx.total_cnt, sp), lkey, llg, llh);
 }
-
 __device__ __forceinline__ void write_split(SplitInfo* o, double bg, uint64_t bkey, int64_t blg, int64_t blh, int64_t tc,
                                             int64_t tg, int64_t th, const QuantScale& q, const SplitParams& sp) {
   const double ninf = -std::numeric_limits<double>::infinity();
@@ -727,22 +751,6 @@ __device__ __forceinline__ LeafScanCtx node_scan_ctx(int64_t tg, int64_t th, int
                        sp.node_bounds ? sp.node_bounds[kNodeInfoStride * node + 2] : kNaN);
 }
 
-// Completion of a round whose results go straight to host-mapped memory: the `n_done`-th caller writes the
-// quantisation scales behind the left counts and raises the flag the host polls.
-__device__ __forceinline__ void finish_to_host(char* host_out, int n_scan, int n_left, int n_done, unsigned* done_counter,
-                                               unsigned seq, const QuantScale& q) {
-  __threadfence_system();
-  const unsigned old = atomicAdd(done_counter, 1u);
-  if (old == (unsigned)(n_done - 1)) {
-    int32_t* tl = reinterpret_cast<int32_t*>(host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
-    QuantScale* qo = reinterpret_cast<QuantScale*>(tl + n_left);
-    *qo = q;
-    *done_counter = 0u;
-    __threadfence_system();
-    *reinterpret_cast<volatile unsigned*>(host_out) = seq;
-  }
-}
-
 // Hand-over between the workgroups of one launch.  Every wave has drained its own stores / atomics
 // (s_waitcnt) before the barrier; one lane then releases at agent scope and draws a ticket.
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -760,6 +768,7 @@ __device__ __forceinline__ void acquire_after_ticket() {
 // feature at a time), the workgroup that finishes a task last merges the blocks' winners.
 __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanArgs a) {
   __shared__ Cand wbest[8];
+  __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int ti = blockIdx.x >> 1, side = blockIdx.x & 1;
@@ -804,39 +813,63 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
     if (node_feature_on(a.sp, key, f, a.F) && node_allows(a.sp, node, f) && m.categorical != kCategoricalSorted)
       scan_cells_wave(f, lane, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
   }
+  wave_best(bg, bkey, blg, blh);
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int w = 1; w < 8; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
-  const int nb = a.range.n_blocks;
-  if (b == 0) {
-    int64_t* nt = a.node_totals + (int64_t)node * 4;
-    nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
-    int64_t* st = a.scan_totals + (int64_t)s * 4;
-    st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
-  }
-  if (nb > 1) {
-    a.block_best[(int64_t)s * nb + b] = Cand{bg, bkey, blg, blh};
-    if (release_and_ticket(&a.tickets[s]) != (unsigned)(nb - 1)) return;
-    acquire_after_ticket();
-    a.tickets[s] = 0u;
-    bg = ninf; bkey = ~0ull; blg = 0; blh = 0;
-    for (int i = 0; i < nb; ++i) {
-      const Cand c = a.block_best[(int64_t)s * nb + i];
-      take_better(bg, bkey, blg, blh, c.gain, c.key, c.lg, c.lh);
+  if (threadIdx.x == 0) {
+    s_last = 0;
+    for (int w = 1; w < 8; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
+    const int nb = a.range.n_blocks;
+    if (b == 0) {
+      int64_t* nt = a.node_totals + (int64_t)node * 4;
+      nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
+      int64_t* st = a.scan_totals + (int64_t)s * 4;
+      st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
+    }
+    bool have_winner = true;
+    if (nb > 1) {
+      a.block_best[(int64_t)s * nb + b] = Cand{bg, bkey, blg, blh};
+      have_winner = release_and_ticket(&a.tickets[s]) == (unsigned)(nb - 1);
+      if (have_winner) {
+        acquire_after_ticket();
+        a.tickets[s] = 0u;
+        bg = ninf; bkey = ~0ull; blg = 0; blh = 0;
+        for (int i = 0; i < nb; ++i) {
+          const Cand c = a.block_best[(int64_t)s * nb + i];
+          take_better(bg, bkey, blg, blh, c.gain, c.key, c.lg, c.lh);
+        }
+      }
+    }
+    if (have_winner) {
+      if (a.best_out) {
+        a.best_out[s] = Cand{bg, bkey, blg, blh};   // distributed: all-gather + merge_winners follow
+      } else {
+        write_split(&a.results[s], bg, bkey, blg, blh, tc, tg, th, q, a.sp);
+        if (release_and_ticket(a.done_counter) == (unsigned)(a.n_scan - 1)) {
+          acquire_after_ticket();
+          *a.done_counter = 0u;
+          s_last = 1;
+        }
+      }
     }
   }
-  if (a.best_out) {
-    a.best_out[s] = Cand{bg, bkey, blg, blh};
-    return;
-  }
-  SplitInfo* out = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
-  write_split(&out[s], bg, bkey, blg, blh, tc, tg, th, q, a.sp);
-  if (!a.root && side == 0) {
+  __syncthreads();
+  if (!s_last) return;
+  // the workgroup that finished the round's last search hands everything to the host in one go: results,
+  // left counts, quantisation scales, then - behind one system-scope fence - the flag the host polls
+  {
+    const int n_left = a.root ? 0 : a.n_tasks;
+    int64_t* out = reinterpret_cast<int64_t*>(a.host_out + kHostDataOffset);
+    const int64_t* res = reinterpret_cast<const int64_t*>(a.results);
+    const int words = a.n_scan * (int)(sizeof(SplitInfo) / 8);
+    for (int i = threadIdx.x; i < words; i += 512) out[i] = res[i];
     int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
-    tl[a.task0 + ti] = a.task_left[a.task0 + ti];
+    for (int i = threadIdx.x; i < n_left; i += 512) tl[i] = a.task_left[i];
+    if (threadIdx.x == 0) *reinterpret_cast<QuantScale*>(tl + n_left) = q;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(a.host_out) = a.seq;
   }
-  finish_to_host(a.host_out, a.n_scan, a.root ? 0 : a.n_tasks, a.n_scan, a.done_counter, a.seq, q);
 }
 
 // Distributed learners: every rank's winners have been gathered ([rank][scan task]); each rank merges them the
@@ -888,16 +921,6 @@ __device__ __forceinline__ bool bin_goes_left(const SplitTask& t, int b, const u
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
-// One child of a task during the split search inside grow_kernel.
-struct ChildSearch {
-  int node;
-  uint32_t key;
-  int64_t tc, tg, th;
-  double bg;
-  uint64_t bkey;
-  int64_t blg, blh;
-};
-
 template <bool ROOT, bool QUANT>
 __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
   constexpr int kWaves = kGrowThreads / kWave;
@@ -908,12 +931,10 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   __shared__ int wave_tot[kWaves];
   __shared__ long long red[2][kWaves];
   __shared__ long long tot[3];
-  __shared__ Cand wbest[2][kWaves];
-  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ti = find_task<false>(inl, blockIdx.x);
-  const SplitTask& t = inl.t[ti];
-  const int ridx = a.task0 + ti;                 // index among the round's tasks
+  const int ti = a.tasks ? find_task_staged<false>(a.tasks, a.n_staged, blockIdx.x) : find_task<false>(inl, blockIdx.x);
+  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const int ridx = ti;                           // index among the round's tasks
   const int u = blockIdx.x - t.first_hchunk;
   const bool solo = !ROOT && t.num_pchunk == 0;  // the whole leaf is this workgroup's
   const NodeRange p = a.nodes[ROOT ? 0 : t.parent_node];
@@ -935,22 +956,62 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   const bool hist_left = t.hist_child == 0;
   const uint4* lines = reinterpret_cast<const uint4*>(a.lines);
   long long sg = 0, sh = 0;
-  // Four rows per lane and trip (one block of 32 mask words per trip): every load of a trip is issued
-  // before its LDS atomics.
+  // Phase 1 - which side does every row take?  The split feature's byte comes from the feature-major matrix
+  // (coalesced while the leaf is dense); sixteen rows per lane are in flight per trip, because this phase is
+  // nothing but two dependent loads per row.  The go-left bits land in the LDS mask words (word = position / 64).
+  if (!ROOT) {
+    const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
+    constexpr int U1 = 16;
+    for (int base = lo; base < hi; base += U1 * kGrowThreads) {
+      int row[U1];
+#pragma unroll
+      for (int k = 0; k < U1; ++k) {
+        const int pos = base + k * kGrowThreads + tid;
+        row[k] = pos < hi ? src[pos] : -1;
+        if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
+      }
+      int bin[U1];
+#pragma unroll
+      for (int k = 0; k < U1; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
+#pragma unroll
+      for (int k = 0; k < U1; ++k) {
+        if (base + k * kGrowThreads < hi) {   // uniform: the whole stripe of 512 positions is outside otherwise
+          const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
+          const unsigned long long m = __ballot(left);
+          if (lane == 0) smask[((base - lo) >> 6) + k * kWaves + wave] = m;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // Phase 2 - the histogram child's rows fetch their lines (bins + packed gradients); four rows per lane and trip,
+  // every load of a trip issued before its LDS atomics.
+  const unsigned long long side_flip = hist_left ? 0ull : ~0ull;
   for (int sub = lo; sub < hi; sub += kSubRows) {
-    const int wbase = ((sub - lo) / kSubRows) * (kSubRows / kWave);
     int row[4];
+    bool take[4];
     unsigned long long pk[4];
     uint4 ra[4], rb[4];
+    bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int pos = sub + k * kGrowThreads + tid;
-      row[k] = pos < hi ? src[pos] : -1;
-      if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckHistRow, row[k], a.N)) row[k] = -1;
+      take[k] = pos < hi;
+      if (!ROOT && pos < hi) take[k] = ((smask[(pos - lo) >> 6] ^ side_flip) >> lane) & 1ull;
+      any = any || take[k];
+    }
+    if (!__any(any)) continue;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      row[k] = -1;
+      if (take[k]) {
+        row[k] = src[sub + k * kGrowThreads + tid];
+        if (!LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckHistRow, row[k], a.N)) { row[k] = -1; take[k] = false; }
+      }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (row[k] >= 0) {
+      if (take[k]) {
         const unsigned line = div3((unsigned)row[k]), slot = (unsigned)row[k] - line * 3u;
         const uint4* Lp = lines + (int64_t)line * 8;
         ra[k] = Lp[slot * 2];
@@ -965,14 +1026,8 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
-      bool left = false;
-      if (!ROOT) {
-        if (row[k] >= 0) left = bin_goes_left(t, line_bin(w, t.feature, row[k]), a.cat_sets);
-        const unsigned long long m = __ballot(left);
-        if (lane == 0) smask[wbase + k * kWaves + wave] = m;
-      }
-      if (row[k] >= 0 && (ROOT || left == hist_left)) {
+      if (take[k]) {
+        const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
         sg += (long long)(int32_t)(pk[k] >> 32);
         sh += (long long)(pk[k] & 0xffffffffull);
         // byte j of the record holds feature (j + row) mod 32: the lanes of a wave work on different
@@ -983,8 +1038,8 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
         for (int j = 0; j < kTileFeatures; ++j) {
           const unsigned f = (j + rot) & 31u;
           if (f < (unsigned)nf) {
-            const unsigned bin = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
-            atomicAdd(&lds[f * kMaxBins + ((bin + 8u * f) & 255u)], pk[k]);
+            const unsigned bn = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
+            atomicAdd(&lds[f * kMaxBins + ((bn + 8u * f) & 255u)], pk[k]);
           }
         }
       }
@@ -1055,141 +1110,24 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   __syncthreads();
 
   if (!solo) {
+    // one unit of a large leaf (or of the root): add to the zeroed slot
     flush_lds_hist<true>(lds, nf, 0, L, fresh, kGrowThreads);
     if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
-    if (!a.tail) return;
-    // the unit that arrives last searches the splits
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) {
-      const bool last = release_and_ticket(&a.tickets[ridx]) == (unsigned)(t.num_hchunk - 1);
-      if (last) { acquire_after_ticket(); a.tickets[ridx] = 0u; }
-      s_last = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (!ROOT) {
-      // rows that went left, over all units
-      int v = 0;
-      for (int i = tid; i < t.num_pchunk; i += kGrowThreads) v += a.chunk_left[t.first_pchunk + i];
-#pragma unroll
-      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-      if (lane == 0) wave_tot[wave] = v;
-      __syncthreads();
-      if (tid == 0) {
-        int all = 0;
-        for (int w = 0; w < kWaves; ++w) all += wave_tot[w];
-        lefts = all;
-        const int64_t* hd = slot_header(L, fresh, 0);
-        tot[0] = hd[0]; tot[1] = hd[1]; tot[2] = hd[2];
-      }
-    } else if (tid == 0) {
-      const int64_t* hd = slot_header(L, fresh, 0);
-      tot[0] = hd[0]; tot[1] = hd[1]; tot[2] = hd[2];
-    }
-    __syncthreads();
-  } else if (!a.tail) {
-    // solo leaf, split search elsewhere (distributed): the histogram goes to the slot as it is
-    for (int e = tid; e < nf * kMaxBins; e += kGrowThreads) {
-      const int fe = e >> 8, b = e & 255;
-      const unsigned long long v = lds[(fe << 8) + ((b + 8 * fe) & 255)];
-      int64_t* blk = feat_block(L, fresh, fe);
-      blk[b] = (int64_t)(int32_t)(v >> 32);
-      blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
-    }
-    if (tid == 0)
-      for (int r = 0; r < L.ranks; ++r) {
-        int64_t* hd = slot_header(L, fresh, r);
-        hd[0] = tot[0]; hd[1] = tot[1]; hd[2] = tot[2];
-      }
     return;
   }
-
-  // ---- split search: child A owns the fresh histogram, child B = parent - A (in the parent's slot) ----
-  const QuantScale q = *a.qs;
-  const SplitParams& sp = a.sp;
-  const double ninf = -std::numeric_limits<double>::infinity();
-  const int sideA = ROOT ? 0 : t.hist_child;
-  ChildSearch A, B;
-  A.node = ROOT ? 0 : (sideA == 0 ? t.left_node : t.right_node);
-  A.key = ROOT ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, sideA);
-  A.tc = tot[0]; A.tg = tot[1]; A.th = tot[2];
-  A.bg = ninf; A.bkey = ~0ull; A.blg = 0; A.blh = 0;
-  B = A;
-  SlotRef parent = fresh;
-  if (!ROOT) {
-    B.node = sideA == 0 ? t.right_node : t.left_node;
-    B.key = child_node_key((uint32_t)t.parent_key, 1 - sideA);
-    const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
-    B.tc = pt[0] - A.tc; B.tg = pt[1] - A.tg; B.th = pt[2] - A.th;
-    parent = old_slot_ref(L, t.parent_slot);
+  // the whole leaf was this workgroup's: the histogram goes to the slot as it is (no atomics, no zeroing)
+  for (int e = tid; e < nf * kMaxBins; e += kGrowThreads) {
+    const int fe = e >> 8, b = e & 255;
+    const unsigned long long v = lds[(fe << 8) + ((b + 8 * fe) & 255)];
+    int64_t* blk = feat_block(L, fresh, fe);
+    blk[b] = (int64_t)(int32_t)(v >> 32);
+    blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
   }
-  // One child at a time (the second pass re-reads A's cells): the search keeps a leaf's context and a
-  // feature's cells in registers, and two of each would cost the whole kernel its second workgroup per CU.
-#pragma unroll 1
-  for (int pass = 0; pass < (ROOT ? 1 : 2); ++pass) {
-    ChildSearch& C = pass == 0 ? A : B;
-    const LeafScanCtx ctx = node_scan_ctx(C.tg, C.th, C.tc, q, sp, C.node);
-    for (int f = wave; f < nf; f += kWaves) {
-      const FeatureMeta m = a.meta[f];
-      if (!m.enabled) continue;
-      int64_t g[4], h[4];
-      int64_t* blkA = feat_block(L, fresh, f);
-      if (solo) {
-        // the finished histogram is still in LDS: unpack; the first pass keeps a copy in the slot for
-        // later subtractions
-        const unsigned long long* c = &lds[f * kMaxBins + ((lane * 4 + 8 * f) & 255)];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned long long v = c[j];
-          g[j] = (int64_t)(int32_t)(v >> 32);
-          h[j] = (int64_t)(v & 0xffffffffull);
-        }
-        if (pass == 0) store_feat_cells(blkA, lane, g, h);
-      } else {
-        load_feat_cells(blkA, lane, g, h);
-      }
-      if (pass == 1) {
-        int64_t gp[4], hp[4];
-        int64_t* blkB = feat_block(L, parent, f);
-        load_feat_cells(blkB, lane, gp, hp);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { g[j] = gp[j] - g[j]; h[j] = hp[j] - h[j]; }
-        store_feat_cells(blkB, lane, g, h);
-      }
-      if (m.categorical != kCategoricalSorted && node_feature_on(sp, C.key, f, nf) && node_allows(sp, C.node, f))
-        scan_cells_wave(f, lane, g, h, m, ctx, sp, C.bg, C.bkey, C.blg, C.blh, C.key);
+  if (tid == 0)
+    for (int r = 0; r < L.ranks; ++r) {
+      int64_t* hd = slot_header(L, fresh, r);
+      hd[0] = tot[0]; hd[1] = tot[1]; hd[2] = tot[2];
     }
-  }
-  if (lane == 0) {
-    wbest[0][wave] = Cand{A.bg, A.bkey, A.blg, A.blh};
-    wbest[1][wave] = Cand{B.bg, B.bkey, B.blg, B.blh};
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  for (int w = 1; w < kWaves; ++w) {
-    take_better(A.bg, A.bkey, A.blg, A.blh, wbest[0][w].gain, wbest[0][w].key, wbest[0][w].lg, wbest[0][w].lh);
-    take_better(B.bg, B.bkey, B.blg, B.blh, wbest[1][w].gain, wbest[1][w].key, wbest[1][w].lg, wbest[1][w].lh);
-  }
-  if (solo) {
-    int64_t* hd = slot_header(L, fresh, 0);
-    hd[0] = A.tc; hd[1] = A.tg; hd[2] = A.th;
-  }
-  SplitInfo* out = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
-  int64_t* ntA = a.node_totals + (int64_t)A.node * 4;
-  ntA[0] = A.tc; ntA[1] = A.tg; ntA[2] = A.th; ntA[3] = 0;
-  if (ROOT) {
-    write_split(&out[0], A.bg, A.bkey, A.blg, A.blh, A.tc, A.tg, A.th, q, sp);
-    finish_to_host(a.host_out, 1, 0, 1, a.done_counter, a.seq, q);
-    return;
-  }
-  int64_t* ntB = a.node_totals + (int64_t)B.node * 4;
-  ntB[0] = B.tc; ntB[1] = B.tg; ntB[2] = B.th; ntB[3] = 0;
-  write_split(&out[2 * ridx + sideA], A.bg, A.bkey, A.blg, A.blh, A.tc, A.tg, A.th, q, sp);
-  write_split(&out[2 * ridx + 1 - sideA], B.bg, B.bkey, B.blg, B.blh, B.tc, B.tg, B.th, q, sp);
-  int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * 2 * (size_t)a.n_tasks);
-  tl[ridx] = lefts;
-  finish_to_host(a.host_out, 2 * a.n_tasks, a.n_tasks, a.n_tasks, a.done_counter, a.seq, q);
 }
 
 // ---------------------------------------------------------------------------
@@ -1576,7 +1514,7 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
   LGA_LAUNCH_CHECK();
   if (!any_multi_chunk) return;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
-                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0);
+                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0, 0);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1608,12 +1546,13 @@ void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool
   LGA_LAUNCH_CHECK();
 }
 
-void grow_scatter(const InlineTasks& inl, int chunk0, int total_chunks, NodeRange* nodes, const int32_t* a0_src,
-                  const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask, const int32_t* chunk_left,
-                  int32_t* task_left, hipStream_t s) {
+void grow_scatter(const SplitTask* staged, int n_staged, const InlineTasks& inl, int total_chunks, NodeRange* nodes,
+                  const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask,
+                  const int32_t* chunk_left, int32_t* task_left, hipStream_t s) {
   if (total_chunks <= 0) return;
-  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, (const SplitTask*)nullptr,
-                     (const int32_t*)nullptr, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, chunk0);
+  hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, staged,
+                     (const int32_t*)nullptr, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0,
+                     n_staged);
   LGA_LAUNCH_CHECK();
 }
 

@@ -134,51 +134,41 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
                int tile_step, int tile_count, hipStream_t s);
 
 // ---- fused growth round over row lines (single feature tile) ----
-// One launch partitions the round's leaves, builds the smaller children's histograms from the same row lines
-// and - with `tail` - searches both children's best splits and hands the results to the host.  A leaf of up
-// to kSoloMaxRows rows is handled by ONE workgroup from start to finish (no atomics on global memory, no
-// second launch).  A larger leaf is cut into units of `unit_rows` rows; its units flush their LDS histograms
-// into the (zeroed) slot, the unit that finishes last runs the split search, and grow_scatter moves the rows.
+// One launch decides every row's side for all leaves of the round and builds the smaller children's
+// histograms from the row lines.  A leaf of up to kSoloMaxRows rows is handled by ONE workgroup from start to
+// finish: flags, row movement, histogram written straight to its slot (no atomics on global memory, no zeroing,
+// no second launch).  A larger leaf is cut into units of `unit_rows` rows; its units add their LDS histograms
+// to the (zeroed) slot and grow_scatter moves the rows.  The split search follows as scan_blocks.
 constexpr int kGrowThreads = 512;
 constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
 constexpr int kSoloMaxRows = 16384;   // upper bound of the solo limit (LDS mask words)
 struct GrowArgs {
+  const SplitTask* tasks;   // staged descriptors of a round above kInlineTasks leaves (n_staged of them), else null: inline
+  int32_t n_staged;
   NodeRange* nodes;
   const int32_t* a0;        // row arenas a parent's `buf` selects (a0 is the bag itself for node 0)
   const int32_t* a1;
   int32_t* a0_dst;          // children go to the OTHER arena
   int32_t* a1_dst;
   uint8_t* lines;
+  const uint8_t* bins_fm;   // [feature][row]: the split feature's bin of a row, one byte, coalesced while a leaf is dense
   int64_t N;
   PoolLayout pool;
   RoundSlots round;
   int32_t F;
   int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows, <= kMaxRowsPerPass)
-  int32_t task0;            // index of inl.t[0] among the round's tasks (rounds above kInlineTasks leaves take several launches)
-  int32_t n_tasks;          // tasks of the whole round
   uint64_t* mask;           // [mask block][32]: go-left bits of multi-unit leaves, read by grow_scatter
   int32_t* chunk_left;      // [mask block]
-  int32_t* task_left;       // [task of the round]: rows that went left (device copy; the tail also tells the host)
-  unsigned* tickets;        // [task of the round]: arrival counter of a multi-unit leaf's units (zero between rounds)
+  int32_t* task_left;       // [task of the round]: rows that went left
   const uint64_t* cat_sets;
-  // tail (split search + hand-over)
-  int32_t tail;
-  const FeatureMeta* meta;
-  int64_t* node_totals;
-  const QuantScale* qs;
-  SplitParams sp;
-  char* host_out;
-  unsigned* done_counter;
-  unsigned seq;
   FusedQuant quant;         // root pass: quantise the float gradients on the way (g != nullptr)
 };
 // root: the single task's "leaf" is node 0 and nothing is partitioned.  total_units = sum of the tasks' units.
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s);
-// Moves the rows of the multi-unit leaves of a grow_round launch: mask blocks chunk0 .. chunk0 + total_chunks - 1
-// of the round; task_left is the launch's first task's entry.
-void grow_scatter(const InlineTasks& inl, int chunk0, int total_chunks, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src,
-                  int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask, const int32_t* chunk_left, int32_t* task_left,
-                  hipStream_t s);
+// Moves the rows of the multi-unit leaves of a grow_round launch (total_chunks mask blocks).
+void grow_scatter(const SplitTask* staged, int n_staged, const InlineTasks& inl, int total_chunks, NodeRange* nodes,
+                  const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst, int32_t* a1_dst, const uint64_t* mask,
+                  const int32_t* chunk_left, int32_t* task_left, hipStream_t s);
 
 // ---- split search as its own launch (distributed learners, data with several feature tiles) ----
 // Which features a rank searches: block b covers features
@@ -207,8 +197,9 @@ struct ScanArgs {
   Cand* block_best;         // [n_scan][n_blocks]
   unsigned* tickets;        // [n_scan], zero between launches
   Cand* best_out;           // distributed: [n_scan] winners of this rank (then all-gather + merge_winners); else null
+  SplitInfo* results;       // not distributed: [n_scan] in device memory; the last search copies them to host_out
   const int32_t* task_left;
-  char* host_out;           // not distributed: results + flag go straight to the host
+  char* host_out;           // host-mapped result block
   unsigned* done_counter;
   unsigned seq;
 };

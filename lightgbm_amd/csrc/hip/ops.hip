@@ -95,9 +95,6 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     g.round = k::RoundSlots{0, 1};
     g.F = (int)a[2];
     g.unit_rows = unit_rows;
-    g.n_tasks = 1;
-    g.tickets = (unsigned*)p[7];
-    g.tail = 0;
     if (p[8]) g.quant = k::FusedQuant{(const float*)p[8], (const float*)p[9], (const uint32_t*)p[10], (QuantScale*)p[11]};
     else k::store_line_gradients((uint8_t*)p[4], (const int64_t*)p[3], N, s);
     k::grow_round(inl, g, t.num_hchunk, true, s);
@@ -115,9 +112,10 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
   if (name == "scan") {
     // Split search of ONE leaf whose histogram sits in slot 0 of `pool` (feature blocks [g 256 | h 256] + header).
     // ptrs: meta, pool, slot_table (filled: {0, chunk_words}), node_totals, qs, split params (host), block_best,
-    //       counters (>= 8 words, zero), scan_totals (4 words), out (device: 64-byte flag block + SplitInfo + QuantScale)
+    //       counters (>= 8 words, zero), scan_totals (4 words), out (device: 64-byte flag block + SplitInfo + QuantScale),
+    //       results (device, one SplitInfo)
     // ints: F, features per slot (multiple of 32)
-    if (nptr < 10 || nint < 2) return -1;
+    if (nptr < 11 || nint < 2) return -1;
     const SplitParams sp = *(const SplitParams*)p[5];
     k::InlineTasks inl{};
     inl.count = 1;
@@ -142,6 +140,7 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     sa.tickets = (unsigned*)p[7] + 4;
     sa.done_counter = (unsigned*)p[7];
     sa.host_out = (char*)p[9];
+    sa.results = (SplitInfo*)p[10];
     sa.seq = 1;
     k::scan_blocks(inl, sa, 1, s);
     return 0;

@@ -199,9 +199,10 @@ def split_scan(g, h, count: int, total_g: int, total_h: int, num_bins, missing_b
     block_best = torch.zeros(n_blocks * 4, dtype=torch.int64, device="cuda")
     counters = torch.zeros(16, dtype=torch.int32, device="cuda")
     out = torch.zeros(8 + 9 + 2, dtype=torch.int64, device="cuda")    # flag block (64 B) | SplitInfo (72 B) | QuantScale
+    results = torch.zeros(9, dtype=torch.int64, device="cuda")
     _op(lib, "scan", [meta_t.data_ptr(), pool.data_ptr(), table.data_ptr(), totals.data_ptr(), qs.data_ptr(),
                       ctypes.addressof(sp), block_best.data_ptr(), counters.data_ptr(), scan_totals.data_ptr(),
-                      out.data_ptr()], [F, fpad])
+                      out.data_ptr(), results.data_ptr()], [F, fpad])
     raw = out.cpu().numpy()
     assert int(raw[:1].view(np.uint32)[0]) == 1, "the split search did not raise its completion flag"
     raw = raw[8:17]
