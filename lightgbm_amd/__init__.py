@@ -6,6 +6,13 @@ CV, a resumable parameter-grid CV search, and the LightGBM text model format.
 The compute path is hand-written HIP for gfx950 (``csrc/hip``) driven by a C++
 core; a same-numerics OpenMP engine serves CPU runs and as the test oracle.
 """
+import os as _os
+
+# The host driver of some machines shares device memory between processes through dmabuf only; RCCL (and CUDA
+# tensor sharing between processes) then needs this before the HIP runtime starts - which is at the first GPU
+# call, not at import - so setting it here covers every launcher that imports the package first.
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 from .basic import Booster, Dataset, LightGBMError, default_device, params_to_string, register_logger, resolve_alias
 from .callback import EarlyStopException, early_stopping, log_evaluation, print_evaluation, record_evaluation, reset_parameter
 from .engine import CVBooster, cv, make_folds, train

@@ -184,6 +184,13 @@ LGA_HD int32_t quantize(float v, int k) {
   return (int32_t)rintf(s);
 }
 
+// Wide fixed point (leaf-value renewal, the CPU engine's full-precision histograms): kWideExtraBits more bits
+// than the packed form, i.e. |q| <= 2^36; int64 sums of up to 2^26 rows cannot overflow.
+constexpr int kWideExtraBits = 20;
+LGA_HD int64_t quantize_wide(float v, int k) {
+  return (int64_t)rint(ldexp((double)v, k));
+}
+
 // (g,h) packed for a single 64-bit add: g in the high, h in the low word.
 // Sums stay separable while the low word does not carry (h >= 0, bounded rows).
 LGA_HD int64_t pack_gh(int32_t g, int32_t h) {

@@ -80,6 +80,8 @@ const ParamDef kParams[] = {
     P(cegb_penalty_split, "", Double, 0, kNone),
     P(cegb_penalty_feature_coupled, "", DoubleList, 0, kNone),
     P(cegb_penalty_feature_lazy, "", DoubleList, 0, kNone),
+    P(use_quantized_grad, "quantized_grad", Bool, kNone, kNone),
+    P(quant_train_renew_leaf, "renew_leaf_values", Bool, kNone, kNone),
     P(path_smooth, "", Double, 0, kNone),
     P(interaction_constraints, "", String, kNone, kNone),
     P(verbosity, "verbose", Int, kNone, kNone),

@@ -66,6 +66,13 @@ struct Config {
   double cegb_penalty_split = 0.0;                    // ... per row of a leaf that is split
   std::vector<double> cegb_penalty_feature_coupled;   // ... per column, paid once, when the model first uses it
   std::vector<double> cegb_penalty_feature_lazy;      // accepted for its name; per-row lazy costs are not implemented
+  // Gradients enter the histograms as fixed-point integers (exact, order-independent sums).  true: 16 bits below
+  // the iteration's largest |gradient| - what the device's packed LDS atomics hold; false (CPU engine only): 36
+  // bits, finer than the float32 gradients themselves for everything within 2^-12 of the largest one.
+  bool use_quantized_grad = true;
+  // After a tree is grown its leaf values are recomputed from 36-bit sums of the float gradients of the leaf's
+  // rows, so the quantisation only ever decides WHERE a tree splits, never what it outputs.
+  bool quant_train_renew_leaf = true;
   double path_smooth = 0.0;                // > 0: pull a child's output towards its parent's (less with more rows)
   std::string interaction_constraints;     // "[0,1,2],[2,3]": features that may appear together on a branch
   int verbosity = 1;

@@ -87,6 +87,10 @@ class Engine {
   // leaves without rows keep.
   virtual void leaf_residual_percentiles(const Tree& tree, double alpha, bool mape_scale,
                                          std::vector<double>* values) = 0;
+  // Exact gradient statistics of the leaves of the tree just grown: per leaf the sums over its in-bag LOCAL rows
+  // of quantize_wide(g, kg) and quantize_wide(h, kh) (common.hpp), with kg / kh = the tree's quantisation
+  // exponents + kWideExtraBits.  sums: [leaf][2] = (sum g, sum h).
+  virtual void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) = 0;
   // Add (sign=+1) or remove (sign=-1) a tree's output by traversal of the binned rows.
   virtual void add_tree_by_traversal(int which, const Tree& tree, double sign) = 0;
 
@@ -95,6 +99,7 @@ class Engine {
   virtual void get_gradients(float* g, float* h) = 0;    // dataset-local row order
   // In-place sum of host values over the ranks of a distributed run (no-op on a single rank).
   virtual void sum_over_ranks(double* v, size_t n) = 0;
+  virtual void sum_over_ranks_i64(int64_t* v, size_t n) = 0;
   virtual std::string profile_json() const { return "{}"; }
   virtual GrowStats grow_stats() const = 0;
 };

@@ -324,6 +324,7 @@ bool Booster::update_one_iter() {
     engine_->select_class(k);
     engine_->set_tree_index((int64_t)iter_ * num_class_ + k);
     Tree tree = engine_->train_tree(sample_features(k));
+    renew_leaf_values_exact(tree);
     renew_leaf_outputs(tree);
     all_stumps = finish_tree(std::move(tree), k) && all_stumps;
   }
@@ -407,6 +408,36 @@ void Booster::dart_normalize() {
   sum_tree_weight_ += dart_shrinkage_;
 }
 
+// The trees are grown on 16-bit fixed-point gradients; the values their leaves output are then taken from
+// 36-bit sums of the float gradients of each leaf's rows (exact integer sums: the same on every engine and for
+// every sharding).  Left alone: trees whose leaf outputs are shaped by the search itself (monotone
+// constraints, path smoothing) and leaves below a split on a category set, which carry that split's extra
+// regularisation.
+void Booster::renew_leaf_values_exact(Tree& tree) {
+  if (!cfg_.quant_train_renew_leaf || tree.num_leaves <= 1) return;
+  if (cfg_.path_smooth > 0.0) return;
+  for (int m : cfg_.monotone_constraints) if (m != 0) return;
+  std::vector<int64_t> sums;
+  int kg = 0, kh = 0;
+  engine_->leaf_gradient_sums(tree, &sums, &kg, &kh);
+  engine_->sum_over_ranks_i64(sums.data(), sums.size());
+  const double gunit = unit_of(kg), hunit = unit_of(kh);
+  std::vector<char> below_set((size_t)tree.num_leaves, 0);
+  for (int i = 0; i < tree.num_leaves - 1; ++i) {
+    const bool set_split = (tree.decision_type[(size_t)i] & kCategoricalMask) && tree.threshold_bin[(size_t)i] < 0;
+    if (!set_split) continue;
+    for (int c : {tree.left_child[(size_t)i], tree.right_child[(size_t)i]})
+      if (c < 0) below_set[(size_t)~c] = 1;
+  }
+  for (int l = 0; l < tree.num_leaves; ++l) {
+    const double G = (double)sums[(size_t)l * 2] * gunit, H = (double)sums[(size_t)l * 2 + 1] * hunit;
+    if (!(H > 0.0)) continue;   // no in-bag row here (possible on a rank's shard only in theory): keep the value
+    const double l2 = cfg_.lambda_l2 + (below_set[(size_t)l] ? cfg_.cat_l2 : 0.0);
+    tree.set_leaf_value(l, leaf_output(G, H, cfg_.lambda_l1, l2, cfg_.max_delta_step));
+    tree.leaf_weight[(size_t)l] = H;
+  }
+}
+
 // regression_l1, quantile and mape take a sign step per row, whose Newton leaf value is bounded by one; the
 // loss-minimising constant of a leaf is a percentile of its residuals, which replaces it (percentile.hpp).
 void Booster::renew_leaf_outputs(Tree& tree) {
@@ -474,6 +505,7 @@ bool Booster::update_one_iter_custom(const float* grad, const float* hess, int64
     engine_->select_class(k);
     engine_->set_tree_index((int64_t)iter_ * num_class_ + k);
     Tree tree = engine_->train_tree(sample_features(k));
+    renew_leaf_values_exact(tree);
     all_stumps = finish_tree(std::move(tree), k) && all_stumps;
   }
   engine_->select_class(0);

@@ -127,6 +127,7 @@ class Booster {
   double sum_tree_weight_ = 0.0;
   double dart_shrinkage_ = 1.0;         // learning rate of the iteration in progress
   void renew_leaf_outputs(Tree& tree);
+  void renew_leaf_values_exact(Tree& tree);
   // ranking (ranking.hpp): per-query gradients; eval_host_metrics adds the metrics the engines do not compute
   // themselves (ndcg / map per query, average_precision, auc_mu) from the engine's scores
   struct RankMetric { bool ndcg; int at; };

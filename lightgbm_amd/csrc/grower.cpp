@@ -242,7 +242,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
     bar_scale = bar_scale < 0.25 ? 0.25 : (bar_scale > 1.5 ? 1.5 : bar_scale);
   }
   prev_root_gain_ = root_gain;
-  const double log_lo = std::log(spec_rows_lo_), log_span = std::log(spec_rows_hi_) - log_lo;
+  const double log_lo = std::log(spec_rows_lo_ * row_shards_), log_span = std::log(spec_rows_hi_ * row_shards_) - log_lo;
   // n_chosen: splits chosen (really or virtually) before the leaf is considered
   auto floor_gain_for = [&](int64_t rows, int n_chosen) {
     if (prev_bar_.empty()) return 0.0;

@@ -45,6 +45,9 @@ class TreeGrower {
   const GrowStats& last_stats() const { return stats_; }
   // Index of the tree about to be grown: seeds its per-node feature sampling.
   void set_tree_index(int64_t i) { tree_index_ = i; }
+  // Data-parallel over `ranks` shards: a leaf's rows (and what splitting it for nothing costs a rank) are spread
+  // over the ranks, so the row counts that make speculation cautious scale with the number of ranks.
+  void set_row_shards(int ranks) { row_shards_ = ranks > 1 ? ranks : 1; }
   SplitParams split_params() const;   // pointers inside stay valid until the next grow()
 
  private:
@@ -77,6 +80,7 @@ class TreeGrower {
   // speculate on a leaf only when its gain reaches a multiple of that bar which rises with its row count
   double spec_lo_ = 0.2, spec_hi_ = 0.95;
   double spec_rows_lo_ = 131072.0, spec_rows_hi_ = 2097152.0;
+  int row_shards_ = 1;
   bool spec_ratio_ = true;        // scale the previous cutoff by the ratio of the roots' best gains
   double prev_root_gain_ = 0.0;
 };

@@ -976,6 +976,10 @@ class HipEngine : public Engine {
   HipEngine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm, ParallelMode mode)
       : train_(train), cfg_(cfg), comm_(comm), grower_(cfg, train.get()) {
     if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
+    if (!cfg.use_quantized_grad)
+      throw std::runtime_error("use_quantized_grad=false (36-bit gradient histograms) is served by the CPU engine: the device's "
+                               "histograms are packed 16-bit fixed point; set device_type=cpu, or keep the default - leaf "
+                               "values are renewed from 36-bit sums either way (quant_train_renew_leaf)");
     if (comm_ && comm_->host_only()) {
       staging_.reset(new StagingComm(comm_));
       comm_ = comm = staging_.get();
@@ -1005,6 +1009,7 @@ class HipEngine : public Engine {
       init_per_class_ = (int64_t)train_->root_init_score().size() == (int64_t)K_ * N_ && K_ > 1;
     }
     backend_.reset(new HipBackend(train_.get(), mir_, cfg, comm, mode, n_base_));
+    if (backend_->mode() == ParallelMode::Data) grower_.set_row_shards(comm->size());
     bag_ptr_ = base_rows_.get();
     bag_n_ = n_base_;
     oob_n_ = 0;
@@ -1429,6 +1434,23 @@ class HipEngine : public Engine {
   void sum_over_ranks(double* v, size_t n) override {
     if (dist()) comm_->allreduce_sum_f64(v, n, false, stream_);
   }
+  void sum_over_ranks_i64(int64_t* v, size_t n) override {   // feature-parallel ranks all hold every row
+    if (dist() && backend_->mode() == ParallelMode::Data) comm_->allreduce_sum_i64(v, n, false, stream_);
+  }
+  void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) override {
+    TraceRange range("lga.leaf_sums");
+    const int L = tree.num_leaves;
+    const int n_spans = upload_spans(nullptr);
+    leaf_acc_.resize((size_t)2 * (size_t)L);
+    k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
+                 backend_->qs_device(), leaf_acc_.get(), stream_);
+    sums->assign((size_t)2 * (size_t)L, 0);
+    LGA_HIP_CHECK(hipMemcpyAsync(sums->data(), leaf_acc_.get(), sizeof(int64_t) * 2 * (size_t)L, hipMemcpyDeviceToHost, stream_));
+    LGA_HIP_CHECK(hipStreamSynchronize(stream_));
+    const QuantScale qs = backend_->quant_scale();
+    *kg = qs.kg + kWideExtraBits;
+    *kh = qs.kh + kWideExtraBits;
+  }
 
   // raw device pointers (used by the bindings for zero-copy access)
   double* scores_device() { return scores_.get(); }
@@ -1585,7 +1607,7 @@ class HipEngine : public Engine {
   std::map<int, std::unique_ptr<DeviceBuffer<int64_t>>> metric_bounds_;   // per dataset (which)
   DeviceBuffer<double> metric_gain_, metric_disc_;
   size_t metric_disc_len_ = 0;
-  DeviceBuffer<int64_t> packed_;
+  DeviceBuffer<int64_t> packed_, leaf_acc_;
   DeviceBuffer<uint32_t> maxbits_, select_scratch_;
   DeviceBuffer<k::LeafSpan> span_dev_;
   DeviceBuffer<uint64_t> sort_keys_;

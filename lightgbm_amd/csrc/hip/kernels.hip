@@ -1154,6 +1154,52 @@ __global__ __launch_bounds__(256) void leaf_add_kernel(const LeafSpan* __restric
 }
 
 // ---------------------------------------------------------------------------
+// exact per-leaf gradient sums (leaf-value renewal)
+// ---------------------------------------------------------------------------
+// Workgroup w owns positions [w * 4096, (w + 1) * 4096) of the bag's row arena.  The leaves' row ranges are
+// contiguous there, so a workgroup meets a handful of them: for each it reduces the 36-bit fixed-point gradients
+// of its share of the range and adds the two sums to the leaf's accumulators (integers: order does not matter).
+__device__ __forceinline__ int span_of(const int32_t* begins, int n_spans, int32_t p);
+constexpr int kLeafSumChunk = 4096;
+__global__ __launch_bounds__(256) void leaf_sums_kernel(const LeafSpan* __restrict__ spans, int n_spans,
+                                                        const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
+                                                        int64_t n_rows, const float* __restrict__ g,
+                                                        const float* __restrict__ h, const QuantScale* __restrict__ qs,
+                                                        unsigned long long* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int32_t* begins = reinterpret_cast<int32_t*>(smem);
+  __shared__ long long red[2][4];
+  for (int i = threadIdx.x; i < n_spans; i += blockDim.x) begins[i] = spans[i].begin;
+  __syncthreads();
+  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  const int64_t p0 = (int64_t)blockIdx.x * kLeafSumChunk;
+  const int64_t p1 = p0 + kLeafSumChunk < n_rows ? p0 + kLeafSumChunk : n_rows;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = span_of(begins, n_spans, (int32_t)p0); i < n_spans; ++i) {
+    const LeafSpan sp = spans[i];
+    if ((int64_t)sp.begin >= p1) break;
+    const int64_t lo = sp.begin > p0 ? sp.begin : p0, hi = sp.end < p1 ? sp.end : p1;
+    if (lo >= hi) continue;   // empty ranges sort in front of the range that owns their position
+    const int32_t* rows = sp.buf ? a1 : a0;
+    long long sg = 0, sh = 0;
+    for (int64_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+      const int32_t r = rows[p];
+      sg += quantize_wide(g[r], kg);
+      sh += quantize_wide(h[r], kh);
+    }
+    sg = wave_sum_i64(sg);
+    sh = wave_sum_i64(sh);
+    __syncthreads();
+    if (lane == 0) { red[0][wave] = sg; red[1][wave] = sh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&acc[2 * sp.leaf], (unsigned long long)(red[0][0] + red[0][1] + red[0][2] + red[0][3]));
+      atomicAdd(&acc[2 * sp.leaf + 1], (unsigned long long)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // percentile leaf outputs
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int span_of(const int32_t* begins, int n_spans, int32_t p) {
@@ -1624,6 +1670,17 @@ void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int
   size_t sm = ((size_t)n_leaves * sizeof(int32_t) + 15) & ~(size_t)15;
   hipLaunchKernelGGL(leaf_add_kernel, dim3(grid_for(n_rows, 256)), dim3(256), sm, s, leaves, n_leaves, a0, a1, n_rows,
                      scores);
+  LGA_LAUNCH_CHECK();
+}
+
+void leaf_sums(const LeafSpan* spans, int n_spans, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+               const float* g, const float* h, const QuantScale* qs, int64_t* acc, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)n_leaves, s));
+  if (n_rows <= 0 || n_spans <= 0) return;
+  const size_t sm = ((size_t)n_spans * sizeof(int32_t) + 15) & ~(size_t)15;
+  const int blocks = (int)((n_rows + kLeafSumChunk - 1) / kLeafSumChunk);
+  hipLaunchKernelGGL(leaf_sums_kernel, dim3(blocks), dim3(256), sm, s, spans, n_spans, a0, a1, n_rows, g, h, qs,
+                     reinterpret_cast<unsigned long long*>(acc));
   LGA_LAUNCH_CHECK();
 }
 

@@ -213,6 +213,10 @@ void merge_winners(const Cand* gathered, int ranks, int n_scan, int n_left, cons
 
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
+// Leaf-value renewal: acc[2 * leaf] / acc[2 * leaf + 1] = sums over the leaf's rows (spans over the bag arena, sorted
+// by begin) of quantize_wide(g, qs->kg + kWideExtraBits) / quantize_wide(h, qs->kh + kWideExtraBits).
+void leaf_sums(const LeafSpan* spans, int n_spans, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
+               const float* g, const float* h, const QuantScale* qs, int64_t* acc, hipStream_t s);
 // Percentile leaf outputs (../percentile.hpp).  residual_keys: per in-bag row one sortable 64-bit key
 // (leaf id << 32 | order-preserving bits of float(label - score)), padding = ~0; leaf_percentiles: per leaf
 // the alpha-percentile of its (sorted) key segment and the segment length.  residual_items: the unsorted

@@ -65,7 +65,8 @@ class HostBackend : public TreeBackend {
   }
 
   void set_bag(const int32_t* rows, int64_t n) { bag_ = rows; bag_n_ = n; }
-  void set_gradients(const int64_t* packed, QuantScale qs) { packed_ = packed; qs_ = qs; }
+  void set_gradients(const int64_t* packed, QuantScale qs) { packed_ = packed; wide_g_ = wide_h_ = nullptr; qs_ = qs; }
+  void set_wide_gradients(const int64_t* g, const int64_t* h, QuantScale qs) { wide_g_ = g; wide_h_ = h; packed_ = nullptr; qs_ = qs; }
 
   int node_capacity() const override { return 2 * capacity_splits_ + 1; }
   QuantScale quant_scale() const override { return qs_; }
@@ -95,6 +96,7 @@ class HostBackend : public TreeBackend {
     return e ? std::max(1, std::atoi(e)) : 1;
   }
   const NodeRange& range(int node) const { return ranges_[(size_t)node]; }
+  ParallelMode mode() const { return mode_; }
   const int32_t* arena(int buf) const { return arena_[buf].data(); }
 
   void begin_tree(const std::vector<FeatureMeta>& meta, const SplitParams& params) override {
@@ -198,19 +200,32 @@ class HostBackend : public TreeBackend {
       const uint8_t* col = fm + (size_t)f * (size_t)N_;
       int64_t* g = gp + (size_t)f * kMaxBins;
       int64_t* h = hp + (size_t)f * kMaxBins;
-      for (int64_t i = 0; i < n; ++i) {
-        int32_t row = rows[i];
-        int64_t p = packed_[row];
-        int b = col[row];
-        g[b] += packed_g(p);
-        h[b] += packed_h(p);
+      if (wide_g_) {
+        for (int64_t i = 0; i < n; ++i) {
+          const int32_t row = rows[i];
+          const int b = col[row];
+          g[b] += wide_g_[row];
+          h[b] += wide_h_[row];
+        }
+      } else {
+        for (int64_t i = 0; i < n; ++i) {
+          int32_t row = rows[i];
+          int64_t p = packed_[row];
+          int b = col[row];
+          g[b] += packed_g(p);
+          h[b] += packed_h(p);
+        }
       }
     }
     int64_t tg = 0, th = 0;
-    for (int64_t i = 0; i < n; ++i) {
-      int64_t p = packed_[rows[i]];
-      tg += packed_g(p);
-      th += packed_h(p);
+    if (wide_g_) {
+      for (int64_t i = 0; i < n; ++i) { tg += wide_g_[rows[i]]; th += wide_h_[rows[i]]; }
+    } else {
+      for (int64_t i = 0; i < n; ++i) {
+        int64_t p = packed_[rows[i]];
+        tg += packed_g(p);
+        th += packed_h(p);
+      }
     }
     int64_t* hd = base + 2 * plane_;
     hd[0] = n; hd[1] = tg; hd[2] = th;
@@ -363,6 +378,8 @@ class HostBackend : public TreeBackend {
   const int32_t* bag_ = nullptr;
   int64_t bag_n_ = 0;
   const int64_t* packed_ = nullptr;
+  const int64_t* wide_g_ = nullptr;   // full-precision mode: 36-bit fixed-point gradients instead of packed_
+  const int64_t* wide_h_ = nullptr;
   QuantScale qs_{0, 0};
 };
 
@@ -567,9 +584,25 @@ class HostEngine : public Engine {
     }
     if (dist()) comm_->allreduce_max_f32(mx, 2, false, nullptr);
     QuantScale qs{quant_exponent(mx[0]), quant_exponent(mx[1])};
-    quantize_rows_host(gc, hc, bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
+    tree_qs_ = qs;
     backend_.set_bag(bag_.data(), (int64_t)bag_.size());
-    backend_.set_gradients(packed_.data(), qs);
+    if (cfg_.use_quantized_grad) {
+      quantize_rows_host(gc, hc, bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
+      backend_.set_gradients(packed_.data(), qs);
+    } else {
+      // full precision: the histograms take 36-bit fixed-point gradients (separate int64 arrays)
+      const QuantScale wide{qs.kg + kWideExtraBits, qs.kh + kWideExtraBits};
+      wide_g_.resize(packed_.size());
+      wide_h_.resize(packed_.size());
+      const int64_t n = (int64_t)bag_.size();
+#pragma omp parallel for schedule(static) if (n > 65536)
+      for (int64_t i = 0; i < n; ++i) {
+        const int32_t r = bag_[(size_t)i];
+        wide_g_[(size_t)r] = quantize_wide(gc[r], wide.kg);
+        wide_h_[(size_t)r] = quantize_wide(hc[r], wide.kh);
+      }
+      backend_.set_wide_gradients(wide_g_.data(), wide_h_.data(), wide);
+    }
     return grower_.grow(backend_, meta, &leaf_nodes_);
   }
 
@@ -650,6 +683,29 @@ class HostEngine : public Engine {
     }
   }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
+  void sum_over_ranks_i64(int64_t* v, size_t n) override {   // feature-parallel ranks all hold every row
+    if (dist() && backend_.mode() == ParallelMode::Data) comm_->allreduce_sum_i64(v, n, false, nullptr);
+  }
+  void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) override {
+    const int L = tree.num_leaves;
+    sums->assign((size_t)L * 2, 0);
+    *kg = tree_qs_.kg + kWideExtraBits;
+    *kh = tree_qs_.kh + kWideExtraBits;
+    const float* gc = gr();
+    const float* hc = he();
+    for (const LeafPiece& pc : leaf_nodes_) {
+      const NodeRange& r = backend_.range(pc.node);
+      const int32_t* rows = backend_.arena(r.buf) + r.begin;
+      int64_t sg = 0, sh = 0;
+#pragma omp parallel for reduction(+ : sg, sh) schedule(static) if (r.count > 65536)
+      for (int32_t i = 0; i < r.count; ++i) {
+        sg += quantize_wide(gc[rows[i]], *kg);
+        sh += quantize_wide(hc[rows[i]], *kh);
+      }
+      (*sums)[(size_t)pc.leaf * 2] += sg;
+      (*sums)[(size_t)pc.leaf * 2 + 1] += sh;
+    }
+  }
   void sum_over_ranks(double* v, size_t n) override {
     if (dist()) comm_->allreduce_sum_f64(v, n, false, nullptr);
   }
@@ -699,7 +755,8 @@ class HostEngine : public Engine {
   std::vector<int32_t> base_, bag_, oob_;
   std::vector<double> scores_;
   std::vector<float> grad_, hess_;
-  std::vector<int64_t> packed_;
+  std::vector<int64_t> packed_, wide_g_, wide_h_;
+  QuantScale tree_qs_{0, 0};   // quantisation exponents of the tree being / just grown (16-bit form)
   std::vector<LeafPiece> leaf_nodes_;
   std::vector<int32_t> missing_bin_;
   std::vector<Valid> valid_;

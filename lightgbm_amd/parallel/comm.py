@@ -10,11 +10,16 @@
   P threads of one process and reduce through shared host buffers.  It tests
   the sharding logic without any process group.
 
-Payloads per growth round (data-parallel): ONE integer all-reduce of the
-round's new histogram slots (counts and gradient totals ride in each slot's
-header), i.e. about tree-depth collectives per tree instead of one per leaf.
-Integer sums make the result independent of rank order and bit-identical to
-serial training.  Feature-parallel exchanges only the per-leaf winners.
+Payloads per growth round (data-parallel, device engine): ONE in-place integer
+reduce-scatter over the round's new histogram slots - the pool lays a round's
+slots out rank-chunk-major, every chunk ending in a copy of the slot headers
+(row counts, gradient totals) - after which each rank searches only the
+features it owns, and ONE all-gather of the ranks' winners (32 bytes per
+child).  That is two collectives per round, i.e. about 2 x tree depth per tree
+instead of two per leaf; a rank receives 1/P of the histogram bytes.  Integer
+sums make the result independent of rank order and bit-identical to serial
+training.  Feature-parallel exchanges only the per-leaf winners.  Host-only
+communicators (the two below) serve reduce-scatter as an all-reduce.
 """
 from __future__ import annotations
 
@@ -132,27 +137,53 @@ class ThreadComm(_CallbackComm):
         hub.barrier.wait()
 
 
+def _share_unique_id(group, make_id):
+    """Rank 0 creates a communicator id, every rank receives it.  All ranks run the SAME collective (one
+    broadcast of id + status byte) whether or not rank 0 succeeded, and all ranks learn about a failure: returns
+    (id bytes, None) everywhere, or (None, error text) everywhere."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    buf = np.zeros(129, dtype=np.uint8)
+    err = None
+    if rank == 0:
+        try:
+            buf[:128] = make_id()
+            buf[128] = 1
+        except Exception as e:      # noqa: BLE001 - reported to every rank below
+            err = str(e)
+    t = torch.from_numpy(buf)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    buf = t.cpu().numpy()
+    if buf[128] != 1:
+        return None, err or "rank 0 could not create a communicator id"
+    return buf[:128].copy(), None
+
+
 class RcclComm:
-    """RCCL communicator owned by the native core (HIP build only)."""
+    """RCCL communicator owned by the native core (HIP build only).
+
+    The host driver of some machines shares device memory between processes through dmabuf only; RCCL then
+    needs ``HSA_ENABLE_IPC_MODE_LEGACY=0`` in the environment BEFORE the HIP runtime starts.  Importing
+    ``lightgbm_amd`` sets it (unless the variable is already set), so import the package before the first GPU call."""
 
     def __init__(self, group=None):
-        import torch
         import torch.distributed as dist
         lib, hip = _lib.load()
         if not hip:
             raise _lib.LightGBMError("RcclComm needs the HIP build and a visible GPU")
         self.rank, self.size = dist.get_rank(group), dist.get_world_size(group)
-        uid = np.zeros(128, dtype=np.uint8)
-        if self.rank == 0:
+
+        def make_id():
+            uid = np.zeros(128, dtype=np.uint8)
             n = ctypes.c_int()
             _lib.check(lib.lga_hip_rccl_unique_id(uid.ctypes.data_as(ctypes.c_void_p), 128, ctypes.byref(n)))
-        # hand rank 0's id to everyone (works on any backend: the tensor lives where the backend needs it)
-        backend = dist.get_backend(group)
-        t = torch.from_numpy(uid)
-        if backend == "nccl":
-            t = t.cuda()
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        uid = t.cpu().numpy()
+            return uid
+        uid, err = _share_unique_id(group, make_id)
+        if uid is None:
+            raise _lib.LightGBMError(f"no RCCL unique id: {err}")
         from .. import _device
         _device.sync_stream(lib)
         h = ctypes.c_void_p()
@@ -189,6 +220,29 @@ class DeviceLoopbackComm:
             self.handle = None
 
 
+def _native_or_fallback(group, make_native):
+    """Creates the native communicator on every rank; should that fail on ANY rank, every rank falls back to the
+    process group's own collectives (slower: buffers are staged through host memory) instead of leaving the job
+    without a communicator.  Every rank runs the same collectives on every path: those inside ``make_native``
+    (see :func:`_share_unique_id`) and one MIN all-reduce of the outcome."""
+    import torch
+    import torch.distributed as dist
+    comm, err = None, None
+    try:
+        comm = make_native(group)
+    except Exception as e:      # noqa: BLE001 - any failure takes the fallback
+        err = e
+    ok = torch.tensor([1 if comm is not None else 0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return comm
+    if comm is not None:
+        comm.close()
+    import warnings
+    warnings.warn(f"native RCCL communicator unavailable ({err}); using torch.distributed collectives")
+    return TorchComm(group)
+
+
 def default_comm(group=None):
     """RCCL when training on GPUs under an ``nccl`` process group, torch.distributed host collectives otherwise
     (CPU engine, or a ``gloo`` group used to rehearse a multi-rank run on fewer GPUs than ranks: the device
@@ -197,22 +251,5 @@ def default_comm(group=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return None
     if _lib.is_hip() and dist.get_backend(group) == "nccl":
-        # The native communicator is created from an id the process group hands round.  Should that fail on
-        # any rank, every rank falls back to the group's own collectives (slower: buffers are staged through
-        # host memory) instead of leaving the job without a communicator.
-        import torch
-        comm, err = None, None
-        try:
-            comm = RcclComm(group)
-        except Exception as e:      # noqa: BLE001 - any failure takes the fallback
-            err = e
-        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
-            return comm
-        if comm is not None:
-            comm.close()
-        import warnings
-        warnings.warn(f"native RCCL communicator unavailable ({err}); using torch.distributed collectives")
-        return TorchComm(group)
+        return _native_or_fallback(group, RcclComm)
     return TorchComm(group)

@@ -369,6 +369,24 @@ def test_gpu_binary_matches_cpu_quality_and_first_tree():
     assert abs(ec["training"]["binary_logloss"][-1] - eg["training"]["binary_logloss"][-1]) < 1e-3
 
 
+def test_gpu_quantised_auc_matches_the_full_precision_cpu_learner():
+    """The device learner (16-bit gradient histograms, leaf values from 36-bit sums) against the CPU engine with
+    36-bit gradient histograms on held-out rows of a Higgs-like task: |AUC difference| <= 0.001.
+    (bench/auc_parity.py runs the same comparison at 1 M rows x 200 trees of 255 leaves.)"""
+    from sklearn.metrics import roc_auc_score
+    X, y = make_higgs_like(250000, seed=21, device="numpy")
+    tr, te = slice(0, 200000), slice(200000, None)
+    p = {"objective": "binary", "num_leaves": 127, "learning_rate": 0.1, "min_sum_hessian_in_leaf": 20.0, "verbose": -1}
+    g = lgb.train({**p, "device_type": "gpu"}, lgb.Dataset(X[tr], label=y[tr], params={**p, "device_type": "gpu"}), 80)
+    c = lgb.train({**p, "device_type": "cpu", "use_quantized_grad": False},
+                  lgb.Dataset(X[tr], label=y[tr], params={**p, "device_type": "cpu"}), 80)
+    ag, ac = roc_auc_score(y[te], g.predict(X[te])), roc_auc_score(y[te], c.predict(X[te]))
+    assert abs(ag - ac) <= 0.001, (ag, ac)
+    with pytest.raises(lgb.LightGBMError, match="CPU engine"):
+        lgb.train({**p, "device_type": "gpu", "use_quantized_grad": False},
+                  lgb.Dataset(X[:5000], label=y[:5000], params={**p, "device_type": "gpu"}), 1)
+
+
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
 def test_gpu_multiclass_matches_cpu(objective):
     """num_class score / gradient vectors on the device: the first iteration (scores all zero, so the
@@ -625,7 +643,7 @@ def _run_ranks(P, fn):
     return out
 
 
-@pytest.mark.parametrize("P,flight,lines", [(2, "1", "0"), (4, "1", "1"), (2, "2", "1"), (4, "2", "0")])
+@pytest.mark.parametrize("P,flight,lines", [(2, "1", "0"), (4, "1", "1"), (2, "2", "1"), (4, "2", "0"), (8, "2", "1")])
 def test_gpu_data_parallel_equals_serial(P, flight, lines, monkeypatch):
     monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)   # "2": overlapped rounds
     monkeypatch.setenv("LGA_ROW_LINES", lines)           # "1": the row-line layout large shards use
@@ -638,6 +656,24 @@ def test_gpu_data_parallel_equals_serial(P, flight, lines, monkeypatch):
         sl = slice(bounds[r], bounds[r + 1])
         d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X[:20000], params=GPU)
         return lgb.train({**params, "tree_learner": "data"}, d, 10, comm=comm).model_to_string()
+    for s in _run_ranks(P, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
+@pytest.mark.parametrize("P,F,leaves", [(2, 40, 31), (3, 70, 63), (8, 5, 15)])
+def test_gpu_data_parallel_over_feature_tiles_and_idle_owners(P, F, leaves):
+    """Reduce-scatter by feature: several feature tiles (records + gradient array instead of row lines), a
+    feature count the ranks do not divide, and more ranks than features (ranks that own nothing to search).
+    The loop-back communicator reduces ONLY the owner's block, like RCCL."""
+    X, y = make_regression(30000, F, seed=11)
+    params = {**GPU, "num_leaves": leaves}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X[:20000], params=GPU), 6)
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X[:20000], params=GPU)
+        return lgb.train({**params, "tree_learner": "data"}, d, 6, comm=comm).model_to_string()
     for s in _run_ranks(P, rank):
         assert trees_of(s) == trees_of(serial)
 
@@ -818,7 +854,8 @@ def test_multi_process_data_parallel_sharing_one_gpu(P, tmp_path):
                               capture_output=True, text=True, timeout=170, env=env)
     r = launch([str(script)])
     assert r.returncode == 0 and r.stdout.count("ok") == P, r.stdout[-2000:] + r.stderr[-2000:]
-    r = launch([os.path.join(root, "bench.py"), "--gpus", str(P), "--rows", "300000", "--steps", "4", "--warmup", "1"],
+    r = launch([os.path.join(root, "bench.py"), "--gpus", str(P), "--rows", "300000", "--steps", "4", "--warmup", "1",
+                "--no-full-run"],
                env=dict(os.environ, LGA_BENCH_BACKEND="gloo"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -208,3 +208,52 @@ dist.destroy_process_group()
     order = np.concatenate([np.arange(0, 2500), np.arange(2500, 5000)])
     serial = lgb.train({**CPU, "num_leaves": 15}, lgb.Dataset(X, label=y, bin_sample=X[order]), 8)
     assert trees_of(serial) == trees_of(m0)
+
+
+def test_every_rank_falls_back_when_rank0_cannot_create_a_communicator_id(tmp_path):
+    """The native communicator's bootstrap keeps all ranks on the same collective sequence: when rank 0 fails to
+    create the id, every rank learns it from the one broadcast and every rank ends up with the fallback."""
+    script = tmp_path / "fallback.py"
+    script.write_text("""
+import os, sys
+import numpy as np, torch.distributed as dist
+sys.path.insert(0, %r)
+from lightgbm_amd.parallel import comm as C
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+
+class Native:
+    def __init__(self, group):
+        def make_id():
+            if os.environ.get("FAIL_ID") == "1":
+                raise RuntimeError("no librccl here")
+            return np.arange(128, dtype=np.uint8)
+        uid, err = C._share_unique_id(group, make_id)
+        if uid is None:
+            raise RuntimeError(err)
+        assert (uid == np.arange(128)).all()
+        if os.environ.get("FAIL_INIT_RANK") == str(rank):
+            raise RuntimeError("comm init failed on this rank")
+    def close(self):
+        pass
+
+import warnings
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    c = C._native_or_fallback(None, Native)
+want_native = os.environ.get("FAIL_ID") != "1" and "FAIL_INIT_RANK" not in os.environ
+assert isinstance(c, Native) == want_native and (want_native or isinstance(c, C.TorchComm)), type(c)
+buf = np.array([rank + 1], dtype=np.int64)
+if not want_native:
+    c.allreduce(buf, "sum")
+    assert buf[0] == 3
+c.close()
+dist.destroy_process_group()
+print("rank", rank, "done", flush=True)
+""" % ROOT)
+    for extra in ({"FAIL_ID": "1"}, {"FAIL_INIT_RANK": "1"}, {}):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                           capture_output=True, text=True, timeout=120, env={**os.environ, **extra})
+        assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-1500:] + r.stderr[-1500:]

@@ -14,13 +14,13 @@ timeout -k 10 200 python $ROOT/bench/predict_bench.py | tail -1 > "$OUT/predict_
 echo "predict bench done"
 timeout -k 10 300 python $ROOT/bench/rank_bench.py 2>/dev/null | grep -v amdgpu.ids > "$OUT/rank_bench.txt"
 echo "ranking bench done"
-rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $ROOT/bench.py --steps 32 --warmup 3 > /tmp/kt.log 2>&1
+rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $ROOT/bench.py --steps 32 --warmup 3 --no-full-run > /tmp/kt.log 2>&1
 python $ROOT/tools/rocpd_stats.py "$(find /tmp/kt -name '*.db' | sort | tail -1)" "$OUT/kernel_stats_32trees.csv" > /dev/null
 echo "kernel trace done"
 pass() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
-  timeout -s KILL 240 rocprofv3 --pmc "$@" -d /tmp/pmc_$name -o p -- python $ROOT/bench.py --steps 7 --warmup 1 > /tmp/pmc_$name.log 2>&1
+  timeout -s KILL 240 rocprofv3 --pmc "$@" -d /tmp/pmc_$name -o p -- python $ROOT/bench.py --steps 7 --warmup 1 --no-full-run > /tmp/pmc_$name.log 2>&1
   python $ROOT/tools/rocpd_pmc.py "$(find /tmp/pmc_$name -name '*.db' | sort | tail -1)" "$OUT/pmc_$name.csv" > /dev/null
   echo "pmc $name done"
 }
