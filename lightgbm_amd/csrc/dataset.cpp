@@ -344,8 +344,12 @@ std::shared_ptr<Dataset> Dataset::load_binary(const std::string& path) {
   r.vec(ds->bins_fm_, (uint64_t)F * n);
   if (ds->bins_fm_.size() != (size_t)F * n) throw std::runtime_error("load_binary: bin matrix has the wrong size");
   r.vec(ds->label_, n);
+  if (ds->label_.size() != n && !ds->label_.empty()) throw std::runtime_error("load_binary: label has the wrong length");
   r.vec(ds->weight_, n);
-  r.vec(ds->init_score_, n);
+  if (!ds->weight_.empty() && ds->weight_.size() != n) throw std::runtime_error("load_binary: weight has the wrong length");
+  // one initial score per row, or one per class and row ([class][row]; at most 4096 classes)
+  r.vec(ds->init_score_, n * 4096);
+  if (ds->init_score_.size() % n != 0) throw std::runtime_error("load_binary: init_score has the wrong length");
   {
     const int c = std::fgetc(r.f);
     if (c != EOF) {
@@ -353,7 +357,18 @@ std::shared_ptr<Dataset> Dataset::load_binary(const std::string& path) {
       r.vec(ds->query_bounds_, n + 1);
       if (!ds->query_bounds_.empty() && (ds->query_bounds_.front() != 0 || ds->query_bounds_.back() != (int64_t)n))
         throw std::runtime_error("load_binary: query boundaries do not cover the rows");
+      for (size_t q = 1; q < ds->query_bounds_.size(); ++q)
+        if (ds->query_bounds_[q] < ds->query_bounds_[q - 1]) throw std::runtime_error("load_binary: query boundaries decrease");
     }
+  }
+  // a truncated or damaged cache must not reach the histogram kernels with bins outside a feature's range
+  for (int f = 0; f < F; ++f) {
+    const int nb = ds->mappers_[(size_t)ds->used_feature_[(size_t)f]].num_bin;
+    const uint8_t* col = ds->bins_fm_.data() + (size_t)f * n;
+    int worst = 0;
+#pragma omp parallel for reduction(max : worst) schedule(static)
+    for (int64_t row = 0; row < (int64_t)n; ++row) worst = std::max(worst, (int)col[row]);
+    if (worst >= nb) throw std::runtime_error("load_binary: a bin value lies outside its feature's range");
   }
   // the row-tile-major copy is derived
   const int T = ds->num_tiles();

@@ -77,6 +77,8 @@ class Engine {
   // Grow a tree on the current gradients/bag.  Leaf values are unshrunk.
   // Index of the iteration the next train_tree() belongs to (seeds per-node feature sampling).
   virtual void set_tree_index(int64_t i) = 0;
+  // Split-search parameters changed between iterations (TreeGrower::update_split_config).
+  virtual void update_split_config(const Config& c) = 0;
   virtual Tree train_tree(const std::vector<FeatureMeta>& meta) = 0;
   // Add `tree` (final leaf values) to the training scores, using the row
   // ranges of the tree just grown for in-bag rows and traversal for the rest.

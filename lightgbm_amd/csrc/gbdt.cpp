@@ -600,14 +600,37 @@ void Booster::rollback_one_iter() {
 void Booster::reset_parameter(const std::string& params) {
   Config c = cfg_;
   c.set(params);
-  // only parameters that do not change the engine's buffers may be reset
-  if (c.num_leaves != cfg_.num_leaves || c.max_bin != cfg_.max_bin || c.boosting != cfg_.boosting ||
-      c.device_type != cfg_.device_type || c.tree_learner != cfg_.tree_learner)
-    throw std::runtime_error("reset_parameter: num_leaves / max_bin / boosting / device / tree_learner cannot change");
-  cfg_.learning_rate = c.learning_rate;
-  cfg_.bagging_fraction = c.bagging_fraction;
-  cfg_.bagging_freq = c.bagging_freq;
-  cfg_.feature_fraction = c.feature_fraction;
+  // What may change between iterations: everything that only steers the NEXT trees - shrinkage, row / feature
+  // sampling, the split search's thresholds and regularisation, DART's drop rates.  Every accepted parameter
+  // is applied; anything else that differs is refused rather than silently dropped.
+  // a depth limit caps num_leaves when a configuration is read; a booster keeps the leaf budget it was built with
+  // (the grower enforces the new depth limit itself)
+  if (c.max_depth != cfg_.max_depth && params.find("leav") == std::string::npos && params.find("leaf_nodes") == std::string::npos)
+    c.num_leaves = cfg_.num_leaves;
+  Config applied = cfg_;
+  applied.learning_rate = c.learning_rate;
+  applied.bagging_fraction = c.bagging_fraction; applied.bagging_freq = c.bagging_freq;
+  applied.pos_bagging_fraction = c.pos_bagging_fraction; applied.neg_bagging_fraction = c.neg_bagging_fraction;
+  applied.feature_fraction = c.feature_fraction; applied.feature_fraction_bynode = c.feature_fraction_bynode;
+  applied.lambda_l1 = c.lambda_l1; applied.lambda_l2 = c.lambda_l2;
+  applied.min_gain_to_split = c.min_gain_to_split; applied.min_sum_hessian_in_leaf = c.min_sum_hessian_in_leaf;
+  applied.min_data_in_leaf = c.min_data_in_leaf; applied.max_depth = c.max_depth; applied.max_delta_step = c.max_delta_step;
+  applied.path_smooth = c.path_smooth; applied.extra_trees = c.extra_trees; applied.cat_l2 = c.cat_l2;
+  applied.drop_rate = c.drop_rate; applied.max_drop = c.max_drop; applied.skip_drop = c.skip_drop;
+  applied.top_rate = c.top_rate; applied.other_rate = c.other_rate;
+  applied.quant_train_renew_leaf = c.quant_train_renew_leaf;
+  applied.verbosity = c.verbosity; applied.metric_freq = c.metric_freq; applied.early_stopping_round = c.early_stopping_round;
+  applied.first_metric_only = c.first_metric_only; applied.num_iterations = c.num_iterations;
+  applied.snapshot_freq = c.snapshot_freq; applied.output_model = c.output_model; applied.num_threads = c.num_threads;
+  if (applied.to_model_string() != c.to_model_string())
+    throw std::runtime_error("reset_parameter: only the learning rate, row / feature sampling fractions, the split search's "
+                             "regularisation and limits (lambda_l1, lambda_l2, min_data_in_leaf, min_sum_hessian_in_leaf, "
+                             "min_gain_to_split, max_depth, max_delta_step, path_smooth, extra_trees) and the DART / GOSS "
+                             "rates can be reset during training; got: " + params);
+  if ((applied.path_smooth > 0.0) != (cfg_.path_smooth > 0.0) && engine_)
+    throw std::runtime_error("reset_parameter: path_smooth cannot be switched on or off during training");
+  cfg_ = applied;
+  if (engine_) engine_->update_split_config(cfg_);
 }
 
 void Booster::refit(const void* data, int dtype, int64_t nrow, int ncol, bool row_major, const float* label,

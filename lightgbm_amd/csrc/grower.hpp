@@ -45,6 +45,15 @@ class TreeGrower {
   const GrowStats& last_stats() const { return stats_; }
   // Index of the tree about to be grown: seeds its per-node feature sampling.
   void set_tree_index(int64_t i) { tree_index_ = i; }
+  // Parameters that may change between iterations (Booster::reset_parameter): the split search's thresholds
+  // and regularisation, depth limit, per-node feature sampling.
+  void update_split_config(const Config& c) {
+    cfg_.lambda_l1 = c.lambda_l1; cfg_.lambda_l2 = c.lambda_l2;
+    cfg_.min_gain_to_split = c.min_gain_to_split; cfg_.min_sum_hessian_in_leaf = c.min_sum_hessian_in_leaf;
+    cfg_.min_data_in_leaf = c.min_data_in_leaf; cfg_.max_depth = c.max_depth; cfg_.max_delta_step = c.max_delta_step;
+    cfg_.feature_fraction_bynode = c.feature_fraction_bynode; cfg_.path_smooth = c.path_smooth;
+    cfg_.extra_trees = c.extra_trees; cfg_.cat_l2 = c.cat_l2;
+  }
   // Data-parallel over `ranks` shards: a leaf's rows (and what splitting it for nothing costs a rank) are spread
   // over the ranks, so the row counts that make speculation cautious scale with the number of ranks.
   void set_row_shards(int ranks) { row_shards_ = ranks > 1 ? ranks : 1; }
@@ -71,7 +80,7 @@ class TreeGrower {
   // interaction constraints as bit sets over inner features (empty: none)
   std::vector<std::vector<uint64_t>> groups_;
   int mask_words_ = 0;
-  const Config cfg_;
+  Config cfg_;
   const Dataset* ds_;
   GrowStats stats_;
   int64_t tree_index_ = 0;

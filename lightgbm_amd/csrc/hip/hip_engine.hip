@@ -1275,6 +1275,7 @@ class HipEngine : public Engine {
   }
 
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
+  void update_split_config(const Config& c) override { grower_.update_split_config(c); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     TraceRange range("lga.train_tree");
     debug_check();

@@ -573,6 +573,7 @@ class HostEngine : public Engine {
   }
 
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
+  void update_split_config(const Config& c) override { grower_.update_split_config(c); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     // quantisation scale from the largest |g| and h of the training rows
     float mx[2] = {0.f, 0.f};

@@ -168,6 +168,7 @@ class CVBooster:
         self.boosters: List[Booster] = []
         self.best_iteration = -1
         self.iterations_run = 0
+        self.higher_better: Dict[str, bool] = {}   # per recorded metric: is a larger value the better one?
 
     def append(self, booster: Booster):
         self.boosters.append(booster)
@@ -388,9 +389,10 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
             raw = [one for _, one in stepped]
             cvbooster.iterations_run = i + 1
             res = _agg_cv_result(raw, eval_train_metric)
-            for _, key, mean, _, std in res:
+            for _, key, mean, higher_better, std in res:
                 results.setdefault(f"{key}-mean", []).append(mean)
                 results.setdefault(f"{key}-stdv", []).append(std)
+                cvbooster.higher_better[key] = bool(higher_better)
             try:
                 for c in cb_after:
                     c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))

@@ -157,7 +157,8 @@ def lgb_cv(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3,
     out.record_evals = rec if record else {}
     if first_key is not None:
         means = np.asarray(res[f"{first_key}-mean"], dtype=np.float64)
-        higher_better = first_key == "auc" or first_key.startswith(("ndcg@", "map@"))
+        # the engine's own flag for the metric (covers average_precision, auc_mu, custom metrics, ...)
+        higher_better = cvb.higher_better.get(first_key, first_key == "auc" or first_key.startswith(("ndcg@", "map@")))
         factor = 1.0 if higher_better else -1.0
         bi = cvb.best_iteration if cvb.best_iteration > 0 else int(np.argmax(factor * means)) + 1
         # the 2017 R callback only recorded a best iteration when the patience criterion fired
@@ -239,17 +240,37 @@ def lgb_dump(booster: Booster, num_iteration: Optional[int] = None) -> str:
     return json.dumps(booster.dump_model(num_iteration=num_iteration))
 
 
+_RDS_MAGIC = "lightgbm_amd booster v1"
+
+
 def saveRDS_lgb_Booster(booster: Booster, file: str) -> None:
-    """``saveRDS.lgb.Booster``: serialise the booster object (the raw model text travels inside)."""
-    import pickle
-    with open(file, "wb") as f:
-        pickle.dump(booster, f)
+    """``saveRDS.lgb.Booster``: the booster as one self-contained file - a JSON header line (best iteration,
+    best scores, parameters) followed by the text model.  Nothing in the file is executable."""
+    import json
+    header = {"format": _RDS_MAGIC, "best_iteration": int(booster.best_iteration),
+              "best_score": getattr(booster, "best_score", {}), "params": dict(booster.params)}
+    with open(file, "w") as f:
+        f.write(json.dumps(header, default=str) + "\n")
+        f.write(booster.model_to_string(num_iteration=-1))
 
 
 def readRDS_lgb_Booster(file: str) -> Booster:
-    import pickle
-    with open(file, "rb") as f:
-        return pickle.load(f)
+    """Reads a file written by :func:`saveRDS_lgb_Booster` (JSON header + text model; no unpickling)."""
+    import json
+    with open(file, "r") as f:
+        first = f.readline()
+        try:
+            header = json.loads(first)
+        except ValueError:
+            header = None
+        if not isinstance(header, dict) or header.get("format") != _RDS_MAGIC:
+            raise ValueError(f"{file}: not a booster file written by saveRDS_lgb_Booster")
+        model = f.read()
+    params = header.get("params") if isinstance(header.get("params"), dict) else None
+    b = Booster(params=params, model_str=model)
+    b.best_iteration = int(header.get("best_iteration", 0))
+    b.best_score = header.get("best_score", {}) if isinstance(header.get("best_score"), dict) else {}
+    return b
 
 
 def lgb_importance(booster: Booster, percentage: bool = True):
