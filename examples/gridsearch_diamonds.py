@@ -46,6 +46,9 @@ def main():
     ap.add_argument("--workers", default=None, help="comma separated GPU ids (or 'cpu,cpu') for worker processes")
     ap.add_argument("--checkpoint", default="paramGrid.jsonl")
     ap.add_argument("--m", type=int, default=5)
+    ap.add_argument("--rows-in-flight", type=int, default=None,
+                    help="grid rows one process evaluates concurrently (default: 4 on the GPU build)")
+    ap.add_argument("--fresh", action="store_true", help="ignore an existing checkpoint instead of resuming from it")
     args = ap.parse_args()
 
     X, y = load_data(args.csv)
@@ -85,10 +88,23 @@ def main():
     t = time.time()
     grid = grid_search_cv(grid, X=train["X"], y=train["y"], dtrain=None if workers else dtrain, nrounds=1000, nfold=5,
                           objective="regression", early_stopping_rounds=5, checkpoint=args.checkpoint,
-                          workers=workers, verbose=True)                      # R:104-119
-    print("grid search             %.1fs" % (time.time() - t))
+                          workers=workers, verbose=True, resume=not args.fresh,
+                          rows_in_flight=args.rows_in_flight)                 # R:104-119
+    secs = time.time() - t
+    iters = int(grid["iteration"].clip(lower=0).sum()) + 5 * len(grid)
+    print("grid search             %.1fs  (%d rows, ~%d boosting iterations x 5 folds)" % (secs, len(grid), iters))
     ranked = rank_grid(grid)                                                  # R:122
-    print(ranked.head())
+    print(ranked.head(12).to_string())
+    if args.full:
+        # what the reference's own saved grid shows (paramGrid.RData): the best rows use every feature and the
+        # smaller leaf minimum, and learning rates <= 0.05 beat 0.1 given enough rounds
+        top12, top10 = ranked.head(12), ranked.head(10)
+        print("trend: top-12 rows with feature_fraction = 1      : %d of 12" % int((top12["feature_fraction"] == 1).sum()))
+        print("trend: top-10 rows with min_data_in_leaf = 20     : %d of 10" % int((top10["min_data_in_leaf"] == 20).sum()))
+        best_by_lr = grid.groupby("learning_rate")["score"].max()
+        print("trend: best score by learning rate                :", {float(k): round(float(v), 7) for k, v in best_by_lr.items()})
+        print("trend: rank of the best learning_rate = 0.1 row   : %d" %
+              (1 + int(np.flatnonzero(ranked["learning_rate"].values == 0.1)[0])))
     pred, _ = refit_top(ranked, args.m, dtrain, test["X"])                    # R:124-143
     print("mean of top-%d rmse     " % args.m, rmse(test["y"], pred))         # R:144
 

@@ -807,6 +807,26 @@ class Booster:
             return self.__boost(grad, hess)
         return fin.value == 1
 
+    @staticmethod
+    def update_group(boosters: List["Booster"], n_iters: int, eval_which: int = 0):
+        """``n_iters`` boosting iterations of several boosters in lockstep (native loop; on the HIP engine the small
+        trees of all boosters of an iteration are grown by ONE kernel launch, one workgroup per tree).  After every
+        iteration dataset ``eval_which`` (0: first validation set, -1: training data, -2: nothing) of every booster is
+        evaluated.  The loop ends early after an iteration in which no booster found anything to split.  Returns
+        ``(values[iteration, booster, metric], finished[booster], iterations_run)``; ``finished[b]``: booster b found
+        nothing to split in the last iteration run."""
+        lib, _ = _lib.load()
+        n = len(boosters)
+        names = boosters[0]._metric_names() if eval_which >= -1 else []
+        stride = max(1, len(names))
+        handles = (ctypes.c_void_p * n)(*[b._handle for b in boosters])
+        values = np.zeros((n_iters, n, stride), dtype=np.float64)
+        finished = (ctypes.c_int * n)()
+        done = ctypes.c_int()
+        check(lib.lga_booster_group_update(handles, n, int(n_iters), int(eval_which),
+                                           values.ctypes.data_as(ctypes.c_void_p), stride, finished, ctypes.byref(done)))
+        return values[: done.value, :, : len(names)], [bool(f) for f in finished], done.value
+
     def __boost(self, grad, hess) -> bool:
         lib, _ = _lib.load()
         K = self.num_model_per_iteration()

@@ -68,6 +68,19 @@ class TreeBackend {
   // Local row count of a node (after the round that created it).
   virtual int64_t node_local_count(int node) const = 0;
 
+  // Optional: the backend grows the WHOLE tree by itself, strictly best-first (ties between equal gains go to the
+  // node created first), after begin_tree.  whole_tree_begin prepares that and says whether this tree can be
+  // grown so (false: grow it in rounds); whole_tree_launch starts the build unless a batched launch already did;
+  // whole_tree_finish waits and reports, for the k-th split in order, the node that was split - its children are
+  // nodes 2k+1 and 2k+2 - and every node's best split.  The node table then holds the row ranges.
+  struct WholeTree {
+    std::vector<int32_t> split_node;
+    std::vector<SplitInfo> best;   // 2 * splits + 1 entries
+  };
+  virtual bool whole_tree_begin(int max_splits) { (void)max_splits; return false; }
+  virtual void whole_tree_launch() {}
+  virtual void whole_tree_finish(WholeTree* out) { (void)out; }
+
   // Asynchronous form: up to max_in_flight() rounds may be submitted before the first one is waited
   // for, so one round's latency-bound tail (split scan, result hand-over, host replay) overlaps with
   // another round's row-level work.  Rounds in flight never share a leaf; a round may depend on the

@@ -50,6 +50,8 @@ int lga_booster_from_string(const char* model, LgaBooster* out);
 int lga_booster_free(LgaBooster b);
 int lga_booster_add_valid(LgaBooster b, LgaDataset ds, const char* name);
 int lga_booster_update(LgaBooster b, int* finished);
+int lga_booster_group_update(LgaBooster* boosters, int n, int n_iters, int which, double* values, int stride,
+                             int* finished, int* iters_done);
 int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess, int64_t n, int* finished);
 int lga_booster_rollback(LgaBooster b);
 int lga_booster_set_leaf_value(LgaBooster b, int tree, int leaf, double value);

@@ -117,6 +117,7 @@ const ParamDef kParams[] = {
     P(num_machines, "num_machine", Int, 1, kNone),
     P(gpu_device_id, "", Int, kNone, kNone),
     P(max_batch_leaves, "", Int, 0, kNone),
+    P(whole_tree_max_rows, "gpu_whole_tree_max_rows", Int, 0, 65536),
     P(profile, "", Bool, kNone, kNone),
     P(device_bin_find, "", Bool, kNone, kNone),
     P(iteration_offset, "", Int, 0, kNone),

@@ -116,6 +116,7 @@ struct Config {
   // device
   int gpu_device_id = 0;
   int max_batch_leaves = 0;   // 0: as many leaves per growth round as the budget allows
+  int whole_tree_max_rows = 65536;   // device: bags up to this many rows are grown by the one-workgroup whole-tree kernel (0: never)
   bool profile = false;
   int iteration_offset = 0;       // number the iterations from here: the random streams (bagging, feature
                                   // sampling) of iteration k are the same wherever that iteration is trained

@@ -80,6 +80,15 @@ class Engine {
   // Split-search parameters changed between iterations (TreeGrower::update_split_config).
   virtual void update_split_config(const Config& c) = 0;
   virtual Tree train_tree(const std::vector<FeatureMeta>& meta) = 0;
+  // train_tree in two steps, so that the trees of several boosters - the folds of a cross-validation - can be
+  // started before any of them is waited for.  train_tree_begin returns true when the engine has PREPARED a
+  // device build that still has to be launched: launch_prepared_trees starts the prepared builds of a group of
+  // engines with as few launches as possible.  train_tree_finish returns the tree (and grows it itself when
+  // nothing was prepared).
+  virtual bool train_tree_begin(const std::vector<FeatureMeta>& meta) { pending_meta_ = meta; return false; }
+  virtual Tree train_tree_finish() { return train_tree(pending_meta_); }
+  // Called on one engine of the group with all engines whose train_tree_begin returned true (itself included).
+  virtual void launch_prepared_trees(Engine* const* group, int n) { (void)group; (void)n; }
   // Add `tree` (final leaf values) to the training scores, using the row
   // ranges of the tree just grown for in-bag rows and traversal for the rest.
   virtual void add_trained_tree_to_train_scores(const Tree& tree) = 0;
@@ -104,6 +113,9 @@ class Engine {
   virtual void sum_over_ranks_i64(int64_t* v, size_t n) = 0;
   virtual std::string profile_json() const { return "{}"; }
   virtual GrowStats grow_stats() const = 0;
+
+ protected:
+  std::vector<FeatureMeta> pending_meta_;
 };
 
 }  // namespace lga

@@ -333,6 +333,38 @@ bool Booster::update_one_iter() {
   return finish_iteration(all_stumps);
 }
 
+bool Booster::update_begin() {
+  two_step_ = false;
+  if (!engine_) throw std::runtime_error("update on a prediction-only booster");
+  if (num_class_ != 1 || is_dart_ || obj_.kind == kObjCustom) return false;   // update_finish runs the iteration
+  ensure_scores();
+  if (!is_rf_) compute_gradients();
+  sample_rows();
+  engine_->select_class(0);
+  engine_->set_tree_index((int64_t)iter_);
+  two_step_ = true;
+  return engine_->train_tree_begin(sample_features(0));
+}
+
+bool Booster::update_finish() {
+  if (!two_step_) return update_one_iter();
+  two_step_ = false;
+  Tree tree = engine_->train_tree_finish();
+  renew_leaf_values_exact(tree);
+  renew_leaf_outputs(tree);
+  const bool all_stumps = finish_tree(std::move(tree), 0);
+  engine_->select_class(0);
+  return finish_iteration(all_stumps);
+}
+
+void Booster::update_group(Booster* const* boosters, int n, int* finished) {
+  std::vector<Engine*> prepared;
+  for (int i = 0; i < n; ++i)
+    if (boosters[i]->update_begin()) prepared.push_back(boosters[i]->engine_.get());
+  if (!prepared.empty()) prepared[0]->launch_prepared_trees(prepared.data(), (int)prepared.size());
+  for (int i = 0; i < n; ++i) finished[i] = boosters[i]->update_finish() ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------
 // DART (Rashmi & Gilad-Bachrach 2015): every iteration a random subset of the existing iterations is
 // muted while the new trees are fitted, then the new trees and the muted ones are rescaled so that the

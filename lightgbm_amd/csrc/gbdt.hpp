@@ -32,6 +32,13 @@ class Booster {
   // One boosting iteration; returns true when no further split was possible
   // (the iteration's tree is then discarded, except for the very first one).
   bool update_one_iter();
+  // One iteration in two steps (single-output boosters; others run the whole iteration in update_finish):
+  // update_begin takes gradients and the bag and prepares the tree - true: a device build is waiting for
+  // launch_prepared_trees - update_finish waits for the tree and applies it.  update_group runs one iteration of
+  // several boosters with their prepared builds started together; finished[i] = boosters[i] could not split.
+  bool update_begin();
+  bool update_finish();
+  static void update_group(Booster* const* boosters, int n, int* finished);
   bool update_one_iter_custom(const float* grad, const float* hess, int64_t n);
   void rollback_one_iter();
   void reset_parameter(const std::string& params);
@@ -111,6 +118,7 @@ class Booster {
   bool is_rf_ = false;
   bool average_output_ = false;
   bool scores_initialised_ = false;
+  bool two_step_ = false;          // between update_begin and update_finish of a two-step iteration
   std::vector<double> init_scores_ = {0.0};   // per class
   int num_class_ = 1;
   int iter_ = 0;                 // iterations attempted (drives bagging / feature sampling streams)

@@ -142,17 +142,59 @@ GrowTrace g_trace;
 }  // namespace
 
 Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces) {
+  if (grow_begin(be, meta)) be.whole_tree_launch();
+  return grow_finish(be, meta, pieces);
+}
+
+// A backend that can grow a whole tree by itself (TreeBackend::whole_tree_begin) is asked to whenever the tree is
+// a plain one: no output ranges (monotone constraints, path smoothing) and no interaction constraints, which the
+// replay below hands down node by node.
+bool TreeGrower::grow_begin(TreeBackend& be, const std::vector<FeatureMeta>& meta) {
+  sp_cur_ = split_params();
+  be.begin_tree(meta, sp_cur_);
+  bool any_monotone = false;
+  for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
+  const bool plain = groups_.empty() && !any_monotone && !(sp_cur_.path_smooth > 0.0) && cfg_.max_batch_leaves <= 0;
+  whole_ = plain && be.whole_tree_begin(cfg_.num_leaves - 1);
+  return whole_;
+}
+
+Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces) {
   const auto t_enter = GrowTrace::clock::now();
   auto t_last_backend = t_enter;
   double backend_us = 0;
   stats_ = GrowStats();
-  const SplitParams sp = split_params();
-  be.begin_tree(meta, sp);
+  const SplitParams sp = sp_cur_;
   const int capacity_splits = (be.node_capacity() - 1) / 2;
   const int budget_total = cfg_.num_leaves - 1;
   if (capacity_splits < budget_total) throw std::runtime_error("backend node capacity below num_leaves");
 
   std::vector<Node> nodes;
+  std::vector<int> chosen;   // node ids in strict best-first order
+  int materialized = 0;
+  double bar_used = 0.0;
+  bool node_info = false;    // nodes carry an output range and their own output
+  if (whole_) {
+    // the backend replayed best-first growth itself: the k-th split's children are nodes 2k+1 and 2k+2
+    TreeBackend::WholeTree wt;
+    be.whole_tree_finish(&wt);
+    if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_enter, t_last_backend); }
+    const size_t n_splits = wt.split_node.size();
+    nodes.resize(2 * n_splits + 1);
+    for (size_t i = 0; i < nodes.size(); ++i) nodes[i].best = wt.best[i];
+    for (size_t k = 0; k < n_splits; ++k) {
+      const int p = wt.split_node[k];
+      Node& n = nodes[(size_t)p];
+      n.left = (int)(2 * k + 1);
+      n.right = (int)(2 * k + 2);
+      n.ready = true;
+      for (int c : {n.left, n.right}) { nodes[(size_t)c].parent = p; nodes[(size_t)c].depth = n.depth + 1; }
+      chosen.push_back(p);
+    }
+    materialized = (int)n_splits;
+    stats_.rounds = 1;
+    prev_root_gain_ = splittable(nodes[0].best) ? nodes[0].best.gain : 0.0;
+  } else {
   nodes.reserve((size_t)be.node_capacity());
   nodes.emplace_back();
   // Interaction constraints: a node may be split on the features already on its branch and on those of every
@@ -183,7 +225,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   bool any_monotone = false;
   for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
   const bool smooth = sp.path_smooth > 0.0;
-  const bool node_info = any_monotone || smooth;   // nodes carry an output range and their own output
+  node_info = any_monotone || smooth;
   {
     const SplitInfo& r = nodes[0].best;
     nodes[0].out = leaf_output((double)r.total_g * gunit, (double)r.total_h * hunit, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
@@ -217,9 +259,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   };
   push(0);
 
-  std::vector<int> chosen;   // node ids in strict best-first order
   int budget = budget_total;
-  int materialized = 0;
   const int max_flight = cfg_.max_batch_leaves > 0 ? 1 : std::max(1, be.max_in_flight());
   struct Flight {
     int ticket;
@@ -411,7 +451,10 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
   stats_.used_splits = (int)chosen.size();
   // the bar for the next tree: suffix minima of this tree's chosen gains (empty when the tree ran out of
   // splittable leaves before its budget: then nothing is held back)
-  const double bar_used = prev_bar_.empty() ? 0.0 : prev_bar_.back() * bar_scale;
+  bar_used = prev_bar_.empty() ? 0.0 : prev_bar_.back() * bar_scale;
+  }   // growth by rounds
+  const QuantScale qs = be.quant_scale();
+  const double gunit = unit_of(qs.kg), hunit = unit_of(qs.kh);
   prev_bar_.clear();
   if ((int)chosen.size() == budget_total && !chosen.empty()) {
     prev_bar_.resize(chosen.size());

@@ -42,6 +42,11 @@ class TreeGrower {
   // Grows one tree (leaf values NOT yet shrunk).  `pieces` lists the backend
   // nodes whose row ranges make up each leaf.
   Tree grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces);
+  // The same in two steps, for callers that start the trees of several boosters before waiting for any of them:
+  // grow_begin returns true when the backend has prepared a whole-tree build (TreeBackend::whole_tree_begin) that
+  // is waiting to be launched - by whole_tree_launch, or by a batched launch of many backends' trees at once.
+  bool grow_begin(TreeBackend& be, const std::vector<FeatureMeta>& meta);
+  Tree grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces);
   const GrowStats& last_stats() const { return stats_; }
   // Index of the tree about to be grown: seeds its per-node feature sampling.
   void set_tree_index(int64_t i) { tree_index_ = i; }
@@ -83,6 +88,8 @@ class TreeGrower {
   Config cfg_;
   const Dataset* ds_;
   GrowStats stats_;
+  SplitParams sp_cur_{};          // of the tree between grow_begin and grow_finish
+  bool whole_ = false;            // ... which the backend grows in one go
   int64_t tree_index_ = 0;
   // the previous tree's chosen gains as suffix minima: prev_bar_[k] = smallest gain chosen from the k-th choice on
   std::vector<double> prev_bar_;

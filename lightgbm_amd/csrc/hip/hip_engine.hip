@@ -203,6 +203,11 @@ class HipBackend : public TreeBackend {
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
     if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
+    tree_kernel_rows_ = std::min<int64_t>(k::kTreeMaxRows, cfg.whole_tree_max_rows);
+    if (const char* e = std::getenv("LGA_TREE_KERNEL_ROWS"))
+      tree_kernel_rows_ = std::max<int64_t>(0, std::min<int64_t>(k::kTreeMaxRows, std::atoll(e)));
+    tree_kernel_on_ = tree_kernel_rows_ > 0;
+    tree_renew_ = cfg.quant_train_renew_leaf ? 1 : 0;
     const size_t n_scan_max = (size_t)(2 * max_batch_ + 2);
     for (int c = 0; c < n_ctx_; ++c) {
       RoundCtx& x = ctx_[c];
@@ -339,6 +344,7 @@ class HipBackend : public TreeBackend {
       // meta_host_ stays alive and unchanged until the copy has run (next sync is in root_round)
     }
     ranges_host_[0] = NodeRange{0, (int32_t)bag_n_, 0, 0};
+    tree_wide_valid_ = false;
     ++prof.trees;
   }
 
@@ -375,6 +381,94 @@ class HipBackend : public TreeBackend {
     return c;
   }
   void wait_round(int ticket, SplitInfo* infos) override { finish_round(ctx_[ticket], infos); }
+
+  // ---- whole tree in one launch (kernels.hpp: TreeArgs): small bags on one device, plain numeric / one-vs-rest
+  // categorical features of one tile ----
+  bool whole_tree_begin(int max_splits) override {
+    tree_prepared_ = false;
+    tree_wide_valid_ = false;
+    if (!tree_kernel_on_ || mode_ != ParallelMode::Serial || T_ != 1 || F_ < 1 || prof.on) return false;
+    if (!root_quant_.g || bag_n_ < 1 || bag_n_ > tree_kernel_rows_ || max_splits < 1 || max_splits > k::kTreeMaxSplits) return false;
+    if (ranged_ || masked_ || !sorted_cat_.empty()) return false;
+    const int bw = F_ <= 8 ? 2 : (F_ <= 16 ? 4 : 8);
+    const size_t cap = arena_[0].size();
+    if (rec_gh_[0].size() < cap) {
+      for (int b = 0; b < 2; ++b) { rec_gh_[b].resize(cap); rec_bins_[b].resize(cap * (size_t)bw); }
+      tree_best_.resize(k::kTreeMaxNodes);
+      tree_out_.resize(sizeof(k::TreeResult));
+      tree_desc_.resize(sizeof(k::TreeArgs));
+      std::memset(tree_out_.get(), 0, sizeof(k::TreeResult));
+    }
+    if (++tree_seq_ == 0) ++tree_seq_;
+    k::TreeArgs& a = *reinterpret_cast<k::TreeArgs*>(tree_desc_.get());
+    a = k::TreeArgs{};
+    a.bag = bag_; a.n = (int32_t)bag_n_; a.F = F_; a.budget = max_splits; a.renew = tree_renew_;
+    a.bins_rt = mir_->bins_rt.get();
+    a.g = root_quant_.g; a.h = root_quant_.h; a.maxbits = root_quant_.maxbits; a.qs_out = qs_dev_.get();
+    for (int b = 0; b < 2; ++b) { a.idx[b] = arena_[b].get(); a.gh[b] = rec_gh_[b].get(); a.bins[b] = rec_bins_[b].get(); }
+    a.meta = meta_dev_.get();
+    a.sp = sp_;
+    a.pool = pool_.get(); a.slot_words = slot_words_;
+    a.nodes = nodes_.get();
+    a.best = tree_best_.get();
+    a.out = reinterpret_cast<k::TreeResult*>(tree_out_.device_ptr());
+    a.seq = tree_seq_;
+    a.timing = tree_timing_ ? 1 : 0;
+    tree_prepared_ = true;
+    tree_launched_ = false;
+    return true;
+  }
+  // The prepared descriptor, for a launch that grows the trees of several backends at once; the caller launches
+  // on this backend's stream and then calls whole_tree_launched().
+  const k::TreeArgs* whole_tree_descriptor() const {
+    return tree_prepared_ ? reinterpret_cast<const k::TreeArgs*>(tree_desc_.get()) : nullptr;
+  }
+  void whole_tree_launched() { tree_launched_ = true; }
+  void whole_tree_launch() override {
+    if (!tree_prepared_ || tree_launched_) return;
+    TraceRange range("lga.whole_tree");
+    k::grow_trees(reinterpret_cast<const k::TreeArgs*>(tree_desc_.device_ptr()), 1, F_, stream_);
+    tree_launched_ = true;
+  }
+  void whole_tree_finish(WholeTree* out) override {
+    if (!tree_prepared_ || !tree_launched_) throw std::runtime_error("whole-tree build was never launched");
+    const k::TreeResult& r = *reinterpret_cast<const k::TreeResult*>(tree_out_.get());
+    {
+      TraceRange wait_range("lga.wait_tree");
+      wait_for(reinterpret_cast<volatile unsigned*>(tree_out_.get()), tree_seq_, stream_);
+    }
+    tree_prepared_ = false;
+    const int n_splits = r.n_splits;
+    if (n_splits < 0 || n_splits > k::kTreeMaxSplits) throw std::runtime_error("whole-tree build returned a bad split count");
+    const int n_nodes = 2 * n_splits + 1;
+    qs_host_ = QuantScale{r.kg, r.kh};
+    out->split_node.assign(r.split_node, r.split_node + n_splits);
+    out->best.assign(r.best, r.best + n_nodes);
+    for (int i = 0; i < n_nodes; ++i) ranges_host_[(size_t)i] = r.range[i];
+    slots_dirty_ = std::max(slots_dirty_, n_splits + 1);
+    tree_wide_valid_ = tree_renew_ != 0;
+    ++prof.rounds;
+    if (tree_timing_) {
+      // LGA_TREE_TIMING=1: the kernel's own phase profile, averaged over 100 trees
+      static const char* names[8] = {"root pass", "selection", "sides + histogram", "prefix", "search", "row movement", "bookkeeping", "hand-over"};
+      for (int i = 0; i < 8; ++i) tree_ticks_[i] += (double)r.phase_ticks[i];
+      tree_ticks_[8] += n_splits;
+      if (++tree_timed_ % 100 == 0) {
+        std::fprintf(stderr, "[tree kernel] per tree (%.0f splits):", tree_ticks_[8] / 100);
+        double total = 0;
+        for (int i = 0; i < 8; ++i) { std::fprintf(stderr, " %s %.1f us,", names[i], tree_ticks_[i] / 100 * 0.01); total += tree_ticks_[i]; }
+        std::fprintf(stderr, " total %.1f us\n", total / 100 * 0.01);
+        for (double& v : tree_ticks_) v = 0;
+      }
+    }
+  }
+  // 36-bit gradient sums of a final leaf's rows as the last whole-tree build left them (false: not available).
+  bool whole_tree_leaf_sums(int node, int64_t* g, int64_t* h) const {
+    if (!tree_wide_valid_) return false;
+    const k::TreeResult& r = *reinterpret_cast<const k::TreeResult*>(tree_out_.get());
+    *g = r.wide[node][0]; *h = r.wide[node][1];
+    return true;
+  }
 
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
   int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
@@ -845,18 +939,17 @@ class HipBackend : public TreeBackend {
   // catches the common case (a round takes tens of microseconds); after that the thread yields its core between
   // polls, so many boosters - cross-validation folds, grid rows - can wait on few cores.  The stream is
   // queried now and then so that a failed launch surfaces as an error instead of an endless wait.
-  void wait_flag(RoundCtx& x) {
-    volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(x.host_block.get());
-    const unsigned seq = x.seq;
+  void wait_flag(RoundCtx& x) { wait_for(reinterpret_cast<volatile unsigned*>(x.host_block.get()), x.seq, x.stream); }
+  static void wait_for(volatile unsigned* flag, unsigned seq, hipStream_t stream) {
     unsigned spins = 0;
     while (*flag != seq) {
       ++spins;
       if (spins > kSpinBeforeYield) std::this_thread::yield();
       if ((spins & 4095u) == 0) {
-        hipError_t q = hipStreamQuery(x.stream);
+        hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) {
           if (*flag == seq) break;
-          throw std::runtime_error("growth round finished without raising its completion flag");
+          throw std::runtime_error("device work finished without raising its completion flag");
         }
         if (q != hipErrorNotReady) LGA_HIP_CHECK(q);
       }
@@ -918,6 +1011,19 @@ class HipBackend : public TreeBackend {
   const uint8_t* hist_src_ = nullptr;
   uint8_t* lines_ = nullptr;
   k::FusedQuant root_quant_{};
+  // whole-tree kernel (kernels.hpp: TreeArgs)
+  bool tree_kernel_on_ = true;
+  int64_t tree_kernel_rows_ = k::kTreeMaxRows;
+  DeviceBuffer<unsigned long long> rec_gh_[2];
+  DeviceBuffer<uint32_t> rec_bins_[2];
+  DeviceBuffer<SplitInfo> tree_best_;
+  MappedBuffer tree_out_, tree_desc_;
+  unsigned tree_seq_ = 0;
+  bool tree_prepared_ = false, tree_launched_ = false, tree_wide_valid_ = false;
+  int tree_renew_ = 0;
+  bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
+  double tree_ticks_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int tree_timed_ = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -1277,7 +1383,12 @@ class HipEngine : public Engine {
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   void update_split_config(const Config& c) override { grower_.update_split_config(c); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
-    TraceRange range("lga.train_tree");
+    train_tree_begin(meta);
+    return train_tree_finish();
+  }
+  bool train_tree_begin(const std::vector<FeatureMeta>& meta) override {
+    trace_push("lga.train_tree");
+    pending_meta_ = meta;
     debug_check();
     if (!have_max_) k::absmax(gr(), he(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
@@ -1290,7 +1401,39 @@ class HipEngine : public Engine {
                   backend_->qs_device(), packed_.get(), stream_);
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
-    return grower_.grow(*backend_, meta, &leaf_nodes_);
+    tree_begun_ = true;
+    const bool prepared = grower_.grow_begin(*backend_, pending_meta_);
+    trace_pop();
+    return prepared;
+  }
+  Tree train_tree_finish() override {
+    if (!tree_begun_) throw std::runtime_error("train_tree_finish without train_tree_begin");
+    tree_begun_ = false;
+    TraceRange range("lga.train_tree");
+    backend_->whole_tree_launch();   // no-op unless a prepared build is still waiting
+    return grower_.grow_finish(*backend_, pending_meta_, &leaf_nodes_);
+  }
+  // The prepared whole-tree builds of a group of engines go out as ONE launch, one workgroup per tree, when the
+  // engines share a stream (boosters created from one thread do); the descriptors are copied into a block this
+  // engine owns, which stays untouched until the group's next launch.
+  void launch_prepared_trees(Engine* const* group, int n) override {
+    std::vector<HipEngine*> same;
+    for (int i = 0; i < n; ++i) {
+      HipEngine* e = dynamic_cast<HipEngine*>(group[i]);
+      if (!e) continue;
+      const k::TreeArgs* d = e->backend_->whole_tree_descriptor();
+      if (!d) continue;
+      if (e->stream_ == stream_ && e->train_->num_features() == train_->num_features()) same.push_back(e);
+      else e->backend_->whole_tree_launch();
+    }
+    if (same.empty()) return;
+    if (same.size() == 1) { same[0]->backend_->whole_tree_launch(); return; }
+    TraceRange range("lga.whole_tree_batch");
+    batch_desc_.resize(sizeof(k::TreeArgs) * same.size());
+    k::TreeArgs* dst = reinterpret_cast<k::TreeArgs*>(batch_desc_.get());
+    for (size_t i = 0; i < same.size(); ++i) dst[i] = *same[i]->backend_->whole_tree_descriptor();
+    k::grow_trees(reinterpret_cast<const k::TreeArgs*>(batch_desc_.device_ptr()), (int)same.size(), train_->num_features(), stream_);
+    for (HipEngine* e : same) e->backend_->whole_tree_launched();
   }
 
   // The new tree's leaf values reach the training scores either through the leaf row ranges the grower
@@ -1441,6 +1584,22 @@ class HipEngine : public Engine {
   void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) override {
     TraceRange range("lga.leaf_sums");
     const int L = tree.num_leaves;
+    {
+      // a tree grown whole comes with its leaves' sums
+      int64_t wg = 0, wh = 0;
+      if (!leaf_nodes_.empty() && backend_->whole_tree_leaf_sums(leaf_nodes_[0].node, &wg, &wh)) {
+        sums->assign((size_t)2 * (size_t)L, 0);
+        for (const LeafPiece& p : leaf_nodes_) {
+          backend_->whole_tree_leaf_sums(p.node, &wg, &wh);
+          (*sums)[(size_t)2 * (size_t)p.leaf] += wg;
+          (*sums)[(size_t)2 * (size_t)p.leaf + 1] += wh;
+        }
+        const QuantScale qs = backend_->quant_scale();
+        *kg = qs.kg + kWideExtraBits;
+        *kh = qs.kh + kWideExtraBits;
+        return;
+      }
+    }
     const int n_spans = upload_spans(nullptr);
     leaf_acc_.resize((size_t)2 * (size_t)L);
     k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
@@ -1623,6 +1782,8 @@ class HipEngine : public Engine {
   bool upload_pending_ = false;
   bool has_init_ = false, have_max_ = false;
   std::vector<LeafPiece> leaf_nodes_;
+  bool tree_begun_ = false;
+  MappedBuffer batch_desc_;      // descriptors of a batched whole-tree launch (launch_prepared_trees)
   std::vector<std::unique_ptr<Valid>> valid_;
 };
 

@@ -211,6 +211,60 @@ void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hip
 void merge_winners(const Cand* gathered, int ranks, int n_scan, int n_left, const int64_t* scan_totals, const QuantScale* qs,
                    const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s);
 
+// ---- whole tree in one launch (small data) ----
+// ONE workgroup grows a complete tree, strictly best-first, without the host: it gathers the bag's rows into
+// record arenas (row id, packed gradients, bin bytes - partitioned physically, so every later pass reads
+// contiguous memory), and per split partitions the leaf's records, builds the smaller child's histogram in LDS,
+// derives the sibling's and searches both children.  A launch with several descriptors grows one tree per
+// workgroup: the fold boosters of a cross-validation, the rows of a parameter grid.  The results of a tree -
+// the split sequence, every node's best split and row range, the 36-bit gradient sums of the final leaves -
+// arrive in host-mapped memory behind a completion flag.
+constexpr int kTreeThreads = 512;                          // 8 waves: 256 vector registers each for the fp64 gain code
+constexpr int kTreeMaxRows = 65536;                        // go-left mask words kept in LDS
+constexpr int kTreeMaxSplits = 255;                        // num_leaves <= 256
+constexpr int kTreeMaxNodes = 2 * kTreeMaxSplits + 1;
+// Host-mapped result block of one tree.
+struct TreeResult {
+  unsigned flag;            // = seq once everything below is written
+  int32_t n_splits;
+  int32_t kg, kh;           // the iteration's quantisation exponents
+  int32_t pad[12];
+  int32_t split_node[kTreeMaxSplits + 1];   // node split by the k-th choice; its children are nodes 2k+1 and 2k+2
+  SplitInfo best[kTreeMaxNodes];
+  NodeRange range[kTreeMaxNodes];
+  int64_t wide[kTreeMaxNodes][2];           // final leaves: sums of quantize_wide(g | h, k + kWideExtraBits) over the rows
+  int64_t phase_ticks[8];   // TreeArgs::timing: 100 MHz ticks spent in root pass, selection, sides + histogram, prefix, search,
+                            // row movement, per-split bookkeeping, hand-over
+};
+struct TreeArgs {
+  const int32_t* bag;       // root row ids of the tree's rows
+  int32_t n;                // 1 .. kTreeMaxRows
+  int32_t F;                // features (one tile)
+  int32_t budget;           // splits at most (num_leaves - 1 <= kTreeMaxSplits)
+  int32_t renew;            // 1: fill TreeResult::wide
+  int32_t timing;           // 1: fill TreeResult::phase_ticks
+  int32_t pad0;
+  const uint8_t* bins_rt;   // [root row][kTileFeatures] bin bytes
+  const float* g;           // root-indexed float gradients / hessians and their absolute maxima (bit patterns)
+  const float* h;
+  const uint32_t* maxbits;
+  QuantScale* qs_out;
+  int32_t* idx[2];          // record arenas, ping-pong per node: row ids (the arenas leaf_add / leaf_sums read),
+  unsigned long long* gh[2];   // packed quantised gradients,
+  uint32_t* bins[2];        // bin bytes, BW 32-bit words per row (BW = 2, 4, 8 for F <= 8, 16, 32)
+  const FeatureMeta* meta;
+  SplitParams sp;
+  int64_t* pool;            // histogram slots (one rank): slot s = pool + s * slot_words, feature f at + f * 512
+  int64_t slot_words;
+  NodeRange* nodes;         // device node table (kTreeMaxNodes entries from index 0)
+  SplitInfo* best;          // device scratch, kTreeMaxNodes entries
+  TreeResult* out;          // host-mapped
+  unsigned seq;
+};
+constexpr int kTreeBatch = 16;    // descriptors per launch (kernel-argument block)
+// descs: n_trees descriptors in DEVICE-visible memory (pinned host memory works: each workgroup reads its own once).
+void grow_trees(const TreeArgs* descs, int n_trees, int max_features, hipStream_t s);
+
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
 // Leaf-value renewal: acc[2 * leaf] / acc[2 * leaf + 1] = sums over the leaf's rows (spans over the bag arena, sorted

@@ -1,0 +1,546 @@
+// Whole-tree kernel for gfx950 (kernels.hpp: TreeArgs): one workgroup of 8 waves grows a complete leaf-wise tree.
+//
+// Small data - the 37 k x 6 folds of r/gridsearchCV.R:26-27,108-115 - cannot fill the device with one tree: a
+// growth round there is a handful of tiny launches and a host round trip, ~20 times per tree.  Here the whole
+// best-first loop runs inside one workgroup, synchronised by workgroup barriers only, so a tree costs one launch
+// and one hand-over, and the device is filled by running MANY trees at once - one workgroup each (the fold
+// boosters of a CV, the rows of a grid) - instead of by spreading one tree over many workgroups.
+//
+// Data layout: the bag's rows are gathered once per tree into record arenas (row id | packed 16-bit gradients |
+// bin bytes) that are partitioned physically, ping-pong between two buffers like the row-index arenas of the
+// growth rounds.  Every pass over a leaf therefore reads consecutive memory - no dependent row-id -> data
+// gathers - and a split of a small leaf is one coalesced load, LDS atomics, one coalesced store.
+//
+// The arithmetic is the growth rounds' (wave_scan.hpp, ../common.hpp): integer histograms, the same candidate
+// order, the same tie rules; the tree equals the one the host replay of grower.cpp builds.
+#include "kernels.hpp"
+#include "device.hpp"
+#include "wave_scan.hpp"
+
+namespace lga {
+namespace k {
+namespace {
+
+constexpr int kTreeWaves = kTreeThreads / kWave;
+constexpr int kMaskWords = kTreeMaxRows / kWave;
+constexpr int kWordsPerThread = kMaskWords / kTreeThreads;
+static_assert(kWordsPerThread * kTreeThreads == kMaskWords, "mask words must divide over the threads");
+constexpr int kNodeCap = 512;   // kTreeMaxNodes rounded up
+
+template <int BW>
+__device__ __forceinline__ void load_words(const uint32_t* __restrict__ p, unsigned (&w)[BW]) {
+  if constexpr (BW == 2) {
+    const uint2 v = *reinterpret_cast<const uint2*>(p);
+    w[0] = v.x; w[1] = v.y;
+  } else if constexpr (BW == 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+  } else {
+    const uint4 v0 = reinterpret_cast<const uint4*>(p)[0], v1 = reinterpret_cast<const uint4*>(p)[1];
+    w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+  }
+}
+template <int BW>
+__device__ __forceinline__ void store_words(uint32_t* __restrict__ p, const unsigned (&w)[BW]) {
+  if constexpr (BW == 2) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
+  } else if constexpr (BW == 4) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+    reinterpret_cast<uint4*>(p)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    reinterpret_cast<uint4*>(p)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  }
+}
+// Byte `f` of a row's bin words; f may differ per lane (selects, no indexed register file).
+template <int BW>
+__device__ __forceinline__ unsigned bin_byte(const unsigned (&w)[BW], unsigned f) {
+  const unsigned q = f >> 2;
+  unsigned d = w[0];
+#pragma unroll
+  for (int i = 1; i < BW; ++i) d = q == (unsigned)i ? w[i] : d;
+  return (d >> ((f & 3u) * 8u)) & 255u;
+}
+
+// Adds one row to the LDS histogram.  Lane l starts at feature l mod nf and walks on from there, so the lanes of a
+// wave work on different features at any moment - a feature with five distinct values does not make 64 lanes
+// queue on five words - and cell (f, bin) sits at f * 256 + ((bin + 8 f) & 255), which keeps equal bins of
+// different features in different banks.
+template <int BW>
+__device__ __forceinline__ void hist_add(unsigned long long* lds, const unsigned (&w)[BW], unsigned long long pk,
+                                         int nf, unsigned f_start, unsigned enabled) {
+  unsigned f = f_start;
+#pragma unroll
+  for (int j = 0; j < BW * 4; ++j) {
+    if (j < nf) {
+      if ((enabled >> f) & 1u) {
+        const unsigned bn = bin_byte<BW>(w, f);
+        atomicAdd(&lds[f * kMaxBins + ((bn + 8u * f) & 255u)], pk);
+      }
+      f = f + 1u == (unsigned)nf ? 0u : f + 1u;
+    }
+  }
+}
+
+// Lane l's four cells (bins 4 l .. 4 l + 3) of feature f in the LDS histogram, unpacked.
+__device__ __forceinline__ void lds_feat_cells(const unsigned long long* lds, int f, int lane, int64_t (&g)[4], int64_t (&h)[4]) {
+  const unsigned long long* c = lds + f * kMaxBins + ((lane * 4 + 8 * f) & 255);   // 8 f and 4 l are multiples of 4: no wrap inside
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const unsigned long long v = c[j];
+    g[j] = (int64_t)(int32_t)(v >> 32);
+    h[j] = (int64_t)(v & 0xffffffffull);
+  }
+}
+
+// Wave-uniform values that come out of LDS or vector loads live in vector registers unless told otherwise: everything
+// uniform is moved to scalar registers (the fp64 gain code needs the vector ones).
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ long long uni(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+struct TreeShared {
+  unsigned long long smask[kMaskWords];
+  int word_prefix[kMaskWords + 1];
+  int wave_tot[kTreeWaves];
+  long long red[2][kTreeWaves];
+  double ngain[kNodeCap];          // gain of an open leaf that may be split; -inf otherwise
+  long long ntot[kNodeCap][3];     // rows, sum g, sum h
+  int nbegin[kNodeCap], ncount[kNodeCap];
+  unsigned nkey[kNodeCap];
+  short nslot[kNodeCap], ndepth[kNodeCap];
+  signed char nbuf[kNodeCap], nsplit[kNodeCap];   // arena of the node's rows; 1 once the node has been split
+  short split_node[kTreeMaxSplits + 1];
+  Cand wbest[kTreeWaves];
+  FeatureMeta meta[kTileFeatures];
+};
+
+template <int BW>
+__device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* lds, TreeShared& S) {
+  constexpr int FC = BW * 4;
+  constexpr int PPW = (2 * FC + kTreeWaves - 1) / kTreeWaves;   // (child, feature) pairs per wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nf = a.F, n = a.n;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  const int kg = quant_exponent(__uint_as_float(a.maxbits[0]));
+  const int kh = quant_exponent(__uint_as_float(a.maxbits[1]));
+  const QuantScale q{kg, kh};
+  const SplitParams& sp = a.sp;
+  if (tid < nf) S.meta[tid] = a.meta[tid];
+  for (int i = tid; i < kNodeCap; i += kTreeThreads) { S.ngain[i] = ninf; S.nsplit[i] = 0; }
+  for (int i = tid; i < nf * kMaxBins; i += kTreeThreads) lds[i] = 0ull;
+  __syncthreads();
+  unsigned enabled = 0u;
+  for (int f = 0; f < nf; ++f) enabled |= S.meta[f].enabled ? (1u << f) : 0u;
+  const unsigned f_start = (unsigned)(lane % nf);
+  // optional phase profile: thread 0 reads the 100 MHz wall clock at the phase boundaries
+  long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_mark = a.timing ? (long long)wall_clock64() : 0;
+  auto lap = [&](int phase) {
+    if (a.timing && tid == 0) {
+      const long long now = (long long)wall_clock64();
+      ticks[phase] += now - t_mark;
+      t_mark = now;
+    }
+  };
+
+  // ---- root: gather the bag into arena 0, quantise on the way, histogram in passes of kMaxRowsPerPass rows ----
+  long long sg = 0, sh = 0;
+  int64_t* slot0 = a.pool;
+  for (int seg = 0; seg < n; seg += kMaxRowsPerPass) {
+    const int seg_hi = min(n, seg + kMaxRowsPerPass);
+    constexpr int U = 4;
+    for (int base = seg; base < seg_hi; base += U * kTreeThreads) {
+      int row[U];
+      unsigned w[U][BW];
+      float gv[U], hv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pos = base + u * kTreeThreads + tid;
+        row[u] = pos < seg_hi ? a.bag[pos] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (row[u] >= 0) {
+          load_words<BW>(reinterpret_cast<const uint32_t*>(a.bins_rt + (int64_t)row[u] * kTileFeatures), w[u]);
+          gv[u] = a.g[row[u]];
+          hv[u] = a.h[row[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (row[u] >= 0) {
+          const int pos = base + u * kTreeThreads + tid;
+          const unsigned long long pk = (unsigned long long)pack_gh(lga::quantize(gv[u], kg), lga::quantize(hv[u], kh));
+          a.idx[0][pos] = row[u];
+          a.gh[0][pos] = pk;
+          store_words<BW>(a.bins[0] + (int64_t)pos * BW, w[u]);
+          sg += (long long)(int32_t)(pk >> 32);
+          sh += (long long)(pk & 0xffffffffull);
+          hist_add<BW>(lds, w[u], pk, nf, f_start, enabled);
+        }
+      }
+    }
+    __syncthreads();
+    // this pass's cells go to slot 0 (first pass: stored; later ones: added - every cell has one owner thread)
+    for (int e = tid; e < nf * kMaxBins; e += kTreeThreads) {
+      const int fe = e >> 8, b = e & 255;
+      const int at = (fe << 8) + ((b + 8 * fe) & 255);
+      const unsigned long long v = lds[at];
+      lds[at] = 0ull;
+      int64_t* blk = slot0 + (int64_t)fe * (2 * kMaxBins);
+      const int64_t vg = (int64_t)(int32_t)(v >> 32), vh = (int64_t)(v & 0xffffffffull);
+      if (seg == 0) { blk[b] = vg; blk[kMaxBins + b] = vh; }
+      else { blk[b] += vg; blk[kMaxBins + b] += vh; }
+    }
+    __syncthreads();
+  }
+  sg = wave_sum_i64(sg);
+  sh = wave_sum_i64(sh);
+  if (lane == 0) { S.red[0][wave] = sg; S.red[1][wave] = sh; }
+  __syncthreads();
+  if (tid == 0) {
+    long long tg = 0, th = 0;
+    for (int w = 0; w < kTreeWaves; ++w) { tg += S.red[0][w]; th += S.red[1][w]; }
+    S.ntot[0][0] = n; S.ntot[0][1] = tg; S.ntot[0][2] = th;
+    S.nbegin[0] = 0; S.ncount[0] = n; S.nbuf[0] = 0; S.nslot[0] = 0; S.ndepth[0] = 0; S.nkey[0] = kRootNodeKey;
+    a.qs_out->kg = kg; a.qs_out->kh = kh;
+  }
+  __syncthreads();
+  // root search: one wave per feature
+  {
+    const LeafScanCtx ctx = node_scan_ctx(S.ntot[0][1], S.ntot[0][2], S.ntot[0][0], q, sp, 0);
+    double bg = ninf;
+    uint64_t bkey = ~0ull;
+    int64_t blg = 0, blh = 0;
+    for (int f = wave; f < nf; f += kTreeWaves) {
+      const FeatureMeta m = S.meta[f];
+      if (!m.enabled) continue;
+      int64_t g[4], h[4];
+      load_feat_cells(slot0 + (int64_t)f * (2 * kMaxBins), lane, g, h);
+      if (node_feature_on(sp, kRootNodeKey, f, nf) && m.categorical != kCategoricalSorted)
+        scan_cells_wave(f, lane, g, h, m, ctx, sp, bg, bkey, blg, blh, kRootNodeKey);
+    }
+    wave_best(bg, bkey, blg, blh);
+    if (lane == 0) S.wbest[wave] = Cand{bg, bkey, blg, blh};
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kTreeWaves; ++w) take_better(bg, bkey, blg, blh, S.wbest[w].gain, S.wbest[w].key, S.wbest[w].lg, S.wbest[w].lh);
+      write_split(&a.best[0], bg, bkey, blg, blh, S.ntot[0][0], S.ntot[0][1], S.ntot[0][2], q, sp);
+      const bool open = bg != ninf && isfinite(bg) && true;   // max_depth >= 1 never blocks the root
+      S.ngain[0] = open ? bg : ninf;
+    }
+    __syncthreads();
+  }
+
+  lap(0);
+  // ---- best-first loop ----
+  int n_splits = 0;
+  for (int k = 0; k < a.budget; ++k) {
+    const int n_nodes = 2 * k + 1;
+    // every wave finds the open leaf with the largest gain (ties: the smaller node id, the replay's push order)
+    double pg = ninf;
+    int pn = 0x7fffffff;
+    for (int i = lane; i < n_nodes; i += kWave) {
+      const double gi = S.ngain[i];
+      if (gi > pg) { pg = gi; pn = i; }     // ascending i: the first of equal gains stays
+    }
+#pragma unroll
+    for (int msk = 32; msk >= 1; msk >>= 1) {
+      const double g2 = shfl_xor_f64(pg, msk);
+      const int n2 = __shfl_xor(pn, msk, kWave);
+      if (g2 > pg || (g2 == pg && n2 < pn)) { pg = g2; pn = n2; }
+    }
+    if (!(pg > ninf)) break;
+    lap(1);
+    const int P = uni(pn), Lc = 2 * k + 1, Rc = 2 * k + 2;
+    const SplitInfo* ps = &a.best[P];
+    const int sf = uni(ps->feature), thr = uni(ps->threshold);
+    const int dl = uni((int)S.meta[sf].categorical) ? kCategoricalTask : uni(ps->default_left);
+    const int mb = uni(S.meta[sf].missing_bin);
+    const bool hist_left = uni((int)(ps->left_cnt <= ps->total_cnt - ps->left_cnt)) != 0;
+    const int begin = uni(S.nbegin[P]), cnt = uni(S.ncount[P]), sb = uni((int)S.nbuf[P]);
+    const int pslot = uni((int)S.nslot[P]);
+    const int64_t* pblk_base = a.pool + (int64_t)pslot * a.slot_words;
+    int64_t* nblk_base = a.pool + (int64_t)(k + 1) * a.slot_words;
+    const int32_t* src_idx = a.idx[sb] + begin;
+    const unsigned long long* src_gh = a.gh[sb] + begin;
+    const uint32_t* src_bins = a.bins[sb] + (int64_t)begin * BW;
+    int32_t* dst_idx = a.idx[1 - sb] + begin;
+    unsigned long long* dst_gh = a.gh[1 - sb] + begin;
+    uint32_t* dst_bins = a.bins[1 - sb] + (int64_t)begin * BW;
+    const bool multi = cnt > kMaxRowsPerPass;
+
+    // phase A: sides of all rows (ballot words in LDS), histogram of the rows of the smaller child
+    sg = 0; sh = 0;
+    for (int seg = 0; seg < cnt; seg += kMaxRowsPerPass) {
+      const int seg_hi = min(cnt, seg + kMaxRowsPerPass);
+      constexpr int U = 4;
+      for (int base = seg; base < seg_hi; base += U * kTreeThreads) {
+        unsigned w[U][BW];
+        unsigned long long pk[U];
+        bool take[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pos = base + u * kTreeThreads + tid;
+          if (pos < seg_hi) load_words<BW>(src_bins + (int64_t)pos * BW, w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pos = base + u * kTreeThreads + tid;
+          bool left = false;
+          if (pos < seg_hi) {
+            const int b = (int)bin_byte<BW>(w[u], (unsigned)sf);
+            left = dl == kCategoricalTask ? b == thr : (b == mb ? dl != 0 : b <= thr);
+          }
+          take[u] = pos < seg_hi && left == hist_left;
+          if (take[u]) pk[u] = src_gh[pos];
+          if (base + u * kTreeThreads + wave * kWave < seg_hi) {   // wave-uniform
+            const unsigned long long m = __ballot(left);
+            if (lane == 0) S.smask[(base >> 6) + u * kTreeWaves + wave] = m;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (take[u]) {
+            sg += (long long)(int32_t)(pk[u] >> 32);
+            sh += (long long)(pk[u] & 0xffffffffull);
+            hist_add<BW>(lds, w[u], pk[u], nf, f_start, enabled);
+          }
+        }
+      }
+      if (multi) {
+        __syncthreads();
+        for (int e = tid; e < nf * kMaxBins; e += kTreeThreads) {
+          const int fe = e >> 8, b = e & 255;
+          const int at = (fe << 8) + ((b + 8 * fe) & 255);
+          const unsigned long long v = lds[at];
+          lds[at] = 0ull;
+          int64_t* blk = nblk_base + (int64_t)fe * (2 * kMaxBins);
+          const int64_t vg = (int64_t)(int32_t)(v >> 32), vh = (int64_t)(v & 0xffffffffull);
+          if (seg == 0) { blk[b] = vg; blk[kMaxBins + b] = vh; }
+          else { blk[b] += vg; blk[kMaxBins + b] += vh; }
+        }
+        __syncthreads();   // the next pass adds to cells that are zero again
+      }
+    }
+    sg = wave_sum_i64(sg);
+    sh = wave_sum_i64(sh);
+    if (lane == 0) { S.red[0][wave] = sg; S.red[1][wave] = sh; }
+    __syncthreads();
+    lap(2);
+
+    // exclusive prefix of the mask words' popcounts (kWordsPerThread consecutive words per thread)
+    const int n_words = (cnt + kWave - 1) / kWave;
+    int pcs[kWordsPerThread];
+    int pc = 0;
+#pragma unroll
+    for (int j = 0; j < kWordsPerThread; ++j) {
+      const int wi = tid * kWordsPerThread + j;
+      pcs[j] = wi < n_words ? __popcll(S.smask[wi]) : 0;
+      pc += pcs[j];
+    }
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int o = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += o;
+    }
+    if (lane == kWave - 1) S.wave_tot[wave] = incl;
+    __syncthreads();
+    {
+      int off = 0;
+      for (int w = 0; w < wave; ++w) off += S.wave_tot[w];
+      int run = off + incl - pc;
+#pragma unroll
+      for (int j = 0; j < kWordsPerThread; ++j) {
+        S.word_prefix[tid * kWordsPerThread + j] = run;
+        run += pcs[j];
+      }
+      if (tid == kTreeThreads - 1) S.word_prefix[kMaskWords] = run;
+    }
+    // totals of the two children (every thread computes them: no further barrier needed for them)
+    long long htg = 0, hth = 0;
+#pragma unroll
+    for (int w = 0; w < kTreeWaves; ++w) { htg += S.red[0][w]; hth += S.red[1][w]; }
+    htg = uni(htg);
+    hth = uni(hth);
+    __syncthreads();
+    const int lefts = uni(S.word_prefix[kMaskWords]);
+    const int Hn = hist_left ? Lc : Rc, Sn = hist_left ? Rc : Lc;
+    const long long hcnt = hist_left ? lefts : cnt - lefts;
+    const long long ptc = uni(S.ntot[P][0]), ptg = uni(S.ntot[P][1]), pth = uni(S.ntot[P][2]);
+    const int cdepth = uni((int)S.ndepth[P]) + 1;
+    const unsigned pkey = uni(S.nkey[P]);
+
+    lap(3);
+    // search: wave w takes the pairs (feature, child) w, w + 8, ... - child = parity of the wave (0: the child whose
+    // histogram was built, 1: its sibling = parent - child, stored over the parent's slot)
+    {
+      const int c = wave & 1;
+      const int node = c == 0 ? Hn : Sn;
+      const int side = node == Lc ? 0 : 1;
+      const unsigned key = child_node_key(pkey, side);
+      const long long tc = c == 0 ? hcnt : ptc - hcnt, tg = c == 0 ? htg : ptg - htg, th = c == 0 ? hth : pth - hth;
+      const LeafScanCtx ctx = node_scan_ctx(tg, th, tc, q, sp, node);
+      double bg = ninf;
+      uint64_t bkey = ~0ull;
+      int64_t blg = 0, blh = 0;
+#pragma unroll
+      for (int j = 0; j < PPW; ++j) {
+        const int pi = wave + kTreeWaves * j;
+        const int fe = pi >> 1;
+        if (fe < nf) {
+          const FeatureMeta m = S.meta[fe];
+          if (m.enabled) {
+            int64_t g[4], h[4];
+            int64_t* nblk = nblk_base + (int64_t)fe * (2 * kMaxBins);
+            if (multi) load_feat_cells(nblk, lane, g, h);
+            else lds_feat_cells(lds, fe, lane, g, h);
+            if (c == 0) {
+              if (!multi) store_feat_cells(nblk, lane, g, h);
+            } else {
+              int64_t* pblk = const_cast<int64_t*>(pblk_base) + (int64_t)fe * (2 * kMaxBins);
+              int64_t og[4], oh[4];
+              load_feat_cells(pblk, lane, og, oh);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) { g[i] = og[i] - g[i]; h[i] = oh[i] - h[i]; }
+              store_feat_cells(pblk, lane, g, h);
+            }
+            if (node_feature_on(sp, key, fe, nf) && m.categorical != kCategoricalSorted)
+              scan_cells_wave(fe, lane, g, h, m, ctx, sp, bg, bkey, blg, blh, key);
+          }
+        }
+      }
+      wave_best(bg, bkey, blg, blh);
+      if (lane == 0) S.wbest[wave] = Cand{bg, bkey, blg, blh};
+    }
+
+    lap(4);
+    // phase B: move the records - lefts to the front, rights behind, in order
+    {
+      constexpr int U = 4;
+      for (int base = 0; base < cnt; base += U * kTreeThreads) {
+        int rid[U];
+        unsigned long long pk[U];
+        unsigned w[U][BW];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pos = base + u * kTreeThreads + tid;
+          if (pos < cnt) {
+            rid[u] = src_idx[pos];
+            pk[u] = src_gh[pos];
+            load_words<BW>(src_bins + (int64_t)pos * BW, w[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pos = base + u * kTreeThreads + tid;
+          if (pos < cnt) {
+            const int wi = pos >> 6;
+            const unsigned long long m = S.smask[wi];
+            const bool left = (m >> lane) & 1ull;
+            const int lrank = S.word_prefix[wi] + __popcll(m & ((1ull << lane) - 1ull));
+            const int d = left ? lrank : lefts + (pos - lrank);
+            dst_idx[d] = rid[u];
+            dst_gh[d] = pk[u];
+            store_words<BW>(dst_bins + (int64_t)d * BW, w[u]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    lap(5);
+    // the LDS histogram is free again; two threads finish the children
+    if (!multi)
+      for (int i = tid; i < nf * kMaxBins; i += kTreeThreads) lds[i] = 0ull;
+    if (tid == 0 || tid == kWave) {
+      const int c = tid == 0 ? 0 : 1;
+      const int node = c == 0 ? Hn : Sn;
+      double bg = ninf;
+      uint64_t bkey = ~0ull;
+      int64_t blg = 0, blh = 0;
+      for (int w = c; w < kTreeWaves; w += 2) take_better(bg, bkey, blg, blh, S.wbest[w].gain, S.wbest[w].key, S.wbest[w].lg, S.wbest[w].lh);
+      const long long tc = c == 0 ? hcnt : ptc - hcnt, tg = c == 0 ? htg : ptg - htg, th = c == 0 ? hth : pth - hth;
+      write_split(&a.best[node], bg, bkey, blg, blh, tc, tg, th, q, sp);
+      S.ntot[node][0] = tc; S.ntot[node][1] = tg; S.ntot[node][2] = th;
+      const bool is_left = node == Lc;
+      S.nbegin[node] = is_left ? begin : begin + lefts;
+      S.ncount[node] = is_left ? lefts : cnt - lefts;
+      S.nbuf[node] = (signed char)(1 - sb);
+      S.nslot[node] = (short)(c == 0 ? k + 1 : pslot);
+      S.ndepth[node] = (short)cdepth;
+      S.nkey[node] = child_node_key(pkey, is_left ? 0 : 1);
+      const bool open = bg != ninf && isfinite(bg) && !(sp.max_depth > 0 && cdepth >= sp.max_depth);
+      S.ngain[node] = open ? bg : ninf;
+      if (c == 0) { S.ngain[P] = ninf; S.nsplit[P] = 1; S.split_node[k] = (short)P; }
+    }
+    n_splits = k + 1;
+    __syncthreads();
+    lap(6);
+  }
+
+  // ---- hand-over ----
+  const int n_nodes = 2 * n_splits + 1;
+  TreeResult* out = a.out;
+  if (a.renew) {
+    // 36-bit sums of the float gradients over every final leaf's rows: one wave per leaf at a time
+    const int wkg = kg + kWideExtraBits, wkh = kh + kWideExtraBits;
+    for (int node = wave; node < n_nodes; node += kTreeWaves) {
+      if (S.nsplit[node]) continue;
+      const int32_t* rows = a.idx[S.nbuf[node]] + S.nbegin[node];
+      const int cnt = S.ncount[node];
+      long long wg = 0, wh = 0;
+      for (int i = lane; i < cnt; i += kWave) {
+        const int32_t r = rows[i];
+        wg += quantize_wide(a.g[r], wkg);
+        wh += quantize_wide(a.h[r], wkh);
+      }
+      wg = wave_sum_i64(wg);
+      wh = wave_sum_i64(wh);
+      if (lane == 0) { out->wide[node][0] = wg; out->wide[node][1] = wh; }
+    }
+  }
+  {
+    const int words = n_nodes * (int)(sizeof(SplitInfo) / 8);
+    const int64_t* res = reinterpret_cast<const int64_t*>(a.best);
+    int64_t* dst = reinterpret_cast<int64_t*>(out->best);
+    for (int i = tid; i < words; i += kTreeThreads) dst[i] = res[i];
+    for (int i = tid; i < n_nodes; i += kTreeThreads) {
+      const NodeRange r{S.nbegin[i], S.ncount[i], (int32_t)S.nbuf[i], 0};
+      out->range[i] = r;
+      a.nodes[i] = r;
+    }
+    for (int i = tid; i < n_splits; i += kTreeThreads) out->split_node[i] = S.split_node[i];
+    if (tid == 0) { out->n_splits = n_splits; out->kg = kg; out->kh = kh; }
+  }
+  lap(7);
+  if (a.timing && tid == 0)
+    for (int i = 0; i < 8; ++i) out->phase_ticks[i] = ticks[i];
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) *reinterpret_cast<volatile unsigned*>(&out->flag) = a.seq;
+}
+
+template <int BW>
+__global__ __launch_bounds__(kTreeThreads) void tree_kernel(const TreeArgs* __restrict__ descs) {
+  __shared__ unsigned long long lds[BW * 4 * kMaxBins];
+  __shared__ TreeShared S;
+  grow_one<BW>(descs[blockIdx.x], lds, S);   // a uniform address: the descriptor's fields arrive through scalar loads
+}
+
+}  // namespace
+
+void grow_trees(const TreeArgs* descs, int n_trees, int max_features, hipStream_t s) {
+  if (n_trees <= 0) return;
+  if (max_features <= 8) hipLaunchKernelGGL(tree_kernel<2>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
+  else if (max_features <= 16) hipLaunchKernelGGL(tree_kernel<4>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
+  else hipLaunchKernelGGL(tree_kernel<8>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
+  LGA_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace k
+}  // namespace lga

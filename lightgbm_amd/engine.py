@@ -232,7 +232,9 @@ class _FoldRunner:
         if self.concurrent:
             import torch
             from concurrent.futures import ThreadPoolExecutor
-            torch.cuda.synchronize()           # the shared binned dataset is complete before side streams read it
+            # the shared binned dataset was built on the caller's stream: complete before side streams read it
+            # (not a device-wide wait - other grid rows may be running on their own streams)
+            torch.cuda.current_stream().synchronize()
             self.streams = [torch.cuda.Stream() for _ in range(k)]
             self.pools = [ThreadPoolExecutor(max_workers=1) for _ in range(k)]
 
@@ -290,12 +292,20 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
        fobj: Optional[Callable] = None, feval=None, init_model=None, early_stopping_rounds: Optional[int] = None,
        fpreproc=None, verbose_eval: Union[bool, int, None] = None, show_stdv: bool = True, seed: int = 0,
        callbacks: Optional[List[Callable]] = None, eval_train_metric: bool = False, return_cvbooster: bool = False,
-       concurrent_folds: Optional[bool] = None, **kwargs) -> Dict[str, Any]:
+       concurrent_folds: Optional[bool] = None, lockstep_chunk: Optional[int] = None, **kwargs) -> Dict[str, Any]:
     """k-fold cross-validation; returns ``{"<metric>-mean": [...], "<metric>-stdv": [...]}`` (+ ``"cvbooster"``).
 
     ``concurrent_folds``: drive the fold boosters from k host threads on k HIP streams (default: on for the
     HIP build when the data has at most 500 k rows - larger folds fill the GPU on their own - and no
-    Python-side objective / metric is used)."""
+    Python-side objective / metric is used).
+
+    ``lockstep_chunk``: run the folds in lockstep inside the native library, this many iterations per call
+    (:meth:`Booster.update_group`): on the HIP engine the k small trees of an iteration are one kernel launch, and
+    Python sees the evaluation results only once per chunk.  The callbacks are then replayed over the chunk's
+    results iteration by iteration and iterations trained beyond an early stop are rolled back, so the outcome
+    is that of the plain loop.  Default: on (chunk = the early-stopping patience, at most 10) for the HIP build
+    with at most 65536 training rows per fold when nothing needs Python between iterations (no ``fobj`` /
+    ``feval`` / ``fpreproc``, no training-data metric, only evaluation callbacks); 0 switches it off."""
     if not isinstance(train_set, Dataset):
         raise TypeError("Training only accepts Dataset object")
     params = _prepare_params(params, kwargs)
@@ -346,7 +356,16 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     on_gpu = _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host")
     if concurrent_folds is None:
         concurrent_folds = on_gpu and n <= 500_000 and fobj is None and feval is None
-    runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu)
+    callbacks = list(callbacks or [])
+    if lockstep_chunk is None:
+        lockstep_chunk = 0
+        plain_callbacks = not any(getattr(c, "before_iteration", False) for c in callbacks)
+        if (on_gpu and fobj is None and feval is None and fpreproc is None and not eval_train_metric and plain_callbacks
+                and max(len(tr) for tr, _ in folds) <= 65536 and int(get_param(params, "num_class", 1) or 1) <= 1
+                and str(get_param(params, "boosting", "gbdt")).lower() not in ("dart",)):
+            lockstep_chunk = min(10, early_stopping_rounds) if early_stopping_rounds and early_stopping_rounds > 0 else 10
+    lockstep = int(lockstep_chunk or 0) > 0 and fobj is None and feval is None and not eval_train_metric
+    runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu and not lockstep)
 
     cvbooster = CVBooster()
     for k, (tr_idx, te_idx) in enumerate(folds):
@@ -363,7 +382,6 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
             return b
         cvbooster.append(runner.construct(k, build))
 
-    callbacks = list(callbacks or [])
     if early_stopping_rounds is not None and early_stopping_rounds > 0:
         callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=False))
     if verbose_eval is True:
@@ -373,36 +391,65 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     cb_before, cb_after = _split_callbacks(callbacks)
 
     results: Dict[str, List[float]] = {}
+
+    def after_iteration(i, raw) -> bool:
+        """Aggregates iteration i's fold results and runs the callbacks; True = early stop."""
+        cvbooster.iterations_run = i + 1
+        res = _agg_cv_result(raw, eval_train_metric)
+        for _, key, mean, higher_better, std in res:
+            results.setdefault(f"{key}-mean", []).append(mean)
+            results.setdefault(f"{key}-stdv", []).append(std)
+            cvbooster.higher_better[key] = bool(higher_better)
+        try:
+            for c in cb_after:
+                c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))
+        except cb.EarlyStopException as es:
+            cvbooster.best_iteration = es.best_iteration + 1
+            for k in results:
+                results[k] = results[k][: cvbooster.best_iteration]
+            return True
+        return False
+
     try:
-        for i in range(num_boost_round):
-            for c in cb_before:
-                c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
-            def step(b):
-                done = b.update(fobj=fobj)
-                one = []
-                if eval_train_metric:
-                    one.extend(b.eval_train(feval))
-                one.extend(b.eval_valid(feval))
-                return done, one
-            stepped = runner.map([(lambda b=b: step(b)) for b in cvbooster.boosters])
-            finished = [d for d, _ in stepped]
-            raw = [one for _, one in stepped]
-            cvbooster.iterations_run = i + 1
-            res = _agg_cv_result(raw, eval_train_metric)
-            for _, key, mean, higher_better, std in res:
-                results.setdefault(f"{key}-mean", []).append(mean)
-                results.setdefault(f"{key}-stdv", []).append(std)
-                cvbooster.higher_better[key] = bool(higher_better)
-            try:
-                for c in cb_after:
-                    c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, res))
-            except cb.EarlyStopException as es:
-                cvbooster.best_iteration = es.best_iteration + 1
-                for k in results:
-                    results[k] = results[k][: cvbooster.best_iteration]
-                break
-            if all(finished):
-                break
+        if lockstep:
+            names = cvbooster.boosters[0]._metric_names()
+            valid_name = cvbooster.boosters[0].name_valid_sets[0]
+            i = 0
+            stop = False
+            while i < num_boost_round and not stop:
+                for c in cb_before:
+                    c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
+                n_it = min(int(lockstep_chunk), num_boost_round - i)
+                values, fin, done = Booster.update_group(cvbooster.boosters, n_it, 0)
+                for j in range(done):
+                    raw = [[(valid_name, mn, float(values[j, b, m]), hb) for m, (mn, hb) in enumerate(names)]
+                           for b in range(len(cvbooster.boosters))]
+                    if after_iteration(i + j, raw) or (all(fin) and j + 1 == done):
+                        # iterations of this chunk that the plain loop would never have run
+                        for _ in range(done - (j + 1)):
+                            for b in cvbooster.boosters:
+                                b.rollback_one_iter()
+                        stop = True
+                        break
+                i += done
+        else:
+            for i in range(num_boost_round):
+                for c in cb_before:
+                    c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
+
+                def step(b):
+                    done = b.update(fobj=fobj)
+                    one = []
+                    if eval_train_metric:
+                        one.extend(b.eval_train(feval))
+                    one.extend(b.eval_valid(feval))
+                    return done, one
+                stepped = runner.map([(lambda b=b: step(b)) for b in cvbooster.boosters])
+                finished = [d for d, _ in stepped]
+                if after_iteration(i, [one for _, one in stepped]):
+                    break
+                if all(finished):
+                    break
     finally:
         runner.close()
     out: Dict[str, Any] = dict(results)

@@ -9,7 +9,12 @@ Mirrors r/gridsearchCV.R:92-144:
   process per GPU (or CPU worker); every finished row is appended to a durable JSON-lines
   checkpoint (fsync per row), the analogue of ``save(paramGrid, ...)`` after every row (R:118);
   a restarted search skips finished rows (R:121 ``load("paramGrid.RData")``); a worker that dies
-  hands its in-flight row back to the queue.
+  hands its in-flight rows back to the queue.  On the HIP build a worker keeps SEVERAL rows in flight
+  (``rows_in_flight``): one 5-fold CV of a 37 k-row table is a chain of tiny latency-bound kernels, so
+  rows x folds host threads, each on its own HIP stream, are what fills the device.
+* :func:`grid_search_cv_distributed` <- the same loop under ``torch.distributed``: every rank pulls the
+  next row from a counter in the rendezvous store, writes its own checkpoint, and the tables are
+  all-gathered; a restart merges every rank's checkpoint first.
 * :func:`rank_grid`         <- ``paramGrid[order(-paramGrid$score), ]`` (R:122).
 * :func:`refit_top` / :func:`average_predictions` <- refit the best m rows with their CV-chosen
   number of rounds and average the predictions (R:124-144).
@@ -68,8 +73,10 @@ class GridCheckpoint:
     """Append-only JSON-lines log of finished grid rows; every append is flushed and fsync'ed."""
 
     def __init__(self, path: Optional[str]):
+        import threading
         self.path = path
         self.done: Dict[int, Dict[str, Any]] = {}
+        self._lock = threading.Lock()        # rows finish on several threads
         if path and os.path.exists(path):
             with open(path, "r") as f:
                 for line in f:
@@ -87,13 +94,14 @@ class GridCheckpoint:
         return row in self.done and self.done[row].get("hash") == phash
 
     def append(self, rec: Dict[str, Any]):
-        self.done[int(rec["row"])] = rec
-        if not self.path:
-            return
-        with open(self.path, "a") as f:
-            f.write(json.dumps(rec) + "\n")
-            f.flush()
-            os.fsync(f.fileno())
+        with self._lock:
+            self.done[int(rec["row"])] = rec
+            if not self.path:
+                return
+            with open(self.path, "a") as f:
+                f.write(json.dumps(rec) + "\n")
+                f.flush()
+                os.fsync(f.fileno())
 
 
 def load_checkpoint(path: str) -> Dict[int, Dict[str, Any]]:
@@ -113,9 +121,74 @@ def _cv_one(params: Dict[str, Any], dtrain, cv_kwargs: Dict[str, Any]) -> Tuple[
     return int(cvm.best_iter), float(cvm.best_score)
 
 
+def _auto_rows_in_flight(dtrain, rows: Sequence[Dict[str, Any]]) -> int:
+    """Rows one process keeps in flight: 4 on the HIP engine for tables of at most 500 k rows (bigger folds
+    fill the device by themselves), 1 on the CPU engine, whose histogram loops already use every core."""
+    from . import _lib
+    env = os.environ.get("LGA_GRID_ROWS_IN_FLIGHT")
+    if env:
+        return max(1, int(env))
+    if not _lib.is_hip():
+        return 1
+    where = [getattr(dtrain, "params", None) or {}] + list(rows)
+    if any(str(r.get("device_type", r.get("device", "gpu"))).lower() in ("cpu", "host") for r in where):
+        return 1
+    return 4 if dtrain.num_data() <= 500_000 else 1
+
+
+def _own_stream():
+    """Context of one row thread: on the HIP build the thread's boosters live on a stream of their own, so that the
+    rows in flight overlap on the device instead of queueing on the default stream."""
+    import contextlib
+    from . import _lib
+    if not _lib.is_hip():
+        return contextlib.nullcontext()
+    import torch
+    if not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    return torch.cuda.stream(torch.cuda.Stream())
+
+
+def _run_rows(next_row: Callable[[], Optional[int]], run_one: Callable[[int], None], in_flight: int):
+    """Drains a row source with ``in_flight`` host threads; the first exception stops the pulls and is re-raised
+    after the rows already started have finished (their results are durable by then)."""
+    if in_flight <= 1:
+        while True:
+            i = next_row()
+            if i is None:
+                return
+            run_one(i)
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    failed: List[BaseException] = []
+    gate = threading.Lock()
+
+    def drain():
+        with _own_stream():
+            _drain()
+
+    def _drain():
+        while not failed:
+            with gate:
+                i = next_row()
+            if i is None:
+                return
+            try:
+                run_one(i)
+            except BaseException as e:          # noqa: BLE001 - re-raised by the caller's thread
+                failed.append(e)
+                return
+
+    with ThreadPoolExecutor(max_workers=in_flight, thread_name_prefix="lga-grid") as pool:
+        for f in [pool.submit(drain) for _ in range(in_flight)]:
+            f.result()
+    if failed:
+        raise failed[0]
+
+
 def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_params, rows, cv_kwargs, task_q, result_q,
-                 fail_after: Optional[int]):
-    """Worker process: pulls row ids until it sees None."""
+                 fail_after: Optional[int], rows_in_flight: Optional[int] = None):
+    """Worker process: pulls row ids until it sees None (one stop marker per worker process)."""
     if device is not None and device != "cpu":
         os.environ["HIP_VISIBLE_DEVICES"] = str(device)
         os.environ["CUDA_VISIBLE_DEVICES"] = str(device)
@@ -125,19 +198,28 @@ def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_pa
     try:
         dtrain = Dataset(X, label=y, weight=weight, params=dataset_params, free_raw_data=False)
         dtrain.construct()
-        n_done = 0
-        while True:
+        n_started = [0]
+        stopped = [False]
+
+        def next_row():
+            if stopped[0]:
+                return None
             item = task_q.get()
             if item is None:
-                break
-            row_id = item
+                stopped[0] = True
+                return None
+            return item
+
+        def run_one(row_id):
             result_q.put(("start", worker_id, row_id, None))
             t0 = time.time()
-            if fail_after is not None and n_done >= fail_after:
+            if fail_after is not None and n_started[0] >= fail_after:
                 os._exit(17)   # fault injection: die with the row in flight
+            n_started[0] += 1
             it, sc = _cv_one(rows[row_id], dtrain, cv_kwargs)
             result_q.put(("done", worker_id, row_id, (it, sc, time.time() - t0)))
-            n_done += 1
+
+        _run_rows(next_row, run_one, rows_in_flight or _auto_rows_in_flight(dtrain, rows))
     except BaseException as e:   # report, then die
         result_q.put(("error", worker_id, -1, repr(e)))
         raise
@@ -150,13 +232,15 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                    resume: bool = True, workers: Optional[Sequence[Any]] = None, compat_sentinel: bool = False,
                    dataset_params: Optional[Dict[str, Any]] = None, verbose: bool = False,
                    inject_fail_after: Optional[int] = None, progress: Optional[Callable[[int, int], None]] = None,
-                   base_params: Optional[Dict[str, Any]] = None):
+                   base_params: Optional[Dict[str, Any]] = None, rows_in_flight: Optional[int] = None):
     """Runs early-stopped k-fold CV for every row of ``param_grid`` and fills ``iteration`` / ``score``.
 
     ``workers``: None -> run in this process; otherwise a list of devices, one worker process each,
     e.g. ``[0, 1, ..., 7]`` (GPU ids) or ``["cpu", "cpu"]``.  ``base_params`` are engine parameters every
-    row shares (a row's own columns win).  Returns the grid as a DataFrame (row order unchanged; rank it
-    with :func:`rank_grid`).
+    row shares (a row's own columns win).  ``rows_in_flight``: grid rows one process evaluates at the same
+    time, each from its own host thread (None: 4 on the HIP engine for tables up to 500 k rows, else 1); every
+    row is an independent deterministic computation, so the table does not depend on it.  Returns the grid as
+    a DataFrame (row order unchanged; rank it with :func:`rank_grid`).
     """
     import pandas as pd
     grid = param_grid.copy() if hasattr(param_grid, "copy") and hasattr(param_grid, "columns") else pd.DataFrame(list(param_grid))
@@ -191,14 +275,19 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
         from .basic import Dataset
         if dtrain is None:
             dtrain = Dataset(X, label=y, weight=weight, params=dataset_params, free_raw_data=False)
-        done_here = 0
-        for i in todo:
-            if inject_fail_after is not None and done_here >= inject_fail_after:
+        dtrain.construct()
+        started = [0]
+        pending = iter(todo)
+
+        def run_one(i):
+            if inject_fail_after is not None and started[0] >= inject_fail_after:
                 raise RuntimeError("injected failure")
+            started[0] += 1
             t0 = time.time()
             it, sc = _cv_one(rows[i], dtrain, cv_kwargs)
             record(i, it, sc, time.time() - t0, "main")
-            done_here += 1
+
+        _run_rows(lambda: next(pending, None), run_one, rows_in_flight or _auto_rows_in_flight(dtrain, rows))
     else:
         if X is None or y is None:
             raise ValueError("worker processes need the raw X and y (a constructed Dataset cannot cross processes)")
@@ -209,14 +298,14 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
             task_q.put(i)
         Xn, yn = np.asarray(X), np.asarray(y)
         procs = {}
-        inflight: Dict[int, Optional[int]] = {}
+        inflight: Dict[int, set] = {}
         for w, dev in enumerate(workers):
             fa = inject_fail_after if w == 0 else None
             p = ctx.Process(target=_worker_main, args=(w, dev, Xn, yn, weight, dataset_params, rows, cv_kwargs, task_q,
-                                                       result_q, fa), daemon=True)
+                                                       result_q, fa, rows_in_flight), daemon=True)
             p.start()
             procs[w] = p
-            inflight[w] = None
+            inflight[w] = set()
         for _ in workers:
             task_q.put(None)
         remaining = set(todo)
@@ -229,20 +318,21 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                 for w in list(alive):
                     if not procs[w].is_alive():
                         alive.discard(w)
-                        lost = inflight.get(w)
-                        if lost is not None and lost in remaining:
+                        lost = sorted(r for r in inflight.get(w, ()) if r in remaining)
+                        if lost:
                             if verbose:
-                                print(f"[grid] worker {w} died; re-queueing row {lost + 1}")
-                            # the dead worker never consumed its stop marker: the re-queued row goes in front of it
-                            task_q.put(lost)
+                                print(f"[grid] worker {w} died; re-queueing rows {[r + 1 for r in lost]}")
+                            # the dead worker never consumed its stop marker: the re-queued rows go in front of it
+                            for r in lost:
+                                task_q.put(r)
                             task_q.put(None)
-                            inflight[w] = None
+                            inflight[w] = set()
                 continue
             if kind == "start":
-                inflight[w] = row_id
+                inflight[w].add(row_id)
             elif kind == "done":
                 it, sc, secs = payload
-                inflight[w] = None
+                inflight[w].discard(row_id)
                 if row_id in remaining:
                     remaining.discard(row_id)
                     record(row_id, it, sc, secs, str(workers[w]))
@@ -271,31 +361,110 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
     return grid
 
 
-def grid_search_cv_distributed(param_grid, X, y, group=None, **kwargs):
-    """Task-parallel search under ``torch.distributed``: rank r evaluates every world_size-th row of the
-    cost-sorted grid on its own GPU; results are all-gathered so every rank returns the full table."""
-    import pandas as pd
+_DIST_CALLS = [0]
+
+
+def _row_counter(group, token: str):
+    """A fetch-and-add counter every rank of ``group`` can reach: a key in the rendezvous store of the default
+    process group (TCPStore / FileStore ``add`` is atomic).  None when this build of torch keeps no such store."""
+    try:
+        import torch.distributed as dist
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:       # noqa: BLE001 - private accessor; absent means static sharding
+        return None
+    key = f"lightgbm_amd/grid/{token}/next"
+    return lambda: int(store.add(key, 1)) - 1
+
+
+def grid_search_cv_distributed(param_grid, X, y, group=None, checkpoint: Optional[str] = None, resume: bool = True,
+                               weight=None, dataset_params: Optional[Dict[str, Any]] = None,
+                               base_params: Optional[Dict[str, Any]] = None, rows_in_flight: Optional[int] = None,
+                               verbose: bool = False, static_shards: bool = False, **cv_args):
+    """Task-parallel search under ``torch.distributed`` (one rank per GPU): the loop of r/gridsearchCV.R:104-121
+    with the rows dealt out dynamically.
+
+    Rank 0 lists the unfinished rows most-expensive-first and broadcasts the list; every rank then pulls the
+    next position from a shared counter until the list is exhausted, so a rank that drew short rows simply draws
+    more of them.  Each rank appends its finished rows to ``<checkpoint>.rank<r>`` (fsync per row, R:118); a
+    restarted search first merges ``<checkpoint>`` and every ``<checkpoint>.rank*`` file, whatever the world
+    size of the run that wrote them (R:121).  All ranks return the full table.  ``cv_args`` are those of
+    :func:`grid_search_cv` (``nrounds``, ``nfold``, ``objective``, ``eval``, ``early_stopping_rounds``, ...).
+    ``static_shards`` forces the fallback used when the process group exposes no store: rank r takes every
+    world_size-th row of the cost-sorted list.
+    """
+    import glob
+    import pandas as pd    # noqa: F401
     import torch.distributed as dist
+    from .basic import Dataset
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     grid = param_grid.copy()
     for c in RESULT_COLUMNS:
         if c not in grid.columns:
             grid.insert(0 if c == "iteration" else 1, c, np.nan)
-    rows = [_row_params(r) for r in grid.to_dict(orient="records")]
-    order = sorted(range(len(rows)), key=lambda i: -_cost_estimate(rows[i]))
-    mine = [i for k, i in enumerate(order) if k % world == rank]
-    sub = grid.iloc[mine].copy()
-    ck = kwargs.pop("checkpoint", None)
-    if ck:
-        ck = f"{ck}.rank{rank}"
-    res = grid_search_cv(sub, X=X, y=y, checkpoint=ck, workers=None, **kwargs)
-    local = [(int(i), float(res.iloc[k]["iteration"]), float(res.iloc[k]["score"])) for k, i in enumerate(mine)]
+    rows = [{**(base_params or {}), **_row_params(r)} for r in grid.to_dict(orient="records")]
+    cv_kwargs = dict(nrounds=cv_args.pop("nrounds", 1000), nfold=cv_args.pop("nfold", 5),
+                     objective=cv_args.pop("objective", "regression"), eval=cv_args.pop("eval", None),
+                     showsd=cv_args.pop("showsd", False), early_stopping_rounds=cv_args.pop("early_stopping_rounds", 5),
+                     verbose=0, stratified=cv_args.pop("stratified", True), seed=cv_args.pop("seed", 0),
+                     compat_sentinel=cv_args.pop("compat_sentinel", False))
+    if cv_args:
+        raise TypeError(f"grid_search_cv_distributed: unknown arguments {sorted(cv_args)}")
+    extra = {k: cv_kwargs[k] for k in ("nrounds", "nfold", "objective", "eval", "early_stopping_rounds", "seed")}
+    hashes = [_params_hash(p, extra) for p in rows]
+
+    # rank 0 decides what is left (one reader of the old files, so every rank works from the same list)
+    _DIST_CALLS[0] += 1
+    plan: List[Any] = [None]
+    if rank == 0:
+        done: Dict[int, Dict[str, Any]] = {}
+        if checkpoint:
+            old = sorted(set(glob.glob(glob.escape(checkpoint) + ".rank*")) | ({checkpoint} if os.path.exists(checkpoint) else set()))
+            if not resume:
+                for f in old:
+                    os.remove(f)
+            else:
+                for f in old:
+                    for i, rec in GridCheckpoint(f).done.items():
+                        if i < len(rows) and rec.get("hash") == hashes[i]:
+                            done[i] = rec
+        todo = [i for i in range(len(rows)) if i not in done]
+        todo.sort(key=lambda i: -_cost_estimate(rows[i]))
+        token = f"{os.getpid()}-{time.time_ns()}-{_DIST_CALLS[0]}"
+        plan = [(todo, {i: (r["iteration"], r["score"]) for i, r in done.items()}, token)]
+    dist.broadcast_object_list(plan, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    todo, finished, token = plan[0]
+
+    counter = None if static_shards else _row_counter(group, token)
+    if counter is None:
+        mine = iter([i for k, i in enumerate(todo) if k % world == rank])
+        next_row = lambda: next(mine, None)                       # noqa: E731
+    else:
+        def next_row():
+            k = counter()
+            return todo[k] if k < len(todo) else None
+
+    ck = GridCheckpoint(f"{checkpoint}.rank{rank}" if checkpoint else None)
+    local: Dict[int, Tuple[float, float]] = {}
+    if todo:
+        dtrain = Dataset(X, label=y, weight=weight, params=dataset_params, free_raw_data=False)
+        dtrain.construct()
+
+        def run_one(i):
+            t0 = time.time()
+            it, sc = _cv_one(rows[i], dtrain, cv_kwargs)
+            ck.append({"row": i, "hash": hashes[i], "params": rows[i], "iteration": it, "score": sc,
+                       "seconds": time.time() - t0, "worker": f"rank{rank}", "status": "ok"})
+            local[i] = (it, sc)
+            if verbose:
+                print(f"[grid rank {rank}] row {i + 1}/{len(rows)}: iteration={it} score={sc:.6g} ({time.time() - t0:.1f}s)")
+
+        _run_rows(next_row, run_one, rows_in_flight or _auto_rows_in_flight(dtrain, rows))
     gathered: List[Any] = [None] * world
     dist.all_gather_object(gathered, local, group=group)
-    for part in gathered:
-        for i, it, sc in part:
-            grid.loc[grid.index[i], "iteration"] = it
-            grid.loc[grid.index[i], "score"] = sc
+    for part in [finished] + gathered:
+        for i, (it, sc) in part.items():
+            grid.loc[grid.index[int(i)], "iteration"] = it
+            grid.loc[grid.index[int(i)], "score"] = sc
     return grid
 
 

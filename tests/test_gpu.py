@@ -255,6 +255,32 @@ def test_gpu_regression_trees_equal_cpu_trees(params):
     assert trees_of(a) == trees_of(b)
 
 
+@pytest.mark.parametrize("n,F,leaves,extra", [
+    (700, 6, 31, {}),
+    (36700, 6, 127, {"bagging_fraction": 0.8, "bagging_freq": 4, "feature_fraction": 0.8}),   # a fold of the reference grid
+    (40000, 12, 255, {"min_data_in_leaf": 3, "lambda_l2": 0.3}),            # two histogram passes at the top, 16 features' layout
+    (65536, 28, 63, {"max_depth": 7, "extra_trees": True}),                 # the row limit, 32 features' layout
+    (20000, 3, 255, {"feature_fraction_bynode": 0.7, "min_data_in_leaf": 1}),
+    (5000, 9, 15, {"objective": "huber", "max_bin": 31}),
+])
+def test_whole_tree_kernel_grows_the_cpu_trees(n, F, leaves, extra):
+    """Bags of up to 65536 rows are grown by ONE workgroup in one launch (the whole best-first loop on the device);
+    the trees are the CPU oracle's and those of the batched growth rounds, and the leaf values renewed from the
+    kernel's own 36-bit sums are the same as well."""
+    X, y = make_regression(n, F, seed=n % 97)
+    X[:, F - 1] = np.abs(np.round(X[:, F - 1] * 1.5))  # a handful of distinct values
+    X[::11, 1] = np.nan
+    cat = [F - 1] if F == 9 else "auto"
+    p = {"num_leaves": leaves, "min_data_in_leaf": 5, "max_cat_to_onehot": 64, **extra}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU, categorical_feature=cat), 10)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat), 10, keep_training_booster=True)
+    c = lgb.train({**GPU, **p, "whole_tree_max_rows": 0}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat), 10,
+                  keep_training_booster=True)
+    assert b.grow_stats()["rounds"] == 1 and c.grow_stats()["rounds"] > 1
+    assert trees_of(a) == trees_of(b) == trees_of(c)
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
+
+
 @pytest.mark.parametrize("first", [0, 10, 20, 30])
 def test_randomised_parity_sweep(first):
     """Random shapes (across the row-line, two-rounds-in-flight and tree-walk size gates), missing values,

@@ -123,6 +123,86 @@ def test_worker_processes_and_dead_worker_requeue(tmp_path):
     assert len(recs) == 8 and len({r["worker"] for r in recs.values()}) >= 1
 
 
+def test_rows_in_flight_do_not_change_the_table(tmp_path):
+    X, y = make_regression(2000, 8, seed=4)
+    ck = str(tmp_path / "ck.jsonl")
+    seq = grid_search_cv(small_grid(), X=X, y=y, rows_in_flight=1, **KW)
+    par = grid_search_cv(small_grid(), X=X, y=y, rows_in_flight=3, checkpoint=ck, **KW)
+    np.testing.assert_array_equal(par["score"].values, seq["score"].values)
+    np.testing.assert_array_equal(par["iteration"].values, seq["iteration"].values)
+    assert len(load_checkpoint(ck)) == 8
+    # a failure on one thread stops the pulls, keeps what finished and surfaces in the caller
+    ck2 = str(tmp_path / "ck2.jsonl")
+    with pytest.raises(RuntimeError, match="injected"):
+        grid_search_cv(small_grid(), X=X, y=y, rows_in_flight=3, checkpoint=ck2, inject_fail_after=4, **KW)
+    assert 1 <= len(load_checkpoint(ck2)) <= 4
+    again = grid_search_cv(small_grid(), X=X, y=y, rows_in_flight=2, checkpoint=ck2, **KW)
+    np.testing.assert_array_equal(again["score"].values, seq["score"].values)
+    # worker processes with two rows in flight each
+    w = grid_search_cv(small_grid(), X=X, y=y, workers=["cpu", "cpu"], rows_in_flight=2, **KW)
+    np.testing.assert_array_equal(w["score"].values, seq["score"].values)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("static", [False, True])
+def test_distributed_search_pulls_rows_dynamically_and_merges_rank_checkpoints(tmp_path, static):
+    """Two gloo processes share the grid through the store counter (r/gridsearchCV.R:104-121 as a task queue):
+    the table equals the in-process one, every row ran exactly once, and a restart - here with rows left behind
+    by a run of a different world size - only computes what no rank's checkpoint holds."""
+    X, y = make_regression(2000, 8, seed=6)
+    full = grid_search_cv(small_grid(), X=X, y=y, **KW)
+    ck = str(tmp_path / "ck.jsonl")
+    # leftovers of an earlier 4-rank run: two finished rows in rank files, one row of a search with other settings
+    first = grid_search_cv(small_grid().iloc[:2], X=X, y=y, checkpoint=ck + ".rank3", **KW)
+    assert first["score"].notna().all()
+    stale = grid_search_cv(small_grid().iloc[:3], X=X, y=y, checkpoint=ck + ".rank1", **{**KW, "nfold": 4})
+    assert stale["score"].notna().all()
+    out = str(tmp_path / "table_rank{}.json")
+    script = f"""
+import os, sys, json
+sys.path.insert(0, {ROOT!r})
+os.environ["LGA_FORCE_HOST"] = "1"
+import torch.distributed as dist
+dist.init_process_group("gloo")
+from lightgbm_amd.grid import grid_search_cv_distributed
+from lightgbm_amd.utils.datasets import make_regression
+from tests.test_grid import small_grid, KW
+X, y = make_regression(2000, 8, seed=6)
+g = grid_search_cv_distributed(small_grid(), X, y, checkpoint={ck!r}, static_shards={static!r}, **KW)
+r = dist.get_rank()
+json.dump({{"iteration": g["iteration"].tolist(), "score": g["score"].tolist()}}, open({out!r}.format(r), "w"))
+dist.destroy_process_group()
+"""
+    path = str(tmp_path / "worker.py")
+    with open(path, "w") as f:
+        f.write(script)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), path],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    t0, t1 = json.load(open(out.format(0))), json.load(open(out.format(1)))
+    assert t0 == t1
+    np.testing.assert_array_equal(np.array(t0["score"]), full["score"].values)
+    np.testing.assert_array_equal(np.array(t0["iteration"]), full["iteration"].values)
+    # this run computed the six rows nobody had, each exactly once
+    new = {}
+    for rank in (0, 1):
+        recs = load_checkpoint(ck + f".rank{rank}")
+        recs = {i: v for i, v in recs.items() if v["worker"].startswith("rank")}
+        assert not (set(recs) & set(new))
+        new.update(recs)
+    assert sorted(new) == [2, 3, 4, 5, 6, 7]
+
+
 def test_trends_of_the_reference_run():
     # NBR:801: lower learning rates reach better CV scores when given enough rounds
     X, y = make_regression(3000, 10, seed=3, noise=0.5)

@@ -1,7 +1,8 @@
 """Randomised CPU-oracle vs HIP-engine parity sweep.
 
 Every seed draws a dataset shape (crossing the engine's size gates: row lines at 2^18 rows, two rounds
-in flight at 2^19, tree-walk score update at 2^20), a feature count (one or two 32-feature tiles),
+in flight at 2^19, tree-walk score update at 2^20; bags up to 2^16 rows take the whole-tree kernel and are
+also trained with it switched off), a feature count (one or two 32-feature tiles),
 missing values, weights and a parameter set, trains a few iterations on both engines and compares the
 model text.  Regression objectives only: their gradients involve no transcendental function, so the
 integer histograms - and with them the trees - are bit-identical.  The percentile-output objectives
@@ -111,8 +112,12 @@ def run_case(seed: int, max_rows: int):
     n, F, p, opts = draw_case(seed, max_rows)
     X, y, w = make_data(seed, n, F, opts)
     models = []
-    for dev in ("cpu", "gpu"):
-        base = {"device_type": dev, "verbose": -1}
+    rows = (n + 1) // 2 if opts["subset"] else n
+    # small bags are grown by the whole-tree kernel: such a case runs the device engine both ways
+    for dev in ("cpu", "gpu") + (("gpu-rounds",) if rows <= 65536 else ()):
+        base = {"device_type": dev.split("-")[0], "verbose": -1}
+        if dev == "gpu-rounds":
+            base["whole_tree_max_rows"] = 0
         cats = [F - 2 if F > 1 else 0] if opts.get("categorical") else "auto"
         dp = {**base, "max_bin": p["max_bin"], "zero_as_missing": p.get("zero_as_missing", False)}
         d = lgb.Dataset(X, label=y, weight=w, params=dp, categorical_feature=cats)
@@ -121,7 +126,7 @@ def run_case(seed: int, max_rows: int):
         b = lgb.train({**base, **p}, d, opts["rounds"])
         s = b.model_to_string()
         models.append(s[s.index("Tree=0"):s.index("end of trees")])
-    return models[0] == models[1], (n, F, p, opts)
+    return all(m == models[0] for m in models[1:]), (n, F, p, opts)
 
 
 def main():

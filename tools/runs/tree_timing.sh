@@ -1,0 +1,8 @@
+#!/bin/bash
+set -e -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/${1:-tt}
+mkdir -p "$OUT"
+cd $ROOT
+LGA_TREE_TIMING=1 timeout -k 10 120 python -u bench/small_tree_bench.py --threads 1 --iters 200 > "$OUT/timing.jsonl" 2> "$OUT/timing.err" || { tail -20 "$OUT/timing.err"; exit 1; }
+cat "$OUT/timing.jsonl"; grep "tree kernel" "$OUT/timing.err" | tail -3
