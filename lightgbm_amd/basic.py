@@ -808,24 +808,30 @@ class Booster:
         return fin.value == 1
 
     @staticmethod
-    def update_group(boosters: List["Booster"], n_iters: int, eval_which: int = 0):
-        """``n_iters`` boosting iterations of several boosters in lockstep (native loop; on the HIP engine the small
-        trees of all boosters of an iteration are grown by ONE kernel launch, one workgroup per tree).  After every
-        iteration dataset ``eval_which`` (0: first validation set, -1: training data, -2: nothing) of every booster is
-        evaluated.  The loop ends early after an iteration in which no booster found anything to split.  Returns
-        ``(values[iteration, booster, metric], finished[booster], iterations_run)``; ``finished[b]``: booster b found
-        nothing to split in the last iteration run."""
+    def update_group(boosters: List["Booster"], n_iters: int, eval_valid: bool = True):
+        """``n_iters`` boosting iterations of several boosters in lockstep, inside the native library; after every
+        iteration the first validation set of every booster is evaluated (``eval_valid``).  On the HIP engine small
+        boosters (at most 65536 training rows, pointwise objective and metrics, plain trees) run the whole chunk on
+        the device - one workgroup per booster does gradients, bag, tree, leaf values, score updates and metric
+        sums of every iteration with no host in between - and all boosters of the call share ONE kernel launch:
+        the folds of a cross-validation, the rows of a parameter grid.  The loop ends early after an iteration in
+        which no booster found anything to split.  Returns ``(values[iteration, booster, metric],
+        no_split[iteration, booster], iterations_run)``."""
         lib, _ = _lib.load()
         n = len(boosters)
-        names = boosters[0]._metric_names() if eval_which >= -1 else []
+        if _lib.is_hip():
+            from . import _device
+            _device.sync_stream(lib)
+        names = boosters[0]._metric_names() if eval_valid else []
         stride = max(1, len(names))
         handles = (ctypes.c_void_p * n)(*[b._handle for b in boosters])
         values = np.zeros((n_iters, n, stride), dtype=np.float64)
-        finished = (ctypes.c_int * n)()
+        finished = np.zeros((n_iters, n), dtype=np.int32)
         done = ctypes.c_int()
-        check(lib.lga_booster_group_update(handles, n, int(n_iters), int(eval_which),
-                                           values.ctypes.data_as(ctypes.c_void_p), stride, finished, ctypes.byref(done)))
-        return values[: done.value, :, : len(names)], [bool(f) for f in finished], done.value
+        check(lib.lga_booster_group_update(handles, n, int(n_iters), 0 if eval_valid else -2,
+                                           values.ctypes.data_as(ctypes.c_void_p), stride,
+                                           finished.ctypes.data_as(ctypes.c_void_p), ctypes.byref(done)))
+        return values[: done.value, :, : len(names)], finished[: done.value].astype(bool), done.value
 
     def __boost(self, grad, hess) -> bool:
         lib, _ = _lib.load()

@@ -257,31 +257,19 @@ int lga_booster_add_valid(LgaBooster b, LgaDataset ds, const char* name) {
   return guard([&] { B(b)->add_valid(DS(ds), name ? name : "valid"); });
 }
 int lga_booster_update(LgaBooster b, int* finished) { return guard([&] { *finished = B(b)->update_one_iter() ? 1 : 0; }); }
-// n_iters iterations of n boosters in lockstep (the folds of a cross-validation): every iteration starts all
-// boosters' trees together, then - which >= -1 - evaluates dataset `which` of every booster.  values:
-// [iteration][booster][metric] with `stride` doubles per booster.  The loop ends early after an iteration in
-// which NO booster found anything to split; finished[b] = booster b found nothing to split in the last
-// iteration run, *iters_done = iterations run.
+// n_iters iterations of n boosters in lockstep (the folds of a cross-validation, the rows of a parameter grid):
+// which == 0 evaluates every booster's first validation set after every iteration, which < 0 nothing.  values:
+// [iteration][booster][metric] with `stride` doubles per booster.  The loop ends early after an iteration in which
+// NO booster found anything to split; finished[iteration * n + b] = booster b found nothing to split in that
+// iteration, *iters_done = iterations run.  (Booster::update_group_chunk: on the device engine small boosters run the whole
+// chunk without the host in between.)
 int lga_booster_group_update(LgaBooster* boosters, int n, int n_iters, int which, double* values, int stride,
                              int* finished, int* iters_done) {
   return guard([&] {
+    if (which > 0) throw std::runtime_error("group updates evaluate validation set 0 or nothing");
     std::vector<Booster*> bs((size_t)n);
-    for (int i = 0; i < n; ++i) { bs[(size_t)i] = B(boosters[i]); finished[i] = 0; }
-    *iters_done = 0;
-    for (int it = 0; it < n_iters; ++it) {
-      Booster::update_group(bs.data(), n, finished);
-      bool all = true;
-      for (int i = 0; i < n; ++i) {
-        all = all && finished[i] != 0;
-        if (which >= -1 && values) {
-          auto r = bs[(size_t)i]->eval(which);
-          if ((int)r.size() > stride) throw std::runtime_error("buffer too small");
-          for (size_t m = 0; m < r.size(); ++m) values[((size_t)it * (size_t)n + (size_t)i) * (size_t)stride + m] = r[m].value;
-        }
-      }
-      *iters_done = it + 1;
-      if (all) break;
-    }
+    for (int i = 0; i < n; ++i) bs[(size_t)i] = B(boosters[i]);
+    *iters_done = Booster::update_group_chunk(bs.data(), n, n_iters, which == 0, values, stride, finished);
   });
 }
 int lga_booster_update_custom(LgaBooster b, const float* grad, const float* hess, int64_t n, int* finished) {

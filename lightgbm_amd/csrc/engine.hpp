@@ -22,6 +22,32 @@ struct EvalResult {
   bool higher_better;
 };
 
+// A chunk of boosting iterations run by the engine itself, without the driver in between (device engine, small
+// data): what the driver decides per iteration, and what comes back.
+struct ChunkIterPlan {
+  std::vector<FeatureMeta> meta;   // the iteration's feature_fraction mask applied
+  int64_t tree_index = 0;
+  bool redraw = false;             // draw a new bag before the tree, from the random stream `bag_iter`
+  uint64_t bag_iter = 0;
+};
+struct ChunkPlan {
+  std::vector<ChunkIterPlan> iters;
+  ObjectiveSpec obj;
+  int bagging = 0;                 // 0: every row, 1: bagging_fraction, 3: by label (bag_fraction for positives, neg_fraction)
+  double bag_fraction = 1.0, neg_fraction = 1.0;
+  uint64_t bag_seed = 0;
+  double learning_rate = 0.1;
+  bool renew = true;               // leaf values from the 36-bit sums
+  bool eval_valid = false;         // evaluate validation set 0 after every iteration
+  std::vector<int32_t> metrics;    // pointwise metrics (at most 4)
+};
+struct ChunkTree {
+  Tree tree;                       // leaf values as the search left them (not renewed, not shrunk)
+  std::vector<int64_t> leaf_sums;  // [leaf][2]: 36-bit sums of g and h over the leaf's in-bag rows (ChunkPlan::renew)
+  int kg = 0, kh = 0;              // their exponents
+  std::vector<double> metric_sums; // [metric][2]: sum of weighted losses, sum of weights
+};
+
 class Engine {
  public:
   virtual ~Engine() {}
@@ -89,6 +115,14 @@ class Engine {
   virtual Tree train_tree_finish() { return train_tree(pending_meta_); }
   // Called on one engine of the group with all engines whose train_tree_begin returned true (itself included).
   virtual void launch_prepared_trees(Engine* const* group, int n) { (void)group; (void)n; }
+  // A chunk of iterations on the engine (ChunkPlan): gradients, bag, tree, leaf values, score updates of the
+  // training data and of validation set 0, metric sums - per iteration, with no driver in between.
+  // train_chunk_begin prepares it (false: this engine / configuration cannot, nothing has happened);
+  // launch_prepared_chunks starts the prepared chunks of a group of engines; train_chunk_finish waits and
+  // reports the iterations' trees.  The engine's scores then stand after the chunk's last iteration.
+  virtual bool train_chunk_begin(const ChunkPlan& plan) { (void)plan; return false; }
+  virtual void launch_prepared_chunks(Engine* const* group, int n) { (void)group; (void)n; }
+  virtual void train_chunk_finish(std::vector<ChunkTree>* out) { (void)out; }
   // Add `tree` (final leaf values) to the training scores, using the row
   // ranges of the tree just grown for in-bag rows and traversal for the rest.
   virtual void add_trained_tree_to_train_scores(const Tree& tree) = 0;

@@ -126,7 +126,9 @@ double Booster::boost_from_average() {
   }
 }
 
-std::vector<FeatureMeta> Booster::sample_features(int cls) {
+std::vector<FeatureMeta> Booster::sample_features(int cls) { return sample_features_at(cls, iter_); }
+
+std::vector<FeatureMeta> Booster::sample_features_at(int cls, int iter) {
   std::vector<FeatureMeta> meta = train_->feature_meta();
   int F = (int)meta.size();
   if (!cfg_.monotone_constraints.empty()) {
@@ -146,7 +148,7 @@ std::vector<FeatureMeta> Booster::sample_features(int cls) {
   std::vector<int> perm((size_t)F);
   std::iota(perm.begin(), perm.end(), 0);
   for (int j = 0; j < k; ++j) {
-    uint64_t r = rng_u64((uint64_t)cfg_.feature_fraction_seed, (uint64_t)iter_ * (uint64_t)num_class_ + (uint64_t)cls,
+    uint64_t r = rng_u64((uint64_t)cfg_.feature_fraction_seed, (uint64_t)iter * (uint64_t)num_class_ + (uint64_t)cls,
                          (uint64_t)j);
     int pick = j + (int)(r % (uint64_t)(F - j));
     std::swap(perm[(size_t)j], perm[(size_t)pick]);
@@ -366,6 +368,184 @@ void Booster::update_group(Booster* const* boosters, int n, int* finished) {
 }
 
 // ---------------------------------------------------------------------------
+// chunks of iterations on the engine (Engine::train_chunk_begin)
+// ---------------------------------------------------------------------------
+namespace {
+bool pointwise_objective(int32_t kind) {
+  switch (kind) {
+    case kObjRegression: case kObjHuber: case kObjFair: case kObjPoisson: case kObjBinary: case kObjCrossEntropy:
+    case kObjGamma: case kObjTweedie: return true;
+    default: return false;   // percentile leaf outputs, ranking, multiclass, custom
+  }
+}
+bool pointwise_metric(int32_t m) { return m != kMetAuc && m != kMetMultiLogloss && m != kMetMultiError; }
+}  // namespace
+
+bool Booster::chunk_eligible(bool eval_valid) const {
+  if (!engine_ || num_class_ != 1 || is_dart_ || is_rf_ || !pointwise_objective(obj_.kind)) return false;
+  if (cfg_.data_sample_strategy == "goss") return false;
+  if (cfg_.path_smooth > 0.0 || !cfg_.interaction_constraints.empty()) return false;
+  for (int m : cfg_.monotone_constraints) if (m != 0) return false;
+  if (!cfg_.feature_contri.empty() || !cfg_.cegb_penalty_feature_coupled.empty() || cfg_.cegb_penalty_split > 0.0) return false;
+  if (eval_valid) {
+    if (engine_->num_valid() != 1 || metrics_.empty() || metrics_.size() > 4) return false;
+    if (!rank_metrics_.empty() || eval_average_precision_ || eval_auc_mu_) return false;
+    for (int32_t m : metrics_) if (!pointwise_metric(m)) return false;
+  } else if (engine_->num_valid() > 1) {
+    return false;
+  }
+  return true;
+}
+
+bool Booster::chunk_begin(int n_iters, bool eval_valid) {
+  ensure_scores();
+  ChunkPlan plan;
+  plan.obj = obj_;
+  plan.learning_rate = cfg_.learning_rate;
+  plan.renew = cfg_.quant_train_renew_leaf;
+  plan.eval_valid = eval_valid;
+  if (eval_valid) plan.metrics = metrics_;
+  const bool balanced = cfg_.pos_bagging_fraction < 1.0 || cfg_.neg_bagging_fraction < 1.0;
+  if (balanced && obj_.kind != kObjBinary)
+    throw std::runtime_error("pos_bagging_fraction / neg_bagging_fraction need objective=binary");
+  const bool bagging = cfg_.bagging_freq > 0 && (cfg_.bagging_fraction < 1.0 || balanced);
+  plan.bagging = !bagging ? 0 : (balanced ? 3 : 1);
+  plan.bag_fraction = balanced ? cfg_.pos_bagging_fraction : cfg_.bagging_fraction;
+  plan.neg_fraction = cfg_.neg_bagging_fraction;
+  plan.bag_seed = (uint64_t)cfg_.bagging_seed;
+  bool drawn = bag_drawn_;
+  for (int j = 0; j < n_iters; ++j) {
+    const int it = iter_ + j;
+    ChunkIterPlan ip;
+    ip.meta = sample_features_at(0, it);
+    ip.tree_index = (int64_t)it;
+    if (bagging) {
+      // the bag of iteration k is drawn at the last multiple of bagging_freq <= k (draw_bag)
+      const int period_start = it - it % cfg_.bagging_freq;
+      ip.redraw = !drawn || period_start == it;
+      ip.bag_iter = (uint64_t)period_start;
+      drawn = true;
+    }
+    plan.iters.push_back(std::move(ip));
+  }
+  if (!engine_->train_chunk_begin(plan)) return false;
+  if (bagging) bag_drawn_ = true;
+  return true;
+}
+
+void Booster::chunk_fetch(std::vector<char>* stump) {
+  engine_->train_chunk_finish(&chunk_trees_);
+  stump->assign(chunk_trees_.size(), 0);
+  for (size_t j = 0; j < chunk_trees_.size(); ++j) (*stump)[j] = chunk_trees_[j].tree.num_leaves <= 1 ? 1 : 0;
+}
+
+// Takes over the first n_keep iterations of the fetched chunk: renews and shrinks the trees' leaf values the way the
+// engine did on its side, stores them, and turns the metric sums into values.  Iterations beyond n_keep - the
+// group stopped before them - are taken out of the engine's scores again.
+void Booster::chunk_commit(int n_keep, bool eval_valid, double* values, int stride, int n_group, int index) {
+  const int n_iters = (int)chunk_trees_.size();
+  const int nv = engine_->num_valid();
+  for (int j = 0; j < n_iters; ++j) {
+    ChunkTree& ct = chunk_trees_[(size_t)j];
+    Tree tree = std::move(ct.tree);
+    const bool is_stump = tree.num_leaves <= 1;
+    if (!is_stump) {
+      if (cfg_.quant_train_renew_leaf) renew_from_sums(tree, ct.leaf_sums, ct.kg, ct.kh);
+      tree.apply_shrinkage(cfg_.learning_rate);
+    }
+    if (j >= n_keep) {
+      if (!is_stump) for (int w = -1; w < nv; ++w) engine_->add_tree_by_traversal(w, tree, -1.0);
+      continue;
+    }
+    const bool first_iteration = (int)trees_.size() < num_class_;
+    const double init = init_scores_[0];
+    if (is_stump) {
+      tree.leaf_value[0] = 0.0;
+      if (first_iteration) tree.add_bias(init);
+    } else if (first_iteration && init != 0.0) {
+      tree.add_bias(init);
+    }
+    trees_.push_back(std::move(tree));
+    // an iteration without a split is dropped again unless it is the very first one (finish_iteration)
+    ++iter_;
+    if (is_stump && (int)trees_.size() > num_class_) trees_.pop_back();
+    if (eval_valid && values) {
+      for (size_t m = 0; m < metrics_.size(); ++m) {
+        const double s0 = ct.metric_sums[2 * m], s1 = ct.metric_sums[2 * m + 1];
+        double v = s1 > 0.0 ? s0 / s1 : 0.0;
+        if (metrics_[m] == kMetRmse) v = std::sqrt(v);
+        values[((size_t)j * (size_t)n_group + (size_t)index) * (size_t)stride + m] = v;
+      }
+    }
+  }
+  chunk_trees_.clear();
+}
+
+int Booster::update_group_chunk(Booster* const* boosters, int n, int n_iters, bool eval_valid, double* values, int stride,
+                                int* finished) {
+  for (size_t i = 0; i < (size_t)n * (size_t)std::max(n_iters, 0); ++i) finished[i] = 0;
+  if (n_iters < 1 || n < 1) return 0;
+  bool chunked = true;
+  for (int i = 0; i < n; ++i) chunked = chunked && boosters[i]->chunk_eligible(eval_valid);
+  if (chunked) {
+    std::vector<Engine*> engines;
+    int prepared = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!boosters[i]->chunk_begin(n_iters, eval_valid)) break;
+      engines.push_back(boosters[i]->engine_.get());
+      ++prepared;
+    }
+    if (prepared == n) {
+      engines[0]->launch_prepared_chunks(engines.data(), n);
+      // waiting for the chunks and assembling their trees is host work per booster: spread it over the cores
+      std::vector<std::vector<char>> stump((size_t)n);
+      std::string failure;
+#pragma omp parallel for schedule(dynamic, 1) if (n >= 8)
+      for (int i = 0; i < n; ++i) {
+        try {
+          boosters[i]->chunk_fetch(&stump[(size_t)i]);
+        } catch (const std::exception& e) {
+#pragma omp critical(lga_chunk_failure)
+          if (failure.empty()) failure = e.what();
+        }
+      }
+      if (!failure.empty()) throw std::runtime_error(failure);
+      // the plain loop stops after an iteration in which no booster found a split
+      int done = n_iters;
+      for (int j = 0; j < n_iters; ++j) {
+        bool all = true;
+        for (int i = 0; i < n; ++i) all = all && stump[(size_t)i][(size_t)j];
+        if (all) { done = j + 1; break; }
+      }
+      for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < done; ++j) finished[(size_t)j * (size_t)n + (size_t)i] = stump[(size_t)i][(size_t)j];
+        boosters[i]->chunk_commit(done, eval_valid, values, stride, n, i);
+      }
+      return done;
+    }
+    if (prepared > 0)
+      throw std::runtime_error("a group of boosters must run on engines of one kind: some prepared a chunk of iterations, others refused");
+  }
+  int done = 0;
+  for (int it = 0; it < n_iters; ++it) {
+    int* fin = finished + (size_t)it * (size_t)n;
+    update_group(boosters, n, fin);
+    bool all = true;
+    for (int i = 0; i < n; ++i) {
+      all = all && fin[i] != 0;
+      if (eval_valid && values) {
+        auto r = boosters[i]->eval(0);
+        if ((int)r.size() > stride) throw std::runtime_error("buffer too small");
+        for (size_t m = 0; m < r.size(); ++m) values[((size_t)it * (size_t)n + (size_t)i) * (size_t)stride + m] = r[m].value;
+      }
+    }
+    done = it + 1;
+    if (all) break;
+  }
+  return done;
+}
+
+// ---------------------------------------------------------------------------
 // DART (Rashmi & Gilad-Bachrach 2015): every iteration a random subset of the existing iterations is
 // muted while the new trees are fitted, then the new trees and the muted ones are rescaled so that the
 // ensemble's output stays on the same scale: with k muted iterations the new trees get the factor
@@ -453,6 +633,10 @@ void Booster::renew_leaf_values_exact(Tree& tree) {
   int kg = 0, kh = 0;
   engine_->leaf_gradient_sums(tree, &sums, &kg, &kh);
   engine_->sum_over_ranks_i64(sums.data(), sums.size());
+  renew_from_sums(tree, sums, kg, kh);
+}
+
+void Booster::renew_from_sums(Tree& tree, const std::vector<int64_t>& sums, int kg, int kh) const {
   const double gunit = unit_of(kg), hunit = unit_of(kh);
   std::vector<char> below_set((size_t)tree.num_leaves, 0);
   for (int i = 0; i < tree.num_leaves - 1; ++i) {

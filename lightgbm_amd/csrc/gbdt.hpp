@@ -39,6 +39,14 @@ class Booster {
   bool update_begin();
   bool update_finish();
   static void update_group(Booster* const* boosters, int n, int* finished);
+  // n_iters iterations of a group of boosters in lockstep, each followed - eval_valid - by the evaluation of every
+  // booster's first validation set: values[(iteration * n + booster) * stride + metric].  When every booster and
+  // its engine can, the iterations run as ONE chunk on the engines (Engine::train_chunk_begin) without the driver
+  // in between; otherwise iteration by iteration (update_group + eval).  The loop ends after an iteration in which
+  // no booster found a split; finished[iteration * n + b] = booster b found none in that iteration.  Returns the
+  // iterations run.
+  static int update_group_chunk(Booster* const* boosters, int n, int n_iters, bool eval_valid, double* values, int stride,
+                                int* finished);
   bool update_one_iter_custom(const float* grad, const float* hess, int64_t n);
   void rollback_one_iter();
   void reset_parameter(const std::string& params);
@@ -118,6 +126,14 @@ class Booster {
   bool is_rf_ = false;
   bool average_output_ = false;
   bool scores_initialised_ = false;
+  // chunks of iterations on the engine
+  bool chunk_eligible(bool eval_valid) const;
+  bool chunk_begin(int n_iters, bool eval_valid);
+  void chunk_fetch(std::vector<char>* stump);      // waits for the chunk; stump[j] = iteration j found no split
+  void chunk_commit(int n_keep, bool eval_valid, double* values, int stride, int n_group, int index);
+  std::vector<ChunkTree> chunk_trees_;
+  void renew_from_sums(Tree& tree, const std::vector<int64_t>& sums, int kg, int kh) const;
+  std::vector<FeatureMeta> sample_features_at(int cls, int iter);
   bool two_step_ = false;          // between update_begin and update_finish of a two-step iteration
   std::vector<double> init_scores_ = {0.0};   // per class
   int num_class_ = 1;

@@ -149,14 +149,28 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
 // A backend that can grow a whole tree by itself (TreeBackend::whole_tree_begin) is asked to whenever the tree is
 // a plain one: no output ranges (monotone constraints, path smoothing) and no interaction constraints, which the
 // replay below hands down node by node.
+bool TreeGrower::plain_trees(const std::vector<FeatureMeta>& meta) const {
+  bool any_monotone = false;
+  for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
+  return groups_.empty() && !any_monotone && !(cfg_.path_smooth > 0.0) && cfg_.max_batch_leaves <= 0;
+}
+
 bool TreeGrower::grow_begin(TreeBackend& be, const std::vector<FeatureMeta>& meta) {
   sp_cur_ = split_params();
   be.begin_tree(meta, sp_cur_);
-  bool any_monotone = false;
-  for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
-  const bool plain = groups_.empty() && !any_monotone && !(sp_cur_.path_smooth > 0.0) && cfg_.max_batch_leaves <= 0;
-  whole_ = plain && be.whole_tree_begin(cfg_.num_leaves - 1);
+  whole_ = plain_trees(meta) && be.whole_tree_begin(cfg_.num_leaves - 1);
   return whole_;
+}
+
+Tree TreeGrower::assemble_whole(TreeBackend& be, const std::vector<FeatureMeta>& meta, const TreeBackend::WholeTree& wt,
+                                QuantScale qs, std::vector<LeafPiece>* pieces) {
+  sp_cur_ = split_params();
+  whole_ = true;
+  given_ = &wt;
+  given_qs_ = qs;
+  Tree t = grow_finish(be, meta, pieces);
+  given_ = nullptr;
+  return t;
 }
 
 Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces) {
@@ -176,8 +190,9 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
   bool node_info = false;    // nodes carry an output range and their own output
   if (whole_) {
     // the backend replayed best-first growth itself: the k-th split's children are nodes 2k+1 and 2k+2
-    TreeBackend::WholeTree wt;
-    be.whole_tree_finish(&wt);
+    TreeBackend::WholeTree own;
+    if (!given_) be.whole_tree_finish(&own);
+    const TreeBackend::WholeTree& wt = given_ ? *given_ : own;
     if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_enter, t_last_backend); }
     const size_t n_splits = wt.split_node.size();
     nodes.resize(2 * n_splits + 1);
@@ -453,7 +468,7 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
   // splittable leaves before its budget: then nothing is held back)
   bar_used = prev_bar_.empty() ? 0.0 : prev_bar_.back() * bar_scale;
   }   // growth by rounds
-  const QuantScale qs = be.quant_scale();
+  const QuantScale qs = given_ ? given_qs_ : be.quant_scale();
   const double gunit = unit_of(qs.kg), hunit = unit_of(qs.kh);
   prev_bar_.clear();
   if ((int)chosen.size() == budget_total && !chosen.empty()) {

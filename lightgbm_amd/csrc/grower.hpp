@@ -47,6 +47,13 @@ class TreeGrower {
   // is waiting to be launched - by whole_tree_launch, or by a batched launch of many backends' trees at once.
   bool grow_begin(TreeBackend& be, const std::vector<FeatureMeta>& meta);
   Tree grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& meta, std::vector<LeafPiece>* pieces);
+  // Assembles a tree the backend grew outside begin / finish (one of a chunk of boosting iterations): `wt` as
+  // whole_tree_finish reports it, `qs` the iteration's quantisation scales.  set_tree_index first.
+  Tree assemble_whole(TreeBackend& be, const std::vector<FeatureMeta>& meta, const TreeBackend::WholeTree& wt, QuantScale qs,
+                      std::vector<LeafPiece>* pieces);
+  // True when trees over `meta` are plain ones a backend may grow whole (see grow_begin) and nothing adjusts the
+  // gains from tree to tree (feature_contri, cost-effective gradient boosting).
+  bool plain_trees(const std::vector<FeatureMeta>& meta) const;
   const GrowStats& last_stats() const { return stats_; }
   // Index of the tree about to be grown: seeds its per-node feature sampling.
   void set_tree_index(int64_t i) { tree_index_ = i; }
@@ -90,6 +97,8 @@ class TreeGrower {
   GrowStats stats_;
   SplitParams sp_cur_{};          // of the tree between grow_begin and grow_finish
   bool whole_ = false;            // ... which the backend grows in one go
+  const TreeBackend::WholeTree* given_ = nullptr;   // assemble_whole: the result to assemble instead of asking the backend
+  QuantScale given_qs_{0, 0};
   int64_t tree_index_ = 0;
   // the previous tree's chosen gains as suffix minima: prev_bar_[k] = smallest gain chosen from the k-th choice on
   std::vector<double> prev_bar_;

@@ -384,23 +384,19 @@ class HipBackend : public TreeBackend {
 
   // ---- whole tree in one launch (kernels.hpp: TreeArgs): small bags on one device, plain numeric / one-vs-rest
   // categorical features of one tile ----
-  bool whole_tree_begin(int max_splits) override {
-    tree_prepared_ = false;
-    tree_wide_valid_ = false;
+  // What does not depend on the tree: the learner, the data layout, the row and leaf limits.
+  bool tree_kernel_possible(int64_t rows, int max_splits) const {
     if (!tree_kernel_on_ || mode_ != ParallelMode::Serial || T_ != 1 || F_ < 1 || prof.on) return false;
-    if (!root_quant_.g || bag_n_ < 1 || bag_n_ > tree_kernel_rows_ || max_splits < 1 || max_splits > k::kTreeMaxSplits) return false;
-    if (ranged_ || masked_ || !sorted_cat_.empty()) return false;
+    return rows >= 1 && rows <= tree_kernel_rows_ && max_splits >= 1 && max_splits <= k::kTreeMaxSplits;
+  }
+  // Descriptor of a build over the current bag; `out_dev` is the device address of its host-mapped result block.
+  void fill_tree_args(k::TreeArgs& a, int max_splits, char* out_dev) {
     const int bw = F_ <= 8 ? 2 : (F_ <= 16 ? 4 : 8);
     const size_t cap = arena_[0].size();
     if (rec_gh_[0].size() < cap) {
       for (int b = 0; b < 2; ++b) { rec_gh_[b].resize(cap); rec_bins_[b].resize(cap * (size_t)bw); }
       tree_best_.resize(k::kTreeMaxNodes);
-      tree_out_.resize(sizeof(k::TreeResult));
-      tree_desc_.resize(sizeof(k::TreeArgs));
-      std::memset(tree_out_.get(), 0, sizeof(k::TreeResult));
     }
-    if (++tree_seq_ == 0) ++tree_seq_;
-    k::TreeArgs& a = *reinterpret_cast<k::TreeArgs*>(tree_desc_.get());
     a = k::TreeArgs{};
     a.bag = bag_; a.n = (int32_t)bag_n_; a.F = F_; a.budget = max_splits; a.renew = tree_renew_;
     a.bins_rt = mir_->bins_rt.get();
@@ -411,9 +407,25 @@ class HipBackend : public TreeBackend {
     a.pool = pool_.get(); a.slot_words = slot_words_;
     a.nodes = nodes_.get();
     a.best = tree_best_.get();
-    a.out = reinterpret_cast<k::TreeResult*>(tree_out_.device_ptr());
+    a.out = out_dev;
+    a.lay = k::tree_layout(max_splits);
+    if (++tree_seq_ == 0) ++tree_seq_;
     a.seq = tree_seq_;
     a.timing = tree_timing_ ? 1 : 0;
+    slots_dirty_ = std::max(slots_dirty_, max_splits + 1);
+  }
+  bool whole_tree_begin(int max_splits) override {
+    tree_prepared_ = false;
+    tree_wide_valid_ = false;
+    if (!tree_kernel_possible(bag_n_, max_splits) || !root_quant_.g) return false;
+    if (ranged_ || masked_ || !sorted_cat_.empty()) return false;
+    tree_lay_ = k::tree_layout(max_splits);
+    if (tree_out_.size() < (size_t)tree_lay_.bytes) {
+      tree_out_.resize((size_t)k::tree_layout(k::kTreeMaxSplits).bytes);
+      tree_desc_.resize(sizeof(k::TreeArgs));
+      std::memset(tree_out_.get(), 0, tree_out_.size());
+    }
+    fill_tree_args(*reinterpret_cast<k::TreeArgs*>(tree_desc_.get()), max_splits, tree_out_.device_ptr());
     tree_prepared_ = true;
     tree_launched_ = false;
     return true;
@@ -430,45 +442,70 @@ class HipBackend : public TreeBackend {
     k::grow_trees(reinterpret_cast<const k::TreeArgs*>(tree_desc_.device_ptr()), 1, F_, stream_);
     tree_launched_ = true;
   }
+  // Reads one result block (host address) into `out`; returns the header.
+  static const k::TreeHeader& read_tree_block(const char* block, const k::TreeLayout& lay, WholeTree* out) {
+    const k::TreeHeader& hd = *reinterpret_cast<const k::TreeHeader*>(block);
+    const int n_splits = hd.n_splits;
+    if (n_splits < 0 || n_splits > k::kTreeMaxSplits) throw std::runtime_error("whole-tree build returned a bad split count");
+    const int32_t* sn = reinterpret_cast<const int32_t*>(block + lay.off_split);
+    const SplitInfo* best = reinterpret_cast<const SplitInfo*>(block + lay.off_best);
+    out->split_node.assign(sn, sn + n_splits);
+    out->best.assign(best, best + (2 * n_splits + 1));
+    return hd;
+  }
   void whole_tree_finish(WholeTree* out) override {
     if (!tree_prepared_ || !tree_launched_) throw std::runtime_error("whole-tree build was never launched");
-    const k::TreeResult& r = *reinterpret_cast<const k::TreeResult*>(tree_out_.get());
     {
       TraceRange wait_range("lga.wait_tree");
       wait_for(reinterpret_cast<volatile unsigned*>(tree_out_.get()), tree_seq_, stream_);
     }
     tree_prepared_ = false;
-    const int n_splits = r.n_splits;
-    if (n_splits < 0 || n_splits > k::kTreeMaxSplits) throw std::runtime_error("whole-tree build returned a bad split count");
-    const int n_nodes = 2 * n_splits + 1;
+    const k::TreeHeader& r = read_tree_block(tree_out_.get(), tree_lay_, out);
+    const int n_splits = r.n_splits, n_nodes = 2 * n_splits + 1;
     qs_host_ = QuantScale{r.kg, r.kh};
-    out->split_node.assign(r.split_node, r.split_node + n_splits);
-    out->best.assign(r.best, r.best + n_nodes);
-    for (int i = 0; i < n_nodes; ++i) ranges_host_[(size_t)i] = r.range[i];
-    slots_dirty_ = std::max(slots_dirty_, n_splits + 1);
+    const NodeRange* ranges = reinterpret_cast<const NodeRange*>(tree_out_.get() + tree_lay_.off_range);
+    for (int i = 0; i < n_nodes; ++i) ranges_host_[(size_t)i] = ranges[i];
     tree_wide_valid_ = tree_renew_ != 0;
     ++prof.rounds;
-    if (tree_timing_) {
-      // LGA_TREE_TIMING=1: the kernel's own phase profile, averaged over 100 trees
-      static const char* names[8] = {"root pass", "selection", "sides + histogram", "prefix", "search", "row movement", "bookkeeping", "hand-over"};
-      for (int i = 0; i < 8; ++i) tree_ticks_[i] += (double)r.phase_ticks[i];
-      tree_ticks_[8] += n_splits;
-      if (++tree_timed_ % 100 == 0) {
-        std::fprintf(stderr, "[tree kernel] per tree (%.0f splits):", tree_ticks_[8] / 100);
-        double total = 0;
-        for (int i = 0; i < 8; ++i) { std::fprintf(stderr, " %s %.1f us,", names[i], tree_ticks_[i] / 100 * 0.01); total += tree_ticks_[i]; }
-        std::fprintf(stderr, " total %.1f us\n", total / 100 * 0.01);
-        for (double& v : tree_ticks_) v = 0;
-      }
+    if (tree_timing_) note_tree_timing(r, 1);
+  }
+  // LGA_TREE_TIMING=1: the kernel's own phase profile, averaged over 100 trees
+  void note_tree_timing(const k::TreeHeader& r, int trees) {
+    static const char* names[8] = {"root pass", "selection", "sides + histogram", "prefix", "search", "row movement", "bookkeeping", "hand-over"};
+    for (int i = 0; i < 8; ++i) tree_ticks_[i] += (double)r.phase_ticks[i];
+    tree_ticks_[8] += r.n_splits;
+    tree_timed_ += trees;
+    if (tree_timed_ % 100 == 0) {
+      std::fprintf(stderr, "[tree kernel] per tree (%.0f splits):", tree_ticks_[8] / 100);
+      double total = 0;
+      for (int i = 0; i < 8; ++i) { std::fprintf(stderr, " %s %.1f us,", names[i], tree_ticks_[i] / 100 * 0.01); total += tree_ticks_[i]; }
+      std::fprintf(stderr, " total %.1f us\n", total / 100 * 0.01);
+      for (double& v : tree_ticks_) v = 0;
     }
   }
   // 36-bit gradient sums of a final leaf's rows as the last whole-tree build left them (false: not available).
   bool whole_tree_leaf_sums(int node, int64_t* g, int64_t* h) const {
     if (!tree_wide_valid_) return false;
-    const k::TreeResult& r = *reinterpret_cast<const k::TreeResult*>(tree_out_.get());
-    *g = r.wide[node][0]; *h = r.wide[node][1];
+    const int64_t* wide = reinterpret_cast<const int64_t*>(tree_out_.get() + tree_lay_.off_wide);
+    *g = wide[2 * node]; *h = wide[2 * node + 1];
     return true;
   }
+  unsigned tree_seq() const { return tree_seq_; }
+  bool tree_timing() const { return tree_timing_; }
+  bool renews_leaves() const { return tree_renew_ != 0; }
+  int num_features() const { return F_; }
+  void set_quant_scale(QuantScale q) { qs_host_ = q; }
+  // For descriptors filled outside begin_tree (boosting chunks): the tree's parameters and feature table.
+  void set_tree_params(const std::vector<FeatureMeta>& meta, const SplitParams& params) {
+    sp_ = params;
+    if (meta.size() != meta_host_.size() || std::memcmp(meta.data(), meta_host_.data(), sizeof(FeatureMeta) * meta.size()) != 0) {
+      meta_host_ = meta;
+      LGA_HIP_CHECK(hipMemcpyAsync(meta_dev_.get(), meta_host_.data(), sizeof(FeatureMeta) * meta_host_.size(), hipMemcpyHostToDevice, stream_));
+    }
+    ranged_ = false; masked_ = false; sorted_cat_.clear();
+    tree_wide_valid_ = false;
+  }
+  static void wait_chunk(volatile unsigned* flag, unsigned seq, hipStream_t stream) { wait_for(flag, seq, stream); }
 
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
   int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
@@ -944,7 +981,9 @@ class HipBackend : public TreeBackend {
     unsigned spins = 0;
     while (*flag != seq) {
       ++spins;
-      if (spins > kSpinBeforeYield) std::this_thread::yield();
+      // a round takes tens of microseconds, a chunk of boosting iterations tens of milliseconds: spin, then yield, then sleep
+      if (spins > 100 * kSpinBeforeYield) std::this_thread::sleep_for(std::chrono::microseconds(30));
+      else if (spins > kSpinBeforeYield) std::this_thread::yield();
       if ((spins & 4095u) == 0) {
         hipError_t q = hipStreamQuery(stream);
         if (q == hipSuccess) {
@@ -1018,6 +1057,7 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<uint32_t> rec_bins_[2];
   DeviceBuffer<SplitInfo> tree_best_;
   MappedBuffer tree_out_, tree_desc_;
+  k::TreeLayout tree_lay_{};
   unsigned tree_seq_ = 0;
   bool tree_prepared_ = false, tree_launched_ = false, tree_wide_valid_ = false;
   int tree_renew_ = 0;
@@ -1436,6 +1476,152 @@ class HipEngine : public Engine {
     for (HipEngine* e : same) e->backend_->whole_tree_launched();
   }
 
+  // ---- chunks of iterations on the device (kernels.hpp: BoostArgs) ----
+  bool train_chunk_begin(const ChunkPlan& plan) override {
+    chunk_prepared_ = false;
+    const int n_iters = (int)plan.iters.size();
+    if (n_iters < 1 || K_ != 1 || dist() || !use_lines_) return false;
+    if (!backend_->tree_kernel_possible(n_base_, cfg_.num_leaves - 1)) return false;
+    if (plan.metrics.size() > 4 || (plan.eval_valid && valid_.size() != 1) || valid_.size() > 1) return false;
+    if (!valid_.empty() && (valid_[0]->n > k::kTreeMaxRows || valid_[0]->shared_scores)) return false;
+    for (const ChunkIterPlan& it : plan.iters) {
+      if (!grower_.plain_trees(it.meta)) return false;
+      for (const FeatureMeta& m : it.meta) if (m.categorical == kCategoricalSorted) return false;
+    }
+    grower_.set_tree_index(plan.iters[0].tree_index);
+    const SplitParams sp0 = grower_.split_params();
+    if (sp0.feature_scale) return false;        // per-feature gain adjustment changes from tree to tree on the host
+    // the descriptor's feature table has every usable feature enabled; the iterations' masks narrow it
+    std::vector<FeatureMeta> base_meta = plan.iters[0].meta;
+    const std::vector<FeatureMeta> all = train_->feature_meta();
+    for (size_t f = 0; f < base_meta.size(); ++f) base_meta[f].enabled = all[f].enabled;
+    backend_->set_tree_params(base_meta, sp0);
+    backend_->set_bag(bag_ptr_, bag_n_);
+    backend_->set_lines(lines_.get());
+    backend_->set_root_quant(gr(), he(), maxbits_.get());
+    const int max_splits = cfg_.num_leaves - 1;
+    const k::TreeLayout lay = k::tree_layout(max_splits);
+    chunk_out_.resize((size_t)lay.bytes * (size_t)n_iters);
+    chunk_iters_.resize(sizeof(k::BoostIter) * (size_t)n_iters);
+    chunk_desc_.resize(sizeof(k::BoostArgs));
+    reinterpret_cast<k::TreeHeader*>(chunk_out_.get())->flag = 0;
+    k::BoostArgs& b = *reinterpret_cast<k::BoostArgs*>(chunk_desc_.get());
+    b = k::BoostArgs{};
+    backend_->fill_tree_args(b.t, max_splits, chunk_out_.device_ptr());
+    b.t.renew = plan.renew ? 1 : 0;
+    b.n_iters = n_iters;
+    b.n_base = (int32_t)n_base_;
+    b.base_rows = base_rows_.get();
+    b.bag_rows = bag_rows_.get();
+    b.scores = sc();
+    b.label = mir_->label.get();
+    b.weight = weight_ptr(mir_);
+    b.g = gr(); b.h = he(); b.maxbits = maxbits_.get();
+    b.obj = plan.obj;
+    b.bagging = plan.bagging;
+    b.bag_fraction = (float)plan.bag_fraction;
+    b.neg_fraction = (float)plan.neg_fraction;
+    b.bag_seed = plan.bag_seed;
+    b.learning_rate = plan.learning_rate;
+    b.bins_fm = mir_->bins_fm.get();
+    b.N = N_;
+    if (!valid_.empty()) {
+      Valid& v = *valid_[0];
+      b.n_valid = (int32_t)v.n;
+      b.valid_N = v.N;
+      b.valid_rows = v.ds->used_indices() ? v.rows.get() : nullptr;
+      b.valid_bins_fm = v.mir->bins_fm.get();
+      b.valid_scores = score_ptr(v);
+      b.valid_label = v.mir->label.get();
+      b.valid_weight = weight_ptr(v.mir);
+    }
+    b.n_metrics = plan.eval_valid ? (int32_t)plan.metrics.size() : 0;
+    for (size_t m = 0; m < plan.metrics.size() && m < 4; ++m) b.metrics[m] = plan.metrics[m];
+    k::BoostIter* its = reinterpret_cast<k::BoostIter*>(chunk_iters_.get());
+    for (int j = 0; j < n_iters; ++j) {
+      const ChunkIterPlan& it = plan.iters[(size_t)j];
+      grower_.set_tree_index(it.tree_index);
+      const SplitParams spj = grower_.split_params();
+      uint32_t mask = 0;
+      for (size_t f = 0; f < it.meta.size(); ++f) if (it.meta[f].enabled) mask |= 1u << f;
+      its[j] = k::BoostIter{mask, it.redraw ? 1u : 0u, it.bag_iter, spj.bynode_seed, spj.extra_seed};
+    }
+    b.iters = reinterpret_cast<const k::BoostIter*>(chunk_iters_.device_ptr());
+    chunk_plan_ = plan;
+    chunk_lay_ = lay;
+    chunk_seq_ = b.t.seq;
+    chunk_prepared_ = true;
+    chunk_launched_ = false;
+    return true;
+  }
+  void launch_prepared_chunks(Engine* const* group, int n) override {
+    std::vector<HipEngine*> same;
+    for (int i = 0; i < n; ++i) {
+      HipEngine* e = dynamic_cast<HipEngine*>(group[i]);
+      if (!e || !e->chunk_prepared_ || e->chunk_launched_) continue;
+      if (e->stream_ == stream_ && e->train_->num_features() == train_->num_features()) same.push_back(e);
+      else e->launch_own_chunk();
+    }
+    if (same.empty()) return;
+    if (same.size() == 1) { same[0]->launch_own_chunk(); return; }
+    TraceRange range("lga.boost_chunk_batch");
+    batch_desc_.resize(sizeof(k::BoostArgs) * same.size());
+    k::BoostArgs* dst = reinterpret_cast<k::BoostArgs*>(batch_desc_.get());
+    for (size_t i = 0; i < same.size(); ++i) dst[i] = *reinterpret_cast<const k::BoostArgs*>(same[i]->chunk_desc_.get());
+    k::boost_chunks(reinterpret_cast<const k::BoostArgs*>(batch_desc_.device_ptr()), (int)same.size(), train_->num_features(), stream_);
+    for (HipEngine* e : same) e->chunk_launched_ = true;
+  }
+  void launch_own_chunk() {
+    k::boost_chunks(reinterpret_cast<const k::BoostArgs*>(chunk_desc_.device_ptr()), 1, train_->num_features(), stream_);
+    chunk_launched_ = true;
+  }
+  void train_chunk_finish(std::vector<ChunkTree>* out) override {
+    if (!chunk_prepared_) throw std::runtime_error("train_chunk_finish without a prepared chunk");
+    if (!chunk_launched_) launch_own_chunk();
+    {
+      TraceRange wait_range("lga.wait_chunk");
+      HipBackend::wait_chunk(reinterpret_cast<volatile unsigned*>(chunk_out_.get()), chunk_seq_, stream_);
+    }
+    chunk_prepared_ = false;
+    const int n_iters = (int)chunk_plan_.iters.size();
+    out->clear();
+    out->resize((size_t)n_iters);
+    for (int j = 0; j < n_iters; ++j) {
+      const char* block = chunk_out_.get() + (size_t)chunk_lay_.bytes * (size_t)j;
+      TreeBackend::WholeTree wt;
+      const k::TreeHeader& hd = HipBackend::read_tree_block(block, chunk_lay_, &wt);
+      const NodeRange* ranges = reinterpret_cast<const NodeRange*>(block + chunk_lay_.off_range);
+      const int64_t* wide = reinterpret_cast<const int64_t*>(block + chunk_lay_.off_wide);
+      ChunkTree& ct = (*out)[(size_t)j];
+      grower_.set_tree_index(chunk_plan_.iters[(size_t)j].tree_index);
+      const QuantScale qs{hd.kg, hd.kh};
+      std::vector<LeafPiece> pieces;
+      ct.tree = grower_.assemble_whole(*backend_, chunk_plan_.iters[(size_t)j].meta, wt, qs, &pieces);
+      ct.kg = hd.kg + kWideExtraBits;
+      ct.kh = hd.kh + kWideExtraBits;
+      if (chunk_plan_.renew) {
+        ct.leaf_sums.assign((size_t)2 * (size_t)ct.tree.num_leaves, 0);
+        for (const LeafPiece& p : pieces) {
+          ct.leaf_sums[(size_t)2 * (size_t)p.leaf] += wide[2 * p.node];
+          ct.leaf_sums[(size_t)2 * (size_t)p.leaf + 1] += wide[2 * p.node + 1];
+        }
+      }
+      for (size_t m = 0; m < chunk_plan_.metrics.size() && chunk_plan_.eval_valid; ++m) {
+        ct.metric_sums.push_back(hd.metric[m][0]);
+        ct.metric_sums.push_back(hd.metric[m][1]);
+      }
+      if (j == n_iters - 1) {
+        // the engine's state after the chunk: the bag, the last tree's row ranges and scales
+        if (chunk_plan_.bagging) { bag_ptr_ = bag_rows_.get(); bag_n_ = hd.bag_n; oob_n_ = n_base_ - bag_n_; }
+        backend_->set_quant_scale(qs);
+        (void)ranges;
+        leaf_nodes_.clear();
+      }
+      if (backend_->tree_timing()) backend_->note_tree_timing(hd, 1);
+    }
+    have_max_ = false;
+  }
+
   // The new tree's leaf values reach the training scores either through the leaf row ranges the grower
   // left behind (a scattered read-modify-write per row) or by walking the tree over the binned rows in
   // storage order (coalesced scores, ~depth one-byte bin reads per row).  Large row sets favour the walk.
@@ -1783,7 +1969,12 @@ class HipEngine : public Engine {
   bool has_init_ = false, have_max_ = false;
   std::vector<LeafPiece> leaf_nodes_;
   bool tree_begun_ = false;
-  MappedBuffer batch_desc_;      // descriptors of a batched whole-tree launch (launch_prepared_trees)
+  MappedBuffer batch_desc_;      // descriptors of a batched whole-tree / chunk launch
+  MappedBuffer chunk_out_, chunk_iters_, chunk_desc_;
+  ChunkPlan chunk_plan_;
+  k::TreeLayout chunk_lay_{};
+  unsigned chunk_seq_ = 0;
+  bool chunk_prepared_ = false, chunk_launched_ = false;
   std::vector<std::unique_ptr<Valid>> valid_;
 };
 

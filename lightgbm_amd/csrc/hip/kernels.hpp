@@ -223,26 +223,39 @@ constexpr int kTreeThreads = 512;                          // 8 waves: 256 vecto
 constexpr int kTreeMaxRows = 65536;                        // go-left mask words kept in LDS
 constexpr int kTreeMaxSplits = 255;                        // num_leaves <= 256
 constexpr int kTreeMaxNodes = 2 * kTreeMaxSplits + 1;
-// Host-mapped result block of one tree.
-struct TreeResult {
-  unsigned flag;            // = seq once everything below is written
+// Host-mapped result block of one tree: this header, then - at the offsets of TreeLayout - the split sequence
+// (node split by the k-th choice; its children are nodes 2k+1 and 2k+2), every node's best split and row range,
+// and per node the sums of quantize_wide(g | h, k + kWideExtraBits) over its rows (final leaves only).
+struct TreeHeader {
+  unsigned flag;            // = seq once everything is written (a boosting chunk raises only its last tree's)
   int32_t n_splits;
   int32_t kg, kh;           // the iteration's quantisation exponents
-  int32_t pad[12];
-  int32_t split_node[kTreeMaxSplits + 1];   // node split by the k-th choice; its children are nodes 2k+1 and 2k+2
-  SplitInfo best[kTreeMaxNodes];
-  NodeRange range[kTreeMaxNodes];
-  int64_t wide[kTreeMaxNodes][2];           // final leaves: sums of quantize_wide(g | h, k + kWideExtraBits) over the rows
+  int32_t bag_n;            // boosting chunk: rows of the bag the tree was grown on
+  int32_t pad[3];
+  double metric[4][2];      // boosting chunk: per metric (sum of weighted losses, sum of weights) over the validation rows
   int64_t phase_ticks[8];   // TreeArgs::timing: 100 MHz ticks spent in root pass, selection, sides + histogram, prefix, search,
                             // row movement, per-split bookkeeping, hand-over
 };
+struct TreeLayout {
+  int32_t off_split, off_best, off_range, off_wide, bytes;
+};
+inline TreeLayout tree_layout(int max_splits) {
+  const int nodes = 2 * max_splits + 1;
+  TreeLayout l;
+  l.off_split = (int32_t)sizeof(TreeHeader);
+  l.off_best = l.off_split + ((max_splits * 4 + 7) & ~7);
+  l.off_range = l.off_best + nodes * (int32_t)sizeof(SplitInfo);
+  l.off_wide = l.off_range + nodes * (int32_t)sizeof(NodeRange);
+  l.bytes = (l.off_wide + nodes * 16 + 63) & ~63;
+  return l;
+}
 struct TreeArgs {
   const int32_t* bag;       // root row ids of the tree's rows
   int32_t n;                // 1 .. kTreeMaxRows
   int32_t F;                // features (one tile)
   int32_t budget;           // splits at most (num_leaves - 1 <= kTreeMaxSplits)
-  int32_t renew;            // 1: fill TreeResult::wide
-  int32_t timing;           // 1: fill TreeResult::phase_ticks
+  int32_t renew;            // 1: fill the per-node wide sums
+  int32_t timing;           // 1: fill TreeHeader::phase_ticks
   int32_t pad0;
   const uint8_t* bins_rt;   // [root row][kTileFeatures] bin bytes
   const float* g;           // root-indexed float gradients / hessians and their absolute maxima (bit patterns)
@@ -258,9 +271,59 @@ struct TreeArgs {
   int64_t slot_words;
   NodeRange* nodes;         // device node table (kTreeMaxNodes entries from index 0)
   SplitInfo* best;          // device scratch, kTreeMaxNodes entries
-  TreeResult* out;          // host-mapped
+  char* out;                // host-mapped result block (TreeHeader + arrays at `lay`)
+  TreeLayout lay;
   unsigned seq;
 };
+
+// ---- boosting chunk: several whole ITERATIONS per launch ----
+// The workgroup that grows a booster's trees also does everything between two trees: gradients of the objective
+// at the current scores (with their maxima), the bag of the iteration, the tree, its leaf values (renewed from the
+// 36-bit sums, times the learning rate), the score update of the training rows (in-bag rows through their leaf's
+// row range, the others by walking the tree) and of ONE validation set, and that set's metric sums.  The host sees
+// a chunk of iterations at once: per iteration a tree result block whose header also carries the metric sums.
+// Arithmetic and summation order are those of the per-iteration kernels (gradients, leaf_add, traverse_add,
+// metric_sum), so a chunk leaves the scores, trees and metric values the step-by-step path would.
+struct BoostIter {          // what differs between the iterations of a chunk
+  uint32_t enabled;         // feature_fraction mask of the iteration's tree
+  uint32_t redraw;          // 1: draw a new bag before the tree (stream `bag_iter`)
+  uint64_t bag_iter;
+  uint64_t bynode_seed, extra_seed;   // SplitParams seeds of the tree
+};
+struct BoostArgs {
+  TreeArgs t;               // t.bag / t.n: the bag as it stands (a redraw rewrites bag_rows and the count); t.out: first block
+  int32_t n_iters;
+  int32_t n_base;           // training rows
+  const int32_t* base_rows; // their root row ids
+  int32_t* bag_rows;        // [bag | out-of-bag], n_base entries
+  double* scores;           // root-indexed training scores
+  const float* label;
+  const float* weight;      // or null
+  float* g;                 // = t.g / t.h, writable
+  float* h;
+  uint32_t* maxbits;
+  ObjectiveSpec obj;
+  int32_t bagging;          // 0: every row, 1: bagging_fraction, 3: by label (pos / neg fractions)
+  float bag_fraction, neg_fraction;
+  int32_t pad0;
+  uint64_t bag_seed;
+  double learning_rate;
+  // one validation set (n_valid == 0: none)
+  int32_t n_valid;
+  int32_t n_metrics;
+  int64_t valid_N;          // root rows of the validation data
+  const int32_t* valid_rows;      // root row ids, or null = identity
+  const uint8_t* valid_bins_fm;   // [feature][root row]
+  double* valid_scores;
+  const float* valid_label;
+  const float* valid_weight;
+  int32_t metrics[4];
+  const uint8_t* bins_fm;   // training data, [feature][root row]: out-of-bag rows walk the tree
+  int64_t N;                // root rows of the training data
+  const BoostIter* iters;   // n_iters entries
+};
+void boost_chunks(const BoostArgs* descs, int n_boosters, int max_features, hipStream_t s);
+
 constexpr int kTreeBatch = 16;    // descriptors per launch (kernel-argument block)
 // descs: n_trees descriptors in DEVICE-visible memory (pinned host memory works: each workgroup reads its own once).
 void grow_trees(const TreeArgs* descs, int n_trees, int max_features, hipStream_t s);

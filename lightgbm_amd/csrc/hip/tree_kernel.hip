@@ -116,20 +116,66 @@ struct TreeShared {
   short split_node[kTreeMaxSplits + 1];
   Cand wbest[kTreeWaves];
   FeatureMeta meta[kTileFeatures];
+  // the tree as a walkable table (boosting chunks): a split node's decision word - feature | threshold << 8 |
+  // default_left << 16 | categorical << 17 | (missing bin + 1) << 18 - and left child (the right one follows it),
+  // every node's parent, a final leaf's output
+  int ndec[kNodeCap];
+  short nleft[kNodeCap], nparent[kNodeCap];
+  double nvalue[kNodeCap];
+  float fmax[2][kTreeWaves];
+  double msum[4][2];
+  int bag_n;
 };
 
+// Exclusive prefix over the go-left mask words S.smask[0 .. n_words): S.word_prefix, total in S.word_prefix[kMaskWords].
+__device__ __forceinline__ void mask_prefix(TreeShared& S, int n_words) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int pcs[kWordsPerThread];
+  int pc = 0;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    const int wi = tid * kWordsPerThread + j;
+    pcs[j] = wi < n_words ? __popcll(S.smask[wi]) : 0;
+    pc += pcs[j];
+  }
+  int incl = pc;
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const int o = __shfl_up(incl, d, kWave);
+    if (lane >= d) incl += o;
+  }
+  if (lane == kWave - 1) S.wave_tot[wave] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += S.wave_tot[w];
+  int run = off + incl - pc;
+#pragma unroll
+  for (int j = 0; j < kWordsPerThread; ++j) {
+    S.word_prefix[tid * kWordsPerThread + j] = run;
+    run += pcs[j];
+  }
+  if (tid == kTreeThreads - 1) S.word_prefix[kMaskWords] = run;
+  __syncthreads();
+}
+
+// Grows one tree over the rows bag[0 .. n); leaves the node tables in S and every node's best split in a.best.
+// feature_mask: features the tree may use, on top of the descriptor's own enabled flags.  ticks: phase profile
+// (thread 0).  Returns the number of splits.
 template <int BW>
-__device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* lds, TreeShared& S) {
+__device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __restrict__ bag, int n, unsigned feature_mask,
+                                        const SplitParams& sp, int kg, int kh, unsigned long long* lds, TreeShared& S,
+                                        long long (&ticks)[8]) {
   constexpr int FC = BW * 4;
   constexpr int PPW = (2 * FC + kTreeWaves - 1) / kTreeWaves;   // (child, feature) pairs per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nf = a.F, n = a.n;
+  const int nf = a.F;
   const double ninf = -std::numeric_limits<double>::infinity();
-  const int kg = quant_exponent(__uint_as_float(a.maxbits[0]));
-  const int kh = quant_exponent(__uint_as_float(a.maxbits[1]));
   const QuantScale q{kg, kh};
-  const SplitParams& sp = a.sp;
-  if (tid < nf) S.meta[tid] = a.meta[tid];
+  if (tid < nf) {
+    FeatureMeta m = a.meta[tid];
+    if (!((feature_mask >> tid) & 1u)) m.enabled = 0;
+    S.meta[tid] = m;
+  }
   for (int i = tid; i < kNodeCap; i += kTreeThreads) { S.ngain[i] = ninf; S.nsplit[i] = 0; }
   for (int i = tid; i < nf * kMaxBins; i += kTreeThreads) lds[i] = 0ull;
   __syncthreads();
@@ -137,7 +183,6 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
   for (int f = 0; f < nf; ++f) enabled |= S.meta[f].enabled ? (1u << f) : 0u;
   const unsigned f_start = (unsigned)(lane % nf);
   // optional phase profile: thread 0 reads the 100 MHz wall clock at the phase boundaries
-  long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   long long t_mark = a.timing ? (long long)wall_clock64() : 0;
   auto lap = [&](int phase) {
     if (a.timing && tid == 0) {
@@ -160,7 +205,7 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int pos = base + u * kTreeThreads + tid;
-        row[u] = pos < seg_hi ? a.bag[pos] : -1;
+        row[u] = pos < seg_hi ? bag[pos] : -1;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -207,6 +252,7 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
     for (int w = 0; w < kTreeWaves; ++w) { tg += S.red[0][w]; th += S.red[1][w]; }
     S.ntot[0][0] = n; S.ntot[0][1] = tg; S.ntot[0][2] = th;
     S.nbegin[0] = 0; S.ncount[0] = n; S.nbuf[0] = 0; S.nslot[0] = 0; S.ndepth[0] = 0; S.nkey[0] = kRootNodeKey;
+    S.nparent[0] = -1;
     a.qs_out->kg = kg; a.qs_out->kh = kh;
   }
   __syncthreads();
@@ -333,42 +379,14 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
     __syncthreads();
     lap(2);
 
-    // exclusive prefix of the mask words' popcounts (kWordsPerThread consecutive words per thread)
-    const int n_words = (cnt + kWave - 1) / kWave;
-    int pcs[kWordsPerThread];
-    int pc = 0;
-#pragma unroll
-    for (int j = 0; j < kWordsPerThread; ++j) {
-      const int wi = tid * kWordsPerThread + j;
-      pcs[j] = wi < n_words ? __popcll(S.smask[wi]) : 0;
-      pc += pcs[j];
-    }
-    int incl = pc;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-      const int o = __shfl_up(incl, d, kWave);
-      if (lane >= d) incl += o;
-    }
-    if (lane == kWave - 1) S.wave_tot[wave] = incl;
-    __syncthreads();
-    {
-      int off = 0;
-      for (int w = 0; w < wave; ++w) off += S.wave_tot[w];
-      int run = off + incl - pc;
-#pragma unroll
-      for (int j = 0; j < kWordsPerThread; ++j) {
-        S.word_prefix[tid * kWordsPerThread + j] = run;
-        run += pcs[j];
-      }
-      if (tid == kTreeThreads - 1) S.word_prefix[kMaskWords] = run;
-    }
+    // exclusive prefix of the mask words' popcounts
+    mask_prefix(S, (cnt + kWave - 1) / kWave);
     // totals of the two children (every thread computes them: no further barrier needed for them)
     long long htg = 0, hth = 0;
 #pragma unroll
     for (int w = 0; w < kTreeWaves; ++w) { htg += S.red[0][w]; hth += S.red[1][w]; }
     htg = uni(htg);
     hth = uni(hth);
-    __syncthreads();
     const int lefts = uni(S.word_prefix[kMaskWords]);
     const int Hn = hist_left ? Lc : Rc, Sn = hist_left ? Rc : Lc;
     const long long hcnt = hist_left ? lefts : cnt - lefts;
@@ -476,17 +494,47 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
       S.nkey[node] = child_node_key(pkey, is_left ? 0 : 1);
       const bool open = bg != ninf && isfinite(bg) && !(sp.max_depth > 0 && cdepth >= sp.max_depth);
       S.ngain[node] = open ? bg : ninf;
-      if (c == 0) { S.ngain[P] = ninf; S.nsplit[P] = 1; S.split_node[k] = (short)P; }
+      S.nparent[node] = (short)P;
+      if (c == 0) {
+        S.ngain[P] = ninf; S.nsplit[P] = 1; S.split_node[k] = (short)P;
+        S.nleft[P] = (short)Lc;
+        S.ndec[P] = sf | (thr << 8) | ((dl == kCategoricalTask ? 0 : (dl & 1)) << 16) | ((dl == kCategoricalTask ? 1 : 0) << 17) | ((mb + 1) << 18);
+      }
     }
     n_splits = k + 1;
     __syncthreads();
     lap(6);
   }
 
-  // ---- hand-over ----
+  return n_splits;
+}
+
+// A final leaf's output as the host assembles it (grower.cpp, gbdt.cpp: renew_leaf_values_exact): the Newton step of
+// its side of the parent's best split on the quantised sums, replaced - leaf-value renewal - by the step on the
+// 36-bit sums of its rows when those hold any hessian; then the learning rate.
+__device__ __forceinline__ double leaf_value_of(const SplitInfo& ps, bool is_left, long long wide_g, long long wide_h, bool renew,
+                                                int kg, int kh, const SplitParams& sp, double learning_rate) {
+  const double gunit = unit_of(kg), hunit = unit_of(kh);
+  const double sg = (double)(is_left ? ps.left_g : ps.total_g - ps.left_g) * gunit;
+  const double sh = (double)(is_left ? ps.left_h : ps.total_h - ps.left_h) * hunit;
+  double v = leaf_output(sg, sh, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+  if (renew) {
+    const double G = (double)wide_g * unit_of(kg + kWideExtraBits), H = (double)wide_h * unit_of(kh + kWideExtraBits);
+    if (H > 0.0) v = leaf_output(G, H, sp.lambda_l1, sp.lambda_l2, sp.max_delta_step);
+  }
+  return v * learning_rate;
+}
+
+// Writes a grown tree's result block (everything but the completion flag).  boost: also work out the leaves' outputs
+// (S.nvalue) and add them to the training scores of the leaves' rows.
+template <bool BOOST>
+__device__ __forceinline__ void tree_handover(const TreeArgs& a, char* out, int n_splits, int kg, int kh, int bag_n,
+                                              const SplitParams& sp, double learning_rate, double* scores, TreeShared& S) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_nodes = 2 * n_splits + 1;
-  TreeResult* out = a.out;
-  if (a.renew) {
+  TreeHeader* hd = reinterpret_cast<TreeHeader*>(out);
+  int64_t* wide = reinterpret_cast<int64_t*>(out + a.lay.off_wide);
+  if (a.renew || BOOST) {
     // 36-bit sums of the float gradients over every final leaf's rows: one wave per leaf at a time
     const int wkg = kg + kWideExtraBits, wkh = kh + kWideExtraBits;
     for (int node = wave; node < n_nodes; node += kTreeWaves) {
@@ -494,42 +542,245 @@ __device__ __forceinline__ void grow_one(const TreeArgs& a, unsigned long long* 
       const int32_t* rows = a.idx[S.nbuf[node]] + S.nbegin[node];
       const int cnt = S.ncount[node];
       long long wg = 0, wh = 0;
-      for (int i = lane; i < cnt; i += kWave) {
-        const int32_t r = rows[i];
-        wg += quantize_wide(a.g[r], wkg);
-        wh += quantize_wide(a.h[r], wkh);
+      if (a.renew) {
+        for (int i = lane; i < cnt; i += kWave) {
+          const int32_t r = rows[i];
+          wg += quantize_wide(a.g[r], wkg);
+          wh += quantize_wide(a.h[r], wkh);
+        }
+        wg = wave_sum_i64(wg);
+        wh = wave_sum_i64(wh);
+        if (lane == 0) { wide[2 * node] = wg; wide[2 * node + 1] = wh; }
       }
-      wg = wave_sum_i64(wg);
-      wh = wave_sum_i64(wh);
-      if (lane == 0) { out->wide[node][0] = wg; out->wide[node][1] = wh; }
+      if (BOOST && n_splits > 0) {
+        const int p = S.nparent[node];
+        const double v = leaf_value_of(a.best[p], S.nleft[p] == node, wg, wh, a.renew != 0, kg, kh, sp, learning_rate);
+        if (lane == 0) S.nvalue[node] = v;
+        for (int i = lane; i < cnt; i += kWave) scores[rows[i]] += v;
+      }
     }
   }
   {
     const int words = n_nodes * (int)(sizeof(SplitInfo) / 8);
     const int64_t* res = reinterpret_cast<const int64_t*>(a.best);
-    int64_t* dst = reinterpret_cast<int64_t*>(out->best);
+    int64_t* dst = reinterpret_cast<int64_t*>(out + a.lay.off_best);
+    NodeRange* ranges = reinterpret_cast<NodeRange*>(out + a.lay.off_range);
+    int32_t* splits = reinterpret_cast<int32_t*>(out + a.lay.off_split);
     for (int i = tid; i < words; i += kTreeThreads) dst[i] = res[i];
     for (int i = tid; i < n_nodes; i += kTreeThreads) {
       const NodeRange r{S.nbegin[i], S.ncount[i], (int32_t)S.nbuf[i], 0};
-      out->range[i] = r;
+      ranges[i] = r;
       a.nodes[i] = r;
     }
-    for (int i = tid; i < n_splits; i += kTreeThreads) out->split_node[i] = S.split_node[i];
-    if (tid == 0) { out->n_splits = n_splits; out->kg = kg; out->kh = kh; }
+    for (int i = tid; i < n_splits; i += kTreeThreads) splits[i] = S.split_node[i];
+    if (tid == 0) { hd->n_splits = n_splits; hd->kg = kg; hd->kh = kh; hd->bag_n = bag_n; }
   }
-  lap(7);
-  if (a.timing && tid == 0)
-    for (int i = 0; i < 8; ++i) out->phase_ticks[i] = ticks[i];
+}
+
+// One tree per workgroup.
+template <int BW>
+__device__ __forceinline__ void tree_one(const TreeArgs& a, unsigned long long* lds, TreeShared& S) {
+  const int tid = threadIdx.x;
+  const int kg = quant_exponent(__uint_as_float(a.maxbits[0]));
+  const int kh = quant_exponent(__uint_as_float(a.maxbits[1]));
+  long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t0 = a.timing ? (long long)wall_clock64() : 0;
+  const int n_splits = grow_one<BW>(a, a.bag, a.n, ~0u, a.sp, kg, kh, lds, S, ticks);
+  const long long t1 = a.timing ? (long long)wall_clock64() : 0;
+  tree_handover<false>(a, a.out, n_splits, kg, kh, a.n, a.sp, 1.0, nullptr, S);
+  TreeHeader* hd = reinterpret_cast<TreeHeader*>(a.out);
+  if (a.timing && tid == 0) {
+    ticks[7] = (long long)wall_clock64() - t1;
+    (void)t0;
+    for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = ticks[i];
+  }
   __threadfence_system();
   __syncthreads();
-  if (tid == 0) *reinterpret_cast<volatile unsigned*>(&out->flag) = a.seq;
+  if (tid == 0) *reinterpret_cast<volatile unsigned*>(&hd->flag) = a.seq;
+}
+
+// Walks the tree in S over one row of a feature-major bin matrix; returns the final leaf's node.
+__device__ __forceinline__ int walk_tree(const TreeShared& S, const uint8_t* __restrict__ bins_fm, int64_t N, int64_t r) {
+  int node = 0;
+  while (S.nsplit[node]) {
+    const int d = S.ndec[node];
+    const int b = bins_fm[(int64_t)(d & 255) * N + r];
+    const int thr = (d >> 8) & 255, mb = (d >> 18) - 1;
+    const bool left = (d & (1 << 17)) ? (b == thr) : ((b == mb) ? ((d >> 16) & 1) != 0 : (b <= thr));
+    node = left ? S.nleft[node] : S.nleft[node] + 1;
+  }
+  return node;
+}
+
+// A chunk of boosting iterations of one booster (kernels.hpp: BoostArgs).
+template <int BW>
+__device__ __forceinline__ void boost_one(const BoostArgs& b, unsigned long long* lds, TreeShared& S) {
+  const TreeArgs& a = b.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_base = b.n_base;
+  const int32_t* bag = a.bag;
+  if (tid == 0) S.bag_n = a.n;
+  __syncthreads();
+  for (int it = 0; it < b.n_iters; ++it) {
+    const BoostIter I = b.iters[it];
+    char* out = a.out + (int64_t)it * a.lay.bytes;
+    long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // ---- gradients of the objective at the current scores, and their maxima ----
+    {
+      float mg = 0.f, mh = 0.f;
+      constexpr int U = 4;
+      for (int i0 = tid; i0 < n_base; i0 += U * kTreeThreads) {
+        int r[U];
+        double sc[U];
+        float lb[U], wt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int i = i0 + u * kTreeThreads;
+          r[u] = i < n_base ? b.base_rows[i] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (r[u] >= 0) { sc[u] = b.scores[r[u]]; lb[u] = b.label[r[u]]; wt[u] = b.weight ? b.weight[r[u]] : 1.0f; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (r[u] >= 0) {
+            float gg, hh;
+            grad_hess(b.obj, sc[u], lb[u], wt[u], &gg, &hh);
+            b.g[r[u]] = gg;
+            b.h[r[u]] = hh;
+            mg = fmaxf(mg, fabsf(gg));
+            mh = fmaxf(mh, hh);
+          }
+        }
+      }
+      mg = wave_max_f32(mg);
+      mh = wave_max_f32(mh);
+      if (lane == 0) { S.fmax[0][wave] = mg; S.fmax[1][wave] = mh; }
+    }
+    // ---- the bag of this iteration ----
+    if (b.bagging && I.redraw) {
+      // keep bits of the training rows in order, then a stable split: the kept rows first
+      for (int base = 0; base < n_base; base += kTreeThreads) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < n_base) {
+          const int32_t row = b.base_rows[i];
+          const float frac = (b.bagging == 3 && !(b.label[row] > 0.0f)) ? b.neg_fraction : b.bag_fraction;
+          keep = rng_uniform(b.bag_seed, I.bag_iter, (uint64_t)(uint32_t)row) < frac;
+        }
+        if (base + wave * kWave < n_base) {
+          const unsigned long long m = __ballot(keep);
+          if (lane == 0) S.smask[(base >> 6) + wave] = m;
+        }
+      }
+      __syncthreads();
+      mask_prefix(S, (n_base + kWave - 1) / kWave);
+      const int kept = S.word_prefix[kMaskWords];
+      for (int i = tid; i < n_base; i += kTreeThreads) {
+        const int wi = i >> 6;
+        const unsigned long long m = S.smask[wi];
+        const bool keep = (m >> lane) & 1ull;
+        const int rank = S.word_prefix[wi] + __popcll(m & ((1ull << lane) - 1ull));
+        b.bag_rows[keep ? rank : kept + (i - rank)] = b.base_rows[i];
+      }
+      if (tid == 0) S.bag_n = kept;
+      bag = b.bag_rows;
+    }
+    __syncthreads();
+    float vmg = 0.f, vmh = 0.f;
+#pragma unroll
+    for (int w = 0; w < kTreeWaves; ++w) { vmg = fmaxf(vmg, S.fmax[0][w]); vmh = fmaxf(vmh, S.fmax[1][w]); }
+    if (tid == 0) { b.maxbits[0] = __float_as_uint(vmg); b.maxbits[1] = __float_as_uint(vmh); }
+    const int kg = uni(quant_exponent(vmg)), kh = uni(quant_exponent(vmh));
+    const int bag_n = uni(S.bag_n);
+    // ---- the tree ----
+    SplitParams sp = a.sp;
+    sp.bynode_seed = I.bynode_seed;
+    sp.extra_seed = I.extra_seed;
+    int n_splits = 0;
+    if (bag_n > 0) n_splits = grow_one<BW>(a, bag, bag_n, I.enabled, sp, kg, kh, lds, S, ticks);
+    else {
+      // an empty bag: a tree without a split over no rows
+      if (tid == 0) {
+        S.nsplit[0] = 0; S.nbegin[0] = 0; S.ncount[0] = 0; S.nbuf[0] = 0;
+        write_split(&a.best[0], -std::numeric_limits<double>::infinity(), ~0ull, 0, 0, 0, 0, 0, QuantScale{kg, kh}, sp);
+      }
+      __syncthreads();
+    }
+    // ---- leaf outputs, in-bag scores, result block ----
+    tree_handover<true>(a, out, n_splits, kg, kh, bag_n, sp, b.learning_rate, b.scores, S);
+    __syncthreads();
+    TreeHeader* hd = reinterpret_cast<TreeHeader*>(out);
+    if (n_splits > 0) {
+      // out-of-bag training rows and the validation rows walk the tree
+      for (int i = bag_n + tid; i < n_base; i += kTreeThreads) {
+        const int32_t r = bag[i];
+        b.scores[r] += S.nvalue[walk_tree(S, b.bins_fm, b.N, r)];
+      }
+      for (int i = tid; i < b.n_valid; i += kTreeThreads) {
+        const int64_t r = b.valid_rows ? (int64_t)b.valid_rows[i] : (int64_t)i;
+        b.valid_scores[r] += S.nvalue[walk_tree(S, b.valid_bins_fm, b.valid_N, r)];
+      }
+    }
+    __syncthreads();
+    // ---- metric sums over the validation rows, in the order of metric_sum_kernel: virtual workgroups of 256
+    // threads (one element each here), a wave-butterfly and a four-wave sum per workgroup, the workgroups' partial
+    // sums lane-strided over 64 lanes, one more butterfly ----
+    if (b.n_valid > 0 && b.n_metrics > 0) {
+      double* part = reinterpret_cast<double*>(lds);      // [virtual workgroup][2]; the histogram is not in use here
+      const int n = b.n_valid;
+      const int B = (n + 255) / 256;                       // <= 256: n_valid <= kTreeMaxRows
+      for (int m = 0; m < b.n_metrics; ++m) {
+        for (int vb = wave; vb < B; vb += kTreeWaves) {
+          double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+          for (int vw = 0; vw < 4; ++vw) {
+            const int i = vb * 256 + vw * 64 + lane;
+            double v0 = 0.0, v1 = 0.0;
+            if (i < n) {
+              const int64_t r = b.valid_rows ? (int64_t)b.valid_rows[i] : (int64_t)i;
+              const double w = b.valid_weight ? (double)b.valid_weight[r] : 1.0;
+              const double raw = b.valid_scores[r];
+              const double pred = transform_score(b.obj.kind, b.obj.sigmoid, raw);
+              v0 += w * point_loss(b.metrics[m], pred, raw, b.valid_label[r], b.obj);
+              v1 += w;
+            }
+            t0 += wave_sum_f64(v0);
+            t1 += wave_sum_f64(v1);
+          }
+          if (lane == 0) { part[2 * vb] = t0; part[2 * vb + 1] = t1; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+          double a0 = 0.0, a1 = 0.0;
+          for (int vb = lane; vb < B; vb += 64) { a0 += part[2 * vb]; a1 += part[2 * vb + 1]; }
+          a0 = wave_sum_f64(a0);
+          a1 = wave_sum_f64(a1);
+          if (lane == 0) { hd->metric[m][0] = a0; hd->metric[m][1] = a1; }
+        }
+        __syncthreads();
+      }
+    }
+    if (a.timing && tid == 0)
+      for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = ticks[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) *reinterpret_cast<volatile unsigned*>(&reinterpret_cast<TreeHeader*>(a.out)->flag) = a.seq;
+}
+
+template <int BW>
+__global__ __launch_bounds__(kTreeThreads) void boost_kernel(const BoostArgs* __restrict__ descs) {
+  __shared__ unsigned long long lds[BW * 4 * kMaxBins];
+  __shared__ TreeShared S;
+  boost_one<BW>(descs[blockIdx.x], lds, S);
 }
 
 template <int BW>
 __global__ __launch_bounds__(kTreeThreads) void tree_kernel(const TreeArgs* __restrict__ descs) {
   __shared__ unsigned long long lds[BW * 4 * kMaxBins];
   __shared__ TreeShared S;
-  grow_one<BW>(descs[blockIdx.x], lds, S);   // a uniform address: the descriptor's fields arrive through scalar loads
+  tree_one<BW>(descs[blockIdx.x], lds, S);   // a uniform address: the descriptor's fields arrive through scalar loads
 }
 
 }  // namespace
@@ -539,6 +790,14 @@ void grow_trees(const TreeArgs* descs, int n_trees, int max_features, hipStream_
   if (max_features <= 8) hipLaunchKernelGGL(tree_kernel<2>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
   else if (max_features <= 16) hipLaunchKernelGGL(tree_kernel<4>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
   else hipLaunchKernelGGL(tree_kernel<8>, dim3(n_trees), dim3(kTreeThreads), 0, s, descs);
+  LGA_HIP_CHECK(hipGetLastError());
+}
+
+void boost_chunks(const BoostArgs* descs, int n_boosters, int max_features, hipStream_t s) {
+  if (n_boosters <= 0) return;
+  if (max_features <= 8) hipLaunchKernelGGL(boost_kernel<2>, dim3(n_boosters), dim3(kTreeThreads), 0, s, descs);
+  else if (max_features <= 16) hipLaunchKernelGGL(boost_kernel<4>, dim3(n_boosters), dim3(kTreeThreads), 0, s, descs);
+  else hipLaunchKernelGGL(boost_kernel<8>, dim3(n_boosters), dim3(kTreeThreads), 0, s, descs);
   LGA_HIP_CHECK(hipGetLastError());
 }
 

@@ -300,12 +300,41 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
     Python-side objective / metric is used).
 
     ``lockstep_chunk``: run the folds in lockstep inside the native library, this many iterations per call
-    (:meth:`Booster.update_group`): on the HIP engine the k small trees of an iteration are one kernel launch, and
-    Python sees the evaluation results only once per chunk.  The callbacks are then replayed over the chunk's
-    results iteration by iteration and iterations trained beyond an early stop are rolled back, so the outcome
-    is that of the plain loop.  Default: on (chunk = the early-stopping patience, at most 10) for the HIP build
-    with at most 65536 training rows per fold when nothing needs Python between iterations (no ``fobj`` /
+    (:meth:`Booster.update_group`): on the HIP engine small folds then run whole chunks of iterations on the device
+    in one kernel launch, and Python sees the evaluation results once per chunk.  The callbacks are replayed over
+    the chunk's results iteration by iteration and iterations trained beyond an early stop are rolled back, so the
+    outcome is that of the plain loop.  Default: on (10 iterations per chunk) for the HIP
+    build with at most 65536 training rows per fold when nothing needs Python between iterations (no ``fobj`` /
     ``feval`` / ``fpreproc``, no training-data metric, only evaluation callbacks); 0 switches it off."""
+    return drive_lockstep(cv_steps(params, train_set, num_boost_round, folds, nfold, stratified, shuffle, metrics, fobj, feval,
+                                   init_model, early_stopping_rounds, fpreproc, verbose_eval, show_stdv, seed, callbacks,
+                                   eval_train_metric, return_cvbooster, concurrent_folds, lockstep_chunk, **kwargs))
+
+
+def drive_lockstep(steps):
+    """Runs a generator of lockstep requests - ``(boosters, n_iters)``, answered with
+    :meth:`Booster.update_group`'s result - to its end and returns its value.  Schedulers that batch the
+    requests of MANY such generators into one native call (the grid search) drive the generators themselves."""
+    try:
+        request = next(steps)
+        while True:
+            boosters, n_iters = request
+            request = steps.send(Booster.update_group(boosters, n_iters, True))
+    except StopIteration as stop:
+        return stop.value
+
+
+def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: int = 100, folds=None, nfold: int = 5,
+       stratified: bool = True, shuffle: bool = True, metrics: Union[str, List[str], None] = None,
+       fobj: Optional[Callable] = None, feval=None, init_model=None, early_stopping_rounds: Optional[int] = None,
+       fpreproc=None, verbose_eval: Union[bool, int, None] = None, show_stdv: bool = True, seed: int = 0,
+       callbacks: Optional[List[Callable]] = None, eval_train_metric: bool = False, return_cvbooster: bool = False,
+       concurrent_folds: Optional[bool] = None, lockstep_chunk: Optional[int] = None, rollback_overrun: bool = True,
+       **kwargs):
+    """:func:`cv` as a generator: in lockstep mode it yields ``(fold boosters, n_iters)`` whenever it wants the
+    folds advanced and expects :meth:`Booster.update_group`'s result back; its return value is :func:`cv`'s.
+    ``rollback_overrun=False`` leaves the iterations a chunk trained beyond an early stop in the fold boosters
+    (callers that only read the evaluation history)."""
     if not isinstance(train_set, Dataset):
         raise TypeError("Training only accepts Dataset object")
     params = _prepare_params(params, kwargs)
@@ -363,7 +392,7 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
         if (on_gpu and fobj is None and feval is None and fpreproc is None and not eval_train_metric and plain_callbacks
                 and max(len(tr) for tr, _ in folds) <= 65536 and int(get_param(params, "num_class", 1) or 1) <= 1
                 and str(get_param(params, "boosting", "gbdt")).lower() not in ("dart",)):
-            lockstep_chunk = min(10, early_stopping_rounds) if early_stopping_rounds and early_stopping_rounds > 0 else 10
+            lockstep_chunk = 10
     lockstep = int(lockstep_chunk or 0) > 0 and fobj is None and feval is None and not eval_train_metric
     runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu and not lockstep)
 
@@ -420,15 +449,16 @@ def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: in
                 for c in cb_before:
                     c(cb.CallbackEnv(cvbooster, params, i, 0, num_boost_round, None))
                 n_it = min(int(lockstep_chunk), num_boost_round - i)
-                values, fin, done = Booster.update_group(cvbooster.boosters, n_it, 0)
+                # the answer may hold fewer iterations than asked for (a scheduler batching several searches)
+                values, no_split, done = yield (cvbooster.boosters, n_it)
                 for j in range(done):
                     raw = [[(valid_name, mn, float(values[j, b, m]), hb) for m, (mn, hb) in enumerate(names)]
                            for b in range(len(cvbooster.boosters))]
-                    if after_iteration(i + j, raw) or (all(fin) and j + 1 == done):
+                    if after_iteration(i + j, raw) or bool(no_split[j].all()):
                         # iterations of this chunk that the plain loop would never have run
-                        for _ in range(done - (j + 1)):
-                            for b in cvbooster.boosters:
-                                b.rollback_one_iter()
+                        for b, bst in enumerate(cvbooster.boosters if rollback_overrun else []):
+                            for _ in range(int((~no_split[j + 1: done, b]).sum())):
+                                bst.rollback_one_iter()
                         stop = True
                         break
                 i += done

@@ -121,9 +121,57 @@ def _cv_one(params: Dict[str, Any], dtrain, cv_kwargs: Dict[str, Any]) -> Tuple[
     return int(cvm.best_iter), float(cvm.best_score)
 
 
+def _cv_one_steps(params: Dict[str, Any], dtrain, cv_kwargs: Dict[str, Any]):
+    """:func:`_cv_one` as a generator of lockstep requests (rstyle.lgb_cv_steps)."""
+    from .rstyle import lgb_cv_steps
+    cvm = yield from lgb_cv_steps(params, dtrain, rollback_overrun=False, **cv_kwargs)   # the boosters are dropped
+    return int(cvm.best_iter), float(cvm.best_score)
+
+
+def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable[[int], Any],
+                      finish_row: Callable[[int, Any, float], None], width: int):
+    """Continuous batching of grid rows on one device: up to ``width`` rows are alive at a time, each a generator
+    that asks for its fold boosters to be advanced a few iterations (engine.cv_steps); the requests of all living
+    rows are answered by ONE native call - on the HIP engine one kernel launch with one workgroup per booster - and a
+    row that ends (early stop, rounds used up) hands its place to the next one.  A row that never asks (it ran in
+    the plain per-iteration loop) simply finishes when started."""
+    from .basic import Booster
+    alive: Dict[int, List[Any]] = {}      # row -> [generator, pending request, start time]
+    exhausted = False
+    while True:
+        while not exhausted and len(alive) < width:
+            i = next_row()
+            if i is None:
+                exhausted = True
+                break
+            t0 = time.time()
+            gen = start_row(i)
+            try:
+                alive[i] = [gen, next(gen), t0]
+            except StopIteration as stop:
+                finish_row(i, stop.value, time.time() - t0)
+        if not alive:
+            return
+        ids = list(alive)
+        n_iters = min(alive[i][1][1] for i in ids)
+        boosters = [b for i in ids for b in alive[i][1][0]]
+        values, no_split, done = Booster.update_group(boosters, n_iters, True)
+        at = 0
+        for i in ids:
+            gen, (bs, _), t0 = alive[i]
+            part = (values[:, at: at + len(bs)], no_split[:, at: at + len(bs)], done)
+            at += len(bs)
+            try:
+                alive[i][1] = gen.send(part)
+            except StopIteration as stop:
+                del alive[i]
+                finish_row(i, stop.value, time.time() - t0)
+
+
 def _auto_rows_in_flight(dtrain, rows: Sequence[Dict[str, Any]]) -> int:
-    """Rows one process keeps in flight: 4 on the HIP engine for tables of at most 500 k rows (bigger folds
-    fill the device by themselves), 1 on the CPU engine, whose histogram loops already use every core."""
+    """Rows one process keeps in flight.  HIP engine: 48 for tables of at most 65536 rows - their folds run as
+    one-workgroup boosters, 48 rows x 5 folds fill the 256 compute units - 4 up to 500 k rows (bigger folds fill
+    the device by themselves); 1 on the CPU engine, whose histogram loops already use every core."""
     from . import _lib
     env = os.environ.get("LGA_GRID_ROWS_IN_FLIGHT")
     if env:
@@ -133,6 +181,8 @@ def _auto_rows_in_flight(dtrain, rows: Sequence[Dict[str, Any]]) -> int:
     where = [getattr(dtrain, "params", None) or {}] + list(rows)
     if any(str(r.get("device_type", r.get("device", "gpu"))).lower() in ("cpu", "host") for r in where):
         return 1
+    if dtrain.num_data() <= 65536:
+        return 48
     return 4 if dtrain.num_data() <= 500_000 else 1
 
 
@@ -186,8 +236,33 @@ def _run_rows(next_row: Callable[[], Optional[int]], run_one: Callable[[int], No
         raise failed[0]
 
 
+def _drain_rows(next_row: Callable[[], Optional[int]], rows, dtrain, cv_kwargs, on_start: Callable[[int], None],
+                on_done: Callable[[int, int, float, float], None], in_flight: Optional[int], batch: Optional[bool]):
+    """Evaluates grid rows from ``next_row`` until it returns None.  batch (None: HIP build and at most 65536 rows):
+    one thread batches the living rows' boosters into single native calls (_run_rows_batched); otherwise
+    ``in_flight`` host threads run one row each (_run_rows)."""
+    from . import _lib
+    in_flight = in_flight or _auto_rows_in_flight(dtrain, rows)
+    if batch is None:
+        batch = in_flight > 1 and _lib.is_hip() and dtrain.num_data() <= 65536 and _auto_rows_in_flight(dtrain, rows) > 1
+    if batch:
+        def start_row(i):
+            on_start(i)
+            return _cv_one_steps(rows[i], dtrain, cv_kwargs)
+
+        _run_rows_batched(next_row, start_row, lambda i, res, secs: on_done(i, res[0], res[1], secs), in_flight)
+    else:
+        def run_one(i):
+            on_start(i)
+            t0 = time.time()
+            it, sc = _cv_one(rows[i], dtrain, cv_kwargs)
+            on_done(i, it, sc, time.time() - t0)
+
+        _run_rows(next_row, run_one, in_flight)
+
+
 def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_params, rows, cv_kwargs, task_q, result_q,
-                 fail_after: Optional[int], rows_in_flight: Optional[int] = None):
+                 fail_after: Optional[int], rows_in_flight: Optional[int] = None, batch_rows: Optional[bool] = None):
     """Worker process: pulls row ids until it sees None (one stop marker per worker process)."""
     if device is not None and device != "cpu":
         os.environ["HIP_VISIBLE_DEVICES"] = str(device)
@@ -210,16 +285,16 @@ def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_pa
                 return None
             return item
 
-        def run_one(row_id):
+        def on_start(row_id):
             result_q.put(("start", worker_id, row_id, None))
-            t0 = time.time()
             if fail_after is not None and n_started[0] >= fail_after:
                 os._exit(17)   # fault injection: die with the row in flight
             n_started[0] += 1
-            it, sc = _cv_one(rows[row_id], dtrain, cv_kwargs)
-            result_q.put(("done", worker_id, row_id, (it, sc, time.time() - t0)))
 
-        _run_rows(next_row, run_one, rows_in_flight or _auto_rows_in_flight(dtrain, rows))
+        def on_done(row_id, it, sc, secs):
+            result_q.put(("done", worker_id, row_id, (it, sc, secs)))
+
+        _drain_rows(next_row, rows, dtrain, cv_kwargs, on_start, on_done, rows_in_flight, batch_rows)
     except BaseException as e:   # report, then die
         result_q.put(("error", worker_id, -1, repr(e)))
         raise
@@ -232,15 +307,19 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                    resume: bool = True, workers: Optional[Sequence[Any]] = None, compat_sentinel: bool = False,
                    dataset_params: Optional[Dict[str, Any]] = None, verbose: bool = False,
                    inject_fail_after: Optional[int] = None, progress: Optional[Callable[[int, int], None]] = None,
-                   base_params: Optional[Dict[str, Any]] = None, rows_in_flight: Optional[int] = None):
+                   base_params: Optional[Dict[str, Any]] = None, rows_in_flight: Optional[int] = None,
+                   batch_rows: Optional[bool] = None, lockstep_chunk: Optional[int] = None):
     """Runs early-stopped k-fold CV for every row of ``param_grid`` and fills ``iteration`` / ``score``.
 
     ``workers``: None -> run in this process; otherwise a list of devices, one worker process each,
     e.g. ``[0, 1, ..., 7]`` (GPU ids) or ``["cpu", "cpu"]``.  ``base_params`` are engine parameters every
     row shares (a row's own columns win).  ``rows_in_flight``: grid rows one process evaluates at the same
     time, each from its own host thread (None: 4 on the HIP engine for tables up to 500 k rows, else 1); every
-    row is an independent deterministic computation, so the table does not depend on it.  Returns the grid as
-    a DataFrame (row order unchanged; rank it with :func:`rank_grid`).
+    row is an independent deterministic computation, so the table does not depend on it.  ``batch_rows``: keep
+    the rows in flight alive in ONE thread and advance all their fold boosters with single native calls
+    (continuous batching; None: on for the HIP build with at most 65536 rows, where a call is one kernel launch
+    with one workgroup per booster); ``lockstep_chunk``: iterations per such call (engine.cv).  Returns the grid as a DataFrame (row order unchanged; rank it with
+    :func:`rank_grid`).
     """
     import pandas as pd
     grid = param_grid.copy() if hasattr(param_grid, "copy") and hasattr(param_grid, "columns") else pd.DataFrame(list(param_grid))
@@ -250,7 +329,7 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
     rows = [{**(base_params or {}), **_row_params(r)} for r in grid.to_dict(orient="records")]
     cv_kwargs = dict(nrounds=nrounds, nfold=nfold, objective=objective, eval=eval, showsd=showsd,
                      early_stopping_rounds=early_stopping_rounds, verbose=0, stratified=stratified, seed=seed,
-                     compat_sentinel=compat_sentinel)
+                     compat_sentinel=compat_sentinel, lockstep_chunk=lockstep_chunk)
     extra = {k: cv_kwargs[k] for k in ("nrounds", "nfold", "objective", "eval", "early_stopping_rounds", "seed")}
     hashes = [_params_hash(p, extra) for p in rows]
     ck = GridCheckpoint(checkpoint if (checkpoint and (resume or not os.path.exists(checkpoint))) else checkpoint)
@@ -279,15 +358,13 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
         started = [0]
         pending = iter(todo)
 
-        def run_one(i):
+        def on_start(i):
             if inject_fail_after is not None and started[0] >= inject_fail_after:
                 raise RuntimeError("injected failure")
             started[0] += 1
-            t0 = time.time()
-            it, sc = _cv_one(rows[i], dtrain, cv_kwargs)
-            record(i, it, sc, time.time() - t0, "main")
 
-        _run_rows(lambda: next(pending, None), run_one, rows_in_flight or _auto_rows_in_flight(dtrain, rows))
+        _drain_rows(lambda: next(pending, None), rows, dtrain, cv_kwargs, on_start,
+                    lambda i, it, sc, secs: record(i, it, sc, secs, "main"), rows_in_flight, batch_rows)
     else:
         if X is None or y is None:
             raise ValueError("worker processes need the raw X and y (a constructed Dataset cannot cross processes)")
@@ -302,7 +379,7 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
         for w, dev in enumerate(workers):
             fa = inject_fail_after if w == 0 else None
             p = ctx.Process(target=_worker_main, args=(w, dev, Xn, yn, weight, dataset_params, rows, cv_kwargs, task_q,
-                                                       result_q, fa, rows_in_flight), daemon=True)
+                                                       result_q, fa, rows_in_flight, batch_rows), daemon=True)
             p.start()
             procs[w] = p
             inflight[w] = set()

@@ -125,7 +125,21 @@ def as_list(x) -> Dict[str, Any]:
 def lgb_cv(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3, label=None, weight=None, obj=None,
            eval=None, verbose: int = 1, record: bool = True, eval_freq: int = 1, showsd: bool = True,
            stratified: bool = True, folds=None, init_model=None, early_stopping_rounds: Optional[int] = None,
-           callbacks: Optional[list] = None, seed: int = 0, compat_sentinel: bool = False, **kwargs) -> RCVBooster:
+           callbacks: Optional[list] = None, seed: int = 0, compat_sentinel: bool = False,
+           lockstep_chunk: Optional[int] = None, **kwargs) -> RCVBooster:
+    from .engine import drive_lockstep
+    return drive_lockstep(lgb_cv_steps(params, data, nrounds, nfold, label, weight, obj, eval, verbose, record, eval_freq, showsd,
+                                       stratified, folds, init_model, early_stopping_rounds, callbacks, seed, compat_sentinel,
+                                       lockstep_chunk, **kwargs))
+
+
+def lgb_cv_steps(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3, label=None, weight=None, obj=None,
+                 eval=None, verbose: int = 1, record: bool = True, eval_freq: int = 1, showsd: bool = True,
+                 stratified: bool = True, folds=None, init_model=None, early_stopping_rounds: Optional[int] = None,
+                 callbacks: Optional[list] = None, seed: int = 0, compat_sentinel: bool = False,
+                 lockstep_chunk: Optional[int] = None, rollback_overrun: bool = True, **kwargs):
+    """:func:`lgb_cv` as a generator of lockstep requests (:func:`lightgbm_amd.engine.cv_steps`)."""
+    from .engine import cv_steps
     p = _row_to_params(params)
     p.update(kwargs)
     if isinstance(obj, str):
@@ -137,10 +151,12 @@ def lgb_cv(params=None, data: Dataset = None, nrounds: int = 10, nfold: int = 3,
         data.set_label(label)
     if weight is not None:
         data.set_weight(weight)
-    res = _cv(p, data, num_boost_round=int(nrounds), folds=folds, nfold=int(nfold), stratified=stratified,
-              fobj=obj if callable(obj) else None, feval=eval if callable(eval) else None,
-              early_stopping_rounds=early_stopping_rounds, verbose_eval=eval_freq if verbose and verbose > 0 else None,
-              show_stdv=showsd, seed=seed, callbacks=callbacks, return_cvbooster=True)
+    res = yield from cv_steps(p, data, num_boost_round=int(nrounds), folds=folds, nfold=int(nfold), stratified=stratified,
+                              fobj=obj if callable(obj) else None, feval=eval if callable(eval) else None,
+                              early_stopping_rounds=early_stopping_rounds,
+                              verbose_eval=eval_freq if verbose and verbose > 0 else None,
+                              show_stdv=showsd, seed=seed, callbacks=callbacks, return_cvbooster=True,
+                              lockstep_chunk=lockstep_chunk, rollback_overrun=rollback_overrun)
     cvb = res.pop("cvbooster")
     out = RCVBooster()
     out.boosters = cvb.boosters

@@ -141,6 +141,12 @@ def test_rows_in_flight_do_not_change_the_table(tmp_path):
     # worker processes with two rows in flight each
     w = grid_search_cv(small_grid(), X=X, y=y, workers=["cpu", "cpu"], rows_in_flight=2, **KW)
     np.testing.assert_array_equal(w["score"].values, seq["score"].values)
+    # continuous batching: one thread keeps three rows alive and advances all their fold boosters per native call
+    ck3 = str(tmp_path / "ck3.jsonl")
+    bat = grid_search_cv(small_grid(), X=X, y=y, rows_in_flight=3, batch_rows=True, lockstep_chunk=4, checkpoint=ck3, **KW)
+    np.testing.assert_array_equal(bat["score"].values, seq["score"].values)
+    np.testing.assert_array_equal(bat["iteration"].values, seq["iteration"].values)
+    assert len(load_checkpoint(ck3)) == 8
 
 
 def _free_port():
