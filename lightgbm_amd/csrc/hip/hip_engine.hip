@@ -467,6 +467,7 @@ class HipBackend : public TreeBackend {
     for (int i = 0; i < n_nodes; ++i) ranges_host_[(size_t)i] = ranges[i];
     tree_wide_valid_ = tree_renew_ != 0;
     ++prof.rounds;
+    ++whole_trees_;
     if (tree_timing_) note_tree_timing(r, 1);
   }
   // LGA_TREE_TIMING=1: the kernel's own phase profile, averaged over 100 trees
@@ -491,6 +492,7 @@ class HipBackend : public TreeBackend {
     return true;
   }
   unsigned tree_seq() const { return tree_seq_; }
+  int64_t whole_trees_grown() const { return whole_trees_; }
   bool tree_timing() const { return tree_timing_; }
   bool renews_leaves() const { return tree_renew_ != 0; }
   int num_features() const { return F_; }
@@ -1061,6 +1063,7 @@ class HipBackend : public TreeBackend {
   unsigned tree_seq_ = 0;
   bool tree_prepared_ = false, tree_launched_ = false, tree_wide_valid_ = false;
   int tree_renew_ = 0;
+  int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
   double tree_ticks_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   int tree_timed_ = 0;
@@ -1620,6 +1623,7 @@ class HipEngine : public Engine {
       if (backend_->tree_timing()) backend_->note_tree_timing(hd, 1);
     }
     have_max_ = false;
+    chunk_iters_total_ += n_iters;
   }
 
   // The new tree's leaf values reach the training scores either through the leaf row ranges the grower
@@ -1759,7 +1763,12 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
 
-  std::string profile_json() const override { return backend_->prof.json(); }
+  std::string profile_json() const override {
+    std::string j = backend_->prof.json();
+    j.insert(1, "\"chunk_iterations\":" + std::to_string(chunk_iters_total_) + ",\"whole_trees\":" +
+                    std::to_string(backend_->whole_trees_grown()) + ",");
+    return j;
+  }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
   void sum_over_ranks(double* v, size_t n) override {
     if (dist()) comm_->allreduce_sum_f64(v, n, false, stream_);
@@ -1975,6 +1984,7 @@ class HipEngine : public Engine {
   k::TreeLayout chunk_lay_{};
   unsigned chunk_seq_ = 0;
   bool chunk_prepared_ = false, chunk_launched_ = false;
+  int64_t chunk_iters_total_ = 0;
   std::vector<std::unique_ptr<Valid>> valid_;
 };
 

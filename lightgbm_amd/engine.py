@@ -9,6 +9,8 @@
 """
 from __future__ import annotations
 
+import json
+
 import copy
 from typing import Any, Callable, Dict, Iterable, List, Optional, Tuple, Union
 
@@ -111,7 +113,38 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
     need_eval = bool(booster.valid_sets) or is_valid_contain_train
     booster.best_iteration = 0
     evaluation_result_list: List[Tuple] = []
-    for i in range(num_boost_round):
+    # Small data on the HIP engine: whole chunks of iterations run on the device without Python - or the host - in
+    # between (Booster.update_group); the callbacks are replayed over a chunk's evaluation results and iterations
+    # trained beyond an early stop are rolled back, so the model is the plain loop's.
+    from . import _lib
+    chunk = 0
+    if (_lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host") and comm is None
+            and fobj is None and feval is None and not cb_before and snapshot_freq <= 0 and not is_valid_contain_train
+            and len(booster.valid_sets) <= 1 and train_set.num_data() <= 65536):
+        chunk = 10 if need_eval else 50
+    i = 0
+    while chunk and i < num_boost_round:
+        values, no_split, done = Booster.update_group([booster], min(chunk, num_boost_round - i), need_eval)
+        names = booster._metric_names() if need_eval else []
+        stop = False
+        for j in range(done):
+            evaluation_result_list = [(booster.name_valid_sets[0], mn, float(values[j, 0, m]), hb) for m, (mn, hb) in enumerate(names)]
+            try:
+                for c in cb_after:
+                    c(cb.CallbackEnv(booster, params, i + j, 0, num_boost_round, evaluation_result_list))
+            except cb.EarlyStopException as es:
+                booster.best_iteration = es.best_iteration + 1
+                evaluation_result_list = es.best_score
+                stop = True
+            if stop or bool(no_split[j, 0]):
+                for _ in range(int((~no_split[j + 1: done, 0]).sum())):
+                    booster.rollback_one_iter()
+                stop = True
+                break
+        i += done
+        if stop:
+            break
+    for i in range(num_boost_round if not chunk else 0):
         for c in cb_before:
             c(cb.CallbackEnv(booster, params, i, 0, num_boost_round, None))
         finished = booster.update(fobj=fobj)
@@ -396,11 +429,32 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
     lockstep = int(lockstep_chunk or 0) > 0 and fobj is None and feval is None and not eval_train_metric
     runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu and not lockstep)
 
+    # The same folds come back for every row of a parameter grid: their (train, test) subsets - index lists over
+    # the shared bins - are kept on the dataset and reused while the dataset parameters agree.
+    fold_sets = None
+    if fpreproc is None:
+        import hashlib
+        h = hashlib.sha1()
+        for tr_idx, te_idx in folds:
+            h.update(np.ascontiguousarray(te_idx, dtype=np.int64).tobytes())
+            h.update(b"|")
+        key = (h.hexdigest(), len(folds), json.dumps(train_set.params, sort_keys=True, default=str))
+        cache = train_set.__dict__.setdefault("_cv_fold_sets", {})
+        fold_sets = cache.get(key)
+        if fold_sets is None:
+            if len(cache) >= 4:
+                cache.clear()
+            fold_sets = cache[key] = [(train_set.subset(tr_idx).construct(), train_set.subset(te_idx).construct())
+                                      for tr_idx, te_idx in folds]
+
     cvbooster = CVBooster()
     for k, (tr_idx, te_idx) in enumerate(folds):
-        def build(tr_idx=tr_idx, te_idx=te_idx):
-            tr = train_set.subset(tr_idx)
-            te = train_set.subset(te_idx)
+        def build(tr_idx=tr_idx, te_idx=te_idx, k=k):
+            if fold_sets is not None:
+                tr, te = fold_sets[k]
+            else:
+                tr = train_set.subset(tr_idx)
+                te = train_set.subset(te_idx)
             fold_params = params
             if fpreproc is not None:
                 tr, te, fold_params = fpreproc(tr, te, dict(params))

@@ -138,7 +138,11 @@ def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable
     from .basic import Booster
     alive: Dict[int, List[Any]] = {}      # row -> [generator, pending request, start time]
     exhausted = False
+    trace = os.environ.get("LGA_GRID_TRACE")
+    t_start = t_native = t_rows = 0.0
+    n_calls = n_booster_iters = 0
     while True:
+        t_a = time.perf_counter()
         while not exhausted and len(alive) < width:
             i = next_row()
             if i is None:
@@ -151,11 +155,20 @@ def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable
             except StopIteration as stop:
                 finish_row(i, stop.value, time.time() - t0)
         if not alive:
+            if trace:
+                print(f"[grid trace] {n_calls} native calls, {n_booster_iters} booster iterations: starting rows {t_start:.2f}s, "
+                      f"native calls {t_native:.2f}s, per-row processing {t_rows:.2f}s", flush=True)
             return
         ids = list(alive)
         n_iters = min(alive[i][1][1] for i in ids)
         boosters = [b for i in ids for b in alive[i][1][0]]
+        t_b = time.perf_counter()
         values, no_split, done = Booster.update_group(boosters, n_iters, True)
+        t_c = time.perf_counter()
+        t_start += t_b - t_a
+        t_native += t_c - t_b
+        n_calls += 1
+        n_booster_iters += done * len(boosters)
         at = 0
         for i in ids:
             gen, (bs, _), t0 = alive[i]
@@ -166,6 +179,7 @@ def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable
             except StopIteration as stop:
                 del alive[i]
                 finish_row(i, stop.value, time.time() - t0)
+        t_rows += time.perf_counter() - t_c
 
 
 def _auto_rows_in_flight(dtrain, rows: Sequence[Dict[str, Any]]) -> int:

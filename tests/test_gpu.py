@@ -281,6 +281,75 @@ def test_whole_tree_kernel_grows_the_cpu_trees(n, F, leaves, extra):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
 
 
+@pytest.mark.parametrize("case", ["diamonds", "huber-nan-extra", "binary-bynode", "poisson-weights"])
+def test_boosting_chunks_on_the_device_equal_the_step_by_step_paths(case):
+    """Small boosters run whole chunks of iterations on the device - one workgroup does gradients, bag, tree, leaf values,
+    score updates and metric sums, with no host in between.  train() and cv() then give the CPU oracle's trees and,
+    bit for bit, the metric values of the per-iteration device path; early stopping ends at the same iteration."""
+    from lightgbm_amd.utils.datasets import make_diamonds_like
+    if case == "diamonds":
+        X, y = make_diamonds_like(45000, seed=0)
+        w = None
+        p = {"objective": "regression", "num_leaves": 63, "learning_rate": 0.1, "min_data_in_leaf": 20, "bagging_fraction": 0.8,
+             "bagging_freq": 4, "feature_fraction": 0.8, "metric": ["l2", "l1"]}
+    elif case == "huber-nan-extra":
+        X, y = make_regression(20000, 12, seed=2)
+        X[::9, 3] = np.nan
+        w = None
+        p = {"objective": "huber", "num_leaves": 31, "learning_rate": 0.2, "metric": "rmse", "max_depth": 6, "bagging_fraction": 0.5,
+             "bagging_freq": 1, "extra_trees": True}
+    elif case == "binary-bynode":
+        X, y = make_regression(30000, 28, seed=5)
+        y = (y > 0).astype(float)
+        w = None
+        p = {"objective": "binary", "num_leaves": 15, "learning_rate": 0.2, "metric": ["binary_logloss", "binary_error"],
+             "feature_fraction_bynode": 0.6, "pos_bagging_fraction": 0.7, "neg_bagging_fraction": 0.9, "bagging_freq": 2}
+    else:
+        X, y = make_regression(9000, 5, seed=8)
+        y = np.floor(np.exp(np.clip(y / 3, -3, 2)))
+        w = 0.5 + np.random.RandomState(1).rand(len(y))
+        p = {"objective": "poisson", "num_leaves": 20, "learning_rate": 0.1, "metric": "poisson", "min_data_in_leaf": 30}
+    n_tr = len(y) * 4 // 5
+    runs = {}
+    for tag, extra in (("cpu", CPU), ("chunks", GPU), ("steps", {**GPU, "whole_tree_max_rows": 0})):
+        pp = {**extra, **p}
+        dtr = lgb.Dataset(X[:n_tr], label=y[:n_tr], weight=None if w is None else w[:n_tr], params=pp)
+        dva = dtr.create_valid(X[n_tr:], label=y[n_tr:], weight=None if w is None else w[n_tr:])
+        ev = {}
+        b = lgb.train(pp, dtr, 60, valid_sets=[dva], valid_names=["va"], early_stopping_rounds=4, evals_result=ev,
+                      keep_training_booster=True)
+        cvr = lgb.cv(pp, lgb.Dataset(X, label=y, weight=w, params=pp), 35, nfold=3, early_stopping_rounds=4, seed=2)
+        runs[tag] = (b, ev, cvr)
+    assert runs["chunks"][0].profile()["chunk_iterations"] > 0 and runs["steps"][0].profile()["chunk_iterations"] == 0
+    assert trees_of(runs["cpu"][0]) == trees_of(runs["chunks"][0]) == trees_of(runs["steps"][0])
+    assert runs["cpu"][0].best_iteration == runs["chunks"][0].best_iteration == runs["steps"][0].best_iteration
+    assert runs["chunks"][1] == runs["steps"][1]                       # evaluation history, bit for bit
+    assert runs["chunks"][2] == runs["steps"][2]                       # cross-validation history, bit for bit
+    for k, v in runs["cpu"][2].items():
+        np.testing.assert_allclose(runs["chunks"][2][k], v, rtol=1e-9)
+    b = runs["chunks"][0]
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X[:n_tr], raw_score=True, device="cpu"), atol=1e-9)
+    np.testing.assert_allclose(b._inner_predict(0, raw=True), b.predict(X[n_tr:], raw_score=True, device="cpu"), atol=1e-9)
+
+
+def test_grid_rows_are_batched_into_single_launches_with_the_same_table():
+    """Continuous batching: one thread keeps many grid rows alive and advances all their fold boosters with one
+    native call - one kernel launch, one workgroup per booster; the table is the one-row-at-a-time table."""
+    from lightgbm_amd.grid import expand_grid, grid_search_cv
+    from lightgbm_amd.utils.datasets import make_diamonds_like
+    X, y = make_diamonds_like(12000, seed=1)
+    grid = expand_grid(iteration=None, score=None, learning_rate=[0.3, 0.1], num_leaves=[15, 63], min_data_in_leaf=[20],
+                       feature_fraction=[0.8, 1], bagging_fraction=[0.7, 1], bagging_freq=4)
+    kw = dict(nrounds=80, nfold=4, objective="regression", early_stopping_rounds=4, seed=3)
+    one = grid_search_cv(grid, X=X, y=y, rows_in_flight=1, **kw)
+    many = grid_search_cv(grid, X=X, y=y, rows_in_flight=11, **kw)
+    cpu = grid_search_cv(grid, X=X, y=y, rows_in_flight=1, dataset_params={"device_type": "cpu"}, base_params={"device_type": "cpu"}, **kw)
+    np.testing.assert_array_equal(one["score"].values, many["score"].values)
+    np.testing.assert_array_equal(one["iteration"].values, many["iteration"].values)
+    np.testing.assert_array_equal(one["iteration"].values, cpu["iteration"].values)
+    np.testing.assert_allclose(one["score"].values, cpu["score"].values, rtol=1e-9)
+
+
 @pytest.mark.parametrize("first", [0, 10, 20, 30])
 def test_randomised_parity_sweep(first):
     """Random shapes (across the row-line, two-rounds-in-flight and tree-walk size gates), missing values,

@@ -1,4 +1,13 @@
-set -o pipefail
-O=gpurun_out/r2f; mkdir -p $O
-timeout -k 10 300 python -u -m pytest tests/test_gpu.py -m gpu -x -q --timeout 100 --timeout-method thread -k "kernel" > $O/kernels.log 2>&1; rc=$?; tail -5 $O/kernels.log; [ $rc -eq 0 ] || exit $rc
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > $O/gpu_tests.log 2>&1; rc=$?; tail -15 $O/gpu_tests.log; [ $rc -eq 0 ] || exit $rc
+#!/bin/bash
+# GPU test suite (optionally a -k expression), then nothing else.
+set -e -o pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
+OUT=$ROOT/gpurun_out/${1:-gt}
+mkdir -p "$OUT"
+cd $ROOT
+if [ -n "$2" ]; then
+  timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --timeout 170 --timeout-method thread -k "$2" > "$OUT/pytest.log" 2>&1 || { tail -60 "$OUT/pytest.log"; exit 1; }
+else
+  timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --timeout 170 --timeout-method thread > "$OUT/pytest.log" 2>&1 || { tail -60 "$OUT/pytest.log"; exit 1; }
+fi
+tail -5 "$OUT/pytest.log"
