@@ -475,13 +475,17 @@ class HipBackend : public TreeBackend {
     static const char* names[8] = {"root pass", "selection", "sides + histogram", "prefix", "search", "row movement", "bookkeeping", "hand-over"};
     for (int i = 0; i < 8; ++i) tree_ticks_[i] += (double)r.phase_ticks[i];
     tree_ticks_[8] += r.n_splits;
+    tree_cycles_ += (double)r.shader_cycles;
     tree_timed_ += trees;
     if (tree_timed_ % 100 == 0) {
       std::fprintf(stderr, "[tree kernel] per tree (%.0f splits):", tree_ticks_[8] / 100);
       double total = 0;
       for (int i = 0; i < 8; ++i) { std::fprintf(stderr, " %s %.1f us,", names[i], tree_ticks_[i] / 100 * 0.01); total += tree_ticks_[i]; }
-      std::fprintf(stderr, " total %.1f us\n", total / 100 * 0.01);
+      std::fprintf(stderr, " total %.1f us", total / 100 * 0.01);
+      if (tree_cycles_ > 0) std::fprintf(stderr, " at %.0f MHz shader clock", tree_cycles_ / (total * 0.01));
+      std::fprintf(stderr, "\n");
       for (double& v : tree_ticks_) v = 0;
+      tree_cycles_ = 0;
     }
   }
   // 36-bit gradient sums of a final leaf's rows as the last whole-tree build left them (false: not available).
@@ -1066,6 +1070,7 @@ class HipBackend : public TreeBackend {
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
   double tree_ticks_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double tree_cycles_ = 0;
   int tree_timed_ = 0;
 };
 
@@ -1547,7 +1552,7 @@ class HipEngine : public Engine {
       const SplitParams spj = grower_.split_params();
       uint32_t mask = 0;
       for (size_t f = 0; f < it.meta.size(); ++f) if (it.meta[f].enabled) mask |= 1u << f;
-      its[j] = k::BoostIter{mask, it.redraw ? 1u : 0u, it.bag_iter, spj.bynode_seed, spj.extra_seed};
+      its[j] = k::BoostIter{mask, it.redraw ? 1u : 0u, it.bag_iter, spj};
     }
     b.iters = reinterpret_cast<const k::BoostIter*>(chunk_iters_.device_ptr());
     chunk_plan_ = plan;

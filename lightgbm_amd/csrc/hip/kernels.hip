@@ -623,16 +623,17 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
     if (!m.enabled) continue;
     int64_t g[4], h[4];
     int64_t* blk = feat_block(a.pool, self, f);
-    load_feat_cells(blk, lane, g, h);
+    const int bpl = bins_per_lane(m.num_bin);
+    load_feat_cells(blk, lane, bpl, g, h);
     if (!direct) {
       int64_t cg[4], ch[4];
-      load_feat_cells(feat_block(a.pool, fresh, f), lane, cg, ch);
+      load_feat_cells(feat_block(a.pool, fresh, f), lane, bpl, cg, ch);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
-      store_feat_cells(blk, lane, g, h);
+      store_feat_cells(blk, lane, bpl, g, h);
     }
     if (node_feature_on(a.sp, key, f, a.F) && node_allows(a.sp, node, f) && m.categorical != kCategoricalSorted)
-      scan_cells_wave(f, lane, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
+      scan_cells_wave(f, lane, bpl, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
   }
   wave_best(bg, bkey, blg, blh);
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};

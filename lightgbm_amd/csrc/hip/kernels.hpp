@@ -235,6 +235,7 @@ struct TreeHeader {
   double metric[4][2];      // boosting chunk: per metric (sum of weighted losses, sum of weights) over the validation rows
   int64_t phase_ticks[8];   // TreeArgs::timing: 100 MHz ticks spent in root pass, selection, sides + histogram, prefix, search,
                             // row movement, per-split bookkeeping, hand-over
+  int64_t shader_cycles;    // TreeArgs::timing: shader clock cycles of the whole build (with phase_ticks: the clock rate it ran at)
 };
 struct TreeLayout {
   int32_t off_split, off_best, off_range, off_wide, bytes;
@@ -288,7 +289,7 @@ struct BoostIter {          // what differs between the iterations of a chunk
   uint32_t enabled;         // feature_fraction mask of the iteration's tree
   uint32_t redraw;          // 1: draw a new bag before the tree (stream `bag_iter`)
   uint64_t bag_iter;
-  uint64_t bynode_seed, extra_seed;   // SplitParams seeds of the tree
+  SplitParams sp;           // the tree's split parameters (its per-tree seeds differ); read through scalar loads
 };
 struct BoostArgs {
   TreeArgs t;               // t.bag / t.n: the bag as it stands (a redraw rewrites bag_rows and the count); t.out: first block

@@ -81,12 +81,11 @@ __device__ __forceinline__ void hist_add(unsigned long long* lds, const unsigned
   }
 }
 
-// Lane l's four cells (bins 4 l .. 4 l + 3) of feature f in the LDS histogram, unpacked.
-__device__ __forceinline__ void lds_feat_cells(const unsigned long long* lds, int f, int lane, int64_t (&g)[4], int64_t (&h)[4]) {
-  const unsigned long long* c = lds + f * kMaxBins + ((lane * 4 + 8 * f) & 255);   // 8 f and 4 l are multiples of 4: no wrap inside
+// Lane l's cells (bins l * bpl .. l * bpl + bpl - 1, see load_feat_cells) of feature f in the LDS histogram, unpacked.
+__device__ __forceinline__ void lds_feat_cells(const unsigned long long* lds, int f, int lane, int bpl, int64_t (&g)[4], int64_t (&h)[4]) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const unsigned long long v = c[j];
+    const unsigned long long v = j < bpl ? lds[f * kMaxBins + ((lane * bpl + j + 8 * f) & 255)] : 0ull;
     g[j] = (int64_t)(int32_t)(v >> 32);
     h[j] = (int64_t)(v & 0xffffffffull);
   }
@@ -120,8 +119,11 @@ struct TreeShared {
   // default_left << 16 | categorical << 17 | (missing bin + 1) << 18 - and left child (the right one follows it),
   // every node's parent, a final leaf's output
   int ndec[kNodeCap];
+  int nbest[kNodeCap];            // a leaf's best split, for the pass that applies it: feature | threshold << 8 |
+                                  // default_left << 16 | (the left child is the smaller one) << 17
   short nleft[kNodeCap], nparent[kNodeCap];
   double nvalue[kNodeCap];
+  long long ticks[8], t_mark;     // phase profile (thread 0)
   float fmax[2][kTreeWaves];
   double msum[4][2];
   int bag_n;
@@ -163,8 +165,7 @@ __device__ __forceinline__ void mask_prefix(TreeShared& S, int n_words) {
 // (thread 0).  Returns the number of splits.
 template <int BW>
 __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __restrict__ bag, int n, unsigned feature_mask,
-                                        const SplitParams& sp, int kg, int kh, unsigned long long* lds, TreeShared& S,
-                                        long long (&ticks)[8]) {
+                                        const SplitParams& sp, int kg, int kh, unsigned long long* lds, TreeShared& S) {
   constexpr int FC = BW * 4;
   constexpr int PPW = (2 * FC + kTreeWaves - 1) / kTreeWaves;   // (child, feature) pairs per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -183,12 +184,12 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
   for (int f = 0; f < nf; ++f) enabled |= S.meta[f].enabled ? (1u << f) : 0u;
   const unsigned f_start = (unsigned)(lane % nf);
   // optional phase profile: thread 0 reads the 100 MHz wall clock at the phase boundaries
-  long long t_mark = a.timing ? (long long)wall_clock64() : 0;
+  if (a.timing && tid == 0) S.t_mark = (long long)wall_clock64();
   auto lap = [&](int phase) {
     if (a.timing && tid == 0) {
       const long long now = (long long)wall_clock64();
-      ticks[phase] += now - t_mark;
-      t_mark = now;
+      S.ticks[phase] += now - S.t_mark;
+      S.t_mark = now;
     }
   };
 
@@ -266,9 +267,10 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
       const FeatureMeta m = S.meta[f];
       if (!m.enabled) continue;
       int64_t g[4], h[4];
-      load_feat_cells(slot0 + (int64_t)f * (2 * kMaxBins), lane, g, h);
+      const int bpl = bins_per_lane(m.num_bin);
+      load_feat_cells(slot0 + (int64_t)f * (2 * kMaxBins), lane, bpl, g, h);
       if (node_feature_on(sp, kRootNodeKey, f, nf) && m.categorical != kCategoricalSorted)
-        scan_cells_wave(f, lane, g, h, m, ctx, sp, bg, bkey, blg, blh, kRootNodeKey);
+        scan_cells_wave(f, lane, bpl, g, h, m, ctx, sp, bg, bkey, blg, blh, kRootNodeKey);
     }
     wave_best(bg, bkey, blg, blh);
     if (lane == 0) S.wbest[wave] = Cand{bg, bkey, blg, blh};
@@ -278,6 +280,9 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
       write_split(&a.best[0], bg, bkey, blg, blh, S.ntot[0][0], S.ntot[0][1], S.ntot[0][2], q, sp);
       const bool open = bg != ninf && isfinite(bg) && true;   // max_depth >= 1 never blocks the root
       S.ngain[0] = open ? bg : ninf;
+      const SplitInfo& w = a.best[0];
+      S.nbest[0] = (w.feature & 255) | ((w.threshold & 255) << 8) | ((w.default_left & 1) << 16) |
+                   ((w.left_cnt <= w.total_cnt - w.left_cnt ? 1 : 0) << 17);
     }
     __syncthreads();
   }
@@ -303,11 +308,11 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     if (!(pg > ninf)) break;
     lap(1);
     const int P = uni(pn), Lc = 2 * k + 1, Rc = 2 * k + 2;
-    const SplitInfo* ps = &a.best[P];
-    const int sf = uni(ps->feature), thr = uni(ps->threshold);
-    const int dl = uni((int)S.meta[sf].categorical) ? kCategoricalTask : uni(ps->default_left);
+    const int pb = uni(S.nbest[P]);
+    const int sf = pb & 255, thr = (pb >> 8) & 255;
+    const int dl = uni((int)S.meta[sf].categorical) ? kCategoricalTask : ((pb >> 16) & 1);
     const int mb = uni(S.meta[sf].missing_bin);
-    const bool hist_left = uni((int)(ps->left_cnt <= ps->total_cnt - ps->left_cnt)) != 0;
+    const bool hist_left = ((pb >> 17) & 1) != 0;
     const int begin = uni(S.nbegin[P]), cnt = uni(S.ncount[P]), sb = uni((int)S.nbuf[P]);
     const int pslot = uni((int)S.nslot[P]);
     const int64_t* pblk_base = a.pool + (int64_t)pslot * a.slot_words;
@@ -319,58 +324,90 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     unsigned long long* dst_gh = a.gh[1 - sb] + begin;
     uint32_t* dst_bins = a.bins[1 - sb] + (int64_t)begin * BW;
     const bool multi = cnt > kMaxRowsPerPass;
+    constexpr int U = 4;
+    const bool small = cnt <= U * kTreeThreads;   // the leaf is one trip: its records stay in registers until they move
+
+    // The parent's histogram rows come from global memory: the waves that derive the sibling ask for them now and
+    // meet them again after the pass over the rows (only while they fit the registers: up to two features per wave).
+    constexpr bool kPrefetch = PPW <= 2;
+    int64_t pre_g[kPrefetch ? PPW : 1][4], pre_h[kPrefetch ? PPW : 1][4];
+    if constexpr (kPrefetch) {
+      if (wave & 1) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+          const int fe = (wave + kTreeWaves * j) >> 1;
+          if (fe < nf && ((enabled >> fe) & 1u))
+            load_feat_cells(pblk_base + (int64_t)fe * (2 * kMaxBins), lane, bins_per_lane(S.meta[fe].num_bin), pre_g[j], pre_h[j]);
+        }
+      }
+    }
 
     // phase A: sides of all rows (ballot words in LDS), histogram of the rows of the smaller child
     sg = 0; sh = 0;
-    for (int seg = 0; seg < cnt; seg += kMaxRowsPerPass) {
-      const int seg_hi = min(cnt, seg + kMaxRowsPerPass);
-      constexpr int U = 4;
-      for (int base = seg; base < seg_hi; base += U * kTreeThreads) {
-        unsigned w[U][BW];
-        unsigned long long pk[U];
-        bool take[U];
+    int rid0[U];
+    unsigned long long pk0[U];
+    unsigned w0[U][BW];
+    // one trip over positions base + u * 512 + tid: all loads first (bins, gradients - and the row ids when the
+    // records are kept), then sides and ballots, then the LDS adds
+    auto trip = [&](int base, int seg_hi, bool keep, int (&rid)[U], unsigned long long (&pk)[U], unsigned (&w)[U][BW]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int pos = base + u * kTreeThreads + tid;
-          if (pos < seg_hi) load_words<BW>(src_bins + (int64_t)pos * BW, w[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int pos = base + u * kTreeThreads + tid;
-          bool left = false;
-          if (pos < seg_hi) {
-            const int b = (int)bin_byte<BW>(w[u], (unsigned)sf);
-            left = dl == kCategoricalTask ? b == thr : (b == mb ? dl != 0 : b <= thr);
-          }
-          take[u] = pos < seg_hi && left == hist_left;
-          if (take[u]) pk[u] = src_gh[pos];
-          if (base + u * kTreeThreads + wave * kWave < seg_hi) {   // wave-uniform
-            const unsigned long long m = __ballot(left);
-            if (lane == 0) S.smask[(base >> 6) + u * kTreeWaves + wave] = m;
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (take[u]) {
-            sg += (long long)(int32_t)(pk[u] >> 32);
-            sh += (long long)(pk[u] & 0xffffffffull);
-            hist_add<BW>(lds, w[u], pk[u], nf, f_start, enabled);
-          }
+      for (int u = 0; u < U; ++u) {
+        const int pos = base + u * kTreeThreads + tid;
+        if (pos < seg_hi) {
+          load_words<BW>(src_bins + (int64_t)pos * BW, w[u]);
+          pk[u] = src_gh[pos];
+          if (keep) rid[u] = src_idx[pos];
         }
       }
-      if (multi) {
-        __syncthreads();
-        for (int e = tid; e < nf * kMaxBins; e += kTreeThreads) {
-          const int fe = e >> 8, b = e & 255;
-          const int at = (fe << 8) + ((b + 8 * fe) & 255);
-          const unsigned long long v = lds[at];
-          lds[at] = 0ull;
-          int64_t* blk = nblk_base + (int64_t)fe * (2 * kMaxBins);
-          const int64_t vg = (int64_t)(int32_t)(v >> 32), vh = (int64_t)(v & 0xffffffffull);
-          if (seg == 0) { blk[b] = vg; blk[kMaxBins + b] = vh; }
-          else { blk[b] += vg; blk[kMaxBins + b] += vh; }
+      bool take[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pos = base + u * kTreeThreads + tid;
+        bool left = false;
+        if (pos < seg_hi) {
+          const int b = (int)bin_byte<BW>(w[u], (unsigned)sf);
+          left = dl == kCategoricalTask ? b == thr : (b == mb ? dl != 0 : b <= thr);
         }
-        __syncthreads();   // the next pass adds to cells that are zero again
+        take[u] = pos < seg_hi && left == hist_left;
+        if (base + u * kTreeThreads + wave * kWave < seg_hi) {   // wave-uniform
+          const unsigned long long m = __ballot(left);
+          if (lane == 0) S.smask[(base >> 6) + u * kTreeWaves + wave] = m;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (take[u]) {
+          sg += (long long)(int32_t)(pk[u] >> 32);
+          sh += (long long)(pk[u] & 0xffffffffull);
+          hist_add<BW>(lds, w[u], pk[u], nf, f_start, enabled);
+        }
+      }
+    };
+    if (small) {
+      trip(0, cnt, true, rid0, pk0, w0);
+    } else {
+      for (int seg = 0; seg < cnt; seg += kMaxRowsPerPass) {
+        const int seg_hi = min(cnt, seg + kMaxRowsPerPass);
+        for (int base = seg; base < seg_hi; base += U * kTreeThreads) {
+          int rid[U];
+          unsigned long long pk[U];
+          unsigned w[U][BW];
+          trip(base, seg_hi, false, rid, pk, w);
+        }
+        if (multi) {
+          __syncthreads();
+          for (int e = tid; e < nf * kMaxBins; e += kTreeThreads) {
+            const int fe = e >> 8, b = e & 255;
+            const int at = (fe << 8) + ((b + 8 * fe) & 255);
+            const unsigned long long v = lds[at];
+            lds[at] = 0ull;
+            int64_t* blk = nblk_base + (int64_t)fe * (2 * kMaxBins);
+            const int64_t vg = (int64_t)(int32_t)(v >> 32), vh = (int64_t)(v & 0xffffffffull);
+            if (seg == 0) { blk[b] = vg; blk[kMaxBins + b] = vh; }
+            else { blk[b] += vg; blk[kMaxBins + b] += vh; }
+          }
+          __syncthreads();   // the next pass adds to cells that are zero again
+        }
       }
     }
     sg = wave_sum_i64(sg);
@@ -379,21 +416,55 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     __syncthreads();
     lap(2);
 
-    // exclusive prefix of the mask words' popcounts
-    mask_prefix(S, (cnt + kWave - 1) / kWave);
+    // exclusive prefix of the mask words' popcounts.  One trip: at most 32 words - every wave scans them itself and
+    // keeps the prefixes of its own four words in registers (no further barrier)
+    int lefts;
+    int wp0[U];
+    if (small) {
+      const int n_words = (cnt + kWave - 1) / kWave;
+      const int pc = lane < n_words ? __popcll(S.smask[lane]) : 0;
+      int incl = pc;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const int o = __shfl_up(incl, d, kWave);
+        if (lane >= d) incl += o;
+      }
+      lefts = uni(__shfl(incl, 31, kWave));
+#pragma unroll
+      for (int u = 0; u < U; ++u) wp0[u] = uni(__shfl(incl - pc, u * kTreeWaves + wave, kWave));
+    } else {
+      mask_prefix(S, (cnt + kWave - 1) / kWave);
+      lefts = uni(S.word_prefix[kMaskWords]);
+    }
     // totals of the two children (every thread computes them: no further barrier needed for them)
     long long htg = 0, hth = 0;
 #pragma unroll
     for (int w = 0; w < kTreeWaves; ++w) { htg += S.red[0][w]; hth += S.red[1][w]; }
     htg = uni(htg);
     hth = uni(hth);
-    const int lefts = uni(S.word_prefix[kMaskWords]);
     const int Hn = hist_left ? Lc : Rc, Sn = hist_left ? Rc : Lc;
     const long long hcnt = hist_left ? lefts : cnt - lefts;
     const long long ptc = uni(S.ntot[P][0]), ptg = uni(S.ntot[P][1]), pth = uni(S.ntot[P][2]);
     const int cdepth = uni((int)S.ndepth[P]) + 1;
     const unsigned pkey = uni(S.nkey[P]);
 
+    // a one-trip leaf moves its records now, out of the registers (the stores need not be waited for, and the
+    // registers are free for the search)
+    if (small) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pos = u * kTreeThreads + tid;
+        if (pos < cnt) {
+          const unsigned long long m = S.smask[u * kTreeWaves + wave];
+          const bool left = (m >> lane) & 1ull;
+          const int lrank = wp0[u] + __popcll(m & ((1ull << lane) - 1ull));
+          const int d = left ? lrank : lefts + (pos - lrank);
+          dst_idx[d] = rid0[u];
+          dst_gh[d] = pk0[u];
+          store_words<BW>(dst_bins + (int64_t)d * BW, w0[u]);
+        }
+      }
+    }
     lap(3);
     // search: wave w takes the pairs (feature, child) w, w + 8, ... - child = parity of the wave (0: the child whose
     // histogram was built, 1: its sibling = parent - child, stored over the parent's slot)
@@ -407,7 +478,9 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
       double bg = ninf;
       uint64_t bkey = ~0ull;
       int64_t blg = 0, blh = 0;
-#pragma unroll
+      // a child that cannot be split - too few rows for two leaves, or at the depth limit - only needs its histogram
+      const bool searched = tc >= 2 * (long long)sp.min_data_in_leaf && !(sp.max_depth > 0 && cdepth >= sp.max_depth);
+#pragma unroll 1
       for (int j = 0; j < PPW; ++j) {
         const int pi = wave + kTreeWaves * j;
         const int fe = pi >> 1;
@@ -416,20 +489,32 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
           if (m.enabled) {
             int64_t g[4], h[4];
             int64_t* nblk = nblk_base + (int64_t)fe * (2 * kMaxBins);
-            if (multi) load_feat_cells(nblk, lane, g, h);
-            else lds_feat_cells(lds, fe, lane, g, h);
+            const int bpl = bins_per_lane(m.num_bin);
+            if (multi) load_feat_cells(nblk, lane, bpl, g, h);
+            else lds_feat_cells(lds, fe, lane, bpl, g, h);
             if (c == 0) {
-              if (!multi) store_feat_cells(nblk, lane, g, h);
+              if (!multi) store_feat_cells(nblk, lane, bpl, g, h);
             } else {
               int64_t* pblk = const_cast<int64_t*>(pblk_base) + (int64_t)fe * (2 * kMaxBins);
-              int64_t og[4], oh[4];
-              load_feat_cells(pblk, lane, og, oh);
+              if constexpr (kPrefetch) {
+                // (j is not a compile-time index here: pick the prefetched row by hand)
 #pragma unroll
-              for (int i = 0; i < 4; ++i) { g[i] = og[i] - g[i]; h[i] = oh[i] - h[i]; }
-              store_feat_cells(pblk, lane, g, h);
+                for (int i = 0; i < 4; ++i) {
+                  const int64_t og = (PPW > 1 && j == 1) ? pre_g[PPW > 1 ? 1 : 0][i] : pre_g[0][i];
+                  const int64_t oh = (PPW > 1 && j == 1) ? pre_h[PPW > 1 ? 1 : 0][i] : pre_h[0][i];
+                  g[i] = og - g[i];
+                  h[i] = oh - h[i];
+                }
+              } else {
+                int64_t og[4], oh[4];
+                load_feat_cells(pblk, lane, bpl, og, oh);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { g[i] = og[i] - g[i]; h[i] = oh[i] - h[i]; }
+              }
+              store_feat_cells(pblk, lane, bpl, g, h);
             }
-            if (node_feature_on(sp, key, fe, nf) && m.categorical != kCategoricalSorted)
-              scan_cells_wave(fe, lane, g, h, m, ctx, sp, bg, bkey, blg, blh, key);
+            if (searched && node_feature_on(sp, key, fe, nf) && m.categorical != kCategoricalSorted)
+              scan_cells_wave(fe, lane, bpl, g, h, m, ctx, sp, bg, bkey, blg, blh, key);
           }
         }
       }
@@ -438,9 +523,8 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     }
 
     lap(4);
-    // phase B: move the records - lefts to the front, rights behind, in order
-    {
-      constexpr int U = 4;
+    // phase B for larger leaves: move the records - lefts to the front, rights behind, in order
+    if (!small) {
       for (int base = 0; base < cnt; base += U * kTreeThreads) {
         int rid[U];
         unsigned long long pk[U];
@@ -484,6 +568,11 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
       for (int w = c; w < kTreeWaves; w += 2) take_better(bg, bkey, blg, blh, S.wbest[w].gain, S.wbest[w].key, S.wbest[w].lg, S.wbest[w].lh);
       const long long tc = c == 0 ? hcnt : ptc - hcnt, tg = c == 0 ? htg : ptg - htg, th = c == 0 ? hth : pth - hth;
       write_split(&a.best[node], bg, bkey, blg, blh, tc, tg, th, q, sp);
+      {
+        const SplitInfo& w = a.best[node];
+        S.nbest[node] = (w.feature & 255) | ((w.threshold & 255) << 8) | ((w.default_left & 1) << 16) |
+                        ((w.left_cnt <= w.total_cnt - w.left_cnt ? 1 : 0) << 17);
+      }
       S.ntot[node][0] = tc; S.ntot[node][1] = tg; S.ntot[node][2] = th;
       const bool is_left = node == Lc;
       S.nbegin[node] = is_left ? begin : begin + lefts;
@@ -583,16 +672,15 @@ __device__ __forceinline__ void tree_one(const TreeArgs& a, unsigned long long* 
   const int tid = threadIdx.x;
   const int kg = quant_exponent(__uint_as_float(a.maxbits[0]));
   const int kh = quant_exponent(__uint_as_float(a.maxbits[1]));
-  long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const long long t0 = a.timing ? (long long)wall_clock64() : 0;
-  const int n_splits = grow_one<BW>(a, a.bag, a.n, ~0u, a.sp, kg, kh, lds, S, ticks);
-  const long long t1 = a.timing ? (long long)wall_clock64() : 0;
+  if (tid < 8) S.ticks[tid] = 0;
+  const long long c0 = a.timing ? (long long)clock64() : 0;
+  const int n_splits = grow_one<BW>(a, a.bag, a.n, ~0u, a.sp, kg, kh, lds, S);
   tree_handover<false>(a, a.out, n_splits, kg, kh, a.n, a.sp, 1.0, nullptr, S);
   TreeHeader* hd = reinterpret_cast<TreeHeader*>(a.out);
   if (a.timing && tid == 0) {
-    ticks[7] = (long long)wall_clock64() - t1;
-    (void)t0;
-    for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = ticks[i];
+    S.ticks[7] += (long long)wall_clock64() - S.t_mark;
+    for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = S.ticks[i];
+    hd->shader_cycles = (long long)clock64() - c0;
   }
   __threadfence_system();
   __syncthreads();
@@ -622,9 +710,9 @@ __device__ __forceinline__ void boost_one(const BoostArgs& b, unsigned long long
   if (tid == 0) S.bag_n = a.n;
   __syncthreads();
   for (int it = 0; it < b.n_iters; ++it) {
-    const BoostIter I = b.iters[it];
+    const BoostIter& I = b.iters[it];
     char* out = a.out + (int64_t)it * a.lay.bytes;
-    long long ticks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < 8) S.ticks[tid] = 0;
     // ---- gradients of the objective at the current scores, and their maxima ----
     {
       float mg = 0.f, mh = 0.f;
@@ -694,11 +782,9 @@ __device__ __forceinline__ void boost_one(const BoostArgs& b, unsigned long long
     const int kg = uni(quant_exponent(vmg)), kh = uni(quant_exponent(vmh));
     const int bag_n = uni(S.bag_n);
     // ---- the tree ----
-    SplitParams sp = a.sp;
-    sp.bynode_seed = I.bynode_seed;
-    sp.extra_seed = I.extra_seed;
+    const SplitParams& sp = I.sp;
     int n_splits = 0;
-    if (bag_n > 0) n_splits = grow_one<BW>(a, bag, bag_n, I.enabled, sp, kg, kh, lds, S, ticks);
+    if (bag_n > 0) n_splits = grow_one<BW>(a, bag, bag_n, I.enabled, sp, kg, kh, lds, S);
     else {
       // an empty bag: a tree without a split over no rows
       if (tid == 0) {
@@ -761,8 +847,10 @@ __device__ __forceinline__ void boost_one(const BoostArgs& b, unsigned long long
         __syncthreads();
       }
     }
-    if (a.timing && tid == 0)
-      for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = ticks[i];
+    if (a.timing && tid == 0) {
+      S.ticks[7] += (long long)wall_clock64() - S.t_mark;    // everything around the tree: gradients, bag, scores, metrics
+      for (int i = 0; i < 8; ++i) hd->phase_ticks[i] = S.ticks[i];
+    }
   }
   __threadfence_system();
   __syncthreads();

@@ -80,37 +80,86 @@ __device__ __forceinline__ void take_better(double& g, uint64_t& key, int64_t& l
   if (cand_better(g2, k2, g, key)) { g = g2; key = k2; lg = lg2; lh = lh2; }
 }
 
-// Lane l of a wave holds bins 4 l .. 4 l + 3 of one feature.
-__device__ __forceinline__ void load_feat_cells(const int64_t* __restrict__ blk, int lane, int64_t (&g)[4], int64_t (&h)[4]) {
-  const longlong2* gs = reinterpret_cast<const longlong2*>(blk + lane * 4);
-  const longlong2* hs = reinterpret_cast<const longlong2*>(blk + kMaxBins + lane * 4);
-  const longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
-  g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
-  h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
+// A wave holds one feature's histogram row, `bpl` bins per lane (bins_per_lane: as few as cover the feature's bins):
+// lane l has bins l * bpl .. l * bpl + bpl - 1 in entries 0 .. bpl - 1; further entries are zero.  A feature with
+// up to 64 bins costs a quarter of the gain arithmetic of one with 256.
+__device__ __forceinline__ int bins_per_lane(int num_bin) {
+  const int b = (num_bin + kWave - 1) / kWave;
+  return b < 1 ? 1 : (b > 4 ? 4 : b);
 }
-__device__ __forceinline__ void store_feat_cells(int64_t* __restrict__ blk, int lane, const int64_t (&g)[4], const int64_t (&h)[4]) {
-  longlong2* go = reinterpret_cast<longlong2*>(blk + lane * 4);
-  longlong2* ho = reinterpret_cast<longlong2*>(blk + kMaxBins + lane * 4);
-  go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
-  ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
-}
-
-// Combines the lanes' running bests: on return every lane holds the wave's winner.
-__device__ __forceinline__ void wave_best(double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+__device__ __forceinline__ void load_feat_cells(const int64_t* __restrict__ blk, int lane, int bpl, int64_t (&g)[4], int64_t (&h)[4]) {
+  if (bpl == 4) {
+    const longlong2* gs = reinterpret_cast<const longlong2*>(blk + lane * 4);
+    const longlong2* hs = reinterpret_cast<const longlong2*>(blk + kMaxBins + lane * 4);
+    const longlong2 g01 = gs[0], g23 = gs[1], h01 = hs[0], h23 = hs[1];
+    g[0] = g01.x; g[1] = g01.y; g[2] = g23.x; g[3] = g23.y;
+    h[0] = h01.x; h[1] = h01.y; h[2] = h23.x; h[3] = h23.y;
+  } else {
 #pragma unroll
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    double g2 = shfl_xor_f64(bg, msk);
-    uint64_t k2 = (uint64_t)shfl_xor_i64((int64_t)bkey, msk);
-    int64_t lg2 = shfl_xor_i64(blg, msk), lh2 = shfl_xor_i64(blh, msk);
-    take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
+    for (int j = 0; j < 4; ++j) {
+      g[j] = j < bpl ? blk[lane * bpl + j] : 0;
+      h[j] = j < bpl ? blk[kMaxBins + lane * bpl + j] : 0;
+    }
+  }
+}
+__device__ __forceinline__ void store_feat_cells(int64_t* __restrict__ blk, int lane, int bpl, const int64_t (&g)[4], const int64_t (&h)[4]) {
+  if (bpl == 4) {
+    longlong2* go = reinterpret_cast<longlong2*>(blk + lane * 4);
+    longlong2* ho = reinterpret_cast<longlong2*>(blk + kMaxBins + lane * 4);
+    go[0] = make_longlong2(g[0], g[1]); go[1] = make_longlong2(g[2], g[3]);
+    ho[0] = make_longlong2(h[0], h[1]); ho[1] = make_longlong2(h[2], h[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < bpl) {
+        blk[lane * bpl + j] = g[j];
+        blk[kMaxBins + lane * bpl + j] = h[j];
+      }
+    }
   }
 }
 
-// Best split of ONE feature of one leaf from the feature's histogram held by one wave (g, h: 4 bins per
-// lane; overwritten).  Every lane folds ITS candidates of this feature into its own running best; the lanes'
-// bests are combined once per leaf (wave_best), not once per feature.  The per-feature gain adjustment is
+// Combines the lanes' running bests: on return every lane holds the wave's winner.  The candidates travel by
+// data-parallel-primitive moves - shifts inside the rows of 16 lanes, then the row broadcasts, as in
+// wave_prefix_sum_i64 - which leaves the winner in lane 63; one read-lane hands it to everybody.  (A butterfly of
+// ds_bpermute shuffles costs several times as much: 8 dwords per step through the LDS crossbar.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_take_better(double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+  // lanes without a source keep their own candidate (bound_ctrl off: the old value is the lane's own)
+  const int g_lo = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)__double_as_longlong(bg) & 0xffffffffull),
+                                               (int)(uint32_t)((uint64_t)__double_as_longlong(bg) & 0xffffffffull), CTRL, ROW_MASK, 0xF, false);
+  const int g_hi = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)__double_as_longlong(bg) >> 32),
+                                               (int)(uint32_t)((uint64_t)__double_as_longlong(bg) >> 32), CTRL, ROW_MASK, 0xF, false);
+  const int k_lo = __builtin_amdgcn_update_dpp((int)(uint32_t)(bkey & 0xffffffffull), (int)(uint32_t)(bkey & 0xffffffffull), CTRL, ROW_MASK, 0xF, false);
+  const int k_hi = __builtin_amdgcn_update_dpp((int)(uint32_t)(bkey >> 32), (int)(uint32_t)(bkey >> 32), CTRL, ROW_MASK, 0xF, false);
+  const int a_lo = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)blg & 0xffffffffull), (int)(uint32_t)((uint64_t)blg & 0xffffffffull), CTRL, ROW_MASK, 0xF, false);
+  const int a_hi = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)blg >> 32), (int)(uint32_t)((uint64_t)blg >> 32), CTRL, ROW_MASK, 0xF, false);
+  const int b_lo = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)blh & 0xffffffffull), (int)(uint32_t)((uint64_t)blh & 0xffffffffull), CTRL, ROW_MASK, 0xF, false);
+  const int b_hi = __builtin_amdgcn_update_dpp((int)(uint32_t)((uint64_t)blh >> 32), (int)(uint32_t)((uint64_t)blh >> 32), CTRL, ROW_MASK, 0xF, false);
+  const double g2 = __longlong_as_double((long long)(((uint64_t)(uint32_t)g_hi << 32) | (uint64_t)(uint32_t)g_lo));
+  const uint64_t k2 = ((uint64_t)(uint32_t)k_hi << 32) | (uint64_t)(uint32_t)k_lo;
+  const int64_t lg2 = (int64_t)(((uint64_t)(uint32_t)a_hi << 32) | (uint64_t)(uint32_t)a_lo);
+  const int64_t lh2 = (int64_t)(((uint64_t)(uint32_t)b_hi << 32) | (uint64_t)(uint32_t)b_lo);
+  take_better(bg, bkey, blg, blh, g2, k2, lg2, lh2);
+}
+__device__ __forceinline__ void wave_best(double& bg, uint64_t& bkey, int64_t& blg, int64_t& blh) {
+  dpp_take_better<0x111, 0xF>(bg, bkey, blg, blh);   // row_shr:1
+  dpp_take_better<0x112, 0xF>(bg, bkey, blg, blh);   // row_shr:2
+  dpp_take_better<0x114, 0xF>(bg, bkey, blg, blh);   // row_shr:4
+  dpp_take_better<0x118, 0xF>(bg, bkey, blg, blh);   // row_shr:8: lane 15 of every row holds its row's winner
+  dpp_take_better<0x142, 0xA>(bg, bkey, blg, blh);   // row_bcast:15 into rows 1 and 3
+  dpp_take_better<0x143, 0xC>(bg, bkey, blg, blh);   // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
+  bg = __longlong_as_double(read_lane_i64(__double_as_longlong(bg), 63));
+  bkey = (uint64_t)read_lane_i64((int64_t)bkey, 63);
+  blg = read_lane_i64(blg, 63);
+  blh = read_lane_i64(blh, 63);
+}
+
+// Best split of ONE feature of one leaf from the feature's histogram held by one wave (g, h: bpl bins per lane, see
+// load_feat_cells; overwritten).  Every lane folds ITS candidates of this feature into its own running best; the
+// lanes' bests are combined once per leaf (wave_best), not once per feature.  The per-feature gain adjustment is
 // monotone in the gain, so it may be applied to a lane's best candidate of the feature.
-__device__ __forceinline__ void scan_cells_wave(int f, int lane, int64_t (&g)[4], int64_t (&h)[4], const FeatureMeta m,
+__device__ __forceinline__ void scan_cells_wave(int f, int lane, int bpl, int64_t (&g)[4], int64_t (&h)[4], const FeatureMeta m,
                                                 const LeafScanCtx& ctx, const SplitParams& sp, double& bg, uint64_t& bkey,
                                                 int64_t& blg, int64_t& blh, uint32_t key) {
   const int nb = m.num_bin, mb = m.missing_bin;
@@ -119,41 +168,47 @@ __device__ __forceinline__ void scan_cells_wave(int f, int lane, int64_t (&g)[4]
   double lbg = ninf;
   uint64_t lkey = ~0ull;
   int64_t llg = 0, llh = 0;
-  if (m.categorical) {
-    // one category against the rest: the left child is a single value bin (no prefix sums)
-    const int only_c = extra_trees_threshold(sp, key, f, vb);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int thr = lane * 4 + j;
-      if (thr < vb && (only_c < 0 || thr == only_c))
-        take_better(lbg, lkey, llg, llh, split_gain(g[j], h[j], ctx, sp, 0), cand_key(f, thr, 0), g[j], h[j]);
-    }
-  } else {
-    // stats of the missing-value bin, broadcast from the lane that holds it
-    int64_t mg = 0, mh = 0;
+  const bool cat = m.categorical != 0;
+  // numeric features: thresholds 0 .. last, the left child holds the bins up to the threshold (prefix sums) and - second
+  // candidate per threshold - also the missing-value bin.  Categorical ones: one category against the rest, the left
+  // child is a single value bin.
+  int64_t mg = 0, mh = 0, eg = 0, eh = 0;
+  if (!cat) {
     if (mb >= 0) {
-      const int j = mb & 3;
+      // stats of the missing-value bin, broadcast from the lane that holds it
+      const int ml = mb / bpl, j = mb - ml * bpl;
       int64_t og = j == 0 ? g[0] : j == 1 ? g[1] : j == 2 ? g[2] : g[3];
       int64_t oh = j == 0 ? h[0] : j == 1 ? h[1] : j == 2 ? h[2] : h[3];
-      mg = read_lane_i64(og, mb >> 2);
-      mh = read_lane_i64(oh, mb >> 2);
+      mg = read_lane_i64(og, ml);
+      mh = read_lane_i64(oh, ml);
     }
-    // inclusive prefix inside the lane, exclusive prefix across lanes
+    // inclusive prefix inside the lane, exclusive prefix across lanes (entries beyond bpl are zero)
     g[1] += g[0]; g[2] += g[1]; g[3] += g[2];
     h[1] += h[0]; h[2] += h[1]; h[3] += h[2];
-    const int64_t eg = wave_prefix_sum_i64(g[3]) - g[3], eh = wave_prefix_sum_i64(h[3]) - h[3];
-    const int last = mb >= 0 ? vb - 1 : vb - 2;
-    const int only = extra_trees_threshold(sp, key, f, last + 1);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int thr = lane * 4 + j;
-      if (thr <= last && (only < 0 || thr == only)) {
-        const int64_t lg = eg + g[j], lh = eh + h[j];
-        take_better(lbg, lkey, llg, llh, split_gain(lg, lh, ctx, sp, m.monotone), cand_key(f, thr, 0), lg, lh);
-        if (mb >= 0 && thr <= vb - 2)
-          take_better(lbg, lkey, llg, llh, split_gain(lg + mg, lh + mh, ctx, sp, m.monotone), cand_key(f, thr, 1), lg + mg, lh + mh);
+    eg = wave_prefix_sum_i64(g[3]) - g[3];
+    eh = wave_prefix_sum_i64(h[3]) - h[3];
+  }
+  const int last = cat ? vb - 1 : (mb >= 0 ? vb - 1 : vb - 2);
+  const int only = extra_trees_threshold(sp, key, f, last + 1);
+  const int n_dir = (!cat && mb >= 0) ? 2 : 1;
+  const int mono = cat ? 0 : m.monotone;
+  // ONE copy of the gain arithmetic (it is a few hundred fp64 instructions): the lane's entries pass through entry 0
+  int64_t g0 = g[0], g1 = g[1], g2 = g[2], g3 = g[3], h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3];
+#pragma unroll 1
+  for (int j = 0; j < bpl; ++j) {
+    const int thr = lane * bpl + j;
+    const bool in_range = thr <= last && (only < 0 || thr == only);
+#pragma unroll 1
+    for (int d = 0; d < n_dir; ++d) {
+      const bool valid = in_range && (d == 0 || thr <= vb - 2);
+      if (__any(valid)) {
+        const int64_t lg = eg + g0 + (d ? mg : 0), lh = eh + h0 + (d ? mh : 0);
+        const double gain = valid ? split_gain(lg, lh, ctx, sp, mono) : ninf;
+        if (valid) take_better(lbg, lkey, llg, llh, gain, cand_key(f, thr, d), lg, lh);
       }
     }
+    g0 = g1; g1 = g2; g2 = g3;
+    h0 = h1; h1 = h2; h2 = h3;
   }
   // with a gain adjustment the feature's winner is chosen on the raw gains first, as the host engine does
   if (sp.feature_scale) wave_best(lbg, lkey, llg, llh);
