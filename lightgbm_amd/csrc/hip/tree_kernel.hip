@@ -349,9 +349,10 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     unsigned w0[U][BW];
     // one trip over positions base + u * 512 + tid: all loads first (bins, gradients - and the row ids when the
     // records are kept), then sides and ballots, then the LDS adds
-    auto trip = [&](int base, int seg_hi, bool keep, int (&rid)[U], unsigned long long (&pk)[U], unsigned (&w)[U][BW]) {
+    auto trip = [&](int base, int seg_hi, bool keep, auto& rid, auto& pk, auto& w) {
+      constexpr int N = (int)(sizeof(pk) / sizeof(pk[0]));     // positions per thread and trip
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < N; ++u) {
         const int pos = base + u * kTreeThreads + tid;
         if (pos < seg_hi) {
           load_words<BW>(src_bins + (int64_t)pos * BW, w[u]);
@@ -359,9 +360,9 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
           if (keep) rid[u] = src_idx[pos];
         }
       }
-      bool take[U];
+      bool take[N];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < N; ++u) {
         const int pos = base + u * kTreeThreads + tid;
         bool left = false;
         if (pos < seg_hi) {
@@ -375,7 +376,7 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < N; ++u) {
         if (take[u]) {
           sg += (long long)(int32_t)(pk[u] >> 32);
           sh += (long long)(pk[u] & 0xffffffffull);
@@ -383,15 +384,16 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
         }
       }
     };
+    constexpr int UL = 4;   // (8 positions per thread and trip cost more in spilled registers than the loads in flight gain)
     if (small) {
       trip(0, cnt, true, rid0, pk0, w0);
     } else {
       for (int seg = 0; seg < cnt; seg += kMaxRowsPerPass) {
         const int seg_hi = min(cnt, seg + kMaxRowsPerPass);
-        for (int base = seg; base < seg_hi; base += U * kTreeThreads) {
-          int rid[U];
-          unsigned long long pk[U];
-          unsigned w[U][BW];
+        for (int base = seg; base < seg_hi; base += UL * kTreeThreads) {
+          int rid[UL];
+          unsigned long long pk[UL];
+          unsigned w[UL][BW];
           trip(base, seg_hi, false, rid, pk, w);
         }
         if (multi) {
@@ -525,12 +527,12 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
     lap(4);
     // phase B for larger leaves: move the records - lefts to the front, rights behind, in order
     if (!small) {
-      for (int base = 0; base < cnt; base += U * kTreeThreads) {
-        int rid[U];
-        unsigned long long pk[U];
-        unsigned w[U][BW];
+      for (int base = 0; base < cnt; base += UL * kTreeThreads) {
+        int rid[UL];
+        unsigned long long pk[UL];
+        unsigned w[UL][BW];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UL; ++u) {
           const int pos = base + u * kTreeThreads + tid;
           if (pos < cnt) {
             rid[u] = src_idx[pos];
@@ -539,7 +541,7 @@ __device__ __forceinline__ int grow_one(const TreeArgs& a, const int32_t* __rest
           }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < UL; ++u) {
           const int pos = base + u * kTreeThreads + tid;
           if (pos < cnt) {
             const int wi = pos >> 6;
@@ -615,37 +617,105 @@ __device__ __forceinline__ double leaf_value_of(const SplitInfo& ps, bool is_lef
 }
 
 // Writes a grown tree's result block (everything but the completion flag).  boost: also work out the leaves' outputs
-// (S.nvalue) and add them to the training scores of the leaves' rows.
+// (S.nvalue) and add them to the training scores of the leaves' rows.  The leaves' rows are visited as ONE flat range
+// of arena positions (their ranges tile [0, bag_n)), every thread several positions per trip with all loads of a
+// trip in flight - a leaf-by-leaf walk would be a chain of dependent row-id -> gradient loads per leaf.
+// scratch: at least 3 * kNodeCap 8-byte words of LDS nobody else uses during the call (the histogram).
 template <bool BOOST>
 __device__ __forceinline__ void tree_handover(const TreeArgs& a, char* out, int n_splits, int kg, int kh, int bag_n,
-                                              const SplitParams& sp, double learning_rate, double* scores, TreeShared& S) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                              const SplitParams& sp, double learning_rate, double* scores, TreeShared& S,
+                                              unsigned long long* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const int n_nodes = 2 * n_splits + 1;
   TreeHeader* hd = reinterpret_cast<TreeHeader*>(out);
   int64_t* wide = reinterpret_cast<int64_t*>(out + a.lay.off_wide);
   if (a.renew || BOOST) {
-    // 36-bit sums of the float gradients over every final leaf's rows: one wave per leaf at a time
-    const int wkg = kg + kWideExtraBits, wkh = kh + kWideExtraBits;
-    for (int node = wave; node < n_nodes; node += kTreeWaves) {
-      if (S.nsplit[node]) continue;
-      const int32_t* rows = a.idx[S.nbuf[node]] + S.nbegin[node];
-      const int cnt = S.ncount[node];
-      long long wg = 0, wh = 0;
-      if (a.renew) {
-        for (int i = lane; i < cnt; i += kWave) {
-          const int32_t r = rows[i];
-          wg += quantize_wide(a.g[r], wkg);
-          wh += quantize_wide(a.h[r], wkh);
-        }
-        wg = wave_sum_i64(wg);
-        wh = wave_sum_i64(wh);
-        if (lane == 0) { wide[2 * node] = wg; wide[2 * node + 1] = wh; }
+    unsigned long long* acc = scratch;                                   // [node][2]: 36-bit sums
+    int* lbegin = reinterpret_cast<int*>(scratch + 2 * kNodeCap);        // non-empty final leaves sorted by range begin
+    short* lnode = reinterpret_cast<short*>(lbegin + kNodeCap);
+    __shared__ int n_live;
+    if (tid == 0) n_live = 0;
+    for (int i = tid; i < 2 * n_nodes; i += kTreeThreads) acc[i] = 0ull;
+    __syncthreads();
+    for (int node = tid; node < n_nodes; node += kTreeThreads) {
+      if (S.nsplit[node] || S.ncount[node] == 0) continue;
+      const int b = S.nbegin[node];
+      int rank = 0;
+      for (int o = 0; o < n_nodes; ++o) rank += (!S.nsplit[o] && S.ncount[o] > 0 && S.nbegin[o] < b) ? 1 : 0;
+      lbegin[rank] = b;
+      lnode[rank] = (short)node;
+      atomicAdd(&n_live, 1);
+    }
+    __syncthreads();
+    const int live = n_live;
+    auto leaf_of = [&](int p) {      // the last live leaf whose range begins at or before p
+      int lo = 0, hi = live - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lbegin[mid] <= p) lo = mid; else hi = mid - 1;
       }
+      return (int)lnode[lo];
+    };
+    constexpr int U = 4;
+    if (a.renew) {
+      const int wkg = kg + kWideExtraBits, wkh = kh + kWideExtraBits;
+      for (int p0 = tid; p0 < bag_n; p0 += U * kTreeThreads) {
+        int node[U], r[U];
+        float gv[U], hv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int p = p0 + u * kTreeThreads;
+          node[u] = p < bag_n ? leaf_of(p) : -1;
+          if (node[u] >= 0) r[u] = a.idx[S.nbuf[node[u]]][p];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (node[u] >= 0) { gv[u] = a.g[r[u]]; hv[u] = a.h[r[u]]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // a wave's 64 positions mostly lie in one leaf: one add per wave then
+          long long wg = node[u] >= 0 ? quantize_wide(gv[u], wkg) : 0, wh = node[u] >= 0 ? quantize_wide(hv[u], wkh) : 0;
+          const int first = __builtin_amdgcn_readfirstlane(node[u]);
+          if (__all(node[u] == first)) {
+            if (first >= 0) {
+              wg = wave_sum_i64(wg);
+              wh = wave_sum_i64(wh);
+              if (lane == 0) { atomicAdd(&acc[2 * first], (unsigned long long)wg); atomicAdd(&acc[2 * first + 1], (unsigned long long)wh); }
+            }
+          } else if (node[u] >= 0) {
+            atomicAdd(&acc[2 * node[u]], (unsigned long long)wg);
+            atomicAdd(&acc[2 * node[u] + 1], (unsigned long long)wh);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    for (int node = tid; node < n_nodes; node += kTreeThreads) {
+      if (S.nsplit[node]) continue;
+      const long long wg = (long long)acc[2 * node], wh = (long long)acc[2 * node + 1];
+      if (a.renew) { wide[2 * node] = wg; wide[2 * node + 1] = wh; }
       if (BOOST && n_splits > 0) {
         const int p = S.nparent[node];
-        const double v = leaf_value_of(a.best[p], S.nleft[p] == node, wg, wh, a.renew != 0, kg, kh, sp, learning_rate);
-        if (lane == 0) S.nvalue[node] = v;
-        for (int i = lane; i < cnt; i += kWave) scores[rows[i]] += v;
+        S.nvalue[node] = leaf_value_of(a.best[p], S.nleft[p] == node, wg, wh, a.renew != 0, kg, kh, sp, learning_rate);
+      }
+    }
+    if (BOOST && n_splits > 0) {
+      __syncthreads();
+      for (int p0 = tid; p0 < bag_n; p0 += U * kTreeThreads) {
+        int node[U], r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int p = p0 + u * kTreeThreads;
+          node[u] = p < bag_n ? leaf_of(p) : -1;
+          if (node[u] >= 0) r[u] = a.idx[S.nbuf[node[u]]][p];
+        }
+        double sc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (node[u] >= 0) sc[u] = scores[r[u]];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (node[u] >= 0) scores[r[u]] = sc[u] + S.nvalue[node[u]];
       }
     }
   }
@@ -666,6 +736,45 @@ __device__ __forceinline__ void tree_handover(const TreeArgs& a, char* out, int 
   }
 }
 
+// Adds the tree in S to the scores of rows[first .. n) (rows == nullptr: the rows themselves) by walking it over a
+// feature-major bin matrix; four rows per thread walk together so that their bin reads overlap.
+__device__ __forceinline__ void walk_add(const TreeShared& S, const uint8_t* __restrict__ bins_fm, int64_t N,
+                                         const int32_t* __restrict__ rows, int first, int n, double* __restrict__ scores) {
+  constexpr int U = 4;
+  for (int i0 = first + (int)threadIdx.x; i0 < n; i0 += U * kTreeThreads) {
+    int64_t r[U];
+    int node[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * kTreeThreads;
+      r[u] = i < n ? (rows ? (int64_t)rows[i] : (int64_t)i) : -1;
+      node[u] = 0;
+    }
+    bool any = true;
+    while (any) {
+      any = false;
+      int b[U], d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        d[u] = (r[u] >= 0 && S.nsplit[node[u]]) ? S.ndec[node[u]] : -1;
+        if (d[u] >= 0) b[u] = bins_fm[(int64_t)(d[u] & 255) * N + r[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (d[u] >= 0) {
+          const int thr = (d[u] >> 8) & 255, mb = (d[u] >> 18) - 1;
+          const bool left = (d[u] & (1 << 17)) ? (b[u] == thr) : ((b[u] == mb) ? ((d[u] >> 16) & 1) != 0 : (b[u] <= thr));
+          node[u] = left ? S.nleft[node[u]] : S.nleft[node[u]] + 1;
+          any = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (r[u] >= 0) scores[r[u]] += S.nvalue[node[u]];
+  }
+}
+
 // One tree per workgroup.
 template <int BW>
 __device__ __forceinline__ void tree_one(const TreeArgs& a, unsigned long long* lds, TreeShared& S) {
@@ -675,7 +784,7 @@ __device__ __forceinline__ void tree_one(const TreeArgs& a, unsigned long long* 
   if (tid < 8) S.ticks[tid] = 0;
   const long long c0 = a.timing ? (long long)clock64() : 0;
   const int n_splits = grow_one<BW>(a, a.bag, a.n, ~0u, a.sp, kg, kh, lds, S);
-  tree_handover<false>(a, a.out, n_splits, kg, kh, a.n, a.sp, 1.0, nullptr, S);
+  tree_handover<false>(a, a.out, n_splits, kg, kh, a.n, a.sp, 1.0, nullptr, S, lds);
   TreeHeader* hd = reinterpret_cast<TreeHeader*>(a.out);
   if (a.timing && tid == 0) {
     S.ticks[7] += (long long)wall_clock64() - S.t_mark;
@@ -685,19 +794,6 @@ __device__ __forceinline__ void tree_one(const TreeArgs& a, unsigned long long* 
   __threadfence_system();
   __syncthreads();
   if (tid == 0) *reinterpret_cast<volatile unsigned*>(&hd->flag) = a.seq;
-}
-
-// Walks the tree in S over one row of a feature-major bin matrix; returns the final leaf's node.
-__device__ __forceinline__ int walk_tree(const TreeShared& S, const uint8_t* __restrict__ bins_fm, int64_t N, int64_t r) {
-  int node = 0;
-  while (S.nsplit[node]) {
-    const int d = S.ndec[node];
-    const int b = bins_fm[(int64_t)(d & 255) * N + r];
-    const int thr = (d >> 8) & 255, mb = (d >> 18) - 1;
-    const bool left = (d & (1 << 17)) ? (b == thr) : ((b == mb) ? ((d >> 16) & 1) != 0 : (b <= thr));
-    node = left ? S.nleft[node] : S.nleft[node] + 1;
-  }
-  return node;
 }
 
 // A chunk of boosting iterations of one booster (kernels.hpp: BoostArgs).
@@ -794,19 +890,13 @@ __device__ __forceinline__ void boost_one(const BoostArgs& b, unsigned long long
       __syncthreads();
     }
     // ---- leaf outputs, in-bag scores, result block ----
-    tree_handover<true>(a, out, n_splits, kg, kh, bag_n, sp, b.learning_rate, b.scores, S);
+    tree_handover<true>(a, out, n_splits, kg, kh, bag_n, sp, b.learning_rate, b.scores, S, lds);
     __syncthreads();
     TreeHeader* hd = reinterpret_cast<TreeHeader*>(out);
     if (n_splits > 0) {
       // out-of-bag training rows and the validation rows walk the tree
-      for (int i = bag_n + tid; i < n_base; i += kTreeThreads) {
-        const int32_t r = bag[i];
-        b.scores[r] += S.nvalue[walk_tree(S, b.bins_fm, b.N, r)];
-      }
-      for (int i = tid; i < b.n_valid; i += kTreeThreads) {
-        const int64_t r = b.valid_rows ? (int64_t)b.valid_rows[i] : (int64_t)i;
-        b.valid_scores[r] += S.nvalue[walk_tree(S, b.valid_bins_fm, b.valid_N, r)];
-      }
+      walk_add(S, b.bins_fm, b.N, bag, bag_n, n_base, b.scores);
+      walk_add(S, b.valid_bins_fm, b.valid_N, b.valid_rows, 0, b.n_valid, b.valid_scores);
     }
     __syncthreads();
     // ---- metric sums over the validation rows, in the order of metric_sum_kernel: virtual workgroups of 256
