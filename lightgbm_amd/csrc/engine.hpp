@@ -111,6 +111,10 @@ class Engine {
   // device build that still has to be launched: launch_prepared_trees starts the prepared builds of a group of
   // engines with as few launches as possible.  train_tree_finish returns the tree (and grows it itself when
   // nothing was prepared).
+  // How many boosters are advanced together with this one (Booster::update_group); 1 = alone.  A device engine
+  // grows the trees of a small booster with ONE workgroup only in company: alone, batched growth rounds over the
+  // whole device are faster.
+  virtual void set_group_size(int n) { (void)n; }
   virtual bool train_tree_begin(const std::vector<FeatureMeta>& meta) { pending_meta_ = meta; return false; }
   virtual Tree train_tree_finish() { return train_tree(pending_meta_); }
   // Called on one engine of the group with all engines whose train_tree_begin returned true (itself included).

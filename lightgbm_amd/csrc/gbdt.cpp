@@ -317,6 +317,7 @@ void Booster::eval_host_metrics(int which, std::vector<EvalResult>* out) {
 bool Booster::update_one_iter() {
   if (!engine_) throw std::runtime_error("update on a prediction-only booster");
   if (obj_.kind == kObjCustom) throw std::runtime_error("objective=custom needs gradients (fobj)");
+  engine_->set_group_size(1);
   ensure_scores();
   if (is_dart_) dart_drop();
   if (!is_rf_) compute_gradients();
@@ -349,7 +350,10 @@ bool Booster::update_begin() {
 }
 
 bool Booster::update_finish() {
-  if (!two_step_) return update_one_iter();
+  if (!two_step_) {
+    // (update_one_iter announces a group of one: keep the size the group set)
+    return update_one_iter();
+  }
   two_step_ = false;
   Tree tree = engine_->train_tree_finish();
   renew_leaf_values_exact(tree);
@@ -361,8 +365,10 @@ bool Booster::update_finish() {
 
 void Booster::update_group(Booster* const* boosters, int n, int* finished) {
   std::vector<Engine*> prepared;
-  for (int i = 0; i < n; ++i)
+  for (int i = 0; i < n; ++i) {
+    if (boosters[i]->engine_) boosters[i]->engine_->set_group_size(n);
     if (boosters[i]->update_begin()) prepared.push_back(boosters[i]->engine_.get());
+  }
   if (!prepared.empty()) prepared[0]->launch_prepared_trees(prepared.data(), (int)prepared.size());
   for (int i = 0; i < n; ++i) finished[i] = boosters[i]->update_finish() ? 1 : 0;
 }
@@ -486,7 +492,10 @@ int Booster::update_group_chunk(Booster* const* boosters, int n, int n_iters, bo
   for (size_t i = 0; i < (size_t)n * (size_t)std::max(n_iters, 0); ++i) finished[i] = 0;
   if (n_iters < 1 || n < 1) return 0;
   bool chunked = true;
-  for (int i = 0; i < n; ++i) chunked = chunked && boosters[i]->chunk_eligible(eval_valid);
+  for (int i = 0; i < n; ++i) {
+    if (boosters[i]->engine_) boosters[i]->engine_->set_group_size(n);
+    chunked = chunked && boosters[i]->chunk_eligible(eval_valid);
+  }
   if (chunked) {
     std::vector<Engine*> engines;
     int prepared = 0;

@@ -207,6 +207,8 @@ class HipBackend : public TreeBackend {
     if (const char* e = std::getenv("LGA_TREE_KERNEL_ROWS"))
       tree_kernel_rows_ = std::max<int64_t>(0, std::min<int64_t>(k::kTreeMaxRows, std::atoll(e)));
     tree_kernel_on_ = tree_kernel_rows_ > 0;
+    // an explicit whole_tree_max_rows asks for the one-workgroup builds also for a booster that trains alone
+    tree_kernel_forced_ = tree_kernel_on_ && std::find(cfg.explicit_keys.begin(), cfg.explicit_keys.end(), "whole_tree_max_rows") != cfg.explicit_keys.end();
     tree_renew_ = cfg.quant_train_renew_leaf ? 1 : 0;
     const size_t n_scan_max = (size_t)(2 * max_batch_ + 2);
     for (int c = 0; c < n_ctx_; ++c) {
@@ -385,8 +387,9 @@ class HipBackend : public TreeBackend {
   // ---- whole tree in one launch (kernels.hpp: TreeArgs): small bags on one device, plain numeric / one-vs-rest
   // categorical features of one tile ----
   // What does not depend on the tree: the learner, the data layout, the row and leaf limits.
+  void set_in_company(bool yes) { in_company_ = yes; }
   bool tree_kernel_possible(int64_t rows, int max_splits) const {
-    if (!tree_kernel_on_ || mode_ != ParallelMode::Serial || T_ != 1 || F_ < 1 || prof.on) return false;
+    if (!tree_kernel_on_ || !(in_company_ || tree_kernel_forced_) || mode_ != ParallelMode::Serial || T_ != 1 || F_ < 1 || prof.on) return false;
     return rows >= 1 && rows <= tree_kernel_rows_ && max_splits >= 1 && max_splits <= k::kTreeMaxSplits;
   }
   // Descriptor of a build over the current bag; `out_dev` is the device address of its host-mapped result block.
@@ -1058,6 +1061,8 @@ class HipBackend : public TreeBackend {
   k::FusedQuant root_quant_{};
   // whole-tree kernel (kernels.hpp: TreeArgs)
   bool tree_kernel_on_ = true;
+  bool tree_kernel_forced_ = false;   // whole_tree_max_rows was given explicitly
+  bool in_company_ = false;           // the booster is advanced together with others (Engine::set_group_size)
   int64_t tree_kernel_rows_ = k::kTreeMaxRows;
   DeviceBuffer<unsigned long long> rec_gh_[2];
   DeviceBuffer<uint32_t> rec_bins_[2];
@@ -1430,6 +1435,7 @@ class HipEngine : public Engine {
 
   void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
   void update_split_config(const Config& c) override { grower_.update_split_config(c); }
+  void set_group_size(int n) override { backend_->set_in_company(n >= 2); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     train_tree_begin(meta);
     return train_tree_finish();

@@ -113,12 +113,15 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
     need_eval = bool(booster.valid_sets) or is_valid_contain_train
     booster.best_iteration = 0
     evaluation_result_list: List[Tuple] = []
-    # Small data on the HIP engine: whole chunks of iterations run on the device without Python - or the host - in
+    # Small data on the HIP engine CAN run whole chunks of iterations on the device without Python - or the host - in
     # between (Booster.update_group); the callbacks are replayed over a chunk's evaluation results and iterations
-    # trained beyond an early stop are rolled back, so the model is the plain loop's.
+    # trained beyond an early stop are rolled back, so the model is the plain loop's.  That path is one workgroup per
+    # booster - made for many boosters at once (cv, grid search); a booster that trains alone is faster with growth
+    # rounds over the whole device, so train() takes it only when whole_tree_max_rows is given explicitly.
     from . import _lib
     chunk = 0
-    if (_lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host") and comm is None
+    if (get_param(params, "whole_tree_max_rows") is not None and int(get_param(params, "whole_tree_max_rows")) > 0 and
+            _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host") and comm is None
             and fobj is None and feval is None and not cb_before and snapshot_freq <= 0 and not is_valid_contain_train
             and len(booster.valid_sets) <= 1 and train_set.num_data() <= 65536):
         chunk = 10 if need_eval else 50

@@ -273,10 +273,15 @@ def test_whole_tree_kernel_grows_the_cpu_trees(n, F, leaves, extra):
     cat = [F - 1] if F == 9 else "auto"
     p = {"num_leaves": leaves, "min_data_in_leaf": 5, "max_cat_to_onehot": 64, **extra}
     a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU, categorical_feature=cat), 10)
-    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat), 10, keep_training_booster=True)
+    b = lgb.train({**GPU, **p, "whole_tree_max_rows": 65536}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat), 10,
+                  keep_training_booster=True)
     c = lgb.train({**GPU, **p, "whole_tree_max_rows": 0}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat), 10,
                   keep_training_booster=True)
-    assert b.grow_stats()["rounds"] == 1 and c.grow_stats()["rounds"] > 1
+    assert b.profile()["chunk_iterations"] == 10 and c.profile()["chunk_iterations"] == 0 and c.grow_stats()["rounds"] > 1
+    d = lgb.Booster({**GPU, **p, "whole_tree_max_rows": 65536}, lgb.Dataset(X, label=y, params=GPU, categorical_feature=cat))
+    for _ in range(10):
+        d.update()                      # one whole-tree launch per iteration, the host in between
+    assert d.profile()["whole_trees"] == 10 and d.grow_stats()["rounds"] == 1 and trees_of(d) == trees_of(a)
     assert trees_of(a) == trees_of(b) == trees_of(c)
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
 
@@ -311,7 +316,7 @@ def test_boosting_chunks_on_the_device_equal_the_step_by_step_paths(case):
         p = {"objective": "poisson", "num_leaves": 20, "learning_rate": 0.1, "metric": "poisson", "min_data_in_leaf": 30}
     n_tr = len(y) * 4 // 5
     runs = {}
-    for tag, extra in (("cpu", CPU), ("chunks", GPU), ("steps", {**GPU, "whole_tree_max_rows": 0})):
+    for tag, extra in (("cpu", CPU), ("chunks", {**GPU, "whole_tree_max_rows": 65536}), ("steps", {**GPU, "whole_tree_max_rows": 0})):
         pp = {**extra, **p}
         dtr = lgb.Dataset(X[:n_tr], label=y[:n_tr], weight=None if w is None else w[:n_tr], params=pp)
         dva = dtr.create_valid(X[n_tr:], label=y[n_tr:], weight=None if w is None else w[n_tr:])

@@ -70,7 +70,7 @@ NOTES = {
     "input_model": "CLI: model file read by `task=predict` / continued training",
     "num_machines": "informational; the communicator defines the world",
     "gpu_device_id": "informational; the current torch device is used",
-    "whole_tree_max_rows": "device engine: a tree over at most this many in-bag rows (<= 65536) is grown by ONE workgroup in one launch - the whole best-first loop on the device, no host round trips - so many small boosters (CV folds, grid rows) run side by side; 0 grows every tree in batched rounds",
+    "whole_tree_max_rows": "device engine: a tree over at most this many in-bag rows (<= 65536) is grown by ONE workgroup in one launch - the whole best-first loop on the device, no host round trips - so many small boosters (CV folds, grid rows) run side by side, whole chunks of iterations without the host; taken when several boosters are advanced together (cv, grid_search_cv, Booster.update_group) or when this parameter is given explicitly - a booster training alone is faster with batched rounds over the whole device; 0 grows every tree in batched rounds",
     "max_batch_leaves": "leaves split per device round (0: as many as the speculative growth wants; 1 reproduces one-leaf-at-a-time growth)",
     "profile": "per-phase HIP-event timers, read with `Booster.profile()`",
     "device_bin_find": "find bin boundaries on the device for GPU datasets (default on)",

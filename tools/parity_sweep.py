@@ -118,6 +118,8 @@ def run_case(seed: int, max_rows: int):
         base = {"device_type": dev.split("-")[0], "verbose": -1}
         if dev == "gpu-rounds":
             base["whole_tree_max_rows"] = 0
+        elif dev == "gpu" and rows <= 65536:
+            base["whole_tree_max_rows"] = 65536      # explicit: also a booster that trains alone takes that path
         cats = [F - 2 if F > 1 else 0] if opts.get("categorical") else "auto"
         dp = {**base, "max_bin": p["max_bin"], "zero_as_missing": p.get("zero_as_missing", False)}
         d = lgb.Dataset(X, label=y, weight=w, params=dp, categorical_feature=cats)

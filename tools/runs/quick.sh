@@ -19,3 +19,4 @@ def table(p):
     return {r["row"]: (r["iteration"], r["score"]) for r in map(json.loads, open(p))}
 print("table == batched-rounds table:", table("/tmp/pg.jsonl") == table(root + "/profiles/r2/grid_full_table_rounds_path.jsonl"))
 PY
+cd $ROOT && timeout -k 10 200 python -u tools/runs/train_modes.py 2>/dev/null | tee "$OUT/train_modes.jsonl"
