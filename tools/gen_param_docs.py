@@ -71,6 +71,30 @@ NOTES = {
     "num_machines": "informational; the communicator defines the world",
     "gpu_device_id": "informational; the current torch device is used",
     "whole_tree_max_rows": "device engine: a tree over at most this many in-bag rows (<= 65536) is grown by ONE workgroup in one launch - the whole best-first loop on the device, no host round trips - so many small boosters (CV folds, grid rows) run side by side, whole chunks of iterations without the host; taken when several boosters are advanced together (cv, grid_search_cv, Booster.update_group) or when this parameter is given explicitly - a booster training alone is faster with batched rounds over the whole device; 0 grows every tree in batched rounds",
+    "pos_bagging_fraction": "binary objective: share of the positive rows kept by balanced bagging (with neg_bagging_fraction; needs bagging_freq > 0)",
+    "neg_bagging_fraction": "binary objective: share of the negative rows kept by balanced bagging",
+    "max_cat_to_onehot": "a categorical feature with at most this many categories is split one category against the rest (on the device); above it, sets of categories sorted by gradient statistics are searched",
+    "cat_smooth": "category-set search: smoothing added to a category's hessian sum before sorting by g / h",
+    "cat_l2": "extra L2 regularisation of a split on a category set",
+    "max_cat_threshold": "category-set search: most categories a set may hold",
+    "min_data_per_group": "category-set search: fewest rows of a category group",
+    "feature_contri": "per feature (raw column order): factor on the gain of its splits",
+    "cegb_tradeoff": "cost-effective gradient boosting: factor on all penalties",
+    "cegb_penalty_split": "cost-effective gradient boosting: penalty per split, times the rows of the leaf",
+    "cegb_penalty_feature_coupled": "cost-effective gradient boosting: per feature, a penalty paid by the first split on that feature in the whole model",
+    "cegb_penalty_feature_lazy": "the per-row lazy penalty is not implemented: a list with a non-zero entry is refused",
+    "use_quantized_grad": "true: 16-bit fixed-point gradient histograms (the device engine's only form; bit-identical on both engines); false: CPU engine only, 36-bit gradient histograms - the full-precision reference the AUC parity record is measured against",
+    "quant_train_renew_leaf": "leaf values are recomputed from exact 36-bit sums of the float gradients of each leaf's rows (both engines; off: the values the 16-bit search produced)",
+    "path_smooth": "> 0: a child's output is pulled towards its parent's, the more so the fewer rows it holds",
+    "interaction_constraints": "groups of raw column indices, e.g. [0,1,2],[2,3]: a branch may only combine features of one group",
+    "max_bin_by_feature": "per raw column: its own max_bin",
+    "lambdarank_truncation_level": "lambdarank: only pairs with a document in the top-k of the current ranking contribute",
+    "lambdarank_norm": "lambdarank: normalise a query's gradients by the sum of its pair weights",
+    "label_gain": "ranking: gain of each integer relevance grade (default 2^grade - 1)",
+    "objective_seed": "rank_xendcg: seed of the per-iteration noise",
+    "eval_at": "ndcg / map cut-offs (alias ndcg_eval_at)",
+    "label_column": "command line, text data files: index of the label column",
+    "header": "command line, text data files: the first line holds column names",
     "max_batch_leaves": "leaves split per device round (0: as many as the speculative growth wants; 1 reproduces one-leaf-at-a-time growth)",
     "profile": "per-phase HIP-event timers, read with `Booster.profile()`",
     "device_bin_find": "find bin boundaries on the device for GPU datasets (default on)",
