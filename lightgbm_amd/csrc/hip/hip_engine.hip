@@ -1456,6 +1456,7 @@ class HipEngine : public Engine {
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
     tree_begun_ = true;
+    leaf_ids_valid_ = false;
     const bool prepared = grower_.grow_begin(*backend_, pending_meta_);
     trace_pop();
     return prepared;
@@ -1643,6 +1644,14 @@ class HipEngine : public Engine {
   void add_trained_tree_to_train_scores(const Tree& tree) override {
     TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
+    if (leaf_ids_valid_ && leaf_ids_leaves_ == tree.num_leaves) {
+      // the leaf of every row is known from the walk that took the leaf sums: the tree's structure has not changed
+      // since, only its leaf values
+      leaf_ids_valid_ = false;
+      const TreeOnDevice td = upload_tree(tree);
+      k::leaf_value_add(leaf_of_row_.get(), td.leaf_value, td.num_leaves, base_or_null(), n_base_, sc(), stream_);
+      return;
+    }
     if (walk) {
       traverse(upload_tree(tree), mir_, N_, base_or_null(), n_base_, 1.0, sc());
       return;
@@ -1806,10 +1815,26 @@ class HipEngine : public Engine {
         return;
       }
     }
-    const int n_spans = upload_spans(nullptr);
     leaf_acc_.resize((size_t)2 * (size_t)L);
-    k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
-                 backend_->qs_device(), leaf_acc_.get(), stream_);
+    // Large data with every row in the bag: one walk over the rows in storage order yields the sums AND every row's
+    // leaf, which turns the score update that follows into a lookup (add_trained_tree_to_train_scores).
+    leaf_ids_valid_ = false;
+    bool walked = false;
+    // (a walk costs one dependent bin read per level; LGA_WALK_DEPTH caps the row-weighted mean leaf depth it is taken for)
+    if (score_update_ != 1 && n_base_ >= kWalkMinRows && oob_n_ == 0 && bag_n_ == n_base_ && L > 1 &&
+        !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_) {
+      const TreeOnDevice td = upload_tree(tree);
+      leaf_of_row_.resize((size_t)N_);
+      walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(), N_, base_or_null(), n_base_, gr(), he(),
+                              backend_->qs_device(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
+      leaf_ids_valid_ = walked;
+      leaf_ids_leaves_ = L;
+    }
+    if (!walked) {
+      const int n_spans = upload_spans(nullptr);
+      k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
+                   backend_->qs_device(), leaf_acc_.get(), stream_);
+    }
     sums->assign((size_t)2 * (size_t)L, 0);
     LGA_HIP_CHECK(hipMemcpyAsync(sums->data(), leaf_acc_.get(), sizeof(int64_t) * 2 * (size_t)L, hipMemcpyDeviceToHost, stream_));
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
@@ -1870,6 +1895,21 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipMemcpyAsync(span_dev_.get(), span_host_.get(), sizeof(k::LeafSpan) * (size_t)L, hipMemcpyHostToDevice, stream_));
     mark_upload();
     return L;
+  }
+
+  // Mean depth of the leaves, weighted by their row counts.
+  static double mean_leaf_depth(const Tree& tree) {
+    const int L = tree.num_leaves;
+    if (L <= 1) return 0.0;
+    std::vector<int> depth((size_t)(L - 1), 0);
+    double sum = 0.0, rows = 0.0;
+    for (int i = 0; i < L - 1; ++i) {      // children are created after their parents: a node's depth is known when it is reached
+      for (int c : {tree.left_child[(size_t)i], tree.right_child[(size_t)i]}) {
+        if (c >= 0) depth[(size_t)c] = depth[(size_t)i] + 1;
+        else { sum += (double)(depth[(size_t)i] + 1) * (double)tree.leaf_count[(size_t)~c]; rows += (double)tree.leaf_count[(size_t)~c]; }
+      }
+    }
+    return rows > 0.0 ? sum / rows : 0.0;
   }
 
   void debug_check() {
@@ -1974,6 +2014,10 @@ class HipEngine : public Engine {
   DeviceBuffer<double> metric_gain_, metric_disc_;
   size_t metric_disc_len_ = 0;
   DeviceBuffer<int64_t> packed_, leaf_acc_;
+  DeviceBuffer<uint16_t> leaf_of_row_;   // leaf of every root row as the last walk for leaf sums left it
+  bool leaf_ids_valid_ = false;
+  int leaf_ids_leaves_ = 0;
+  double walk_max_depth_ = std::getenv("LGA_WALK_DEPTH") ? std::atof(std::getenv("LGA_WALK_DEPTH")) : 1e9;   // measured: never worse than the per-leaf row lists
   DeviceBuffer<uint32_t> maxbits_, select_scratch_;
   DeviceBuffer<k::LeafSpan> span_dev_;
   DeviceBuffer<uint64_t> sort_keys_;

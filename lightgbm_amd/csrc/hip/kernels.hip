@@ -1151,6 +1151,67 @@ __global__ __launch_bounds__(256) void traverse_add_kernel(const TreeNodeDev* __
   }
 }
 
+// Leaf of every row + exact leaf sums in ONE walk over the binned rows in storage order (large data without
+// out-of-bag rows): leaf_of_row[r] = the leaf row r ends in, acc[2 * leaf] / acc[2 * leaf + 1] += the 36-bit
+// fixed-point gradient / hessian of the row (quantize_wide, exponents qs + kWideExtraBits).  A workgroup sums in LDS
+// and adds its non-zero cells to global memory once.  The score update then is a coalesced lookup
+// (leaf_value_add_kernel) instead of a second walk, and the sums cost no scattered pass over the leaves' row lists.
+__global__ __launch_bounds__(256) void walk_leaves_kernel(const TreeNodeDev* __restrict__ nodes, int n_internal, int num_leaves,
+                                                          const uint8_t* __restrict__ bins_fm, int64_t N,
+                                                          const int32_t* __restrict__ rows, int64_t n,
+                                                          const float* __restrict__ g, const float* __restrict__ h,
+                                                          const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                          unsigned long long* __restrict__ acc,
+                                                          const uint64_t* __restrict__ node_sets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int4* sn = reinterpret_cast<int4*>(smem);
+  unsigned long long* sacc = reinterpret_cast<unsigned long long*>(smem + (size_t)n_internal * sizeof(TreeNodeDev));
+  const int4* gn = reinterpret_cast<const int4*>(nodes);
+  for (int i = threadIdx.x; i < n_internal; i += blockDim.x) sn[i] = gn[i];
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
+  __syncthreads();
+  const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
+  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    if (!LGA_DEV_CHECK((unsigned long long)r < (unsigned long long)N, kCheckWalkRow, r, N)) continue;
+    const float gv = g[r], hv = h[r];
+    int node = num_leaves <= 1 ? ~0 : 0;
+    while (node >= 0) {
+      const TreeNodeDev t = tn[node];
+      const int b = bins_fm[(int64_t)t.feature * N + r];
+      const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
+      const bool left = (t.meta & 1024) ? ((node_sets[(int64_t)node * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull) != 0
+                        : (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
+      node = left ? t.left : t.right;
+      if (!LGA_DEV_CHECK(node < n_internal && ~node < num_leaves, kCheckWalkNode, node, n_internal)) break;
+    }
+    if (node < 0) {
+      const int leaf = ~node;
+      leaf_of_row[r] = (uint16_t)leaf;
+      atomicAdd(&sacc[2 * leaf], (unsigned long long)quantize_wide(gv, kg));
+      atomicAdd(&sacc[2 * leaf + 1], (unsigned long long)quantize_wide(hv, kh));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x)
+    if (sacc[i] != 0ull) atomicAdd(&acc[i], sacc[i]);
+}
+
+__global__ __launch_bounds__(256) void leaf_value_add_kernel(const uint16_t* __restrict__ leaf_of_row,
+                                                             const double* __restrict__ leaf_value, int num_leaves,
+                                                             const int32_t* __restrict__ rows, int64_t n,
+                                                             double* __restrict__ scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lv = reinterpret_cast<double*>(smem);
+  for (int i = threadIdx.x; i < num_leaves; i += blockDim.x) lv[i] = leaf_value[i];
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = rows ? rows[i] : i;
+    scores[r] += lv[leaf_of_row[r]];
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(double* __restrict__ scores, const int32_t* __restrict__ rows,
                                                         int64_t n, double scale, double add) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1530,6 +1591,27 @@ void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double
   if (n_leaves <= 0) return;
   hipLaunchKernelGGL(leaf_percentiles_kernel, dim3((n_leaves + 255) / 256), dim3(256), 0, s, keys, n_rows, n_leaves,
                      alpha, values, counts);
+  LGA_LAUNCH_CHECK();
+}
+
+bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, int64_t N,
+                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
+                 int64_t* acc, const uint64_t* node_sets, hipStream_t s) {
+  const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)2 * (size_t)num_leaves * sizeof(unsigned long long);
+  if (sm > 48 * 1024 || num_leaves > 65535) return false;   // the caller takes the per-leaf row lists instead
+  LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)num_leaves, s));
+  if (n <= 0) return true;
+  hipLaunchKernelGGL(walk_leaves_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), sm, s, nodes, n_internal, num_leaves, bins_fm, N,
+                     rows, n, g, h, qs, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
+  LGA_LAUNCH_CHECK();
+  return true;
+}
+
+void leaf_value_add(const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves, const int32_t* rows, int64_t n,
+                    double* scores, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(leaf_value_add_kernel, dim3(grid_for(n, 256)), dim3(256), (size_t)num_leaves * sizeof(double), s, leaf_of_row,
+                     leaf_value, num_leaves, rows, n, scores);
   LGA_LAUNCH_CHECK();
 }
 

@@ -349,6 +349,14 @@ void residual_items(const LeafSpan* spans, int n_spans, const int32_t* a0, const
 void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
                   const uint8_t* bins_fm, int64_t N, const int32_t* rows, int64_t n, double sign, double* scores,
                   const uint64_t* node_sets, hipStream_t s);
+// Large data, every row in the bag: one walk in storage order gives every row's leaf (leaf_of_row, indexed by root row)
+// and the leaves' 36-bit gradient sums (acc as for leaf_sums); leaf_value_add then updates the scores by lookup.
+// walk_leaves returns false when the tree does not fit the kernel's LDS (nothing launched).
+bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, int64_t N,
+                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
+                 int64_t* acc, const uint64_t* node_sets, hipStream_t s);
+void leaf_value_add(const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves, const int32_t* rows, int64_t n,
+                    double* scores, hipStream_t s);
 // node_sets: kCatSetWords words per internal node, read for nodes whose meta has bit 10 set (a categorical
 // split on a set of bins); may be null when the tree has none.
 // items: n_items x (slot, feature); out: n_items x 2 x kMaxBins (gradient row, hessian row).
