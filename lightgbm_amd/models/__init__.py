@@ -1,5 +1,4 @@
-"""Model-level objects: the tree-ensemble file format as NumPy arrays, and the two model families."""
+"""Model-level objects: the tree-ensemble file format as NumPy arrays (an independent reader of the text model)."""
 from .ensemble import TreeArrays, TreeEnsemble
-from .families import GBDT, RandomForest
 
-__all__ = ["TreeArrays", "TreeEnsemble", "GBDT", "RandomForest"]
+__all__ = ["TreeArrays", "TreeEnsemble"]

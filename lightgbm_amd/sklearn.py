@@ -152,6 +152,14 @@ class LGBMModel(BaseEstimator):
     def predict(self, X, raw_score: bool = False, num_iteration: Optional[int] = None, pred_leaf: bool = False, **kw):
         return self.booster_.predict(X, raw_score=raw_score, num_iteration=num_iteration, pred_leaf=pred_leaf, **kw)
 
+    def staged_predict(self, X, step: int = 1, **kw):
+        """Predictions of the first ``step, 2 * step, ...`` trees - the curves "bagging_boosting.ipynb":118-137
+        draws for a growing forest and a growing boosted ensemble (``predict(ntree_limit=k)`` there)."""
+        b = self.booster_
+        per_iter = max(1, b.num_model_per_iteration())
+        for k in range(step, b.num_trees() // per_iter + 1, step):
+            yield b.predict(X, num_iteration=k, **kw)
+
 
 class LGBMRegressor(RegressorMixin, LGBMModel):
     pass

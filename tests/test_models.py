@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 import lightgbm_amd as lgb
-from lightgbm_amd.models import GBDT, RandomForest, TreeEnsemble
+from lightgbm_amd.models import TreeEnsemble
+from lightgbm_amd.sklearn import LGBMRandomForestRegressor, LGBMRegressor
 from lightgbm_amd.utils.datasets import make_regression
 
 CPU = {"device_type": "cpu", "verbose": -1}
@@ -65,8 +66,9 @@ def test_text_round_trip_is_stable_and_counts_are_consistent(tmp_path):
 def test_random_forest_family_averages_and_stages():
     X, y = _data(5000, 8, seed=3, nan=False)
     Xt, yt = _data(2000, 8, seed=4, nan=False)
-    rf = RandomForest(n_estimators=40, device_type="cpu", bagging_seed=77, feature_fraction_seed=5).fit(X, y)
-    gb = GBDT(n_estimators=40, device_type="cpu", learning_rate=0.2).fit(X, y)
+    rf = LGBMRandomForestRegressor(n_estimators=40, num_leaves=127, min_child_samples=5, colsample_bytree=0.8, device_type="cpu",
+                                   bagging_seed=77, feature_fraction_seed=5).fit(X, y)
+    gb = LGBMRegressor(n_estimators=40, device_type="cpu", learning_rate=0.2).fit(X, y)
     ens = TreeEnsemble.from_booster(rf.booster_)
     assert ens.average_output
     np.testing.assert_allclose(ens.predict(Xt), rf.predict(Xt), rtol=1e-12, atol=1e-12)
