@@ -497,28 +497,30 @@ int Booster::update_group_chunk(Booster* const* boosters, int n, int n_iters, bo
     chunked = chunked && boosters[i]->chunk_eligible(eval_valid);
   }
   if (chunked) {
-    std::vector<Engine*> engines;
-    int prepared = 0;
-    for (int i = 0; i < n; ++i) {
-      if (!boosters[i]->chunk_begin(n_iters, eval_valid)) break;
-      engines.push_back(boosters[i]->engine_.get());
-      ++prepared;
-    }
-    if (prepared == n) {
-      engines[0]->launch_prepared_chunks(engines.data(), n);
-      // waiting for the chunks and assembling their trees is host work per booster: spread it over the cores
-      std::vector<std::vector<char>> stump((size_t)n);
-      std::string failure;
+    // preparing, waiting for and taking over the chunks is host work per booster: spread it over the cores
+    std::string failure;
+    auto guarded = [&](auto&& body) {
 #pragma omp parallel for schedule(dynamic, 1) if (n >= 8)
       for (int i = 0; i < n; ++i) {
         try {
-          boosters[i]->chunk_fetch(&stump[(size_t)i]);
+          body(i);
         } catch (const std::exception& e) {
 #pragma omp critical(lga_chunk_failure)
           if (failure.empty()) failure = e.what();
         }
       }
       if (!failure.empty()) throw std::runtime_error(failure);
+    };
+    std::vector<char> prepared((size_t)n, 0);
+    guarded([&](int i) { prepared[(size_t)i] = boosters[i]->chunk_begin(n_iters, eval_valid) ? 1 : 0; });
+    int n_prepared = 0;
+    for (int i = 0; i < n; ++i) n_prepared += prepared[(size_t)i];
+    if (n_prepared == n) {
+      std::vector<Engine*> engines((size_t)n);
+      for (int i = 0; i < n; ++i) engines[(size_t)i] = boosters[i]->engine_.get();
+      engines[0]->launch_prepared_chunks(engines.data(), n);
+      std::vector<std::vector<char>> stump((size_t)n);
+      guarded([&](int i) { boosters[i]->chunk_fetch(&stump[(size_t)i]); });
       // the plain loop stops after an iteration in which no booster found a split
       int done = n_iters;
       for (int j = 0; j < n_iters; ++j) {
@@ -526,13 +528,13 @@ int Booster::update_group_chunk(Booster* const* boosters, int n, int n_iters, bo
         for (int i = 0; i < n; ++i) all = all && stump[(size_t)i][(size_t)j];
         if (all) { done = j + 1; break; }
       }
-      for (int i = 0; i < n; ++i) {
+      guarded([&](int i) {
         for (int j = 0; j < done; ++j) finished[(size_t)j * (size_t)n + (size_t)i] = stump[(size_t)i][(size_t)j];
         boosters[i]->chunk_commit(done, eval_valid, values, stride, n, i);
-      }
+      });
       return done;
     }
-    if (prepared > 0)
+    if (n_prepared > 0)
       throw std::runtime_error("a group of boosters must run on engines of one kind: some prepared a chunk of iterations, others refused");
   }
   int done = 0;

@@ -69,17 +69,24 @@ class DeviceBuffer {
   size_t n_ = 0;
 };
 
+// Page-locked host memory is expensive to obtain (hipHostMalloc maps it into the device's address space: hundreds of
+// microseconds) and boosters come and go by the hundred in a grid search, so released blocks are kept in a
+// process-wide cache by size class (powers of two) and handed out again.  mapped = fine-grained, coherent memory the
+// device can write directly.
+void* host_block_acquire(size_t bytes, bool mapped, size_t* capacity);
+void host_block_release(void* p, size_t capacity, bool mapped);
+
 template <typename T>
 class PinnedBuffer {
  public:
   PinnedBuffer() {}
-  ~PinnedBuffer() { if (p_) (void)hipHostFree(p_); }
+  ~PinnedBuffer() { if (p_) host_block_release(p_, cap_, false); }
   PinnedBuffer(const PinnedBuffer&) = delete;
   PinnedBuffer& operator=(const PinnedBuffer&) = delete;
   void resize(size_t n) {
     if (n <= n_) return;
-    if (p_) (void)hipHostFree(p_);
-    LGA_HIP_CHECK(hipHostMalloc((void**)&p_, n * sizeof(T), hipHostMallocDefault));
+    if (p_) host_block_release(p_, cap_, false);
+    p_ = (T*)host_block_acquire(n * sizeof(T), false, &cap_);
     n_ = n;
   }
   T* get() const { return p_; }
@@ -88,7 +95,7 @@ class PinnedBuffer {
 
  private:
   T* p_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, cap_ = 0;
 };
 
 // Host memory the device can write directly (fine-grained, mapped): results of a growth round land
@@ -96,13 +103,13 @@ class PinnedBuffer {
 class MappedBuffer {
  public:
   MappedBuffer() {}
-  ~MappedBuffer() { if (p_) (void)hipHostFree(p_); }
+  ~MappedBuffer() { if (p_) host_block_release(p_, cap_, true); }
   MappedBuffer(const MappedBuffer&) = delete;
   MappedBuffer& operator=(const MappedBuffer&) = delete;
   void resize(size_t n) {
     if (n <= n_) return;
-    if (p_) (void)hipHostFree(p_);
-    LGA_HIP_CHECK(hipHostMalloc((void**)&p_, n, hipHostMallocMapped | hipHostMallocCoherent));
+    if (p_) host_block_release(p_, cap_, true);
+    p_ = (char*)host_block_acquire(n, true, &cap_);
     LGA_HIP_CHECK(hipHostGetDevicePointer((void**)&d_, p_, 0));
     n_ = n;
   }
@@ -113,7 +120,7 @@ class MappedBuffer {
  private:
   char* p_ = nullptr;
   char* d_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, cap_ = 0;
 };
 
 // Named ranges for rocprofv3 --marker-trace (roctx).  The library is bound at run time and only when

@@ -16,6 +16,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <sstream>
 #include <thread>
@@ -52,6 +53,43 @@ void device_free(void* p) {
   if (!p) return;
   if (g_free) g_free(p); else (void)hipFree(p);
 }
+namespace {
+struct HostBlockCache {
+  std::mutex mu;
+  std::map<size_t, std::vector<void*>> free_blocks[2];   // [mapped][capacity]
+  // blocks stay allocated until the process ends: the runtime may already be shutting down when statics die
+};
+HostBlockCache& host_block_cache() {
+  static HostBlockCache* c = new HostBlockCache();
+  return *c;
+}
+}  // namespace
+
+void* host_block_acquire(size_t bytes, bool mapped, size_t* capacity) {
+  size_t cap = 256;
+  while (cap < bytes) cap <<= 1;
+  *capacity = cap;
+  HostBlockCache& c = host_block_cache();
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto& v = c.free_blocks[mapped ? 1 : 0][cap];
+    if (!v.empty()) {
+      void* p = v.back();
+      v.pop_back();
+      return p;
+    }
+  }
+  void* p = nullptr;
+  LGA_HIP_CHECK(hipHostMalloc(&p, cap, mapped ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault));
+  return p;
+}
+void host_block_release(void* p, size_t capacity, bool mapped) {
+  if (!p) return;
+  HostBlockCache& c = host_block_cache();
+  std::lock_guard<std::mutex> lock(c.mu);
+  c.free_blocks[mapped ? 1 : 0][capacity].push_back(p);
+}
+
 void set_current_stream(hipStream_t s) {
   static bool have_default = false;
   if (!have_default) { g_default_stream = s; have_default = true; }
