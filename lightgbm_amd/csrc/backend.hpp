@@ -96,6 +96,9 @@ class TreeBackend {
     split_round(tasks, h.infos.data());
     return ticket;
   }
+  // Has the round finished?  The grower takes finished rounds first; a backend whose rounds must be replayed in
+  // submission order (ranks that have to make the same decisions in the same order) always says yes.
+  virtual bool round_done(int ticket) { (void)ticket; return true; }
   virtual void wait_round(int ticket, SplitInfo* infos) {
     Held& h = held_[(size_t)ticket];
     for (size_t i = 0; i < h.infos.size(); ++i) infos[i] = h.infos[i];

@@ -112,6 +112,7 @@ struct SplitTask {
   int32_t num_hchunk;
   int32_t depth;         // depth of the children
   int32_t parent_key;    // position key of the parent (uint32 bits; see node_feature_on)
+  int32_t hist_rows;     // rows of hist_child over all ranks: an upper bound of the rows any rank histograms
 };
 
 // Row range of a node inside the two ping-pong row-index arenas.

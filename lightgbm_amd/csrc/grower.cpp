@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <queue>
 #include <stdexcept>
+#include <thread>
 
 namespace lga {
 
@@ -14,6 +15,7 @@ TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds
   if (const char* e = std::getenv("LGA_SPEC_LO")) spec_lo_ = std::atof(e);
   if (const char* e = std::getenv("LGA_SPEC_HI")) spec_hi_ = std::atof(e);
   if (const char* e = std::getenv("LGA_SPEC_RATIO")) spec_ratio_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LGA_OWN_ROUND_ROWS")) own_round_rows_ = std::max(1.0, std::atof(e));
   if (const char* e = std::getenv("LGA_SPEC_ROWS_LO")) spec_rows_lo_ = std::max(1.0, std::atof(e));
   if (const char* e = std::getenv("LGA_SPEC_ROWS_HI")) spec_rows_hi_ = std::max(spec_rows_lo_ * 2.0, std::atof(e));
   {
@@ -316,9 +318,20 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
     ++stats_.rounds;
     flights.push_back(std::move(f));
   };
+  // the next round to replay: the first one found finished, the oldest when polling has gone on for long (its
+  // blocking wait notices a failed launch)
   auto wait_oldest = [&]() {
-    Flight f = std::move(flights.front());
-    flights.erase(flights.begin());
+    size_t pick = 0;
+    if (flights.size() > 1) {
+      bool found = false;
+      for (unsigned spins = 0; !found && spins < 4000000u; ++spins) {
+        for (size_t i = 0; i < flights.size() && !found; ++i)
+          if (be.round_done(flights[i].ticket)) { pick = i; found = true; }
+        if (!found && spins > 20000u) std::this_thread::yield();
+      }
+    }
+    Flight f = std::move(flights[pick]);
+    flights.erase(flights.begin() + (std::ptrdiff_t)pick);
     infos.assign(f.tasks.size() * 2, SplitInfo{});
     const auto t_call = GrowTrace::clock::now();
     be.wait_round(f.ticket, infos.data());
@@ -393,6 +406,7 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
         t.missing_bin = meta[(size_t)c.best.feature].missing_bin;
         int64_t lc = c.best.left_cnt, rc = c.best.total_cnt - c.best.left_cnt;
         t.hist_child = lc <= rc ? 0 : 1;
+        t.hist_rows = (int32_t)std::min<int64_t>(std::min(lc, rc), INT32_MAX);
         t.parent_slot = c.slot;
         t.new_slot = 1 + materialized + (int)tasks.size();
         t.depth = c.depth + 1;
@@ -439,17 +453,38 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
       }
     }
     if (!tasks.empty()) {
+      // Rounds in flight run side by side on the device, so a batch is dealt out over the free places: every large
+      // leaf (a round of its own costs it nothing, and its long row-level work then does not hold back anybody
+      // else's split search and hand-over) while places last, the remaining leaves together - halved when two
+      // places are still free and nothing else is in flight, so that one half's hand-over and replay overlap with
+      // the other half's device work.  Slots are handed out again afterwards: a round's new slots are consecutive.
+      const int free_places = max_flight - (int)flights.size();
+      std::vector<size_t> cut;   // start index of every round after the first
+      if (free_places >= 2 && tasks.size() >= 2) {
+        auto rows_of = [&](const SplitTask& t) { return nodes[(size_t)t.parent_node].best.total_cnt; };
+        if (max_flight > 2) {
+          std::stable_sort(tasks.begin(), tasks.end(), [&](const SplitTask& a, const SplitTask& b) { return rows_of(a) > rows_of(b); });
+          size_t own = 0;
+          while (own < tasks.size() && (int)own < free_places - 1 && (double)rows_of(tasks[own]) >= own_round_rows_ * row_shards_) ++own;
+          if (own == tasks.size()) --own;   // the last one is "the rest"
+          for (size_t i = 1; i <= own; ++i) cut.push_back(i);
+          const size_t rest = tasks.size() - own;
+          if (free_places - (int)own >= 2 && rest >= 2 && (own == 0 ? flights.empty() : rest >= 8)) cut.push_back(own + (rest + 1) / 2);
+        } else if (flights.empty()) {
+          cut.push_back((tasks.size() + 1) / 2);
+        }
+      }
+      for (size_t i = 0; i < tasks.size(); ++i) {
+        SplitTask& t = tasks[i];
+        t.new_slot = 1 + materialized + (int)i;
+        nodes[(size_t)(t.hist_child == 0 ? t.left_node : t.right_node)].slot = t.new_slot;
+      }
       materialized += (int)tasks.size();
-      // Nothing else in flight and room for two rounds: halve the batch, so that from here on one half's
-      // scan / hand-over / replay overlaps with the other half's partition and histogram work.
-      if (flights.empty() && max_flight >= 2 && tasks.size() >= 2) {
-        const size_t half = (tasks.size() + 1) / 2;
-        std::vector<SplitTask> second(tasks.begin() + (std::ptrdiff_t)half, tasks.end());
-        tasks.resize(half);
-        submit(std::move(tasks));
-        submit(std::move(second));
-      } else {
-        submit(std::move(tasks));
+      size_t begin = 0;
+      for (size_t c = 0; c <= cut.size(); ++c) {
+        const size_t end = c < cut.size() ? cut[c] : tasks.size();
+        submit(std::vector<SplitTask>(tasks.begin() + (std::ptrdiff_t)begin, tasks.begin() + (std::ptrdiff_t)end));
+        begin = end;
       }
       continue;
     }

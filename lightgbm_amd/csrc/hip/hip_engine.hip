@@ -237,7 +237,7 @@ class HipBackend : public TreeBackend {
     // gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on their own
     // streams) already fill the hardware queues.
     n_ctx_ = (!prof.on && max_rows >= (int64_t)1 << 19) ? 2 : 1;
-    if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(2, std::atoi(e)));
+    if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(kMaxRoundsInFlight, std::atoi(e)));
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
     if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
@@ -287,6 +287,7 @@ class HipBackend : public TreeBackend {
     prof.init();
   }
   ~HipBackend() override {
+    report_grow_timing();
     for (int c = 0; c < n_ctx_; ++c)
       if (ctx_[c].owns_stream) { (void)hipStreamSynchronize(ctx_[c].stream); (void)hipStreamDestroy(ctx_[c].stream); }
     for (int c = 0; c < n_ctx_; ++c) {
@@ -421,6 +422,11 @@ class HipBackend : public TreeBackend {
     return c;
   }
   void wait_round(int ticket, SplitInfo* infos) override { finish_round(ctx_[ticket], infos); }
+  bool round_done(int ticket) override {
+    if (distributed() || prof.on) return true;   // every rank replays the rounds in submission order
+    const RoundCtx& x = ctx_[ticket];
+    return *reinterpret_cast<const volatile unsigned*>(x.host_block.get()) == x.seq;
+  }
 
   // ---- whole tree in one launch (kernels.hpp: TreeArgs): small bags on one device, plain numeric / one-vs-rest
   // categorical features of one tile ----
@@ -695,15 +701,21 @@ class HipBackend : public TreeBackend {
   void launch_lines(RoundCtx& x, std::vector<SplitTask>& tasks, bool root, k::RoundSlots round) {
     const int B = (int)tasks.size();
     hipStream_t st_ = x.stream;
-    // units: a leaf of up to solo_rows_ rows is one workgroup's; larger ones are cut into units of unit_rows
+    // units: a leaf of up to solo_rows_ rows is one workgroup's from the sides of its rows to its child's histogram;
+    // a larger leaf is partitioned by two launches of their own and the rows of its histogram child (at most
+    // hist_rows of them on any rank) are cut into units of unit_rows consecutive rows, as are the root's
+    auto hist_bound = [&](const SplitTask& t) {
+      const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
+      return root ? cnt : std::min<int64_t>(cnt, std::max(t.hist_rows, 0));
+    };
     int64_t multi_rows = 0;
     for (const auto& t : tasks) {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
-      if (root || cnt > solo_rows_) multi_rows += cnt;
+      if (root || cnt > solo_rows_) multi_rows += hist_bound(t);
     }
     int64_t ur = (multi_rows + target_units_ - 1) / target_units_;
     ur = ((ur + k::kSubRows - 1) / k::kSubRows) * k::kSubRows;
-    ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, std::min(kMaxRowsPerPass, k::kSoloMaxRows)));
+    ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, kMaxRowsPerPass));
     const int unit_rows = (int)ur;
     int np = 0;
     for (auto& t : tasks) {
@@ -711,7 +723,7 @@ class HipBackend : public TreeBackend {
       const bool multi = root || cnt > solo_rows_;
       t.first_pchunk = np;
       t.num_pchunk = (multi && !root) ? ceil_div(cnt, k::kPartChunk) : 0;
-      t.num_hchunk = multi ? std::max(1, ceil_div(cnt, unit_rows)) : 1;
+      t.num_hchunk = multi ? std::max(1, ceil_div(hist_bound(t), unit_rows)) : 1;
       np += t.num_pchunk;
       if (np > max_pchunks_) throw std::runtime_error("chunk table overflow");
     }
@@ -742,10 +754,13 @@ class HipBackend : public TreeBackend {
     a.mask = x.mask.get(); a.chunk_left = x.chunk_left.get(); a.task_left = x.task_left.get();
     a.cat_sets = cat_sets_dev_.get();
     if (root) a.quant = root_quant_;
-    k::grow_round(inl, a, units, root, st_);
-    if (np > 0)
+    a.phase_ticks = (!root && grow_timing_) ? grow_ticks() : nullptr;
+    if (np > 0) {
+      k::grow_flags(inl, a, np, st_);
       k::grow_scatter(staged, a.n_staged, inl, np, nodes_.get(), src0, arena_[1].get(), arena_[0].get(), arena_[1].get(),
                       x.mask.get(), x.chunk_left.get(), x.task_left.get(), st_);
+    }
+    k::grow_round(inl, a, units, root, st_);
     prof.mark(PhaseProfile::kHist, st_);
     if (distributed()) { finish_distributed(x, tasks, root, round, staged, inl); return; }
     prof.mark(PhaseProfile::kComm, st_);
@@ -1064,7 +1079,8 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<NodeRange> nodes_;
   DeviceBuffer<int64_t> node_totals_;
   DeviceBuffer<int32_t> arena_[2];
-  RoundCtx ctx_[2];
+  static constexpr int kMaxRoundsInFlight = 4;
+  RoundCtx ctx_[kMaxRoundsInFlight];
   int n_ctx_ = 1;
   DeviceBuffer<FeatureMeta> meta_dev_;
   DeviceBuffer<QuantScale> qs_dev_;
@@ -1112,6 +1128,25 @@ class HipBackend : public TreeBackend {
   int tree_renew_ = 0;
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
+  // LGA_GROW_TIMING=1: phase profile of the non-root growth kernels, printed when the backend goes away
+  bool grow_timing_ = std::getenv("LGA_GROW_TIMING") != nullptr;
+  DeviceBuffer<unsigned long long> grow_ticks_;
+  unsigned long long* grow_ticks() {
+    if (grow_ticks_.size() == 0) {
+      grow_ticks_.resize(16);
+      LGA_HIP_CHECK(hipMemset(grow_ticks_.get(), 0, 16 * sizeof(unsigned long long)));
+    }
+    return grow_ticks_.get();
+  }
+  void report_grow_timing() {
+    if (!grow_timing_ || grow_ticks_.size() == 0) return;
+    unsigned long long v[16];
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    if (hipMemcpy(v, grow_ticks_.get(), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return;
+    std::fprintf(stderr, "[grow timing] workgroup-ticks (10 ns): flags %llu, prefix %llu, hist rows %llu, masks/move %llu, sums %llu, "
+                         "flush %llu (over %llu multi-unit workgroups), solo store %llu\n", v[0], v[1], v[2], v[3], v[4], v[5], v[7], v[6]);
+    std::fprintf(stderr, "[grow timing] sides kernel: range %llu, row ids %llu, bin bytes %llu, masks %llu (over %llu workgroups)\n", v[8], v[9], v[10], v[11], v[12]);
+  }
   double tree_ticks_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double tree_cycles_ = 0;
   int tree_timed_ = 0;
@@ -1863,7 +1898,8 @@ class HipEngine : public Engine {
         !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_) {
       const TreeOnDevice td = upload_tree(tree);
       leaf_of_row_.resize((size_t)N_);
-      walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(), N_, base_or_null(), n_base_, gr(), he(),
+      walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(),
+                              mir_->tiles == 1 ? mir_->bins_rt.get() : nullptr, N_, base_or_null(), n_base_, gr(), he(),
                               backend_->qs_device(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
       leaf_ids_valid_ = walked;
       leaf_ids_leaves_ = L;

@@ -467,10 +467,17 @@ __device__ __forceinline__ int64_t* slot_header(const PoolLayout& L, const SlotR
 
 // Adds a workgroup's LDS histogram (packed g:int32 | h:uint32 cells, features f0 .. f0 + nf - 1) to a slot.
 // ROTATED: cell (f, bin) sits at f * 256 + ((bin + 8 f) & 255) (row-line kernels).
+// `stagger` (any number that differs between the workgroups of a slot, e.g. the unit index) shifts where a workgroup
+// starts: the units of one leaf finish at about the same time, and without it all of them would add to the same
+// few cache lines at any moment.
 template <bool ROTATED>
 __device__ __forceinline__ void flush_lds_hist(const unsigned long long* lds, int nf, int f0, const PoolLayout& L,
-                                               const SlotRef& s, int nthreads) {
-  for (int e = threadIdx.x; e < nf * kMaxBins; e += nthreads) {
+                                               const SlotRef& s, int nthreads, unsigned stagger = 0) {
+  const int cells = nf * kMaxBins;
+  const int shift = (int)((stagger * 1031u) % (unsigned)cells) & ~63;
+  for (int e0 = threadIdx.x; e0 < cells; e0 += nthreads) {
+    int e = e0 + shift;
+    if (e >= cells) e -= cells;
     const int fe = e >> 8, b = e & 255;
     const unsigned long long v = ROTATED ? lds[(fe << 8) + ((b + 8 * fe) & 255)] : lds[e];
     if (v != 0ull) {
@@ -743,32 +750,110 @@ __device__ __forceinline__ bool bin_goes_left(const SplitTask& t, int b, const u
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
+// Sides of the rows of the multi-unit leaves: one workgroup per block of kPartChunk rows writes the block's
+// go-left mask words and left count for partition_scatter_kernel.  Nothing but two dependent loads per row
+// (row id, then the split feature's byte from the feature-major matrix), eight rows per lane in flight and
+// next to no LDS, so a CU holds eight of these workgroups.
+__global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks inl, GrowArgs a) {
+  constexpr int kWords = kPartChunk / kWave;
+  constexpr int U = kPartChunk / kPartThreads;
+  __shared__ int wave_left[kPartThreads / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x;
+  const int ti = a.tasks ? find_task_staged<true>(a.tasks, a.n_staged, wg) : find_task<true>(inl, wg);
+  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const int c = wg - t.first_pchunk;
+  if (c >= t.num_pchunk) return;
+  const bool timed = a.phase_ticks && (wg & 63) == 0;   // LGA_GROW_TIMING: every 64th workgroup, see grow_kernel
+  unsigned long long t_prev = timed ? wall_clock64() : 0ull;
+  auto stamp = [&](int phase) {
+    if (timed) {
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) {
+        const unsigned long long now = wall_clock64();
+        atomicAdd(&a.phase_ticks[phase], now - t_prev);
+        t_prev = now;
+      }
+    }
+  };
+  const NodeRange p = a.nodes[t.parent_node];
+  const int32_t* src = (p.buf ? a.a1 : a.a0) + p.begin;
+  const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
+  const int base = c * kPartChunk;
+  if (timed && p.count < 0) return;   // (keeps the range load ahead of the first stamp)
+  stamp(8);
+  int row[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int pos = base + k * kPartThreads + tid;
+    row[k] = pos < p.count ? src[pos] : -1;
+    if (pos < p.count && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
+  }
+  stamp(9);
+  int bin[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
+  stamp(10);
+  int lefts = 0;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
+    const unsigned long long m = __ballot(left);
+    lefts += __popcll(m);
+    if (lane == 0) a.mask[(int64_t)wg * kWords + k * (kPartThreads / kWave) + wave] = m;
+  }
+  if (lane == 0) wave_left[wave] = lefts;
+  __syncthreads();
+  if (tid == 0) {
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < kPartThreads / kWave; ++w) all += wave_left[w];
+    a.chunk_left[wg] = all;
+  }
+  stamp(11);
+  if (timed && tid == 0) atomicAdd(&a.phase_ticks[12], 1ull);
+}
+
 template <bool ROOT, bool QUANT>
 __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
   constexpr int kWaves = kGrowThreads / kWave;
   constexpr int kMaskWords = kSoloMaxRows / kWave;
+  constexpr int U1 = kSoloMaxRows / kGrowThreads;   // rows per lane of a (non-root) unit: all of them in one trip
   __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
   __shared__ unsigned long long smask[kMaskWords];
   __shared__ int word_prefix[kMaskWords + 1];
   __shared__ int wave_tot[kWaves];
   __shared__ long long red[2][kWaves];
   __shared__ long long tot[3];
+  __shared__ int32_t hist_rows[kGrowListRows];   // the histogram child's rows of this unit, compacted
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ti = a.tasks ? find_task_staged<false>(a.tasks, a.n_staged, blockIdx.x) : find_task<false>(inl, blockIdx.x);
   const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
   const int ridx = ti;                           // index among the round's tasks
   const int u = blockIdx.x - t.first_hchunk;
-  const bool solo = !ROOT && t.num_pchunk == 0;  // the whole leaf is this workgroup's
-  const NodeRange p = a.nodes[ROOT ? 0 : t.parent_node];
-  const int32_t* src = (p.buf ? a.a1 : a.a0) + p.begin;
+  const bool solo = !ROOT && t.num_pchunk == 0;  // the whole leaf is this workgroup's: sides, row movement, histogram
+  // otherwise the workgroup histograms one unit of consecutive rows: of the root, or of the histogram child of a
+  // multi-unit leaf, whose rows grow_flags_kernel + partition_scatter_kernel have moved already
+  const bool dense = ROOT || !solo;
+  const NodeRange p = a.nodes[ROOT ? 0 : (solo ? t.parent_node : (t.hist_child ? t.right_node : t.left_node))];
+  const int32_t* src = ((ROOT || solo) ? (p.buf ? a.a1 : a.a0) : (p.buf ? a.a1_dst : a.a0_dst)) + p.begin;
   const int lo = solo ? 0 : u * a.unit_rows;
   const int hi = solo ? p.count : min(lo + a.unit_rows, p.count);
+  if (dense && u > 0 && lo >= p.count) return;   // the child has fewer rows on this rank than the grid was sized for
   const int nf = a.F;
   const PoolLayout& L = a.pool;
   const SlotRef fresh = new_slot_ref(L, a.round, t.new_slot);
   if (u == 0 && tid == 0) publish_slot(L, t.new_slot, fresh);
+  // phase profile (LGA_GROW_TIMING): thread 0 adds the time since its previous stamp to phase_ticks[phase]
+  unsigned long long t_prev = a.phase_ticks ? wall_clock64() : 0ull;
+  auto stamp = [&](int phase) {
+    if (a.phase_ticks && tid == 0) {
+      const unsigned long long now = wall_clock64();
+      atomicAdd(&a.phase_ticks[phase], now - t_prev);
+      t_prev = now;
+    }
+  };
   for (int i = tid; i < nf * kMaxBins; i += kGrowThreads) lds[i] = 0ull;
-  __syncthreads();
   int kg = 0, kh = 0;
   if (QUANT) {
     kg = quant_exponent(__uint_as_float(a.quant.maxbits[0]));
@@ -778,62 +863,15 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   const bool hist_left = t.hist_child == 0;
   const uint4* lines = reinterpret_cast<const uint4*>(a.lines);
   long long sg = 0, sh = 0;
-  // Phase 1 - which side does every row take?  The split feature's byte comes from the feature-major matrix
-  // (coalesced while the leaf is dense); sixteen rows per lane are in flight per trip, because this phase is
-  // nothing but two dependent loads per row.  The go-left bits land in the LDS mask words (word = position / 64).
-  if (!ROOT) {
-    const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
-    constexpr int U1 = 16;
-    for (int base = lo; base < hi; base += U1 * kGrowThreads) {
-      int row[U1];
-#pragma unroll
-      for (int k = 0; k < U1; ++k) {
-        const int pos = base + k * kGrowThreads + tid;
-        row[k] = pos < hi ? src[pos] : -1;
-        if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
-      }
-      int bin[U1];
-#pragma unroll
-      for (int k = 0; k < U1; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
-#pragma unroll
-      for (int k = 0; k < U1; ++k) {
-        if (base + k * kGrowThreads < hi) {   // uniform: the whole stripe of 512 positions is outside otherwise
-          const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
-          const unsigned long long m = __ballot(left);
-          if (lane == 0) smask[((base - lo) >> 6) + k * kWaves + wave] = m;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // Phase 2 - the histogram child's rows fetch their lines (bins + packed gradients); four rows per lane and trip,
-  // every load of a trip issued before its LDS atomics.
-  const unsigned long long side_flip = hist_left ? 0ull : ~0ull;
-  for (int sub = lo; sub < hi; sub += kSubRows) {
-    int row[4];
-    bool take[4];
+  // One trip of histogram work: up to four rows per lane fetch their lines (bins + packed gradients), every load
+  // issued before the LDS atomics.  row < 0: nothing to do for that slot.
+  auto add_rows = [&](int (&row)[4]) {
     unsigned long long pk[4];
     uint4 ra[4], rb[4];
-    bool any = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int pos = sub + k * kGrowThreads + tid;
-      take[k] = pos < hi;
-      if (!ROOT && pos < hi) take[k] = ((smask[(pos - lo) >> 6] ^ side_flip) >> lane) & 1ull;
-      any = any || take[k];
-    }
-    if (!__any(any)) continue;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      row[k] = -1;
-      if (take[k]) {
-        row[k] = src[sub + k * kGrowThreads + tid];
-        if (!LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckHistRow, row[k], a.N)) { row[k] = -1; take[k] = false; }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (take[k]) {
+      if (row[k] >= 0 && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckHistRow, row[k], a.N)) row[k] = -1;
+      if (row[k] >= 0) {
         const unsigned line = div3((unsigned)row[k]), slot = (unsigned)row[k] - line * 3u;
         const uint4* Lp = lines + (int64_t)line * 8;
         ra[k] = Lp[slot * 2];
@@ -846,9 +884,10 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
         }
       }
     }
+    if (a.phase_ticks) { __builtin_amdgcn_s_waitcnt(0); stamp(1); }   // profile only: loads done
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (take[k]) {
+      if (row[k] >= 0) {
         const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
         sg += (long long)(int32_t)(pk[k] >> 32);
         sh += (long long)(pk[k] & 0xffffffffull);
@@ -866,33 +905,146 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
         }
       }
     }
-  }
-  __syncthreads();
-  // exclusive prefix of the mask words' popcounts
-  int lefts = 0;
-  if (!ROOT) {
-    const int n_words = (hi - lo + kWave - 1) / kWave;
-    int pc = 0, incl = 0;
-    if (tid < kMaskWords) {
-      pc = tid < n_words ? __popcll(smask[tid]) : 0;
-      incl = pc;
+  };
+  // rows, sum g, sum h of what the workgroup put into its histogram -> tot[]
+  auto reduce_sums = [&](int rows) {
+    sg = wave_sum_i64(sg);
+    sh = wave_sum_i64(sh);
+    if (lane == 0) { red[0][wave] = sg; red[1][wave] = sh; }
+    __syncthreads();
+    if (tid == 0) {
+      long long tg = 0, th = 0;
 #pragma unroll
-      for (int d = 1; d < kWave; d <<= 1) {
-        const int o = __shfl_up(incl, d, kWave);
-        if (lane >= d) incl += o;
+      for (int w = 0; w < kWaves; ++w) { tg += red[0][w]; th += red[1][w]; }
+      tot[0] = rows;
+      tot[1] = tg;
+      tot[2] = th;
+    }
+    __syncthreads();
+  };
+  int lefts = 0;
+  if (dense) {
+    // The grid holds the units the child was EXPECTED to have (its row count is only estimated by the search and only
+    // known on the device): workgroup u takes units u, u + num_hchunk, ... until the child's rows are used up, and
+    // adds each unit's histogram to the (zeroed) slot before the 32-bit halves of its LDS cells could overflow.
+    const int stride = ROOT ? (int)gridDim.x : t.num_hchunk;
+    for (int unit = u; unit == u || unit * a.unit_rows < p.count; unit += stride) {
+      const int ulo = unit * a.unit_rows, uhi = min(ulo + a.unit_rows, p.count);
+      if (unit != u) {
+        for (int i = tid; i < nf * kMaxBins; i += kGrowThreads) lds[i] = 0ull;
+        sg = 0; sh = 0;
       }
-      if (lane == kWave - 1) wave_tot[wave] = incl;
+      __syncthreads();
+      stamp(0);
+      for (int sub = ulo; sub < uhi; sub += kSubRows) {
+        int row[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pos = sub + k * kGrowThreads + tid;
+          row[k] = pos < uhi ? src[pos] : -1;
+        }
+        add_rows(row);
+        if (a.phase_ticks) { __builtin_amdgcn_s_waitcnt(0); stamp(2); }
+      }
+      __syncthreads();
+      stamp(3);
+      reduce_sums(max(uhi - ulo, 0));
+      stamp(4);
+      flush_lds_hist<true>(lds, nf, 0, L, fresh, kGrowThreads, (unsigned)unit);
+      if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
+      __syncthreads();
+      stamp(5);
+      if (a.phase_ticks && tid == 0) atomicAdd(&a.phase_ticks[7], 1ull);
+    }
+    return;
+  } else {
+    // Phase 1 - which side does every row take?  The split feature's byte comes from the feature-major matrix
+    // (coalesced while the leaf is dense); all rows of the unit (up to sixteen per lane) are in flight at once,
+    // because this phase is nothing but two dependent loads per row.  The go-left bits land in the LDS mask
+    // words (word = position / 64).
+    const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
+    int row[U1];
+#pragma unroll
+    for (int k = 0; k < U1; ++k) {
+      const int pos = lo + k * kGrowThreads + tid;
+      row[k] = pos < hi ? src[pos] : -1;
+      if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
+    }
+    int bin[U1];
+#pragma unroll
+    for (int k = 0; k < U1; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
+    unsigned long long mine[U1];   // the mask word each of this lane's rows sits in
+#pragma unroll
+    for (int k = 0; k < U1; ++k) {
+      mine[k] = 0ull;
+      if (lo + k * kGrowThreads < hi) {   // uniform: the whole stripe of 512 positions is outside otherwise
+        const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
+        mine[k] = __ballot(left);
+        if (lane == 0) smask[k * kWaves + wave] = mine[k];
+      }
     }
     __syncthreads();
-    if (tid < kMaskWords) {
-      int off = 0;
-      for (int w = 0; w < wave; ++w) off += wave_tot[w];
-      word_prefix[tid] = off + incl - pc;
-      if (tid == kMaskWords - 1) word_prefix[kMaskWords] = off + incl;
+    stamp(0);
+    // exclusive prefix of the mask words' popcounts
+    {
+      const int n_words = (hi - lo + kWave - 1) / kWave;
+      int pc = 0, incl = 0;
+      if (tid < kMaskWords) {
+        pc = tid < n_words ? __popcll(smask[tid]) : 0;
+        incl = pc;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+          const int o = __shfl_up(incl, d, kWave);
+          if (lane >= d) incl += o;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+      }
+      __syncthreads();
+      if (tid < kMaskWords) {
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += wave_tot[w];
+        word_prefix[tid] = off + incl - pc;
+        if (tid == kMaskWords - 1) word_prefix[kMaskWords] = off + incl;
+      }
+      __syncthreads();
+      lefts = word_prefix[kMaskWords];
     }
-    __syncthreads();
-    lefts = word_prefix[kMaskWords];
-    if (solo) {
+    stamp(1);
+    // Phase 2 - the histogram child's rows, compacted: every lane knows the rank of its rows among the child's rows
+    // of this unit and drops them into the LDS list, a window of kGrowListRows ranks at a time; the list is then
+    // worked off by full waves, whatever share of the unit the child takes.
+    const int n_hist = hist_left ? lefts : (hi - lo) - lefts;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int w0 = 0; w0 < n_hist; w0 += kGrowListRows) {
+#pragma unroll
+      for (int k = 0; k < U1; ++k) {
+        const int q = k * kGrowThreads + tid;   // position inside the unit
+        if (lo + q < hi) {
+          const bool left = (mine[k] >> lane) & 1ull;
+          if (left == hist_left) {
+            const int lrank = word_prefix[k * kWaves + wave] + __popcll(mine[k] & below);
+            const int rank = (hist_left ? lrank : q - lrank) - w0;
+            if ((unsigned)rank < (unsigned)kGrowListRows) hist_rows[rank] = row[k];
+          }
+        }
+      }
+      __syncthreads();
+      const int n_list = min(kGrowListRows, n_hist - w0);
+      for (int i0 = 0; i0 < n_list; i0 += 4 * kGrowThreads) {
+        int r4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * kGrowThreads + tid;
+          r4[k] = i < n_list ? hist_rows[i] : -1;
+        }
+        add_rows(r4);
+      }
+      __syncthreads();
+    }
+    stamp(2);
+  }
+  if (!dense) {
+    {
       // the leaf fits this workgroup: move its rows right away - lefts to the front, rights behind, in order
       int32_t* dst = (p.buf ? a.a0_dst : a.a1_dst) + p.begin;
       for (int pos = tid; pos < p.count; pos += kGrowThreads) {
@@ -908,35 +1060,10 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
         a.nodes[t.right_node] = NodeRange{p.begin + lefts, p.count - lefts, 1 - p.buf, 0};
         a.task_left[ridx] = lefts;
       }
-    } else {
-      // masks and left counts of this unit's blocks for grow_scatter
-      const int blocks = (hi - lo + kSubRows - 1) / kSubRows;
-      const int64_t gb = (int64_t)t.first_pchunk + (int64_t)u * (a.unit_rows / kSubRows);
-      for (int i = tid; i < blocks * (kSubRows / kWave); i += kGrowThreads) a.mask[gb * (kSubRows / kWave) + i] = smask[i];
-      if (tid < blocks) a.chunk_left[gb + tid] = word_prefix[(tid + 1) * (kSubRows / kWave)] - word_prefix[tid * (kSubRows / kWave)];
     }
   }
-  // rows, sum g, sum h of what this workgroup put into its histogram
-  sg = wave_sum_i64(sg);
-  sh = wave_sum_i64(sh);
-  if (lane == 0) { red[0][wave] = sg; red[1][wave] = sh; }
-  __syncthreads();
-  if (tid == 0) {
-    long long tg = 0, th = 0;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w) { tg += red[0][w]; th += red[1][w]; }
-    tot[0] = ROOT ? (hi - lo) : (hist_left ? lefts : (hi - lo) - lefts);
-    tot[1] = tg;
-    tot[2] = th;
-  }
-  __syncthreads();
-
-  if (!solo) {
-    // one unit of a large leaf (or of the root): add to the zeroed slot
-    flush_lds_hist<true>(lds, nf, 0, L, fresh, kGrowThreads);
-    if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
-    return;
-  }
+  stamp(3);
+  reduce_sums(hist_left ? lefts : (hi - lo) - lefts);
   // the whole leaf was this workgroup's: the histogram goes to the slot as it is (no atomics, no zeroing)
   for (int e = tid; e < nf * kMaxBins; e += kGrowThreads) {
     const int fe = e >> 8, b = e & 255;
@@ -950,6 +1077,8 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
       int64_t* hd = slot_header(L, fresh, r);
       hd[0] = tot[0]; hd[1] = tot[1]; hd[2] = tot[2];
     }
+  __syncthreads();
+  stamp(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -1191,6 +1320,87 @@ __global__ __launch_bounds__(256) void walk_leaves_kernel(const TreeNodeDev* __r
       leaf_of_row[r] = (uint16_t)leaf;
       atomicAdd(&sacc[2 * leaf], (unsigned long long)quantize_wide(gv, kg));
       atomicAdd(&sacc[2 * leaf + 1], (unsigned long long)quantize_wide(hv, kh));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x)
+    if (sacc[i] != 0ull) atomicAdd(&acc[i], sacc[i]);
+}
+
+// The same walk for data of a single feature tile: a row's 32 bin bytes are fetched ONCE (two 16-byte loads from the
+// row-major records, consecutive lanes = consecutive rows) and every step of the walk picks its byte from registers,
+// so a step costs an LDS node read instead of a dependent global load.  Four rows per lane walk interleaved.
+__device__ __forceinline__ int record_bin(const unsigned (&w)[8], int feature) {
+  const unsigned q = (unsigned)feature >> 2;
+  unsigned d = w[0];
+#pragma unroll
+  for (int i = 1; i < 8; ++i) d = q == (unsigned)i ? w[i] : d;
+  return (int)((d >> (((unsigned)feature & 3u) * 8)) & 255u);
+}
+__global__ __launch_bounds__(256) void walk_leaves_records_kernel(const TreeNodeDev* __restrict__ nodes, int n_internal, int num_leaves,
+                                                                  const uint4* __restrict__ recs, int64_t N,
+                                                                  const int32_t* __restrict__ rows, int64_t n,
+                                                                  const float* __restrict__ g, const float* __restrict__ h,
+                                                                  const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                                  unsigned long long* __restrict__ acc,
+                                                                  const uint64_t* __restrict__ node_sets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int R = 4;
+  int4* sn = reinterpret_cast<int4*>(smem);
+  unsigned long long* sacc = reinterpret_cast<unsigned long long*>(smem + (size_t)n_internal * sizeof(TreeNodeDev));
+  const int4* gn = reinterpret_cast<const int4*>(nodes);
+  for (int i = threadIdx.x; i < n_internal; i += blockDim.x) sn[i] = gn[i];
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
+  __syncthreads();
+  const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
+  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  for (int64_t base = (int64_t)blockIdx.x * (R * 256); base < n; base += (int64_t)gridDim.x * (R * 256)) {
+    int64_t r[R];
+    unsigned w[R][8];
+    float gv[R], hv[R];
+    int node[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      r[k] = i < n ? (rows ? (int64_t)rows[i] : i) : -1;
+      if (r[k] >= 0 && !LGA_DEV_CHECK((unsigned long long)r[k] < (unsigned long long)N, kCheckWalkRow, r[k], N)) r[k] = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      node[k] = (r[k] >= 0 && num_leaves > 1) ? 0 : ~0;
+      if (r[k] >= 0) {
+        const uint4 a = recs[r[k] * 2], b = recs[r[k] * 2 + 1];
+        w[k][0] = a.x; w[k][1] = a.y; w[k][2] = a.z; w[k][3] = a.w;
+        w[k][4] = b.x; w[k][5] = b.y; w[k][6] = b.z; w[k][7] = b.w;
+        gv[k] = g[r[k]];
+        hv[k] = h[r[k]];
+      }
+    }
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (node[k] >= 0) {
+          const TreeNodeDev t = tn[node[k]];
+          const int b = record_bin(w[k], t.feature);
+          const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
+          const bool left = (t.meta & 1024) ? ((node_sets[(int64_t)node[k] * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull) != 0
+                            : (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
+          node[k] = left ? t.left : t.right;
+          if (!LGA_DEV_CHECK(node[k] < n_internal && ~node[k] < num_leaves, kCheckWalkNode, node[k], n_internal)) { node[k] = ~0; r[k] = -1; }
+          more = more || node[k] >= 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (r[k] >= 0) {
+        const int leaf = ~node[k];
+        leaf_of_row[r[k]] = (uint16_t)leaf;
+        atomicAdd(&sacc[2 * leaf], (unsigned long long)quantize_wide(gv[k], kg));
+        atomicAdd(&sacc[2 * leaf + 1], (unsigned long long)quantize_wide(hv[k], kh));
+      }
     }
   }
   __syncthreads();
@@ -1460,7 +1670,7 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s) {
   if (total_units <= 0) return;
-  if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > kMaxRowsPerPass || a.unit_rows > kSoloMaxRows)
+  if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > kMaxRowsPerPass)
     throw std::runtime_error("growth round: bad unit size");
   if (a.F > kTileFeatures) throw std::runtime_error("row lines hold a single feature tile");
   if (root) {
@@ -1472,6 +1682,12 @@ void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool
     if (a.quant.g) throw std::runtime_error("fused quantisation belongs to the root pass");
     hipLaunchKernelGGL((grow_kernel<false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
   }
+  LGA_LAUNCH_CHECK();
+}
+
+void grow_flags(const InlineTasks& inl, const GrowArgs& a, int total_chunks, hipStream_t s) {
+  if (total_chunks <= 0) return;
+  hipLaunchKernelGGL(grow_flags_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, inl, a);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1594,13 +1810,20 @@ void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double
   LGA_LAUNCH_CHECK();
 }
 
-bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, int64_t N,
+bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
                  const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
                  int64_t* acc, const uint64_t* node_sets, hipStream_t s) {
   const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)2 * (size_t)num_leaves * sizeof(unsigned long long);
   if (sm > 48 * 1024 || num_leaves > 65535) return false;   // the caller takes the per-leaf row lists instead
   LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)num_leaves, s));
   if (n <= 0) return true;
+  if (records) {
+    hipLaunchKernelGGL(walk_leaves_records_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), sm, s, nodes, n_internal, num_leaves,
+                       reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, leaf_of_row,
+                       reinterpret_cast<unsigned long long*>(acc), node_sets);
+    LGA_LAUNCH_CHECK();
+    return true;
+  }
   hipLaunchKernelGGL(walk_leaves_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), sm, s, nodes, n_internal, num_leaves, bins_fm, N,
                      rows, n, g, h, qs, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
   LGA_LAUNCH_CHECK();

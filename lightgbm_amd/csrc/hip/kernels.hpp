@@ -141,7 +141,8 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 // to the (zeroed) slot and grow_scatter moves the rows.  The split search follows as scan_blocks.
 constexpr int kGrowThreads = 512;
 constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
-constexpr int kSoloMaxRows = 16384;   // upper bound of the solo limit (LDS mask words)
+constexpr int kSoloMaxRows = 8192;    // rows of a non-root unit / upper bound of the solo limit: sixteen rows per lane, one trip
+constexpr int kGrowListRows = 3072;   // LDS list of a unit's histogram rows (worked off in windows of this many)
 struct GrowArgs {
   const SplitTask* tasks;   // staged descriptors of a round above kInlineTasks leaves (n_staged of them), else null: inline
   int32_t n_staged;
@@ -156,13 +157,16 @@ struct GrowArgs {
   PoolLayout pool;
   RoundSlots round;
   int32_t F;
-  int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows, <= kMaxRowsPerPass)
+  int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows; <= kSoloMaxRows, the root's <= kMaxRowsPerPass)
   uint64_t* mask;           // [mask block][32]: go-left bits of multi-unit leaves, read by grow_scatter
   int32_t* chunk_left;      // [mask block]
   int32_t* task_left;       // [task of the round]: rows that went left
   const uint64_t* cat_sets;
   FusedQuant quant;         // root pass: quantise the float gradients on the way (g != nullptr)
+  unsigned long long* phase_ticks;   // LGA_GROW_TIMING: [8] sums of the workgroups' phase durations (100 MHz ticks), else null
 };
+// Sides of the rows of the multi-unit leaves (total_chunks blocks of kPartChunk rows): masks + left counts for grow_scatter.
+void grow_flags(const InlineTasks& inl, const GrowArgs& a, int total_chunks, hipStream_t s);
 // root: the single task's "leaf" is node 0 and nothing is partitioned.  total_units = sum of the tasks' units.
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s);
 // Moves the rows of the multi-unit leaves of a grow_round launch (total_chunks mask blocks).
@@ -352,7 +356,8 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 // Large data, every row in the bag: one walk in storage order gives every row's leaf (leaf_of_row, indexed by root row)
 // and the leaves' 36-bit gradient sums (acc as for leaf_sums); leaf_value_add then updates the scores by lookup.
 // walk_leaves returns false when the tree does not fit the kernel's LDS (nothing launched).
-bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, int64_t N,
+// records != nullptr (data of ONE feature tile): the row-major 32-byte bin records; the walk then reads a row's bins once.
+bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
                  const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
                  int64_t* acc, const uint64_t* node_sets, hipStream_t s);
 void leaf_value_add(const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves, const int32_t* rows, int64_t n,

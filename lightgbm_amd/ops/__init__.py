@@ -85,7 +85,7 @@ def hist_build(bins_rt, rows, packed, num_features: int, rows_per_chunk: int = 4
     fpad = T * TILE
     slot_words = fpad * 2 * BINS + SLOT_HEADER
     nch = max(1, -(-n // rows_per_chunk))
-    task = np.zeros(16, dtype=np.int32)
+    task = np.zeros(17, dtype=np.int32)
     task[13] = nch   # num_hchunk; left_node = 0, hist_child = 0, new_slot = 0, first_hchunk = 0
     tasks = _i32(task)
     chunk_task = torch.zeros(nch, dtype=torch.int32, device="cuda")
@@ -141,7 +141,7 @@ def partition_rows(rows, bins_fm, feature: int, threshold: int, missing_bin: int
     n = int(rows.numel())
     N = int(bins_fm.shape[1])
     nch = max(1, -(-n // 2048))
-    task = np.zeros(16, dtype=np.int32)
+    task = np.zeros(17, dtype=np.int32)
     task[0], task[1], task[2] = 0, 1, 2
     task[3], task[4], task[5], task[6] = feature, threshold, int(default_left), missing_bin
     task[10], task[11] = 0, nch
