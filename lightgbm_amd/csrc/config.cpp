@@ -32,6 +32,7 @@ const ParamDef kParams[] = {
     P(metric, "metrics,metric_types", StringList, kNone, kNone),
     P(tree_learner, "tree,tree_type,tree_learner_type", String, kNone, kNone),
     P(device_type, "device", String, kNone, kNone),
+    P(top_k, "topk", Int, 1, kNone),
     P(num_iterations,
       "num_iteration,n_iter,num_tree,num_trees,num_round,num_rounds,nrounds,num_boost_round,n_estimators,max_iter",
       Int, 0, kNone),
@@ -433,7 +434,7 @@ void Config::check() {
   if (t == "serial") tree_learner = "serial";
   else if (t == "feature" || t == "feature_parallel") tree_learner = "feature";
   else if (t == "data" || t == "data_parallel") tree_learner = "data";
-  else if (t == "voting" || t == "voting_parallel") tree_learner = "data";  // served by the data-parallel learner
+  else if (t == "voting" || t == "voting_parallel") tree_learner = "voting";
   else throw std::runtime_error("unknown tree_learner \"" + tree_learner + "\"");
   std::string d = lower(device_type);
   if (d == "cpu") device_type = "cpu";

@@ -16,6 +16,7 @@ struct Config {
   std::string objective = "regression";
   std::string boosting = "gbdt";
   std::string tree_learner = "serial";
+  int top_k = 20;            // voting-parallel learner: features every rank votes for per leaf (2 x top_k histograms are summed)
   std::string device_type = "cpu";
   int num_iterations = 100;
   double learning_rate = 0.1;

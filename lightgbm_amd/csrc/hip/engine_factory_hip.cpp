@@ -7,8 +7,11 @@ namespace lga {
 std::unique_ptr<Engine> make_engine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm) {
   ParallelMode mode = cfg.tree_learner == "feature" ? ParallelMode::Feature
                       : cfg.tree_learner == "data"  ? ParallelMode::Data
+                      : cfg.tree_learner == "voting" ? ParallelMode::Voting
                                                     : ParallelMode::Serial;
-  if (cfg.device_type == "gpu") return make_hip_engine(train, cfg, comm, mode);
+  // The device learner sums whole histograms by reduce-scatter over xGMI (exact, and what voting approximates):
+  // tree_learner=voting takes that learner on the device; the vote itself is the CPU engine's (host_engine.cpp).
+  if (cfg.device_type == "gpu") return make_hip_engine(train, cfg, comm, mode == ParallelMode::Voting ? ParallelMode::Data : mode);
   engine_ensure_host_bins(train.get());
   return make_host_engine(train, cfg, comm, mode);
 }

@@ -1145,7 +1145,7 @@ class HipBackend : public TreeBackend {
     if (hipMemcpy(v, grow_ticks_.get(), sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return;
     std::fprintf(stderr, "[grow timing] workgroup-ticks (10 ns): flags %llu, prefix %llu, hist rows %llu, masks/move %llu, sums %llu, "
                          "flush %llu (over %llu multi-unit workgroups), solo store %llu\n", v[0], v[1], v[2], v[3], v[4], v[5], v[7], v[6]);
-    std::fprintf(stderr, "[grow timing] sides kernel: range %llu, row ids %llu, bin bytes %llu, masks %llu (over %llu workgroups)\n", v[8], v[9], v[10], v[11], v[12]);
+    std::fprintf(stderr, "[grow timing] sides kernel (sampled workgroups): first row ids %llu, blocks %llu, counts %llu (over %llu workgroups)\n", v[8], v[9], v[10], v[12]);
   }
   double tree_ticks_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   double tree_cycles_ = 0;

@@ -750,21 +750,22 @@ __device__ __forceinline__ bool bin_goes_left(const SplitTask& t, int b, const u
   return (b == t.missing_bin) ? (t.default_left != 0) : (b <= t.threshold);
 }
 
-// Sides of the rows of the multi-unit leaves: one workgroup per block of kPartChunk rows writes the block's
-// go-left mask words and left count for partition_scatter_kernel.  Nothing but two dependent loads per row
-// (row id, then the split feature's byte from the feature-major matrix), eight rows per lane in flight and
-// next to no LDS, so a CU holds eight of these workgroups.
+// Sides of the rows of the multi-unit leaves: go-left mask words and left counts per block of kPartChunk rows for
+// partition_scatter_kernel.  The grid has one workgroup per block, but only every kFlagBlocks-th one works: it takes
+// kFlagBlocks consecutive blocks of its leaf, and fetches the row ids of the next block while the split feature's
+// bytes of the current one (feature-major matrix, one dependent load per row) are on their way - two memory
+// round trips per workgroup would otherwise be all a workgroup ever does.  Next to no LDS: a CU holds eight.
 __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks inl, GrowArgs a) {
   constexpr int kWords = kPartChunk / kWave;
   constexpr int U = kPartChunk / kPartThreads;
-  __shared__ int wave_left[kPartThreads / kWave];
+  __shared__ int wave_left[kFlagBlocks][kPartThreads / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
   const int ti = a.tasks ? find_task_staged<true>(a.tasks, a.n_staged, wg) : find_task<true>(inl, wg);
   const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
-  const int c = wg - t.first_pchunk;
-  if (c >= t.num_pchunk) return;
-  const bool timed = a.phase_ticks && (wg & 63) == 0;   // LGA_GROW_TIMING: every 64th workgroup, see grow_kernel
+  const int c0 = wg - t.first_pchunk;
+  if (c0 >= t.num_pchunk || (c0 % kFlagBlocks) != 0) return;
+  const bool timed = a.phase_ticks && (wg & 255) == 0;   // LGA_GROW_TIMING: a sample of the workgroups, see grow_kernel
   unsigned long long t_prev = timed ? wall_clock64() : 0ull;
   auto stamp = [&](int phase) {
     if (timed) {
@@ -779,38 +780,50 @@ __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks in
   const NodeRange p = a.nodes[t.parent_node];
   const int32_t* src = (p.buf ? a.a1 : a.a0) + p.begin;
   const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
-  const int base = c * kPartChunk;
-  if (timed && p.count < 0) return;   // (keeps the range load ahead of the first stamp)
-  stamp(8);
-  int row[U];
+  const int n_blocks = min(kFlagBlocks, t.num_pchunk - c0);
+  int next[U];
 #pragma unroll
   for (int k = 0; k < U; ++k) {
-    const int pos = base + k * kPartThreads + tid;
-    row[k] = pos < p.count ? src[pos] : -1;
-    if (pos < p.count && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
+    const int pos = c0 * kPartChunk + k * kPartThreads + tid;
+    next[k] = pos < p.count ? src[pos] : -1;
+  }
+  stamp(8);
+  for (int j = 0; j < n_blocks; ++j) {
+    int row[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      row[k] = next[k];
+      if (row[k] >= 0 && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
+    }
+    if (j + 1 < n_blocks) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int pos = (c0 + j + 1) * kPartChunk + k * kPartThreads + tid;
+        next[k] = pos < p.count ? src[pos] : -1;
+      }
+    }
+    int bin[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
+    int lefts = 0;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
+      const unsigned long long m = __ballot(left);
+      lefts += __popcll(m);
+      if (lane == 0) a.mask[(int64_t)(wg + j) * kWords + k * (kPartThreads / kWave) + wave] = m;
+    }
+    if (lane == 0) wave_left[j][wave] = lefts;
   }
   stamp(9);
-  int bin[U];
-#pragma unroll
-  for (int k = 0; k < U; ++k) bin[k] = row[k] >= 0 ? (int)fcol[row[k]] : 0;
-  stamp(10);
-  int lefts = 0;
-#pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
-    const unsigned long long m = __ballot(left);
-    lefts += __popcll(m);
-    if (lane == 0) a.mask[(int64_t)wg * kWords + k * (kPartThreads / kWave) + wave] = m;
-  }
-  if (lane == 0) wave_left[wave] = lefts;
   __syncthreads();
-  if (tid == 0) {
+  if (tid < n_blocks) {
     int all = 0;
 #pragma unroll
-    for (int w = 0; w < kPartThreads / kWave; ++w) all += wave_left[w];
-    a.chunk_left[wg] = all;
+    for (int w = 0; w < kPartThreads / kWave; ++w) all += wave_left[tid][w];
+    a.chunk_left[wg + tid] = all;
   }
-  stamp(11);
+  stamp(10);
   if (timed && tid == 0) atomicAdd(&a.phase_ticks[12], 1ull);
 }
 
@@ -936,6 +949,8 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
       }
       __syncthreads();
       stamp(0);
+      // (fetching trip i + 1 while trip i goes into the histogram was measured slower: 128 VGPRs with spills,
+      // root pass 244 -> 260 us - the other waves of the CU already fill the gaps)
       for (int sub = ulo; sub < uhi; sub += kSubRows) {
         int row[4];
 #pragma unroll

@@ -142,6 +142,7 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 constexpr int kGrowThreads = 512;
 constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
 constexpr int kSoloMaxRows = 8192;    // rows of a non-root unit / upper bound of the solo limit: sixteen rows per lane, one trip
+constexpr int kFlagBlocks = 1;        // blocks of kPartChunk rows a working workgroup of grow_flags_kernel takes (measured: 4 is slower - a big leaf's launch is one wave of workgroups either way, and fewer, longer workgroups only serialise it)
 constexpr int kGrowListRows = 3072;   // LDS list of a unit's histogram rows (worked off in windows of this many)
 struct GrowArgs {
   const SplitTask* tasks;   // staged descriptors of a round above kInlineTasks leaves (n_staged of them), else null: inline

@@ -60,6 +60,7 @@ class HostBackend : public TreeBackend {
     cat_.cat_l2 = cfg.cat_l2;
     cat_.max_cat_threshold = cfg.max_cat_threshold;
     cat_.min_data_per_group = cfg.min_data_per_group;
+    top_k_ = cfg.top_k;
     if (comm_ && comm_->size() > 1 && mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
     if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
   }
@@ -232,7 +233,7 @@ class HostBackend : public TreeBackend {
   }
 
   void reduce_slots(int first, int count) {
-    if (mode_ != ParallelMode::Data) return;
+    if (mode_ != ParallelMode::Data) return;   // (voting keeps local histograms: vote_and_search sums what it needs)
     comm_->allreduce_sum_i64(slot(first), (size_t)count * slot_words_, false, nullptr);
   }
 
@@ -243,6 +244,10 @@ class HostBackend : public TreeBackend {
   };
 
   void scan_feature(const int64_t* g, const int64_t* h, int f, const LeafScanCtx& ctx, uint32_t key, Cand* best) const {
+    scan_feature_with(sp_, g, h, f, ctx, key, best);
+  }
+  void scan_feature_with(const SplitParams& sp_, const int64_t* g, const int64_t* h, int f, const LeafScanCtx& ctx, uint32_t key,
+                         Cand* best) const {
     const FeatureMeta& m = meta_[(size_t)f];
     int nb = m.num_bin, mb = m.missing_bin;
     int vb = mb >= 0 ? nb - 1 : nb;   // value bins
@@ -292,6 +297,11 @@ class HostBackend : public TreeBackend {
       }
       const int64_t* hd = self + 2 * plane_;
       int64_t tc = hd[0], tg = hd[1], th = hd[2];
+      if (mode_ == ParallelMode::Voting) {   // local sums: the search follows the vote (vote_and_search)
+        local[(size_t)i] = Cand{ninf, worst_key, 0, 0};
+        sets[(size_t)i].gain = ninf;
+        continue;
+      }
       const bool ranged = !bounds_.empty();
       const double* nb = ranged ? &bounds_[(size_t)kNodeInfoStride * (size_t)s.node] : nullptr;
       LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_, ranged ? nb[0] : -kInf, ranged ? nb[1] : kInf,
@@ -318,6 +328,7 @@ class HostBackend : public TreeBackend {
       SplitInfo& o = out[i];
       o.total_g = tg; o.total_h = th; o.total_cnt = tc;
     }
+    if (mode_ == ParallelMode::Voting) vote_and_search(st, n, gunit, hunit, local.data(), sets.data(), out);
     if (mode_ == ParallelMode::Feature) {
       // exchange per-rank winners; every rank applies the same total order
       int P = comm_->size();
@@ -358,7 +369,112 @@ class HostBackend : public TreeBackend {
     }
   }
 
+  // Voting-parallel search (PV-Tree; upstream LightGBM's tree_learner=voting).  The slots hold LOCAL histograms
+  // (siblings by local subtraction).  Per searched node: (1) every rank searches its local histogram - leaf-size
+  // limits scaled down by the number of ranks - and votes for its top_k features by local gain; (2) the votes are
+  // all-gathered and the 2 x top_k features with the most votes (ties: larger sum of local gains, then lower
+  // index) are chosen, the same on every rank; (3) only those features' histogram rows, and the node's totals,
+  // are summed over the ranks; (4) the split is searched in the summed rows with the global totals.  With
+  // 2 x top_k >= the number of features the result is the data-parallel learner's.
+  void vote_and_search(const ScanTask* st, int n, double gunit, double hunit, Cand* best_out, CatSetSplit* sets, SplitInfo* out) {
+    const int P = comm_->size();
+    const int k = std::max(1, std::min(top_k_, F_));
+    const int n_sel = std::min(F_, 2 * k);
+    const double ninf = -std::numeric_limits<double>::infinity();
+    struct Vote { int32_t feature; float gain; };
+    std::vector<Vote> mine((size_t)n * (size_t)k, Vote{-1, 0.0f});
+    SplitParams local_sp = sp_;
+    local_sp.min_data_in_leaf = std::max(1, (int)(sp_.min_data_in_leaf / P));
+    local_sp.min_sum_hessian_in_leaf = sp_.min_sum_hessian_in_leaf / P;
+    const bool ranged = !bounds_.empty();
+    auto usable = [&](const ScanTask& s, int f) {
+      return meta_[(size_t)f].enabled && node_feature_on(sp_, s.key, f, F_) && node_allows(sp_, s.node, f);
+    };
+#pragma omp parallel for schedule(dynamic) if (n * F_ >= 512)
+    for (int i = 0; i < n; ++i) {
+      const ScanTask& s = st[i];
+      const int64_t* self = slot(s.slot);
+      const int64_t* hd = self + 2 * plane_;
+      const double* nb = ranged ? &bounds_[(size_t)kNodeInfoStride * (size_t)s.node] : nullptr;
+      const LeafScanCtx ctx = make_scan_ctx(hd[1], hd[2], hd[0], gunit, hunit, local_sp, ranged ? nb[0] : -kInf, ranged ? nb[1] : kInf,
+                                            ranged ? nb[2] : std::numeric_limits<double>::quiet_NaN());
+      std::vector<std::pair<double, int>> gains;
+      for (int f = 0; f < F_; ++f) {
+        if (!usable(s, f)) continue;
+        Cand c{ninf, ~0ull, 0, 0};
+        scan_feature_with(local_sp, self + (size_t)f * kMaxBins, self + plane_ + (size_t)f * kMaxBins, f, ctx, s.key, &c);
+        if (c.gain > ninf) gains.emplace_back(c.gain, f);
+      }
+      std::sort(gains.begin(), gains.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+      });
+      for (int j = 0; j < k && j < (int)gains.size(); ++j)
+        mine[(size_t)i * (size_t)k + (size_t)j] = Vote{gains[(size_t)j].second, (float)gains[(size_t)j].first};
+    }
+    std::vector<Vote> all((size_t)n * (size_t)k * (size_t)P);
+    comm_->allgather_bytes(mine.data(), all.data(), mine.size() * sizeof(Vote), false, nullptr);
+    // the chosen features of every node, then their local rows + the node's local totals in one buffer
+    const size_t per_node = 4 + (size_t)n_sel * 2 * kMaxBins;
+    std::vector<int32_t> chosen((size_t)n * (size_t)n_sel, -1);
+    std::vector<int64_t> buf((size_t)n * per_node, 0);
+    for (int i = 0; i < n; ++i) {
+      std::vector<int> count((size_t)F_, 0);
+      std::vector<double> weight((size_t)F_, 0.0);
+      for (int r = 0; r < P; ++r)
+        for (int j = 0; j < k; ++j) {
+          const Vote& v = all[((size_t)r * (size_t)n + (size_t)i) * (size_t)k + (size_t)j];
+          if (v.feature >= 0 && v.feature < F_) { ++count[(size_t)v.feature]; weight[(size_t)v.feature] += v.gain; }
+        }
+      std::vector<int> order;
+      for (int f = 0; f < F_; ++f)
+        if (count[(size_t)f] > 0) order.push_back(f);
+      std::sort(order.begin(), order.end(), [&](int a, int b) {
+        if (count[(size_t)a] != count[(size_t)b]) return count[(size_t)a] > count[(size_t)b];
+        if (weight[(size_t)a] != weight[(size_t)b]) return weight[(size_t)a] > weight[(size_t)b];
+        return a < b;
+      });
+      const int64_t* self = slot(st[i].slot);
+      int64_t* dst = buf.data() + (size_t)i * per_node;
+      const int64_t* hd = self + 2 * plane_;
+      dst[0] = hd[0]; dst[1] = hd[1]; dst[2] = hd[2];
+      for (int j = 0; j < n_sel && j < (int)order.size(); ++j) {
+        const int f = order[(size_t)j];
+        chosen[(size_t)i * (size_t)n_sel + (size_t)j] = f;
+        std::memcpy(dst + 4 + (size_t)j * 2 * kMaxBins, self + (size_t)f * kMaxBins, kMaxBins * sizeof(int64_t));
+        std::memcpy(dst + 4 + (size_t)j * 2 * kMaxBins + kMaxBins, self + plane_ + (size_t)f * kMaxBins, kMaxBins * sizeof(int64_t));
+      }
+    }
+    comm_->allreduce_sum_i64(buf.data(), buf.size(), false, nullptr);
+#pragma omp parallel for schedule(dynamic) if (n * n_sel >= 512)
+    for (int i = 0; i < n; ++i) {
+      const ScanTask& s = st[i];
+      const int64_t* src = buf.data() + (size_t)i * per_node;
+      const int64_t tc = src[0], tg = src[1], th = src[2];
+      const double* nb = ranged ? &bounds_[(size_t)kNodeInfoStride * (size_t)s.node] : nullptr;
+      const LeafScanCtx ctx = make_scan_ctx(tg, th, tc, gunit, hunit, sp_, ranged ? nb[0] : -kInf, ranged ? nb[1] : kInf,
+                                            ranged ? nb[2] : std::numeric_limits<double>::quiet_NaN());
+      Cand best{ninf, ~0ull, 0, 0};
+      CatSetSplit& cs = sets[(size_t)i];
+      auto rows_of = [&](int j) { return src + 4 + (size_t)j * 2 * kMaxBins; };
+      for (int j = 0; j < n_sel; ++j) {
+        const int f = chosen[(size_t)i * (size_t)n_sel + (size_t)j];
+        if (f >= 0 && meta_[(size_t)f].categorical != kCategoricalSorted) scan_feature(rows_of(j), rows_of(j) + kMaxBins, f, ctx, s.key, &best);
+      }
+      cs.gain = best.gain;   // a category set must beat the best plain split
+      for (int j = 0; j < n_sel; ++j) {
+        const int f = chosen[(size_t)i * (size_t)n_sel + (size_t)j];
+        if (f < 0 || meta_[(size_t)f].categorical != kCategoricalSorted) continue;
+        const FeatureMeta& m = meta_[(size_t)f];
+        categorical_set_search(rows_of(j), rows_of(j) + kMaxBins, m.missing_bin >= 0 ? m.num_bin - 1 : m.num_bin, f, ctx, sp_, cat_, &cs);
+      }
+      best_out[(size_t)i] = best;
+      SplitInfo& o = out[i];
+      o.total_g = tg; o.total_h = th; o.total_cnt = tc;
+    }
+  }
+
   static constexpr double kInf = std::numeric_limits<double>::infinity();
+  int top_k_ = 20;
   std::vector<double> bounds_;   // [node][lo, hi, out]; empty unless monotone constraints / path smoothing are active
   std::vector<uint64_t> masks_;  // [node][words]; empty unless interaction constraints are active
   std::vector<uint64_t> cat_sets_;   // [node][kCatSetWords]: bins going left in the node's best split, when it is a set split
@@ -685,7 +801,7 @@ class HostEngine : public Engine {
   }
   GrowStats grow_stats() const override { return grower_.last_stats(); }
   void sum_over_ranks_i64(int64_t* v, size_t n) override {   // feature-parallel ranks all hold every row
-    if (dist() && backend_.mode() == ParallelMode::Data) comm_->allreduce_sum_i64(v, n, false, nullptr);
+    if (dist() && (backend_.mode() == ParallelMode::Data || backend_.mode() == ParallelMode::Voting)) comm_->allreduce_sum_i64(v, n, false, nullptr);
   }
   void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) override {
     const int L = tree.num_leaves;

@@ -8,7 +8,8 @@
 
 namespace lga {
 
-enum class ParallelMode { Serial, Data, Feature };
+// Voting: rows sharded as in Data; only the histograms of the features the ranks vote for are summed (PV-Tree).
+enum class ParallelMode { Serial, Data, Feature, Voting };
 
 std::unique_ptr<Engine> make_host_engine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm,
                                          ParallelMode mode);

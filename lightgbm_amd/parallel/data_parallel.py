@@ -56,11 +56,16 @@ def distributed_dataset(X_local, label=None, weight=None, params: Optional[Dict[
 
 
 def train_data_parallel(params: Dict[str, Any], X_local, y_local, num_boost_round: int = 100, group=None,
-                        weight=None, **train_kwargs):
-    """Trains one model over all ranks' shards; every rank returns the same booster."""
+                        weight=None, tree_learner: str = "data", **train_kwargs):
+    """Trains one model over all ranks' shards; every rank returns the same booster.
+
+    ``tree_learner="voting"`` sums only the histogram rows of the features the ranks vote for (``top_k`` votes
+    per rank and leaf; CPU engine - the device engine sums whole histograms by reduce-scatter either way)."""
     from ..engine import train
+    if tree_learner not in ("data", "voting"):
+        raise ValueError("rows are sharded by tree_learner='data' and 'voting'")
     p = dict(params)
-    p["tree_learner"] = "data"
+    p["tree_learner"] = tree_learner
     ds = distributed_dataset(X_local, y_local, weight=weight, params=p, group=group)
     comm = default_comm(group)
     try:

@@ -126,6 +126,45 @@ def test_data_parallel_equals_serial_binary_first_trees_and_auc():
     assert abs(res[0][1] - ev0["training"]["auc"][-1]) < 1e-4 and res[0][1] == res[1][1]
 
 
+@pytest.mark.parametrize("P", [2, 4])
+def test_voting_parallel_with_enough_votes_equals_serial(P):
+    """2 x top_k >= number of features: every histogram row is summed, so the vote changes nothing."""
+    X, y = make_regression(6000, 9, seed=0)
+    params = {**CPU, "num_leaves": 31, "min_data_in_leaf": 20}
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X), 10)
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X)
+        return lgb.train({**params, "tree_learner": "voting", "top_k": 5}, d, 10, comm=comm).model_to_string()
+    for s in run_ranks(P, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
+def test_voting_parallel_with_few_votes_agrees_across_ranks_and_keeps_the_quality():
+    """top_k = 3 of 28 features: at most 6 histogram rows per node cross the ranks.  The ranks must still grow the
+    same model, and - PV-Tree's claim - lose next to nothing against the learner that sums every row."""
+    X, y = make_higgs_like(12000, seed=5, device="numpy")
+    Xt, yt = make_higgs_like(6000, seed=6, device="numpy")
+    params = {**CPU, "objective": "binary", "num_leaves": 15, "min_data_in_leaf": 20, "learning_rate": 0.1}
+    from sklearn.metrics import roc_auc_score
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X), 40)
+    auc_serial = roc_auc_score(yt, serial.predict(Xt))
+    P = 3
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=X)
+        return lgb.train({**params, "tree_learner": "voting", "top_k": 3}, d, 40, comm=comm).model_to_string()
+    res = run_ranks(P, rank)
+    assert trees_of(res[0]) == trees_of(res[1]) == trees_of(res[2])
+    assert trees_of(res[0]) != trees_of(serial)          # it IS an approximation at this top_k
+    auc_vote = roc_auc_score(yt, lgb.Booster(model_str=res[0]).predict(Xt))
+    assert auc_vote > auc_serial - 0.01, (auc_vote, auc_serial)
+
+
 @pytest.mark.parametrize("P,F", [(2, 70), (3, 100)])
 def test_feature_parallel_equals_serial(P, F):
     X, y = make_regression(3000, F, seed=2)
