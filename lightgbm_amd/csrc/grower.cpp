@@ -15,6 +15,7 @@ TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds
   if (const char* e = std::getenv("LGA_SPEC_LO")) spec_lo_ = std::atof(e);
   if (const char* e = std::getenv("LGA_SPEC_HI")) spec_hi_ = std::atof(e);
   if (const char* e = std::getenv("LGA_SPEC_RATIO")) spec_ratio_ = std::atoi(e) != 0;
+  if (const char* e = std::getenv("LGA_CERTAIN_SPLITS")) certain_splits_ = std::atoi(e) != 0;
   if (const char* e = std::getenv("LGA_OWN_ROUND_ROWS")) own_round_rows_ = std::max(1.0, std::atof(e));
   if (const char* e = std::getenv("LGA_SPEC_ROWS_LO")) spec_rows_lo_ = std::max(1.0, std::atof(e));
   if (const char* e = std::getenv("LGA_SPEC_ROWS_HI")) spec_rows_hi_ = std::max(spec_rows_lo_ * 2.0, std::atof(e));
@@ -309,9 +310,17 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
     return (spec_lo_ + (spec_hi_ - spec_lo_) * t) * bar;
   };
 
+  const bool dump_rounds = g_trace.on && std::getenv("LGA_GROW_DUMP") && tree_index_ == std::atoll(std::getenv("LGA_GROW_DUMP"));
   auto submit = [&](std::vector<SplitTask>&& tasks) {
     Flight f;
     f.tasks = std::move(tasks);
+    if (dump_rounds) {
+      int64_t most = 0, sum = 0;
+      for (const SplitTask& t : f.tasks) { const int64_t r = nodes[(size_t)t.parent_node].best.total_cnt; most = std::max(most, r); sum += r; }
+      std::fprintf(stderr, "[grow dump] round %d: %zu leaves, %lld rows (largest %lld), %zu rounds already in flight, %zu splits chosen, at %.1f us\n",
+                   stats_.rounds, f.tasks.size(), (long long)sum, (long long)most, flights.size(), chosen.size(),
+                   GrowTrace::us(t_enter, GrowTrace::clock::now()));
+    }
     const auto t_call = GrowTrace::clock::now();
     f.ticket = be.submit_round(f.tasks);
     if (g_trace.on) { t_last_backend = GrowTrace::clock::now(); backend_us += GrowTrace::us(t_call, t_last_backend); }
@@ -378,13 +387,30 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
       auto virt = frontier;
       int vseq = seq;
       int vbudget = budget;
+      // Splits that are CERTAIN to get their turn need no gain estimate: the subtree of a leaf cannot take more
+      // splits than its rows and its hessian sum leave room for (min_data_in_leaf, min_sum_hessian_in_leaf), so a
+      // leaf is split for sure if the budget outlasts everything that could be chosen ahead of it - the known
+      // candidates with larger gains (the virtual replay pops them first) and all that the leaves among them whose
+      // children are not known yet could still grow (`absorb`).  Typical case: a leaf of millions of rows with a
+      // modest gain behind a few small leaves with large ones.
+      int64_t absorb = 0;
+      auto max_subtree_splits = [&](const Node& n) -> int64_t {
+        const SplitInfo& b = n.best;
+        int64_t most = std::numeric_limits<int64_t>::max() / 4;
+        if (cfg_.min_data_in_leaf > 1) most = std::min<int64_t>(most, b.total_cnt / cfg_.min_data_in_leaf);
+        if (cfg_.min_sum_hessian_in_leaf > 0.0) {
+          const double leaves = (double)b.total_h * hunit / cfg_.min_sum_hessian_in_leaf;
+          if (leaves < (double)most) most = (int64_t)leaves;
+        }
+        return std::max<int64_t>(most - 1, 0);
+      };
       while (!virt.empty() && vbudget > 0 && (int)tasks.size() < max_new) {
         Entry e = virt.top();
         virt.pop();
         --vbudget;
         Node& c = nodes[(size_t)e.node];
         if (c.left >= 0) {
-          if (!c.ready) continue;                         // in flight: children unknown
+          if (!c.ready) { absorb += max_subtree_splits(c); continue; }   // in flight: children unknown
           for (int child : {c.left, c.right}) {
             const SplitInfo& s = nodes[(size_t)child].best;
             if (splittable(s)) virt.push(Entry{s.gain, vseq, child});
@@ -393,7 +419,9 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
           continue;
         }
         const bool is_stall_leaf = e.node == frontier.top().node;
-        if (!is_stall_leaf && e.gain < floor_gain_for(c.best.total_cnt, budget_total - vbudget - 1)) continue;
+        const bool certain = certain_splits_ && (int64_t)vbudget >= absorb;
+        absorb += max_subtree_splits(c);
+        if (!is_stall_leaf && !certain && e.gain < floor_gain_for(c.best.total_cnt, budget_total - vbudget - 1)) continue;
         SplitTask t{};
         t.parent_node = e.node;
         t.left_node = (int)nodes.size();

@@ -106,6 +106,7 @@ class TreeGrower {
   double spec_lo_ = 0.2, spec_hi_ = 0.95;
   double spec_rows_lo_ = 131072.0, spec_rows_hi_ = 2097152.0;
   int row_shards_ = 1;
+  bool certain_splits_ = true;   // split leaves whose turn is certain ahead of time (LGA_CERTAIN_SPLITS=0: gain estimates only)
   double own_round_rows_ = 262144.0;   // leaves of at least this many rows (per rank) get a round of their own while places are free (LGA_OWN_ROUND_ROWS)
   bool spec_ratio_ = true;        // scale the previous cutoff by the ratio of the roots' best gains
   double prev_root_gain_ = 0.0;
