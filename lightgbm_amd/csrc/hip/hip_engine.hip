@@ -708,10 +708,14 @@ class HipBackend : public TreeBackend {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
       return root ? cnt : std::min<int64_t>(cnt, std::max(t.hist_rows, 0));
     };
+    // (partition_scatter_kernel leaves a leaf of ONE block to the kernel that made its masks - the tile path's does
+    // finish such leaves, grow_flags_kernel does not: a multi-unit leaf here always spans at least two blocks)
+    static_assert(k::kSoloMaxRows >= k::kPartChunk, "leaves of up to one partition block must be solo leaves");
+    const int64_t solo_limit = std::max<int64_t>(solo_rows_, k::kPartChunk);
     int64_t multi_rows = 0;
     for (const auto& t : tasks) {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
-      if (root || cnt > solo_rows_) multi_rows += hist_bound(t);
+      if (root || cnt > solo_limit) multi_rows += hist_bound(t);
     }
     int64_t ur = (multi_rows + target_units_ - 1) / target_units_;
     ur = ((ur + k::kSubRows - 1) / k::kSubRows) * k::kSubRows;
@@ -720,7 +724,7 @@ class HipBackend : public TreeBackend {
     int np = 0;
     for (auto& t : tasks) {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
-      const bool multi = root || cnt > solo_rows_;
+      const bool multi = root || cnt > solo_limit;
       t.first_pchunk = np;
       t.num_pchunk = (multi && !root) ? ceil_div(cnt, k::kPartChunk) : 0;
       t.num_hchunk = multi ? std::max(1, ceil_div(hist_bound(t), unit_rows)) : 1;
