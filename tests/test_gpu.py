@@ -429,12 +429,14 @@ def test_index_checking_build_catches_a_bad_row_and_passes_clean_runs():
     assert r.returncode == 0 and "CAUGHT" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2")])
+@pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2"), ("1", "4")])
 def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
-    """The large-data paths - bin records interleaved with the packed gradients, two growth rounds in
-    flight on two streams - against the CPU oracle (both are size-gated, so they are forced here)."""
+    """The large-data paths - bin records interleaved with the packed gradients, two (or four: large leaves then get
+    rounds of their own and rounds are replayed as they finish) growth rounds in flight on as many streams - against
+    the CPU oracle (both are size-gated, so they are forced here)."""
     monkeypatch.setenv("LGA_ROW_LINES", lines)
     monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)
+    monkeypatch.setenv("LGA_OWN_ROUND_ROWS", "9000")   # (only read with more than two rounds in flight)
     X, y = make_regression(50001, 9, seed=11)     # row count not divisible by three
     X[::17, 2] = np.nan
     p = {"num_leaves": 63, "min_data_in_leaf": 10, "bagging_fraction": 0.7, "bagging_freq": 1}

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import lightgbm_amd as lgb
-from lightgbm_amd.utils.datasets import make_diamonds_like, make_regression
+from lightgbm_amd.utils.datasets import make_diamonds_like, make_higgs_like, make_regression
 
 CPU = {"device_type": "cpu", "verbose": -1}
 
@@ -74,6 +74,24 @@ def test_batched_growth_equals_strict_best_first(leaves, extra):
     assert trees_of(strict) == trees_of(batched)
     assert batched.grow_stats()["rounds"] < strict.grow_stats()["rounds"]
     assert batched.grow_stats()["used_splits"] == strict.grow_stats()["used_splits"]
+
+
+@pytest.mark.parametrize("flight", ["1", "3"])
+def test_certain_splits_ahead_of_time_do_not_change_the_trees(flight, monkeypatch):
+    """Leaves whose turn is certain (the budget outlasts everything that could be chosen ahead of them, given
+    min_sum_hessian_in_leaf / min_data_in_leaf) are split before the replay reaches them: fewer rounds, same trees -
+    with one round at a time and with several in flight (rounds dealt out over the free places)."""
+    X, y = make_higgs_like(20000, seed=3, device="numpy")
+    p = {**CPU, "objective": "binary", "num_leaves": 63, "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 20.0}
+    monkeypatch.setenv("LGA_HOST_IN_FLIGHT", flight)
+    monkeypatch.setenv("LGA_OWN_ROUND_ROWS", "3000")
+    strict = lgb.train({**p, "max_batch_leaves": 1}, lgb.Dataset(X, label=y), 6)
+    monkeypatch.setenv("LGA_CERTAIN_SPLITS", "0")
+    estimates_only = lgb.train(p, lgb.Dataset(X, label=y), 6, keep_training_booster=True)
+    monkeypatch.setenv("LGA_CERTAIN_SPLITS", "1")
+    with_certain = lgb.train(p, lgb.Dataset(X, label=y), 6, keep_training_booster=True)
+    assert trees_of(strict) == trees_of(estimates_only) == trees_of(with_certain)
+    assert with_certain.grow_stats()["used_splits"] == estimates_only.grow_stats()["used_splits"]
 
 
 def test_num_leaves_and_min_data_constraints_hold():
