@@ -182,7 +182,19 @@ class HipBackend : public TreeBackend {
     else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
     // Histogram pool layout (kernels.hpp: PoolLayout): the data-parallel learner splits every slot into one
     // chunk per rank, so that one in-place reduce-scatter per round hands each rank the features it searches.
-    lay_.ranks = mode_ == ParallelMode::Data ? comm_->size() : 1;
+    // Narrow data (a slot of at most 512 KiB: up to four feature tiles) is summed WHOLE instead: one all-reduce per
+    // round and every rank searches every feature - the exchange is latency-bound there, and this way a round costs
+    // one collective instead of two (reduce-scatter + winner all-gather) and no merge launch.  Wide data keeps the
+    // reduce-scatter, whose traffic per link is 1/P of an all-reduce's.  LGA_DP_EXCHANGE=allreduce / reduce_scatter
+    // overrides the size rule (for A/B runs on a multi-GPU node).
+    dp_allreduce_ = mode_ == ParallelMode::Data && (size_t)T_ * kTileFeatures * 2 * kMaxBins * sizeof(int64_t) <= (size_t)512 << 10;
+    if (const char* e = std::getenv("LGA_DP_EXCHANGE")) {
+      const std::string v = e;
+      if (v == "allreduce") dp_allreduce_ = mode_ == ParallelMode::Data;
+      else if (v == "reduce_scatter") dp_allreduce_ = false;
+      else throw std::runtime_error("LGA_DP_EXCHANGE is allreduce or reduce_scatter");
+    }
+    lay_.ranks = (mode_ == ParallelMode::Data && !dp_allreduce_) ? comm_->size() : 1;
     lay_.fpr = lay_.ranks > 1 ? std::max(1, (F_ + lay_.ranks - 1) / lay_.ranks) : std::max(1, T_ * kTileFeatures);
     lay_.chunk_words = (int64_t)lay_.fpr * 2 * kMaxBins + kSlotHeader;
     lay_.slot_words = lay_.chunk_words * lay_.ranks;
@@ -221,7 +233,7 @@ class HipBackend : public TreeBackend {
     if (cfg.profile || std::getenv("LGA_ROCTX")) trace_enable(true);
     // Which features this rank searches (kernels.hpp: ScanRange).
     scan_range_ = k::ScanRange{0, F_, 64, 0, 1, std::max(1, (F_ + 63) / 64)};
-    if (mode_ == ParallelMode::Data) {
+    if (mode_ == ParallelMode::Data && !dp_allreduce_) {
       const int r = comm_->rank();
       const int f0 = std::min(F_, r * lay_.fpr), f1 = std::min(F_, (r + 1) * lay_.fpr);
       scan_range_ = k::ScanRange{f0, f1, 64, 0, 1, std::max(1, (f1 - f0 + 63) / 64)};
@@ -911,12 +923,25 @@ class HipBackend : public TreeBackend {
       int64_t* region = pool_.get() + (size_t)round.first_slot * slot_words_;
       const size_t block = (size_t)round.n_slots * (size_t)lay_.chunk_words;
       // features searched over category sets need their full rows on every rank: sum everything then
-      if (sorted_cat_.empty()) comm_->reduce_scatter_sum_i64(region, block, true, cs);
+      if (sorted_cat_.empty() && !dp_allreduce_) comm_->reduce_scatter_sum_i64(region, block, true, cs);
       else comm_->allreduce_sum_i64(region, block * (size_t)lay_.ranks, true, cs);
     }
     prof.mark(PhaseProfile::kScan, cs);
     const int n_scan = root ? 1 : 2 * B;
     k::ScanArgs sa = scan_args(x, root, B, round);
+    if (mode_ == ParallelMode::Data && dp_allreduce_) {
+      // every rank holds the summed histograms of every feature: the search and its hand-over are the serial ones,
+      // and every rank arrives at the same splits by itself
+      sa.tasks = staged;
+      k::scan_blocks(inl, sa, n_scan, cs);
+      if (comm_stream_) {
+        LGA_HIP_CHECK(hipEventRecord(x.ev_reduced, comm_stream_));
+        LGA_HIP_CHECK(hipStreamWaitEvent(st_, x.ev_reduced, 0));
+      }
+      prof.mark(PhaseProfile::kFetch, st_);
+      prof.mark(PhaseProfile::kCount, st_);
+      return;
+    }
     sa.best_out = x.best_local.get();
     sa.tasks = staged;
     k::scan_blocks(inl, sa, n_scan, cs);
@@ -1083,6 +1108,7 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<NodeRange> nodes_;
   DeviceBuffer<int64_t> node_totals_;
   DeviceBuffer<int32_t> arena_[2];
+  bool dp_allreduce_ = false;   // data-parallel exchange: whole histograms by all-reduce (narrow data) instead of reduce-scatter by feature
   static constexpr int kMaxRoundsInFlight = 4;
   RoundCtx ctx_[kMaxRoundsInFlight];
   int n_ctx_ = 1;

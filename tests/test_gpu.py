@@ -745,8 +745,12 @@ def _run_ranks(P, fn):
     return out
 
 
+@pytest.mark.parametrize("exchange", ["allreduce", "reduce_scatter"])
 @pytest.mark.parametrize("P,flight,lines", [(2, "1", "0"), (4, "1", "1"), (2, "2", "1"), (4, "2", "0"), (8, "2", "1")])
-def test_gpu_data_parallel_equals_serial(P, flight, lines, monkeypatch):
+def test_gpu_data_parallel_equals_serial(P, flight, lines, exchange, monkeypatch):
+    """Both exchanges of the data-parallel learner: whole histograms by all-reduce (the default for narrow data: one
+    collective per round, every rank searches every feature) and reduce-scatter by feature + winner all-gather."""
+    monkeypatch.setenv("LGA_DP_EXCHANGE", exchange)
     monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)   # "2": overlapped rounds
     monkeypatch.setenv("LGA_ROW_LINES", lines)           # "1": the row-line layout large shards use
     X, y = make_regression(40000, 10, seed=8)
@@ -763,10 +767,11 @@ def test_gpu_data_parallel_equals_serial(P, flight, lines, monkeypatch):
 
 
 @pytest.mark.parametrize("P,F,leaves", [(2, 40, 31), (3, 70, 63), (8, 5, 15)])
-def test_gpu_data_parallel_over_feature_tiles_and_idle_owners(P, F, leaves):
+def test_gpu_data_parallel_over_feature_tiles_and_idle_owners(P, F, leaves, monkeypatch):
     """Reduce-scatter by feature: several feature tiles (records + gradient array instead of row lines), a
     feature count the ranks do not divide, and more ranks than features (ranks that own nothing to search).
     The loop-back communicator reduces ONLY the owner's block, like RCCL."""
+    monkeypatch.setenv("LGA_DP_EXCHANGE", "reduce_scatter")
     X, y = make_regression(30000, F, seed=11)
     params = {**GPU, "num_leaves": leaves}
     serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=X[:20000], params=GPU), 6)
