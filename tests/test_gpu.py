@@ -445,6 +445,25 @@ def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     assert trees_of(a) == trees_of(b)
 
 
+def test_large_data_paths_match_the_cpu_engine():
+    """2^20 rows and more take paths the small tests never reach by themselves: row lines, two rounds in flight, large
+    leaves as sides / move / dense child histogram launches, leaf ids and exact leaf sums from one tree walk.  Same
+    splits as the CPU engine; leaf values agree to the last bits (the initial score is summed in another order)."""
+    X, y = make_regression((1 << 20) + 12345, 12, seed=3)
+    p = {"num_leaves": 63, "min_data_in_leaf": 20}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 4)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 4)
+    la, lb = trees_of(a).split("\n"), trees_of(b).split("\n")
+    assert len(la) == len(lb)
+    approx = ("leaf_value=", "internal_value=", "leaf_weight=", "internal_weight=", "split_gain=")
+    for x, z in zip(la, lb):
+        if x.startswith(approx):
+            np.testing.assert_allclose(np.array(x.split("=")[1].split(), dtype=float), np.array(z.split("=")[1].split(), dtype=float),
+                                       rtol=1e-9, atol=1e-12)
+        else:
+            assert x == z
+
+
 def test_gpu_balanced_bagging_draws_the_cpu_bag():
     X, y = make_higgs_like(80000, seed=5, device="numpy")
     y = (y > 0) & (X[:, 0] > 0.3)
