@@ -1015,8 +1015,12 @@ class Booster:
 
     # -- model IO --
     def model_to_string(self, num_iteration: Optional[int] = None, start_iteration: int = 0,
-                        importance_type: str = "split") -> str:
+                        importance_type: Optional[str] = None) -> str:
+        """``importance_type`` ("split" / "gain") of the ``feature_importances`` block; default: the booster's
+        ``saved_feature_importance_type`` parameter (0 = split counts)."""
         lib, _ = _lib.load()
+        if importance_type is None:
+            importance_type = "gain" if int(get_param(self.params, "saved_feature_importance_type", 0) or 0) == 1 else "split"
         if num_iteration is None:
             num_iteration = self.best_iteration if self.best_iteration > 0 else -1
         out, n = ctypes.c_char_p(), ctypes.c_int64()
@@ -1028,7 +1032,7 @@ class Booster:
         return text
 
     def save_model(self, filename: str, num_iteration: Optional[int] = None, start_iteration: int = 0,
-                   importance_type: str = "split") -> "Booster":
+                   importance_type: Optional[str] = None) -> "Booster":
         text = self.model_to_string(num_iteration, start_iteration, importance_type)
         tmp = f"{filename}.tmp.{os.getpid()}"
         with open(tmp, "w") as f:

@@ -119,8 +119,10 @@ def main(argv=None) -> int:
     elif task == "predict":
         b = Booster(model_file=kv.pop("input_model"))
         X, _ = _load_table(kv.pop("data"), int(kv.pop("label_column_predict", str(label_column))), header, b.num_feature())
+        n_it = int(kv.pop("num_iteration_predict", "-1"))
         p = b.predict(X, raw_score=_flag(kv, "predict_raw_score"), pred_leaf=_flag(kv, "predict_leaf_index"),
-                      pred_contrib=_flag(kv, "predict_contrib"))
+                      pred_contrib=_flag(kv, "predict_contrib"), num_iteration=n_it if n_it > 0 else None,
+                      start_iteration=int(kv.pop("start_iteration_predict", "0")))
         np.savetxt(kv.pop("output_result", "LightGBM_predict_result.txt"), p, fmt="%.17g", delimiter="\t")
     elif task == "refit":
         b = Booster(model_file=kv.pop("input_model"))

@@ -122,6 +122,20 @@ const ParamDef kParams[] = {
     P(profile, "", Bool, kNone, kNone),
     P(device_bin_find, "", Bool, kNone, kNone),
     P(iteration_offset, "", Int, 0, kNone),
+    P(early_stopping_min_delta, "", Double, 0, kNone),
+    P(saved_feature_importance_type, "", Int, 0, 1),
+    P(monotone_constraints_method, "monotone_constraining_method,mc_method", String, kNone, kNone),
+    P(force_col_wise, "", Bool, kNone, kNone),
+    P(force_row_wise, "", Bool, kNone, kNone),
+    P(histogram_pool_size, "hist_pool_size", Double, kNone, kNone),
+    P(gpu_platform_id, "", Int, kNone, kNone),
+    P(gpu_use_dp, "", Bool, kNone, kNone),
+    P(num_gpu, "", Int, 1, kNone),
+    P(two_round, "two_round_loading,use_two_round_loading", Bool, kNone, kNone),
+    P(precise_float_parser, "", Bool, kNone, kNone),
+    P(enable_bundle, "is_enable_bundle,bundle", Bool, kNone, kNone),
+    P(num_grad_quant_bins, "", Int, 2, kNone),
+    P(stochastic_rounding, "", Bool, kNone, kNone),
 };
 #pragma GCC diagnostic pop
 #undef P
@@ -436,6 +450,12 @@ void Config::check() {
   else if (t == "data" || t == "data_parallel") tree_learner = "data";
   else if (t == "voting" || t == "voting_parallel") tree_learner = "voting";
   else throw std::runtime_error("unknown tree_learner \"" + tree_learner + "\"");
+  {
+    const std::string m = lower(monotone_constraints_method);
+    if (m != "basic" && m != "intermediate" && m != "advanced")
+      throw std::runtime_error("unknown monotone_constraints_method \"" + monotone_constraints_method + "\"");
+    monotone_constraints_method = m;   // intermediate / advanced: served by the basic method (same guarantee, more conservative splits)
+  }
   std::string d = lower(device_type);
   if (d == "cpu") device_type = "cpu";
   else if (d == "gpu" || d == "hip" || d == "cuda" || d == "rocm") device_type = "gpu";

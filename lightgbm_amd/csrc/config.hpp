@@ -123,6 +123,24 @@ struct Config {
                                   // sampling) of iteration k are the same wherever that iteration is trained
   bool device_bin_find = true;   // device-resident raw matrices: find bin boundaries on the GPU
 
+  // accepted for scripts written against upstream LightGBM; they select between implementations this engine has
+  // one of (histograms are always built row-wise over device-resident rows, gradients quantised to 16 bits with
+  // round-to-nearest, dense storage), so they change nothing here
+  bool force_col_wise = false, force_row_wise = false;
+  double histogram_pool_size = -1.0;
+  int gpu_platform_id = -1;
+  bool gpu_use_dp = false;
+  int num_gpu = 1;
+  bool two_round = false;
+  bool precise_float_parser = false;
+  bool enable_bundle = true;
+  int num_grad_quant_bins = 4;
+  bool stochastic_rounding = true;
+  std::string monotone_constraints_method = "basic";   // the one method implemented; the stricter upstream methods fall back to it
+  // behaviour
+  double early_stopping_min_delta = 0.0;      // an improvement counts from this much on (train / cv early stopping)
+  int saved_feature_importance_type = 0;      // feature_importances block of saved models: 0 split counts, 1 total gains
+
   // Names of parameters that were explicitly set (after alias resolution).
   std::vector<std::string> explicit_keys;
   // Unknown keys seen while parsing (reported as warnings, not errors).

@@ -100,7 +100,8 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
     elif isinstance(verbose_eval, int) and not isinstance(verbose_eval, bool) and verbose_eval > 0:
         callbacks.append(cb.log_evaluation(verbose_eval))
     if early_stopping_rounds is not None and early_stopping_rounds > 0:
-        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=bool(verbose_eval)))
+        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=bool(verbose_eval),
+                                           min_delta=float(get_param(params, "early_stopping_min_delta", 0.0) or 0.0)))
     if evals_result is not None:
         callbacks.append(cb.record_evaluation(evals_result))
     cb_before, cb_after = _split_callbacks(callbacks)
@@ -469,7 +470,8 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
         cvbooster.append(runner.construct(k, build))
 
     if early_stopping_rounds is not None and early_stopping_rounds > 0:
-        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=False))
+        callbacks.append(cb.early_stopping(early_stopping_rounds, first_metric_only, verbose=False,
+                                           min_delta=float(get_param(params, "early_stopping_min_delta", 0.0) or 0.0)))
     if verbose_eval is True:
         callbacks.append(cb.log_evaluation(show_stdv=show_stdv))
     elif isinstance(verbose_eval, int) and not isinstance(verbose_eval, bool) and verbose_eval and verbose_eval > 0:

@@ -76,3 +76,41 @@ def test_master_seed_settles_the_other_random_streams():
     assert not np.array_equal(fit(seed=1), fit(seed=2))                       # bag and feature subsets follow the seed
     assert np.array_equal(fit(seed=1, bagging_seed=9, feature_fraction_seed=9),
                           fit(seed=2, bagging_seed=9, feature_fraction_seed=9))   # explicit stream seeds win
+
+
+def test_upstream_parameters_without_a_choice_here_are_accepted_silently():
+    """Switches between implementations this engine has one of (histogram orientation, OpenCL platform, bundling,
+    two-round loading, gradient quantisation bins) parse as known parameters and do not change the model."""
+    import lightgbm_amd as lgb
+    from lightgbm_amd.utils.datasets import make_regression
+    X, y = make_regression(1500, 5, seed=1)
+    base = {"device_type": "cpu", "verbose": -1, "num_leaves": 7}
+    extra = {"force_col_wise": True, "histogram_pool_size": 512.0, "gpu_platform_id": 0, "gpu_use_dp": True, "num_gpu": 1,
+             "two_round": True, "enable_bundle": False, "num_grad_quant_bins": 8, "stochastic_rounding": False,
+             "monotone_constraints_method": "advanced", "precise_float_parser": True}
+    a = lgb.train(base, lgb.Dataset(X, label=y), 3)
+    b = lgb.train({**base, **extra}, lgb.Dataset(X, label=y), 3)
+    cut = lambda s: s[s.index("Tree=0"):s.index("end of trees")]
+    assert cut(a.model_to_string()) == cut(b.model_to_string())
+    assert "[monotone_constraints_method: advanced]" in b.model_to_string()
+    with pytest.raises(lgb.LightGBMError):
+        lgb.train({**base, "monotone_constraints_method": "sometimes"}, lgb.Dataset(X, label=y), 1)
+
+
+def test_saved_feature_importance_type_and_early_stopping_min_delta():
+    import lightgbm_amd as lgb
+    from lightgbm_amd.utils.datasets import make_regression
+    X, y = make_regression(3000, 5, seed=2)
+    p = {"device_type": "cpu", "verbose": -1, "num_leaves": 7}
+    b = lgb.train({**p, "saved_feature_importance_type": 1}, lgb.Dataset(X, label=y), 5)
+    block = b.model_to_string().split("feature_importances:\n")[1].split("\n\n")[0]
+    assert any("." in line.split("=")[1] for line in block.splitlines())            # gains, not counts
+    block0 = b.model_to_string(importance_type="split").split("feature_importances:\n")[1].split("\n\n")[0]
+    assert all(line.split("=")[1].isdigit() for line in block0.splitlines())
+    # an improvement below min_delta does not count: training stops right after the patience runs out
+    d = lgb.Dataset(X[:2000], label=y[:2000])
+    v = d.create_valid(X[2000:], label=y[2000:])
+    loose = lgb.train({**p, "learning_rate": 0.05}, d, 200, valid_sets=[v], early_stopping_rounds=5, verbose_eval=False)
+    strict = lgb.train({**p, "learning_rate": 0.05, "early_stopping_min_delta": 1e9}, d, 200, valid_sets=[v],
+                       early_stopping_rounds=5, verbose_eval=False)
+    assert strict.best_iteration == 1 and strict.current_iteration() <= 7 < loose.current_iteration()
