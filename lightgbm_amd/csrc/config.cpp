@@ -113,6 +113,7 @@ const ParamDef kParams[] = {
     P(snapshot_freq, "save_period", Int, kNone, kNone),
     P(output_model, "model_output,model_out", String, kNone, kNone),
     P(input_model, "model_input,model_in", String, kNone, kNone),
+    P(forcedsplits_filename, "fs,forced_splits_filename,forced_splits_file,forced_splits", String, kNone, kNone),
     P(label_column, "label", String, kNone, kNone),
     P(header, "has_header", Bool, kNone, kNone),
     P(num_machines, "num_machine", Int, 1, kNone),

@@ -110,6 +110,7 @@ struct Config {
   int snapshot_freq = -1;
   std::string output_model = "LightGBM_model.txt";
   std::string input_model = "";
+  std::string forcedsplits_filename = "";   // JSON file: splits every tree starts with ({"feature", "threshold", "left", "right"} nested)
   std::string label_column = "0";   // text data files: index of the label column
   bool header = false;              // text data files: the first line holds column names
   // distributed

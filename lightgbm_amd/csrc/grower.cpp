@@ -4,7 +4,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
+#include <sstream>
 #include <queue>
+#include <functional>
 #include <stdexcept>
 #include <thread>
 
@@ -40,6 +43,7 @@ TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds
       refresh_gain_adjustment();
     }
   }
+  if (!cfg_.forcedsplits_filename.empty()) load_forced_splits(cfg_.forcedsplits_filename);
   // interaction_constraints = "[0,1,2],[2,3]": groups of raw-matrix columns; columns without a usable
   // feature (constant ones) drop out
   const std::string& ic = cfg_.interaction_constraints;
@@ -77,6 +81,79 @@ TreeGrower::TreeGrower(const Config& cfg, const Dataset* ds) : cfg_(cfg), ds_(ds
     }
     if (open || groups_.empty()) bad();
   }
+}
+
+namespace {
+// The forced-splits file is one JSON object per node: {"feature": 3, "threshold": 0.5, "left": {...}, "right": {...}}
+// ("left" / "right" optional).  A reader for exactly that shape (numbers, nested objects; anything else is an error).
+struct ForcedJson {
+  const std::string& t;
+  size_t i = 0;
+  explicit ForcedJson(const std::string& text) : t(text) {}
+  [[noreturn]] void bad(const char* what) const {
+    throw std::runtime_error(std::string("forcedsplits_filename: ") + what + " near offset " + std::to_string(i));
+  }
+  void ws() { while (i < t.size() && (t[i] == ' ' || t[i] == '\n' || t[i] == '\t' || t[i] == '\r')) ++i; }
+  bool eat(char c) { ws(); if (i < t.size() && t[i] == c) { ++i; return true; } return false; }
+  std::string key() {
+    ws();
+    if (i >= t.size() || t[i] != '"') bad("expected a quoted key");
+    const size_t e = t.find('"', i + 1);
+    if (e == std::string::npos) bad("unterminated string");
+    std::string k = t.substr(i + 1, e - i - 1);
+    i = e + 1;
+    return k;
+  }
+  double number() {
+    ws();
+    char* end = nullptr;
+    const double v = std::strtod(t.c_str() + i, &end);
+    if (end == t.c_str() + i) bad("expected a number");
+    i = (size_t)(end - t.c_str());
+    return v;
+  }
+};
+}  // namespace
+
+void TreeGrower::load_forced_splits(const std::string& path) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("forcedsplits_filename: cannot read " + path);
+  std::stringstream buf;
+  buf << in.rdbuf();
+  const std::string text = buf.str();
+  ForcedJson js(text);
+  // recursive descent over nested objects; returns the node's index in forced_ (-1 for an empty object)
+  std::function<int(int)> node = [&](int depth) -> int {
+    if (depth > 64) js.bad("nesting too deep");
+    if (!js.eat('{')) js.bad("expected {");
+    ForcedSplit f;
+    bool has_feature = false, has_threshold = false;
+    const int me = (int)forced_.size();
+    forced_.push_back(f);
+    if (!js.eat('}')) {
+      do {
+        const std::string k = js.key();
+        if (!js.eat(':')) js.bad("expected :");
+        if (k == "feature") { f.feature = (int)js.number(); has_feature = true; }
+        else if (k == "threshold") { f.threshold = js.number(); has_threshold = true; }
+        else if (k == "left") f.left = node(depth + 1);
+        else if (k == "right") f.right = node(depth + 1);
+        else js.bad("unknown key (feature, threshold, left, right)");
+      } while (js.eat(','));
+      if (!js.eat('}')) js.bad("expected }");
+    }
+    if (!has_feature || !has_threshold) {
+      if (has_feature != has_threshold) js.bad("a node needs both feature and threshold");
+      f.feature = -1;   // an empty object: nothing forced below here
+    }
+    if (f.feature >= ds_->num_total_features()) throw std::runtime_error("forcedsplits_filename: feature " + std::to_string(f.feature) + " does not exist");
+    forced_[(size_t)me] = f;
+    return f.feature < 0 ? -1 : me;
+  };
+  const int root = node(0);
+  js.ws();
+  if (js.i != text.size()) js.bad("trailing text");
+  if (root < 0) forced_.clear();
 }
 
 void TreeGrower::refresh_gain_adjustment() {
@@ -155,7 +232,7 @@ Tree TreeGrower::grow(TreeBackend& be, const std::vector<FeatureMeta>& meta, std
 bool TreeGrower::plain_trees(const std::vector<FeatureMeta>& meta) const {
   bool any_monotone = false;
   for (const FeatureMeta& m : meta) any_monotone = any_monotone || (m.enabled && m.monotone != 0);
-  return groups_.empty() && !any_monotone && !(cfg_.path_smooth > 0.0) && cfg_.max_batch_leaves <= 0;
+  return groups_.empty() && forced_.empty() && !any_monotone && !(cfg_.path_smooth > 0.0) && cfg_.max_batch_leaves <= 0;
 }
 
 bool TreeGrower::grow_begin(TreeBackend& be, const std::vector<FeatureMeta>& meta) {
@@ -267,6 +344,36 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
 
   auto depth_blocked = [&](int depth) { return cfg_.max_depth > 0 && depth >= cfg_.max_depth; };
   if (depth_blocked(0)) nodes[0].best.feature = -1;
+  // Forced splits (forcedsplits_filename): a node that has one takes it instead of the split the search found and
+  // goes first in the replay (kForcedGain); where the left sums of a searched split would come from the histogram
+  // scan, a forced split's are its left child's totals, known once the children have been searched.  A forced
+  // split that cannot be made (feature unused or categorical, threshold beyond the last value bin, depth limit)
+  // ends the forcing on its branch.
+  constexpr double kForcedGain = 1e300;
+  if (!forced_.empty() && node_info)
+    throw std::runtime_error("forcedsplits_filename cannot be combined with monotone constraints or path smoothing");
+  const double searched_root_gain = splittable(nodes[0].best) ? nodes[0].best.gain : 0.0;
+  auto apply_forced = [&](int id) {
+    Node& n = nodes[(size_t)id];
+    if (n.forced_index < 0 || depth_blocked(n.depth) || n.best.total_cnt < 2) { n.forced_index = -1; return; }
+    const ForcedSplit& F = forced_[(size_t)n.forced_index];
+    const int inner = F.feature >= 0 ? ds_->inner_feature(F.feature) : -1;
+    if (inner < 0 || meta[(size_t)inner].categorical) { n.forced_index = -1; return; }
+    const FeatureMeta& m = meta[(size_t)inner];
+    const int value_bins = m.missing_bin >= 0 ? m.num_bin - 1 : m.num_bin;
+    const int thr = ds_->inner_mapper(inner).value_to_bin(F.threshold);
+    if (thr < 0 || thr >= value_bins - 1) { n.forced_index = -1; return; }   // every value would go left
+    SplitInfo& b = n.best;
+    b.feature = inner;
+    b.threshold = thr;
+    b.default_left = 0;
+    b.gain = kForcedGain;
+    b.left_cnt = b.total_cnt / 2;   // placeholders until the children are known
+    b.left_g = b.total_g / 2;
+    b.left_h = b.total_h / 2;
+    n.forced = true;
+  };
+  if (!forced_.empty()) { nodes[0].forced_index = 0; apply_forced(0); }
 
   std::priority_queue<Entry, std::vector<Entry>, EntryLess> frontier;
   int seq = 0;
@@ -294,7 +401,7 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
   // million rows for nothing costs about as much device time as a whole extra round, a leaf of a few thousand
   // rows next to nothing, so the bar is scaled by a factor that rises with the row count, spec_lo_ .. spec_hi_.
   double bar_scale = 1.0;
-  const double root_gain = splittable(nodes[0].best) ? nodes[0].best.gain : 0.0;
+  const double root_gain = searched_root_gain;
   if (spec_ratio_ && prev_root_gain_ > 0.0 && root_gain > 0.0) {
     bar_scale = root_gain / prev_root_gain_;
     bar_scale = bar_scale < 0.25 ? 0.25 : (bar_scale > 1.5 ? 1.5 : bar_scale);
@@ -350,6 +457,16 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
         int id = side == 0 ? f.tasks[i].left_node : f.tasks[i].right_node;
         nodes[(size_t)id].best = infos[i * 2 + (size_t)side];
         if (depth_blocked(nodes[(size_t)id].depth)) nodes[(size_t)id].best.feature = -1;
+      }
+      Node& parent = nodes[(size_t)f.tasks[i].parent_node];
+      if (parent.forced) {
+        const SplitInfo& l = nodes[(size_t)f.tasks[i].left_node].best;
+        parent.best.left_g = l.total_g; parent.best.left_h = l.total_h; parent.best.left_cnt = l.total_cnt;
+        const ForcedSplit& F = forced_[(size_t)parent.forced_index];
+        nodes[(size_t)f.tasks[i].left_node].forced_index = F.left;
+        nodes[(size_t)f.tasks[i].right_node].forced_index = F.right;
+        apply_forced(f.tasks[i].left_node);
+        apply_forced(f.tasks[i].right_node);
       }
       nodes[(size_t)f.tasks[i].parent_node].ready = true;
     }
@@ -566,6 +683,17 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
     const double l2 = sp.lambda_l2 + (set_split ? cfg_.cat_l2 : 0.0);
     double lv = leaf_output(lg, lh, sp.lambda_l1, l2, sp.max_delta_step);
     double rv = leaf_output(rg, rh, sp.lambda_l1, l2, sp.max_delta_step);
+    double split_gain_out = s.gain;
+    if (n.forced) {
+      // a forced split was never valued by the search: its gain is what its sums give (0 when it lowers the objective
+      // or leaves a child without rows, whose output then is 0 as well)
+      const double G = (double)s.total_g * gunit, H = (double)s.total_h * hunit;
+      split_gain_out = leaf_gain(lg, lh, sp.lambda_l1, sp.lambda_l2) + leaf_gain(rg, rh, sp.lambda_l1, sp.lambda_l2) -
+                       leaf_gain(G, H, sp.lambda_l1, sp.lambda_l2);
+      if (!(split_gain_out > 0.0) || !std::isfinite(split_gain_out)) split_gain_out = 0.0;
+      if (!std::isfinite(lv) || nodes[(size_t)n.left].best.total_cnt == 0) lv = 0.0;
+      if (!std::isfinite(rv) || nodes[(size_t)n.right].best.total_cnt == 0) rv = 0.0;
+    }
     if (node_info) {
       // the outputs the split was valued with (smoothed / clamped), kept inside the children's own ranges
       lv = clamp_output(nodes[(size_t)n.left].out, nodes[(size_t)n.left].lo, nodes[(size_t)n.left].hi);
@@ -583,14 +711,14 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
       std::vector<int64_t> categories;
       for (int b = 0; b < (int)bm.upper.size() && b < kMaxBins; ++b)
         if ((bins[b >> 6] >> (b & 63)) & 1ull) categories.push_back((int64_t)bm.upper[(size_t)b]);
-      right_leaf = tree.split_categorical_set(leaf, ds_->real_feature(s.feature), s.feature, bins, categories, s.gain, lv, rv,
+      right_leaf = tree.split_categorical_set(leaf, ds_->real_feature(s.feature), s.feature, bins, categories, split_gain_out, lv, rv,
                                               lc, rc, lh, rh);
     } else if (bm.categorical)
       right_leaf = tree.split_categorical(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
-                                          (int64_t)bm.upper[(size_t)s.threshold], s.gain, lv, rv, lc, rc, lh, rh);
+                                          (int64_t)bm.upper[(size_t)s.threshold], split_gain_out, lv, rv, lc, rc, lh, rh);
     else
       right_leaf = tree.split(leaf, ds_->real_feature(s.feature), s.feature, s.threshold,
-                              real_thr, s.default_left != 0, (int)bm.missing, s.gain, lv, rv,
+                              real_thr, s.default_left != 0, (int)bm.missing, split_gain_out, lv, rv,
                               lc, rc, lh, rh);
     leaf_of_node[(size_t)n.left] = leaf;
     leaf_of_node[(size_t)n.right] = right_leaf;

@@ -78,6 +78,8 @@ class TreeGrower {
     int slot = 0;
     int left = -1, right = -1;   // children node ids once the leaf's split has been submitted
     bool ready = false;          // ... and once that round's results are in
+    bool forced = false;         // its split comes from forcedsplits_filename, not from the search
+    int forced_index = -1;       // entry of forced_ that applies to this node (-1: none)
     uint32_t key = kRootNodeKey; // position key (per-node feature sampling)
     double lo = -std::numeric_limits<double>::infinity();   // output range (monotone constraints)
     double hi = std::numeric_limits<double>::infinity();
@@ -89,6 +91,14 @@ class TreeGrower {
   std::vector<double> gain_scale_, gain_offset_;
   std::vector<double> coupled_penalty_;   // per inner feature, 0 once the feature has been used
   void refresh_gain_adjustment();
+  // forcedsplits_filename: the splits every tree starts with, as a flat tree (index 0 = the root's; empty: none)
+  struct ForcedSplit {
+    int feature = -1;        // column of the raw matrix
+    double threshold = 0.0;  // rows with value <= threshold go left
+    int left = -1, right = -1;
+  };
+  std::vector<ForcedSplit> forced_;
+  void load_forced_splits(const std::string& path);
   // interaction constraints as bit sets over inner features (empty: none)
   std::vector<std::vector<uint64_t>> groups_;
   int mask_words_ = 0;

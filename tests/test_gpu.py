@@ -464,6 +464,21 @@ def test_large_data_paths_match_the_cpu_engine():
             assert x == z
 
 
+def test_gpu_forced_splits_equal_cpu(tmp_path):
+    """forcedsplits_filename on the device engine: the forced nodes' row counts are not known ahead of time (the
+    dense histogram units are sized from a placeholder and loop over what the child really has)."""
+    import json
+    X, y = make_regression(60000, 8, seed=13)
+    path = tmp_path / "forced.json"
+    path.write_text(json.dumps({"feature": 2, "threshold": 0.9, "left": {"feature": 0, "threshold": -1.2},
+                                "right": {"feature": 5, "threshold": 0.0}}))
+    p = {"num_leaves": 31, "min_data_in_leaf": 10, "forcedsplits_filename": str(path)}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 5)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 5)
+    assert trees_of(a) == trees_of(b)
+    assert a.dump_model()["tree_info"][0]["tree_structure"]["split_feature"] == 2
+
+
 def test_gpu_balanced_bagging_draws_the_cpu_bag():
     X, y = make_higgs_like(80000, seed=5, device="numpy")
     y = (y > 0) & (X[:, 0] > 0.3)

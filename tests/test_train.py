@@ -662,3 +662,34 @@ def test_quantised_binary_auc_matches_full_precision():
     assert abs(aq - af) < 0.001, (aq, af)
     # the full-precision histograms really are finer: the two learners do not grow identical trees
     assert trees_of(quant) != trees_of(full)
+
+
+def test_forced_splits_start_every_tree(tmp_path):
+    """forcedsplits_filename: the root splits on column 3 at 0.25, its left child on column 1 at -0.5, whatever the
+    search would have chosen; growth below continues as usual (best-first over the remaining budget)."""
+    import json
+    X, y = make_regression(5000, 6, seed=9)
+    path = tmp_path / "forced.json"
+    path.write_text(json.dumps({"feature": 3, "threshold": 0.25, "left": {"feature": 1, "threshold": -0.5}, "right": {}}))
+    p = {**CPU, "num_leaves": 15, "min_data_in_leaf": 20}
+    free = lgb.train(p, lgb.Dataset(X, label=y), 3)
+    forced = lgb.train({**p, "forcedsplits_filename": str(path)}, lgb.Dataset(X, label=y), 3)
+    assert free.dump_model()["tree_info"][0]["tree_structure"]["split_feature"] != 3      # the search prefers another column
+    for t in forced.dump_model()["tree_info"]:
+        root = t["tree_structure"]
+        assert root["split_feature"] == 3 and 0.25 <= root["threshold"] < 0.3
+        left = root["left_child"]
+        assert left["split_feature"] == 1 and -0.5 <= left["threshold"] < -0.45
+        assert t["num_leaves"] == 15
+    # rows really go where the model says: predictions of the text model equal the training scores
+    np.testing.assert_allclose(forced.predict(X), lgb.Booster(model_str=forced.model_to_string()).predict(X), atol=1e-12)
+    # the forced model cannot beat the free one on the training data, but must still learn
+    l2 = lambda b: float(np.mean((b.predict(X) - y) ** 2))
+    assert l2(free) <= l2(forced) < float(np.var(y))
+    # a threshold beyond the data ends the forcing instead of making an empty child
+    path.write_text(json.dumps({"feature": 3, "threshold": 1e9}))
+    same = lgb.train({**p, "forcedsplits_filename": str(path)}, lgb.Dataset(X, label=y), 3)
+    assert trees_of(same) == trees_of(free)
+    path.write_text('{"feature": 3}')
+    with pytest.raises(lgb.LightGBMError):
+        lgb.train({**p, "forcedsplits_filename": str(path)}, lgb.Dataset(X, label=y), 1)
