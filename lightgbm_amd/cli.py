@@ -13,7 +13,9 @@ Mirrors the ``key=value`` / ``config=file`` style of the LightGBM application:
 Data files are CSV, TSV or LibSVM (``label idx:value ...``), told apart by their first line; ``header=true``
 skips a header line.  Like the LightGBM application, side files next to a data file are picked up when they
 exist: ``<file>.weight`` (one weight per row), ``<file>.query`` (one query size per line, for ranking) and
-``<file>.init`` (one initial score per row).
+``<file>.init`` (one initial score per row).  ``weight_column=<idx>`` / ``group_column=<idx>`` take weights / query ids
+from columns of a CSV / TSV file instead and ``ignore_column=<idx>,<idx>`` drops columns (indices count the columns
+that remain once the label is taken out, as upstream does).
 """
 from __future__ import annotations
 
@@ -80,16 +82,54 @@ def _side_file(path: str, suffix: str):
     return np.loadtxt(p, ndmin=1) if os.path.exists(p) else None
 
 
-def _dataset(path: str, label_column: int, header: bool, params, reference=None):
-    """A Dataset from a data file (+ its .weight / .query / .init side files), or from a binned cache."""
+def _column_list(spec: str) -> List[int]:
+    """"3" / "0,2,5" -> indices.  As upstream counts them: over the columns that remain once the label is taken out."""
+    if not spec:
+        return []
+    if spec.startswith("name:"):
+        raise SystemExit("columns are selected by index here (weight_column=3), not by name")
+    return [int(t) for t in spec.split(",") if t.strip() != ""]
+
+
+def _take_columns(X: np.ndarray, columns: Dict[str, str]):
+    """Splits the weight / query-id / ignored columns off a feature matrix: (X, weight or None, query sizes or None)."""
+    w_col = _column_list(columns.get("weight_column", ""))
+    g_col = _column_list(columns.get("group_column", ""))
+    drop = set(_column_list(columns.get("ignore_column", "")))
+    if len(w_col) > 1 or len(g_col) > 1:
+        raise SystemExit("weight_column and group_column name one column each")
+    for c in w_col + g_col + sorted(drop):
+        if not 0 <= c < X.shape[1]:
+            raise SystemExit(f"column {c} does not exist (the data has {X.shape[1]} columns besides the label)")
+    weight = X[:, w_col[0]].copy() if w_col else None
+    group = None
+    if g_col:
+        ids = X[:, g_col[0]]
+        # rows of a query are consecutive: a new query starts wherever the id changes
+        starts = np.flatnonzero(np.concatenate([[True], ids[1:] != ids[:-1]]))
+        group = np.diff(np.concatenate([starts, [len(ids)]]))
+    drop.update(w_col + g_col)
+    if drop:
+        X = np.delete(X, sorted(drop), axis=1)
+    return X, weight, group
+
+
+def _dataset(path: str, label_column: int, header: bool, params, reference=None, columns=None):
+    """A Dataset from a data file (+ its .weight / .query / .init side files, or the weight / query-id columns named
+    by weight_column / group_column; ignore_column drops columns), or from a binned cache."""
     from . import Dataset
     if path.endswith(".bin"):
         return Dataset(path, params=params), None      # the cache holds label / weight / init_score / query sizes
     X, y = _load_table(path, label_column, header, reference.num_feature() if reference is not None else 0)
+    weight, group = _side_file(path, ".weight"), _side_file(path, ".query")
+    if columns:
+        X, w_in, g_in = _take_columns(X, columns)
+        weight = w_in if w_in is not None else weight
+        group = g_in if g_in is not None else group
     if reference is not None and X.shape[1] < reference.num_feature():      # LibSVM rows without the last columns
         X = np.hstack([X, np.zeros((X.shape[0], reference.num_feature() - X.shape[1]))])
-    return Dataset(X, label=y, weight=_side_file(path, ".weight"), group=_side_file(path, ".query"),
-                   init_score=_side_file(path, ".init"), params=params, reference=reference), X
+    return Dataset(X, label=y, weight=weight, group=group, init_score=_side_file(path, ".init"), params=params,
+                   reference=reference), X
 
 
 def _flag(kv, key: str) -> bool:
@@ -102,6 +142,7 @@ def main(argv=None) -> int:
     task = kv.pop("task", "train")
     label_column = int(kv.pop("label_column", "0"))
     header = _flag(kv, "header")
+    columns = {k: kv.pop(k) for k in ("weight_column", "group_column", "ignore_column") if k in kv}
     if task == "train":
         data = kv.pop("data")
         valid = kv.pop("valid", kv.pop("valid_data", None))
@@ -109,16 +150,18 @@ def main(argv=None) -> int:
         init = kv.pop("input_model", None)
         rounds = int(kv.pop("num_iterations", kv.pop("num_trees", kv.pop("num_boost_round", "100"))))
         params = {k: v for k, v in kv.items()}
-        d, _ = _dataset(data, label_column, header, params)
+        d, _ = _dataset(data, label_column, header, params, columns=columns)
         if init:
             d.free_raw_data = False
-        valid_sets = [_dataset(v, label_column, header, params, reference=d)[0] for v in valid.split(",")] if valid else None
+        valid_sets = [_dataset(v, label_column, header, params, reference=d, columns=columns)[0] for v in valid.split(",")] if valid else None
         b = train(params, d, num_boost_round=rounds, valid_sets=valid_sets, verbose_eval=bool(valid_sets), init_model=init)
         b.save_model(out)
         print(f"finished training: {b.num_trees()} trees -> {out}")
     elif task == "predict":
         b = Booster(model_file=kv.pop("input_model"))
         X, _ = _load_table(kv.pop("data"), int(kv.pop("label_column_predict", str(label_column))), header, b.num_feature())
+        if columns:
+            X = _take_columns(X, columns)[0]
         n_it = int(kv.pop("num_iteration_predict", "-1"))
         p = b.predict(X, raw_score=_flag(kv, "predict_raw_score"), pred_leaf=_flag(kv, "predict_leaf_index"),
                       pred_contrib=_flag(kv, "predict_contrib"), num_iteration=n_it if n_it > 0 else None,
@@ -133,7 +176,7 @@ def main(argv=None) -> int:
         print(f"finished refitting -> {out}")
     elif task == "save_binary":
         path = kv.pop("data")
-        d, _ = _dataset(path, label_column, header, {k: v for k, v in kv.items()})
+        d, _ = _dataset(path, label_column, header, {k: v for k, v in kv.items()}, columns=columns)
         d.save_binary(path + ".bin")
         print(f"saved {path}.bin")
     elif task == "convert_model":

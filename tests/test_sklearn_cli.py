@@ -192,3 +192,36 @@ def test_extra_keyword_parameters_survive_clone_and_set_params():
     assert twin.get_params()["path_smooth"] == 2.0 and twin._params()["min_data_per_group"] == 7
     twin.set_params(path_smooth=0.0, num_leaves=9, cat_l2=1.0)
     assert twin.num_leaves == 9 and twin._params()["path_smooth"] == 0.0 and twin._params()["cat_l2"] == 1.0
+
+
+def test_cli_weight_group_and_ignored_columns(tmp_path):
+    """weight_column / group_column / ignore_column of a CSV file against the same data passed as arrays."""
+    from lightgbm_amd import cli
+    rng = np.random.RandomState(4)
+    n_q, per_q = 60, 12
+    n = n_q * per_q
+    X = rng.randn(n, 4)
+    rel = np.clip((X[:, 0] + 0.5 * X[:, 2] + 0.3 * rng.randn(n)).round() + 1, 0, 3)
+    w = rng.uniform(0.5, 2.0, size=n)
+    qid = np.repeat(np.arange(n_q), per_q)
+    junk = rng.randn(n)
+    # label | x0 | weight | x1 | qid | junk | x2 | x3   -> besides the label: weight = 1, qid = 3, junk = 4
+    table = np.column_stack([rel, X[:, 0], w, X[:, 1], qid, junk, X[:, 2], X[:, 3]])
+    path = tmp_path / "rank.csv"
+    np.savetxt(path, table, delimiter=",", fmt="%.10g")
+    table = np.loadtxt(path, delimiter=",")            # the values as the file holds them
+    X, w = table[:, [1, 3, 6, 7]], table[:, 2]
+    out = tmp_path / "m.txt"
+    args = ["task=train", f"data={path}", "objective=lambdarank", "num_leaves=7", "min_data_in_leaf=5", "num_iterations=5",
+            "weight_column=1", "group_column=3", "ignore_column=4", f"output_model={out}", "device_type=cpu", "verbose=-1"]
+    assert cli.main(args) == 0
+    want = lgb.train({"objective": "lambdarank", "num_leaves": 7, "min_data_in_leaf": 5, "device_type": "cpu", "verbose": -1},
+                     lgb.Dataset(X, label=rel, weight=w, group=np.full(n_q, per_q)), 5)
+    got = lgb.Booster(model_file=str(out))
+    assert got.num_feature() == 4
+    cut = lambda s: s[s.index("Tree=0"):s.index("end of trees")]
+    assert cut(got.model_to_string()) == cut(want.model_to_string())
+    res = tmp_path / "p.txt"
+    assert cli.main(["task=predict", f"data={path}", f"input_model={out}", f"output_result={res}",
+                     "weight_column=1", "group_column=3", "ignore_column=4"]) == 0
+    np.testing.assert_allclose(np.loadtxt(res), want.predict(X), atol=1e-12)
