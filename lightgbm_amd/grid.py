@@ -275,15 +275,21 @@ def _drain_rows(next_row: Callable[[], Optional[int]], rows, dtrain, cv_kwargs, 
         _run_rows(next_row, run_one, in_flight)
 
 
-def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_params, rows, cv_kwargs, task_q, result_q,
+def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_params, rows, cv_kwargs, conn,
                  fail_after: Optional[int], rows_in_flight: Optional[int] = None, batch_rows: Optional[bool] = None):
-    """Worker process: pulls row ids until it sees None (one stop marker per worker process)."""
+    """Worker process.  It talks to the scheduler over a pipe of its own - ("want",) is answered with a row id or
+    None (stop), ("start", row), ("done", row, (iteration, score, seconds)), ("error", text), ("exit",) are
+    reports - so a worker that dies, whenever and however, takes no lock with it that another process waits for
+    (a queue shared by all workers would: its write lock lives in shared memory)."""
     if device is not None and device != "cpu":
         os.environ["HIP_VISIBLE_DEVICES"] = str(device)
         os.environ["CUDA_VISIBLE_DEVICES"] = str(device)
     elif device == "cpu":
         os.environ["LGA_FORCE_HOST"] = "1"
+    import threading
     from .basic import Dataset
+    send = threading.Lock()   # the row threads of this process share the pipe: one message at a time ...
+    ask = threading.Lock()    # ... and one unanswered request at a time (reports go on while it waits for its answer)
     try:
         dtrain = Dataset(X, label=y, weight=weight, params=dataset_params, free_raw_data=False)
         dtrain.construct()
@@ -291,28 +297,37 @@ def _worker_main(worker_id: int, device: Optional[str], X, y, weight, dataset_pa
         stopped = [False]
 
         def next_row():
-            if stopped[0]:
-                return None
-            item = task_q.get()
-            if item is None:
-                stopped[0] = True
-                return None
-            return item
+            with ask:
+                if stopped[0]:
+                    return None
+                with send:
+                    conn.send(("want",))
+                item = conn.recv()
+                if item is None:
+                    stopped[0] = True
+                return item
 
         def on_start(row_id):
-            result_q.put(("start", worker_id, row_id, None))
-            if fail_after is not None and n_started[0] >= fail_after:
-                os._exit(17)   # fault injection: die with the row in flight
-            n_started[0] += 1
+            with send:
+                conn.send(("start", row_id))
+                if fail_after is not None and n_started[0] >= fail_after:
+                    os._exit(17)   # fault injection: die with the row in flight
+                n_started[0] += 1
 
         def on_done(row_id, it, sc, secs):
-            result_q.put(("done", worker_id, row_id, (it, sc, secs)))
+            with send:
+                conn.send(("done", row_id, (it, sc, secs)))
 
         _drain_rows(next_row, rows, dtrain, cv_kwargs, on_start, on_done, rows_in_flight, batch_rows)
     except BaseException as e:   # report, then die
-        result_q.put(("error", worker_id, -1, repr(e)))
+        try:
+            with send:
+                conn.send(("error", repr(e)))
+        except OSError:
+            pass
         raise
-    result_q.put(("exit", worker_id, -1, None))
+    with send:
+        conn.send(("exit",))
 
 
 def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds: int = 1000, nfold: int = 5,
@@ -383,55 +398,94 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
         if X is None or y is None:
             raise ValueError("worker processes need the raw X and y (a constructed Dataset cannot cross processes)")
         import multiprocessing as mp
+        from multiprocessing.connection import wait as wait_for_any
         ctx = mp.get_context("spawn")
-        task_q, result_q = ctx.Queue(), ctx.Queue()
-        for i in todo:
-            task_q.put(i)
         Xn, yn = np.asarray(X), np.asarray(y)
-        procs = {}
+        procs, conns = {}, {}
         inflight: Dict[int, set] = {}
         for w, dev in enumerate(workers):
             fa = inject_fail_after if w == 0 else None
-            p = ctx.Process(target=_worker_main, args=(w, dev, Xn, yn, weight, dataset_params, rows, cv_kwargs, task_q,
-                                                       result_q, fa, rows_in_flight, batch_rows), daemon=True)
+            here, there = ctx.Pipe(duplex=True)
+            p = ctx.Process(target=_worker_main, args=(w, dev, Xn, yn, weight, dataset_params, rows, cv_kwargs, there, fa,
+                                                       rows_in_flight, batch_rows), daemon=True)
             p.start()
-            procs[w] = p
+            there.close()    # the worker holds the only other end: its death shows as end-of-file here
+            procs[w], conns[w] = p, here
             inflight[w] = set()
-        for _ in workers:
-            task_q.put(None)
+        pending = list(todo)            # rows nobody has been given yet, cheapest last (todo is sorted by cost)
         remaining = set(todo)
         alive = set(procs.keys())
-        import queue as _q
-        while remaining and alive:
-            try:
-                kind, w, row_id, payload = result_q.get(timeout=1.0)
-            except _q.Empty:
-                for w in list(alive):
-                    if not procs[w].is_alive():
-                        alive.discard(w)
-                        lost = sorted(r for r in inflight.get(w, ()) if r in remaining)
-                        if lost:
-                            if verbose:
-                                print(f"[grid] worker {w} died; re-queueing rows {[r + 1 for r in lost]}")
-                            # the dead worker never consumed its stop marker: the re-queued rows go in front of it
-                            for r in lost:
-                                task_q.put(r)
-                            task_q.put(None)
-                            inflight[w] = set()
-                continue
-            if kind == "start":
-                inflight[w].add(row_id)
-            elif kind == "done":
-                it, sc, secs = payload
-                inflight[w].discard(row_id)
-                if row_id in remaining:
-                    remaining.discard(row_id)
-                    record(row_id, it, sc, secs, str(workers[w]))
-            elif kind == "error":
+
+        waiting: List[int] = []         # workers whose ("want",) has not been answered yet
+
+        def serve_waiting():
+            # rows first; a worker is told to stop only when no row can come to it any more (nothing pending and
+            # no OTHER worker has a row in flight that its death would hand back)
+            while waiting:
+                w = waiting[0]
+                if w not in alive:
+                    waiting.pop(0)
+                    continue
+                if pending:
+                    answer = pending.pop(0)
+                elif not any(inflight[o] for o in alive if o != w):
+                    answer = None
+                else:
+                    return
+                waiting.pop(0)
+                try:
+                    conns[w].send(answer)
+                except OSError:
+                    if answer is not None:
+                        pending.insert(0, answer)
+                    lost_worker(w)
+
+        def lost_worker(w):
+            alive.discard(w)
+            lost = sorted(r for r in inflight.get(w, ()) if r in remaining)
+            if lost:
                 if verbose:
-                    print(f"[grid] worker {w} failed: {payload}")
-            elif kind == "exit":
-                alive.discard(w)
+                    print(f"[grid] worker {w} died; re-queueing rows {[r + 1 for r in lost]}")
+                pending[:0] = lost     # they go first
+            inflight[w] = set()
+
+        while remaining and alive:
+            ready = wait_for_any([conns[w] for w in alive], timeout=1.0)
+            if not ready:
+                for w in list(alive):
+                    if not procs[w].is_alive() and not conns[w].poll():
+                        lost_worker(w)
+                serve_waiting()
+                continue
+            for conn in ready:
+                w = next(k for k, c in conns.items() if c is conn)
+                try:
+                    msg = conn.recv()
+                except (EOFError, OSError):
+                    lost_worker(w)
+                    continue
+                kind = msg[0]
+                if kind == "want":
+                    waiting.append(w)
+                elif kind == "start":
+                    inflight[w].add(msg[1])
+                elif kind == "done":
+                    row_id, (it, sc, secs) = msg[1], msg[2]
+                    inflight[w].discard(row_id)
+                    if row_id in remaining:
+                        remaining.discard(row_id)
+                        record(row_id, it, sc, secs, str(workers[w]))
+                elif kind == "error":
+                    if verbose:
+                        print(f"[grid] worker {w} failed: {msg[1]}")
+                elif kind == "exit":
+                    alive.discard(w)
+            serve_waiting()
+        for w in alive:                 # everything is done: whoever still asks (or is about to) is told to stop
+            try:
+                conns[w].send(None)
+            except OSError:
+                pass
         for p in procs.values():
             p.join(timeout=5)
             if p.is_alive():
