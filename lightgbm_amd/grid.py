@@ -416,30 +416,6 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
         remaining = set(todo)
         alive = set(procs.keys())
 
-        waiting: List[int] = []         # workers whose ("want",) has not been answered yet
-
-        def serve_waiting():
-            # rows first; a worker is told to stop only when no row can come to it any more (nothing pending and
-            # no OTHER worker has a row in flight that its death would hand back)
-            while waiting:
-                w = waiting[0]
-                if w not in alive:
-                    waiting.pop(0)
-                    continue
-                if pending:
-                    answer = pending.pop(0)
-                elif not any(inflight[o] for o in alive if o != w):
-                    answer = None
-                else:
-                    return
-                waiting.pop(0)
-                try:
-                    conns[w].send(answer)
-                except OSError:
-                    if answer is not None:
-                        pending.insert(0, answer)
-                    lost_worker(w)
-
         def lost_worker(w):
             alive.discard(w)
             lost = sorted(r for r in inflight.get(w, ()) if r in remaining)
@@ -455,7 +431,6 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                 for w in list(alive):
                     if not procs[w].is_alive() and not conns[w].poll():
                         lost_worker(w)
-                serve_waiting()
                 continue
             for conn in ready:
                 w = next(k for k, c in conns.items() if c is conn)
@@ -466,7 +441,16 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                     continue
                 kind = msg[0]
                 if kind == "want":
-                    waiting.append(w)
+                    # answered at once, with "stop" when nothing is pending: a worker that batches its rows asks from
+                    # the one thread that also advances them, so it must never be kept waiting.  Rows a worker hands
+                    # back by dying go to whoever asks afterwards, else to this process (below).
+                    answer = pending.pop(0) if pending else None
+                    try:
+                        conn.send(answer)
+                    except OSError:
+                        if answer is not None:
+                            pending.insert(0, answer)
+                        lost_worker(w)
                 elif kind == "start":
                     inflight[w].add(msg[1])
                 elif kind == "done":
@@ -480,7 +464,6 @@ def grid_search_cv(param_grid, X=None, y=None, dtrain=None, weight=None, nrounds
                         print(f"[grid] worker {w} failed: {msg[1]}")
                 elif kind == "exit":
                     alive.discard(w)
-            serve_waiting()
         for w in alive:                 # everything is done: whoever still asks (or is about to) is told to stop
             try:
                 conns[w].send(None)
