@@ -1423,6 +1423,82 @@ __global__ __launch_bounds__(256) void walk_leaves_records_kernel(const TreeNode
     if (sacc[i] != 0ull) atomicAdd(&acc[i], sacc[i]);
 }
 
+// Variant with the rows' bin bytes in LDS (R rows per lane, 36-byte stride: nine dwords, coprime with the bank
+// count, so the lanes of a wave read their bytes from different banks): a step of the walk is a node read and a
+// one-byte read, both LDS, instead of a sixteen-instruction pick from registers.
+template <int R>
+__global__ __launch_bounds__(256) void walk_leaves_lds_kernel(const TreeNodeDev* __restrict__ nodes, int n_internal, int num_leaves,
+                                                              const uint4* __restrict__ recs, int64_t N,
+                                                              const int32_t* __restrict__ rows, int64_t n,
+                                                              const float* __restrict__ g, const float* __restrict__ h,
+                                                              const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                              unsigned long long* __restrict__ acc,
+                                                              const uint64_t* __restrict__ node_sets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kStride = 36;
+  int4* sn = reinterpret_cast<int4*>(smem);
+  unsigned long long* sacc = reinterpret_cast<unsigned long long*>(smem + (size_t)n_internal * sizeof(TreeNodeDev));
+  unsigned char* sbins = reinterpret_cast<unsigned char*>(sacc + 2 * num_leaves);   // [R * 256 rows][36 bytes], 4-byte aligned
+  const int4* gn = reinterpret_cast<const int4*>(nodes);
+  for (int i = threadIdx.x; i < n_internal; i += blockDim.x) sn[i] = gn[i];
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
+  __syncthreads();
+  const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
+  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  for (int64_t base = (int64_t)blockIdx.x * (R * 256); base < n; base += (int64_t)gridDim.x * (R * 256)) {
+    int64_t r[R];
+    float gv[R], hv[R];
+    int node[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      r[k] = i < n ? (rows ? (int64_t)rows[i] : i) : -1;
+      if (r[k] >= 0 && !LGA_DEV_CHECK((unsigned long long)r[k] < (unsigned long long)N, kCheckWalkRow, r[k], N)) r[k] = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      node[k] = (r[k] >= 0 && num_leaves > 1) ? 0 : ~0;
+      if (r[k] >= 0) {
+        const uint4 a = recs[r[k] * 2], b = recs[r[k] * 2 + 1];
+        unsigned* dst = reinterpret_cast<unsigned*>(sbins + (size_t)(k * 256 + (int)threadIdx.x) * kStride);   // only this lane reads it back
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+        dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+        gv[k] = g[r[k]];
+        hv[k] = h[r[k]];
+      }
+    }
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (node[k] >= 0) {
+          const TreeNodeDev t = tn[node[k]];
+          const int b = sbins[(size_t)(k * 256 + (int)threadIdx.x) * kStride + ((unsigned)t.feature & 31u)];
+          const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
+          const bool left = (t.meta & 1024) ? ((node_sets[(int64_t)node[k] * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull) != 0
+                            : (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
+          node[k] = left ? t.left : t.right;
+          if (!LGA_DEV_CHECK(node[k] < n_internal && ~node[k] < num_leaves, kCheckWalkNode, node[k], n_internal)) { node[k] = ~0; r[k] = -1; }
+          more = more || node[k] >= 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (r[k] >= 0) {
+        const int leaf = ~node[k];
+        leaf_of_row[r[k]] = (uint16_t)leaf;
+        atomicAdd(&sacc[2 * leaf], (unsigned long long)quantize_wide(gv[k], kg));
+        atomicAdd(&sacc[2 * leaf + 1], (unsigned long long)quantize_wide(hv[k], kh));
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x)
+    if (sacc[i] != 0ull) atomicAdd(&acc[i], sacc[i]);
+}
+
 __global__ __launch_bounds__(256) void leaf_value_add_kernel(const uint16_t* __restrict__ leaf_of_row,
                                                              const double* __restrict__ leaf_value, int num_leaves,
                                                              const int32_t* __restrict__ rows, int64_t n,
@@ -1832,6 +1908,22 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
   if (sm > 48 * 1024 || num_leaves > 65535) return false;   // the caller takes the per-leaf row lists instead
   LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)num_leaves, s));
   if (n <= 0) return true;
+  // rows per lane whose bin bytes wait in LDS (2 or 4); 0: the bytes are picked from registers.  Measured on the
+  // benchmark: 2 -> 3.51, 4 -> 3.99 (45 KiB of LDS: three workgroups per CU), 0 -> 3.65 ms per tree.
+  static const int lds_rows = std::getenv("LGA_WALK_LDS") ? std::atoi(std::getenv("LGA_WALK_LDS")) : 2;
+  if (records && (lds_rows == 2 || lds_rows == 4)) {
+    const size_t sm_rows = sm + (size_t)lds_rows * 256 * 36;
+    if (lds_rows == 2)
+      hipLaunchKernelGGL((walk_leaves_lds_kernel<2>), dim3(grid_for(n, 512, 4096)), dim3(256), sm_rows, s, nodes, n_internal, num_leaves,
+                         reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, leaf_of_row,
+                         reinterpret_cast<unsigned long long*>(acc), node_sets);
+    else
+      hipLaunchKernelGGL((walk_leaves_lds_kernel<4>), dim3(grid_for(n, 1024, 2048)), dim3(256), sm_rows, s, nodes, n_internal, num_leaves,
+                         reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, leaf_of_row,
+                         reinterpret_cast<unsigned long long*>(acc), node_sets);
+    LGA_LAUNCH_CHECK();
+    return true;
+  }
   if (records) {
     hipLaunchKernelGGL(walk_leaves_records_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), sm, s, nodes, n_internal, num_leaves,
                        reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, leaf_of_row,
