@@ -445,6 +445,20 @@ def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     assert trees_of(a) == trees_of(b)
 
 
+def assert_same_splits(a, b):
+    """Same trees up to the last bits of the values (initial scores summed in another order): every structural line
+    of the model text equal, the value lines close."""
+    la, lb = trees_of(a).split("\n"), trees_of(b).split("\n")
+    assert len(la) == len(lb)
+    approx = ("leaf_value=", "internal_value=", "leaf_weight=", "internal_weight=", "split_gain=")
+    for x, z in zip(la, lb):
+        if x.startswith(approx):
+            np.testing.assert_allclose(np.array(x.split("=")[1].split(), dtype=float), np.array(z.split("=")[1].split(), dtype=float),
+                                       rtol=1e-9, atol=1e-10)
+        else:
+            assert x == z
+
+
 def test_large_data_paths_match_the_cpu_engine():
     """2^20 rows and more take paths the small tests never reach by themselves: row lines, two rounds in flight, large
     leaves as sides / move / dense child histogram launches, leaf ids and exact leaf sums from one tree walk.  Same
@@ -453,15 +467,20 @@ def test_large_data_paths_match_the_cpu_engine():
     p = {"num_leaves": 63, "min_data_in_leaf": 20}
     a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params=CPU), 4)
     b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params=GPU), 4)
-    la, lb = trees_of(a).split("\n"), trees_of(b).split("\n")
-    assert len(la) == len(lb)
-    approx = ("leaf_value=", "internal_value=", "leaf_weight=", "internal_weight=", "split_gain=")
-    for x, z in zip(la, lb):
-        if x.startswith(approx):
-            np.testing.assert_allclose(np.array(x.split("=")[1].split(), dtype=float), np.array(z.split("=")[1].split(), dtype=float),
-                                       rtol=1e-9, atol=1e-12)
-        else:
-            assert x == z
+    assert_same_splits(a, b)
+
+
+def test_dense_histogram_units_cover_children_the_search_underestimated():
+    """The grid of a large leaf's dense histogram units is sized from the child's ESTIMATED row count (hessian share):
+    with weights spread over six orders of magnitude the estimate is off by far, and the units have to loop over
+    what the child really holds.  Same trees as the CPU engine."""
+    X, y = make_regression(120000, 8, seed=21)
+    rng = np.random.RandomState(0)
+    w = np.where(rng.rand(len(y)) < 0.02, 1e3, 1e-3)      # 2 % of the rows carry nearly all the hessian
+    p = {"num_leaves": 31, "min_data_in_leaf": 50, "min_sum_hessian_in_leaf": 0.0}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, weight=w, params=CPU), 6)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, weight=w, params=GPU), 6)
+    assert_same_splits(a, b)      # (the weighted mean the scores start from differs in the twelfth digit)
 
 
 def test_gpu_forced_splits_equal_cpu(tmp_path):
