@@ -124,6 +124,8 @@ const ParamDef kParams[] = {
     P(device_bin_find, "", Bool, kNone, kNone),
     P(iteration_offset, "", Int, 0, kNone),
     P(early_stopping_min_delta, "", Double, 0, kNone),
+    P(multi_error_top_k, "", Int, 1, kNone),
+    P(auc_mu_weights, "", DoubleList, 0, kNone),
     P(saved_feature_importance_type, "", Int, 0, 1),
     P(monotone_constraints_method, "monotone_constraining_method,mc_method", String, kNone, kNone),
     P(force_col_wise, "", Bool, kNone, kNone),

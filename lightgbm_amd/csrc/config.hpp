@@ -102,6 +102,8 @@ struct Config {
   std::vector<double> label_gain;         // gain per relevance grade; empty: 2^grade - 1
   int objective_seed = 5;                 // rank_xendcg's per-document noise
   std::vector<int> eval_at;               // cut-offs of ndcg / map; empty: 1..5
+  int multi_error_top_k = 1;              // multi_error: a row counts as right while fewer than this many classes score at least as high as the true one
+  std::vector<double> auc_mu_weights;     // auc_mu: num_class x num_class misclassification weights, row-major, zero diagonal; empty: all ones
   // metric
   std::vector<std::string> metric;   // empty: derived from the objective
   int metric_freq = 1;

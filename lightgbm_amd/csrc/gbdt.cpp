@@ -53,6 +53,7 @@ void Booster::setup_objective() {
   obj_.fair_c = cfg_.fair_c;
   obj_.poisson_max_delta = cfg_.poisson_max_delta_step;
   obj_.tweedie_rho = cfg_.tweedie_variance_power;
+  obj_.multi_error_top_k = cfg_.multi_error_top_k;
   if (o == "regression") { obj_.kind = kObjRegression; objective_str_ = "regression"; }
   else if (o == "regression_l1") { obj_.kind = kObjRegressionL1; objective_str_ = "regression_l1"; }
   else if (o == "huber") { obj_.kind = kObjHuber; objective_str_ = "huber"; }
@@ -250,16 +251,29 @@ void Booster::eval_host_metrics(int which, std::vector<EvalResult>* out) {
     std::vector<double> score((size_t)n * (size_t)K);      // [class][row]
     engine_->get_scores(which, score.data());
     const std::vector<float> label = ds->local_label(), weight = ds->local_weight();
-    // for every pair of classes: the AUC of telling them apart by the difference of their two raw scores
+    // for every pair of classes: the AUC of telling them apart along (A_i - A_j) . scores, A the matrix of
+    // misclassification weights (auc_mu_weights; all ones off the diagonal: the difference of the two raw scores)
+    const std::vector<double>& A = cfg_.auc_mu_weights;
+    if (!A.empty()) {
+      if ((int)A.size() != K * K) throw std::runtime_error("auc_mu_weights needs num_class x num_class values");
+      for (int i = 0; i < K; ++i)
+        if (A[(size_t)i * (size_t)K + (size_t)i] != 0.0) throw std::runtime_error("auc_mu_weights: the diagonal must be zero");
+    }
     double sum = 0.0;
+    std::vector<double> v((size_t)K);
     for (int i = 0; i < K; ++i)
       for (int j = i + 1; j < K; ++j) {
+        for (int k = 0; k < K; ++k)
+          v[(size_t)k] = A.empty() ? (k == j ? 1.0 : (k == i ? -1.0 : 0.0))
+                                   : A[(size_t)i * (size_t)K + (size_t)k] - A[(size_t)j * (size_t)K + (size_t)k];
         std::vector<std::pair<double, std::pair<float, float>>> items;
         for (int64_t r = 0; r < n; ++r) {
           const int c = (int)label[(size_t)r];
           if (c != i && c != j) continue;
-          items.push_back({score[(size_t)j * (size_t)n + (size_t)r] - score[(size_t)i * (size_t)n + (size_t)r],
-                           {c == j ? 1.0f : 0.0f, weight.empty() ? 1.0f : weight[(size_t)r]}});
+          double t = 0.0;
+          for (int k = 0; k < K; ++k)
+            if (v[(size_t)k] != 0.0) t += v[(size_t)k] * score[(size_t)k * (size_t)n + (size_t)r];
+          items.push_back({t, {c == j ? 1.0f : 0.0f, weight.empty() ? 1.0f : weight[(size_t)r]}});
         }
         sum += auc_host(items);
       }

@@ -56,6 +56,8 @@ struct ObjectiveSpec {
   double fair_c;
   double poisson_max_delta;  // poisson safety term
   double tweedie_rho;        // tweedie variance power, in [1, 2)
+  int32_t multi_error_top_k; // multi_error: classes that may score at least as high as the true one (it included); < 1 reads as 1
+  int32_t pad_;
 };
 
 // label is the raw label; for binary any label > 0 is positive.
@@ -153,7 +155,7 @@ LGA_HD void multiclass_grad_hess(const ObjectiveSpec& o, const double* scores, i
 }
 
 // multi_logloss: -log of the true class's probability (softmax, or that class's own sigmoid under
-// one-vs-all); multi_error: 1 when another class scores at least as high as the true one.
+// one-vs-all); multi_error: 1 when multi_error_top_k classes besides the true one score at least as high as it.
 LGA_HD double multi_point_loss(int32_t metric, const ObjectiveSpec& o, const double* scores, int64_t stride, int64_t r,
                                float label) {
   const int K = o.num_class, y = (int)label;
@@ -161,7 +163,7 @@ LGA_HD double multi_point_loss(int32_t metric, const ObjectiveSpec& o, const dou
   if (metric == kMetMultiError) {
     int at_least = 0;
     for (int k = 0; k < K; ++k) at_least += scores[(int64_t)k * stride + r] >= sy ? 1 : 0;
-    return at_least > 1 ? 1.0 : 0.0;
+    return at_least > (o.multi_error_top_k > 1 ? o.multi_error_top_k : 1) ? 1.0 : 0.0;
   }
   double p;
   if (o.kind == kObjMulticlassOva) {

@@ -177,6 +177,33 @@ def test_auc_mu_is_the_mean_pairwise_auc():
     assert ev["training"]["auc_mu"][-1] == pytest.approx(np.mean(pairs), abs=1e-9)
 
 
+def test_auc_mu_weights_and_multi_error_top_k():
+    from sklearn.metrics import roc_auc_score
+    K = 4
+    X, y = make_classes(4000, K=K, seed=7)
+    A = np.array([[0, 1, 2, 3], [1, 0, 1, 2], [2, 1, 0, 1], [3, 2, 1, 0]], dtype=float)   # ordinal classes: far misses cost more
+    d = lgb.Dataset(X, label=y, params=CPU)
+    ev = {}
+    p = {**CPU, "objective": "multiclass", "num_class": K, "num_leaves": 7, "metric": ["auc_mu", "multi_error"],
+         "auc_mu_weights": A.ravel().tolist(), "multi_error_top_k": 2}
+    b = lgb.train(p, d, 8, valid_sets=[d], evals_result=ev)
+    raw = b.predict(X, raw_score=True)
+    pairs = []
+    for i in range(K):
+        for j in range(i + 1, K):
+            m = (y == i) | (y == j)
+            pairs.append(roc_auc_score(y[m] == j, raw[m] @ (A[i] - A[j])))
+    assert ev["training"]["auc_mu"][-1] == pytest.approx(np.mean(pairs), abs=1e-9)
+    # top-2 error: wrong only when two other classes score at least as high as the true one
+    true_score = raw[np.arange(len(y)), y.astype(int)]
+    wrong = ((raw >= true_score[:, None]).sum(axis=1) > 2).mean()
+    assert ev["training"]["multi_error"][-1] == pytest.approx(wrong, abs=1e-12)
+    top1 = lgb.train({**p, "multi_error_top_k": 1}, d, 8, valid_sets=[d], evals_result=ev)
+    assert ev["training"]["multi_error"][-1] == pytest.approx((raw.argmax(axis=1) != y).mean(), abs=1e-12) and top1 is not None
+    with pytest.raises(lgb.LightGBMError):
+        lgb.train({**p, "auc_mu_weights": [0.0, 1.0, 1.0]}, d, 1, valid_sets=[d])
+
+
 def test_continued_training_of_a_multiclass_model():
     # 4 + 4 rounds through init_model equal 8 rounds in one go (no bagging, nothing random in between)
     rng = np.random.RandomState(11)
