@@ -614,9 +614,12 @@ class HipBackend : public TreeBackend {
   hipStream_t stream() const { return stream_; }
 
  private:
-  int pick_hist_chunk(int64_t total_rows) const {
-    // aim at >= ~1024 workgroups when there is enough work; never exceed the LDS accumulator range
-    int64_t c = (total_rows + 1023) / 1024;
+  int pick_hist_chunk(int64_t total_rows, int tiles) const {
+    // aim at ~1024 workgroups (row chunks x feature tiles) when there is enough work; never exceed the LDS
+    // accumulator range.  Every workgroup clears and flushes a 64 KiB histogram, so wide data wants few, long
+    // chunks: 400 k rows x 63 tiles as 1024-row chunks are 24 k workgroups and 400 M global atomics per pass.
+    const int64_t chunks = std::max<int64_t>(1, 1024 / std::max(tiles, 1));
+    int64_t c = (total_rows + chunks - 1) / chunks;
     c = ((c + 511) / 512) * 512;
     if (c < 1024) c = 1024;
     if (c > kMaxRowsPerPass) c = kMaxRowsPerPass;
@@ -795,7 +798,12 @@ class HipBackend : public TreeBackend {
     const bool inline_tasks = B <= k::kInlineTasks;
     int64_t total_rows = 0;
     for (const auto& t : tasks) total_rows += root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
-    const int hch = pick_hist_chunk(total_rows);
+    int tiles_here = T_;
+    if (mode_ == ParallelMode::Feature) {
+      const int P = comm_->size(), r = comm_->rank();
+      tiles_here = std::max(1, r < T_ ? (T_ - r + P - 1) / P : 0);
+    }
+    const int hch = pick_hist_chunk(total_rows, tiles_here);
     char* st = x.stage_host.get();
     int32_t* pc = reinterpret_cast<int32_t*>(st + off_pch_);
     int32_t* hc = reinterpret_cast<int32_t*>(st + off_hch_);
