@@ -1909,18 +1909,17 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
   LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)num_leaves, s));
   if (n <= 0) return true;
   // rows per lane whose bin bytes wait in LDS (2 or 4); 0: the bytes are picked from registers.  Measured on the
-  // benchmark: 2 -> 3.51, 4 -> 3.99 (45 KiB of LDS: three workgroups per CU), 0 -> 3.65 ms per tree.
+  // benchmark: 2 -> 3.51, 4 -> 3.99 (45 KiB of LDS: three workgroups per CU), 0 -> 3.65 ms per tree (1 and 3 rows
+  // per lane: 3.50 and 3.52).
   static const int lds_rows = std::getenv("LGA_WALK_LDS") ? std::atoi(std::getenv("LGA_WALK_LDS")) : 2;
-  if (records && lds_rows >= 1 && lds_rows <= 4) {
+  if (records && (lds_rows == 2 || lds_rows == 4)) {
     const size_t sm_rows = sm + (size_t)lds_rows * 256 * 36;
     const dim3 grid(grid_for(n, 256 * lds_rows, 4096));
     auto launch = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, grid, dim3(256), sm_rows, s, nodes, n_internal, num_leaves, reinterpret_cast<const uint4*>(records), N,
                          rows, n, g, h, qs, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
     };
-    if (lds_rows == 1) launch(walk_leaves_lds_kernel<1>);
-    else if (lds_rows == 2) launch(walk_leaves_lds_kernel<2>);
-    else if (lds_rows == 3) launch(walk_leaves_lds_kernel<3>);
+    if (lds_rows == 2) launch(walk_leaves_lds_kernel<2>);
     else launch(walk_leaves_lds_kernel<4>);
     LGA_LAUNCH_CHECK();
     return true;
