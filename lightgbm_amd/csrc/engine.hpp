@@ -70,6 +70,12 @@ class Engine {
   // get_scores ([class][row]) see all of them.
   virtual void select_class(int k) = 0;
   virtual void compute_gradients(const ObjectiveSpec& obj) = 0;
+  // The objective whose gradients every iteration starts with (null: none such - ranking, custom gradients, rf).  An
+  // engine may then take the next iteration's gradients in the pass that adds a finished tree to the training
+  // scores; compute_gradients finds them done unless the scores have changed since.  invalidate_... after a change
+  // of the objective's parameters.
+  virtual void set_iteration_objective(const ObjectiveSpec* obj) { (void)obj; }
+  virtual void invalidate_precomputed_gradients() {}
   // Weighted number of training rows per class label (summed over ranks).
   virtual void class_weights(int num_class, std::vector<double>* out) = 0;
   // Ranking gradients (ranking.hpp) taken by the engine itself from its current scores; bounds are the

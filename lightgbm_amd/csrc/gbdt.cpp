@@ -34,6 +34,8 @@ Booster::Booster(std::shared_ptr<Dataset> train, const std::string& params, cons
   }
   engine_ = factory(train_, cfg_);
   if (is_ranking()) setup_ranking();
+  // every iteration starts with the gradients of obj_ at the current scores: the engine may take them early
+  if (!is_rf_ && !is_dart_ && !is_ranking() && obj_.kind != kObjCustom && num_class_ == 1) engine_->set_iteration_objective(&obj_);
   max_feature_idx_ = train_->num_total_features() - 1;
   feature_names_ = train_->names();
   feature_infos_.clear();

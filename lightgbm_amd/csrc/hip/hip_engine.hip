@@ -1343,6 +1343,7 @@ class HipEngine : public Engine {
   void reset_scores(double v) override {
     // initial scores: one vector for every class, or one per class ([class][root row])
     const double* own = has_init_ ? init_score_dev_.get() + (init_per_class_ ? (size_t)cls_ * (size_t)N_ : 0) : nullptr;
+    ++score_version_;
     k::init_scores(sc(), own, base_or_null(), n_base_, v, stream_);
     for (auto& vs : valid_) {
       const double* vi = vs->has_init ? vs->init.get() + (vs->init_per_class ? (size_t)cls_ * (size_t)vs->N : 0)
@@ -1351,11 +1352,11 @@ class HipEngine : public Engine {
     }
   }
   void scale_scores(int which, double f) override {
-    if (which < 0) k::scale_add(sc(), base_or_null(), n_base_, f, 0.0, stream_);
+    if (which < 0) { ++score_version_; k::scale_add(sc(), base_or_null(), n_base_, f, 0.0, stream_); }
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, f, 0.0, stream_); }
   }
   void add_constant(int which, double c) override {
-    if (which < 0) k::scale_add(sc(), base_or_null(), n_base_, 1.0, c, stream_);
+    if (which < 0) { ++score_version_; k::scale_add(sc(), base_or_null(), n_base_, 1.0, c, stream_); }
     else { auto& v = *valid_[(size_t)which]; k::scale_add(score_ptr(v), v.rows.get(), v.n, 1.0, c, stream_); }
   }
 
@@ -1388,10 +1389,17 @@ class HipEngine : public Engine {
       have_max_ = false;
       return;
     }
+    if (iteration_obj_ && grad_version_ == score_version_) {
+      // taken together with the last tree's score update (add_trained_tree_to_train_scores); the scores are unchanged
+      have_max_ = true;
+      return;
+    }
     k::gradients(obj, scores_.get(), mir_->label.get(), weight_ptr(mir_), base_or_null(), n_base_, grad_.get(),
                  hess_.get(), maxbits_.get(), stream_);
     have_max_ = true;
   }
+  void set_iteration_objective(const ObjectiveSpec* obj) override { iteration_obj_ = obj; grad_version_ = 0; ++score_version_; }
+  void invalidate_precomputed_gradients() override { grad_version_ = 0; ++score_version_; }
   bool ranking_gradients(const RankingSpec& spec, const std::vector<int64_t>& bounds,
                          const std::vector<double>& inv_max_dcg, uint64_t iter) override {
     if (!rank_ready_) {
@@ -1639,6 +1647,7 @@ class HipEngine : public Engine {
     b.n_base = (int32_t)n_base_;
     b.base_rows = base_rows_.get();
     b.bag_rows = bag_rows_.get();
+    ++score_version_;
     b.scores = sc();
     b.label = mir_->label.get();
     b.weight = weight_ptr(mir_);
@@ -1755,11 +1764,19 @@ class HipEngine : public Engine {
   void add_trained_tree_to_train_scores(const Tree& tree) override {
     TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
+    ++score_version_;
     if (leaf_ids_valid_ && leaf_ids_leaves_ == tree.num_leaves) {
       // the leaf of every row is known from the walk that took the leaf sums: the tree's structure has not changed
       // since, only its leaf values
       leaf_ids_valid_ = false;
       const TreeOnDevice td = upload_tree(tree);
+      if (iteration_obj_ && K_ == 1 && !is_multiclass(iteration_obj_->kind) && fuse_gradients_) {
+        // ... and the next iteration's gradients come out of the same pass
+        k::leaf_value_add_gradients(*iteration_obj_, leaf_of_row_.get(), td.leaf_value, td.num_leaves, base_or_null(), n_base_, sc(),
+                                    mir_->label.get(), weight_ptr(mir_), grad_.get(), hess_.get(), maxbits_.get(), stream_);
+        grad_version_ = score_version_;
+        return;
+      }
       k::leaf_value_add(leaf_of_row_.get(), td.leaf_value, td.num_leaves, base_or_null(), n_base_, sc(), stream_);
       return;
     }
@@ -1831,6 +1848,7 @@ class HipEngine : public Engine {
       throw std::runtime_error("tree has no bin thresholds (loaded from a model file); cannot traverse binned data");
     const TreeOnDevice td = upload_tree(tree);
     if (which < 0) {
+      ++score_version_;
       traverse(td, mir_, N_, base_or_null(), n_base_, sign, sc());
     } else {
       auto& v = *valid_[(size_t)which];
@@ -2114,6 +2132,11 @@ class HipEngine : public Engine {
   bool use_lines_ = false;
   DeviceBuffer<uint8_t> lines_;
   int score_update_ = 0;   // 0 auto, 1 leaf ranges, 2 tree walk (LGA_SCORE_UPDATE=leaf|walk overrides)
+  // gradients taken ahead of time (set_iteration_objective): valid while the training scores still are the ones they
+  // were taken from - every writer of the training scores moves score_version_ on
+  const ObjectiveSpec* iteration_obj_ = nullptr;
+  uint64_t score_version_ = 1, grad_version_ = 0;
+  bool fuse_gradients_ = std::getenv("LGA_FUSE_GRADIENTS") == nullptr || std::string(std::getenv("LGA_FUSE_GRADIENTS")) != "0";
   bool init_per_class_ = false;
   DeviceBuffer<double> scores_, init_score_dev_, red_dev_, tmp_f64_;
   DeviceBuffer<float> grad_, hess_, tmp_f32_;

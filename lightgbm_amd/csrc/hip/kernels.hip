@@ -1513,6 +1513,61 @@ __global__ __launch_bounds__(256) void leaf_value_add_kernel(const uint16_t* __r
   }
 }
 
+// The score update of a finished tree and the gradients of the NEXT iteration in one pass over the rows (large data,
+// every row's leaf known from the walk): scores[r] += value of r's leaf, then gradients_kernel's work on the new
+// score - one read of the scores instead of a write and a read, one launch instead of two.
+__global__ __launch_bounds__(256) void leaf_value_add_gradients_kernel(ObjectiveSpec obj, const uint16_t* __restrict__ leaf_of_row,
+                                                                       const double* __restrict__ leaf_value, int num_leaves,
+                                                                       const int32_t* __restrict__ rows, int64_t n,
+                                                                       double* __restrict__ scores, const float* __restrict__ label,
+                                                                       const float* __restrict__ weight, float* __restrict__ g,
+                                                                       float* __restrict__ h, uint32_t* maxbits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lv = reinterpret_cast<double*>(smem);
+  for (int i = threadIdx.x; i < num_leaves; i += blockDim.x) lv[i] = leaf_value[i];
+  __syncthreads();
+  constexpr int U = 4;
+  float mg = 0.f, mh = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * U) {
+    int64_t r[U];
+    double sc[U];
+    float lb[U], wt[U];
+    int leaf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * stride;
+      r[u] = i < n ? (rows ? (int64_t)rows[i] : i) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] >= 0) {
+        sc[u] = scores[r[u]]; lb[u] = label[r[u]]; wt[u] = weight ? weight[r[u]] : 1.0f;
+        leaf[u] = min((int)leaf_of_row[r[u]], num_leaves - 1);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (r[u] >= 0) {
+        const double s_new = sc[u] + lv[leaf[u]];
+        scores[r[u]] = s_new;
+        float gg, hh;
+        grad_hess(obj, s_new, lb[u], wt[u], &gg, &hh);
+        g[r[u]] = gg;
+        h[r[u]] = hh;
+        mg = fmaxf(mg, fabsf(gg));
+        mh = fmaxf(mh, hh);
+      }
+    }
+  }
+  mg = wave_max_f32(mg);
+  mh = wave_max_f32(mh);
+  if ((threadIdx.x & 63) == 0) {
+    publish_max(&maxbits[0], mg);
+    publish_max(&maxbits[1], mh);
+  }
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(double* __restrict__ scores, const int32_t* __restrict__ rows,
                                                         int64_t n, double scale, double add) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1942,6 +1997,16 @@ void leaf_value_add(const uint16_t* leaf_of_row, const double* leaf_value, int n
   if (n <= 0) return;
   hipLaunchKernelGGL(leaf_value_add_kernel, dim3(grid_for(n, 256)), dim3(256), (size_t)num_leaves * sizeof(double), s, leaf_of_row,
                      leaf_value, num_leaves, rows, n, scores);
+  LGA_LAUNCH_CHECK();
+}
+
+void leaf_value_add_gradients(const ObjectiveSpec& obj, const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves,
+                              const int32_t* rows, int64_t n, double* scores, const float* label, const float* weight, float* g,
+                              float* h, uint32_t* maxbits, hipStream_t s) {
+  LGA_HIP_CHECK(hipMemsetAsync(maxbits, 0, 2 * sizeof(uint32_t), s));
+  if (n <= 0) return;
+  hipLaunchKernelGGL(leaf_value_add_gradients_kernel, dim3(grid_for(n, 256)), dim3(256), (size_t)num_leaves * sizeof(double), s, obj,
+                     leaf_of_row, leaf_value, num_leaves, rows, n, scores, label, weight, g, h, maxbits);
   LGA_LAUNCH_CHECK();
 }
 

@@ -361,6 +361,10 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
                  const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
                  int64_t* acc, const uint64_t* node_sets, hipStream_t s);
+// leaf_value_add and the gradients of the next iteration (gradients()) in one pass.
+void leaf_value_add_gradients(const ObjectiveSpec& obj, const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves,
+                              const int32_t* rows, int64_t n, double* scores, const float* label, const float* weight, float* g,
+                              float* h, uint32_t* maxbits, hipStream_t s);
 void leaf_value_add(const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves, const int32_t* rows, int64_t n,
                     double* scores, hipStream_t s);
 // node_sets: kCatSetWords words per internal node, read for nodes whose meta has bit 10 set (a categorical

@@ -470,6 +470,29 @@ def test_large_data_paths_match_the_cpu_engine():
     assert_same_splits(a, b)
 
 
+def test_gradients_taken_with_the_score_update_change_nothing(monkeypatch):
+    """Large data: the pass that adds a finished tree to the scores also takes the next iteration's gradients; they are
+    used only while the scores stay as they were (a rollback in between must trigger a fresh pass).  Same models with
+    the fusion switched off."""
+    X, y = make_higgs_like((1 << 20) + 777, seed=9, device="numpy")
+    w = np.where(X[:, 1] > 0, 2.0, 0.5)
+    p = {**GPU, "objective": "binary", "num_leaves": 31, "min_sum_hessian_in_leaf": 10.0}
+
+    def run():
+        b = lgb.Booster(p, lgb.Dataset(X, label=y, weight=w, params=GPU))
+        for _ in range(3):
+            b.update()
+        b.rollback_one_iter()
+        for _ in range(2):
+            b.update()
+        return trees_of(b)
+    monkeypatch.setenv("LGA_FUSE_GRADIENTS", "0")
+    plain = run()
+    monkeypatch.setenv("LGA_FUSE_GRADIENTS", "1")
+    fused = run()
+    assert plain == fused
+
+
 def test_dense_histogram_units_cover_children_the_search_underestimated():
     """The grid of a large leaf's dense histogram units is sized from the child's ESTIMATED row count (hessian share):
     with weights spread over six orders of magnitude the estimate is off by far, and the units have to loop over
