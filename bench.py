@@ -66,6 +66,8 @@ def main():
     # LGA_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, agreed bin boundaries, RCCL
     # communicator) even with one rank - a plumbing check for boxes that have a single GPU
     distributed = world > 1 or os.environ.get("LGA_BENCH_FORCE_DIST") == "1"
+    if distributed and world == 1:
+        os.environ["LGA_DP_KEEP_SINGLE_RANK"] = "1"   # train through the one-rank communicator, not around it
     # LGA_BENCH_BACKEND=gloo rehearses a multi-rank run on a machine with fewer GPUs than ranks: the ranks
     # share the devices and reduce through host memory instead of RCCL (timings then mean nothing)
     backend = os.environ.get("LGA_BENCH_BACKEND", "nccl")

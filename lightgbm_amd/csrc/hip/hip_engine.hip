@@ -178,7 +178,12 @@ class HipBackend : public TreeBackend {
     F_ = root_->num_features();
     T_ = root_->num_tiles();
     N_ = root_->root_rows();
-    if (!comm_ || comm_->size() <= 1) mode_ = ParallelMode::Serial;
+    // LGA_DP_KEEP_SINGLE_RANK=1 keeps the distributed learner for a communicator of ONE rank (the collectives, the
+    // streams and events around them, the distributed search hand-over all run; the sums change nothing): the way to
+    // time that code path on a machine with a single GPU
+    const char* keep_single = std::getenv("LGA_DP_KEEP_SINGLE_RANK");
+    const bool keep_dist = comm_ && comm_->size() == 1 && keep_single && keep_single[0] == '1' && mode_ != ParallelMode::Serial;
+    if (!comm_ || (comm_->size() <= 1 && !keep_dist)) mode_ = ParallelMode::Serial;
     else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
     // Histogram pool layout (kernels.hpp: PoolLayout): the data-parallel learner splits every slot into one
     // chunk per rank, so that one in-place reduce-scatter per round hands each rank the features it searches.
@@ -244,11 +249,14 @@ class HipBackend : public TreeBackend {
       scan_range_ = k::ScanRange{0, F_, kTileFeatures, r, P, std::max(1, owned)};
       if (owned == 0) scan_range_.f_end = 0;   // nothing to search: one empty block keeps the hand-over alive
     }
-    // Two rounds may be in flight unless per-phase event timing is requested: one round's latency-bound tail
-    // (split search, result hand-over, host replay) overlaps with the other's row-level work.  Small data
-    // gains nothing from it: its rounds are pure latency, and concurrent boosters (CV folds on their own
-    // streams) already fill the hardware queues.
-    n_ctx_ = (!prof.on && max_rows >= (int64_t)1 << 19) ? 2 : 1;
+    // Rounds in flight: ONE by default.  A second round lets one round's latency-bound tail (split search, result
+    // hand-over, host replay) overlap with the other's row-level work, but a level's leaves are then dealt over two
+    // rounds, and since leaves whose turn is certain are split ahead of time the rounds are few and full: measured
+    // on the 10.5 M x 28 benchmark, 500 trees take 1.57 s with one round in flight and 1.60 s with two (three
+    // interleaved repeats each), the same within noise from 0.6 M to 2.6 M rows.  The distributed learners would
+    // pay for a second round twice over: each round brings a collective of its own on the shared collective stream
+    // plus two event hand-overs between streams.  LGA_ROUNDS_IN_FLIGHT=2..4 keeps the machinery reachable.
+    n_ctx_ = 1;
     if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(kMaxRoundsInFlight, std::atoi(e)));
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));

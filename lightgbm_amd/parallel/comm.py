@@ -247,8 +247,15 @@ def default_comm(group=None):
     """RCCL when training on GPUs under an ``nccl`` process group, torch.distributed host collectives otherwise
     (CPU engine, or a ``gloo`` group used to rehearse a multi-rank run on fewer GPUs than ranks: the device
     engine then stages its buffers through host memory); None when not distributed."""
+    import os
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) <= 1:
+    if not dist.is_available() or not dist.is_initialized():
+        return None
+    if dist.get_world_size(group) <= 1:
+        # LGA_DP_KEEP_SINGLE_RANK=1: a communicator of one rank, which the device engine then really trains
+        # through (a way to time the distributed code path on a single GPU)
+        if os.environ.get("LGA_DP_KEEP_SINGLE_RANK") == "1" and _lib.is_hip() and dist.get_backend(group) == "nccl":
+            return RcclComm(group)
         return None
     if _lib.is_hip() and dist.get_backend(group) == "nccl":
         return _native_or_fallback(group, RcclComm)

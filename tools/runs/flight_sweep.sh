@@ -8,6 +8,7 @@ run() {
   echo "$*" >> $OUT
   env "$@" timeout -k 10 120 python $ROOT/bench.py --steps 100 --warmup 30 --no-full-run 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])" >> $OUT
 }
+run LGA_ROUNDS_IN_FLIGHT=1
 run LGA_ROUNDS_IN_FLIGHT=2
 run LGA_ROUNDS_IN_FLIGHT=3
 run LGA_ROUNDS_IN_FLIGHT=4
