@@ -990,6 +990,15 @@ class Booster:
             num_iteration = -1
         data, _, _ = _encode_pandas_categories(data, self.pandas_categorical)
         mat, _ = _to_matrix(data)
+        early = kwargs.get("pred_early_stop", get_param(self.params, "pred_early_stop", False))
+        if early and not pred_leaf and not pred_contrib:
+            info = self.objective_info()
+            kind = info["objective"].split(" ")[0]
+            if kind in ("binary", "multiclass", "multiclassova") and not info["average_output"]:
+                freq = int(kwargs.get("pred_early_stop_freq", get_param(self.params, "pred_early_stop_freq", 10)))
+                margin = float(kwargs.get("pred_early_stop_margin", get_param(self.params, "pred_early_stop_margin", 10.0)))
+                return self._predict_early_stop(mat, start_iteration, num_iteration, raw_score, device, kind,
+                                                info["sigmoid"], max(freq, 1), margin)
         ptype = 3 if pred_contrib else (2 if pred_leaf else (1 if raw_score else 0))
         used = ctypes.c_int()
         check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
@@ -1012,6 +1021,42 @@ class Booster:
         if pred_contrib or K > 1:
             return out.reshape(nrow, width)
         return out
+
+    def _predict_early_stop(self, mat, start_iteration, num_iteration, raw_score, device, kind, sigmoid, freq, margin):
+        """Classification with ``pred_early_stop``: the raw score is built up ``freq`` iterations at a time, and a row
+        whose margin (binary: 2|score|; multiclass: best minus second-best class score) exceeds ``margin`` keeps
+        the score it has - the trees that are left are not evaluated for it."""
+        lib, _ = _lib.load()
+        used = ctypes.c_int()
+        check(lib.lga_booster_used_iterations(self._handle, start_iteration, num_iteration, ctypes.byref(used)))
+        K = self.num_model_per_iteration()
+        if _is_torch(mat):
+            mat = mat.cpu().numpy()
+        mat = np.asarray(mat)
+        n = mat.shape[0]
+        raw = np.zeros((n, K), dtype=np.float64)
+        active = np.arange(n)
+        it, end = start_iteration, start_iteration + used.value
+        while it < end and active.size:
+            step = min(freq, end - it)
+            part = self.predict(mat[active], start_iteration=it, num_iteration=step, raw_score=True, device=device,
+                                pred_early_stop=False)
+            raw[active] += np.asarray(part, dtype=np.float64).reshape(active.size, K)
+            it += step
+            cur = raw[active]
+            if K == 1:
+                m = 2.0 * np.abs(cur[:, 0])
+            else:
+                top = np.partition(cur, K - 2, axis=1)
+                m = top[:, K - 1] - top[:, K - 2]
+            active = active[m <= margin]
+        if not raw_score:
+            if kind == "multiclass":
+                e = np.exp(raw - raw.max(axis=1, keepdims=True))
+                raw = e / e.sum(axis=1, keepdims=True)
+            else:
+                raw = 1.0 / (1.0 + np.exp(-sigmoid * raw))
+        return raw[:, 0] if K == 1 else raw
 
     # -- model IO --
     def model_to_string(self, num_iteration: Optional[int] = None, start_iteration: int = 0,

@@ -165,7 +165,10 @@ def main(argv=None) -> int:
         n_it = int(kv.pop("num_iteration_predict", "-1"))
         p = b.predict(X, raw_score=_flag(kv, "predict_raw_score"), pred_leaf=_flag(kv, "predict_leaf_index"),
                       pred_contrib=_flag(kv, "predict_contrib"), num_iteration=n_it if n_it > 0 else None,
-                      start_iteration=int(kv.pop("start_iteration_predict", "0")))
+                      start_iteration=int(kv.pop("start_iteration_predict", "0")),
+                      pred_early_stop=_flag(kv, "pred_early_stop"),
+                      pred_early_stop_freq=int(kv.pop("pred_early_stop_freq", "10")),
+                      pred_early_stop_margin=float(kv.pop("pred_early_stop_margin", "10.0")))
         np.savetxt(kv.pop("output_result", "LightGBM_predict_result.txt"), p, fmt="%.17g", delimiter="\t")
     elif task == "refit":
         b = Booster(model_file=kv.pop("input_model"))

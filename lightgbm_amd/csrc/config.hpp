@@ -139,6 +139,10 @@ struct Config {
   bool enable_bundle = true;
   int num_grad_quant_bins = 4;
   bool stochastic_rounding = true;
+  // prediction (read by Booster.predict from the booster's parameters; the trainers ignore them)
+  bool pred_early_stop = false;
+  int pred_early_stop_freq = 10;
+  double pred_early_stop_margin = 10.0;
   std::string monotone_constraints_method = "basic";   // the one method implemented; the stricter upstream methods fall back to it
   // behaviour
   double early_stopping_min_delta = 0.0;      // an improvement counts from this much on (train / cv early stopping)

@@ -114,3 +114,38 @@ def test_saved_feature_importance_type_and_early_stopping_min_delta():
     strict = lgb.train({**p, "learning_rate": 0.05, "early_stopping_min_delta": 1e9}, d, 200, valid_sets=[v],
                        early_stopping_rounds=5, verbose_eval=False)
     assert strict.best_iteration == 1 and strict.current_iteration() <= 7 < loose.current_iteration()
+
+
+def test_pred_early_stop_keeps_confident_rows_short():
+    """pred_early_stop: rows whose margin is wide after a check keep the score they have; a margin nobody reaches
+    changes nothing (upstream: prediction_early_stop.cpp semantics - binary 2|score|, multiclass best - second)."""
+    rng = np.random.RandomState(5)
+    X = rng.randn(1500, 6)
+    y = (X[:, 0] + 0.3 * rng.randn(1500) > 0).astype(float)
+    b = lgb.train({"objective": "binary", "device_type": "cpu", "verbose": -1, "num_leaves": 15}, lgb.Dataset(X, label=y), 60)
+    full = b.predict(X, raw_score=True)
+    same = b.predict(X, raw_score=True, pred_early_stop=True, pred_early_stop_freq=7, pred_early_stop_margin=1e9)
+    np.testing.assert_allclose(same, full, rtol=1e-12, atol=1e-12)
+    early = b.predict(X, raw_score=True, pred_early_stop=True, pred_early_stop_freq=5, pred_early_stop_margin=3.0)
+    stopped = np.abs(early - full) > 1e-9   # (summing the chunks' scores differs from one pass in the last bits)
+    assert stopped.any() and not stopped.all()
+    assert (2 * np.abs(early[stopped]) > 3.0).all()            # they stopped because the margin was reached
+    assert ((early > 0) == (full > 0))[stopped].mean() > 0.99   # ... and on the side they end on
+    # a stopped row holds the score of a whole number of checks
+    at = {k: b.predict(X, raw_score=True, num_iteration=k) for k in range(5, 60, 5)}
+    assert all(any(abs(early[i] - at[k][i]) < 1e-9 for k in at) for i in np.flatnonzero(stopped)[:50])
+    prob = b.predict(X, pred_early_stop=True, pred_early_stop_freq=5, pred_early_stop_margin=3.0)
+    np.testing.assert_allclose(prob, 1 / (1 + np.exp(-early)), rtol=1e-12)
+    # multiclass, and the parameters taken from the booster
+    y3 = np.digitize(X[:, 1], [-0.5, 0.5]).astype(float)
+    p3 = {"objective": "multiclass", "num_class": 3, "device_type": "cpu", "verbose": -1, "num_leaves": 7,
+          "pred_early_stop": True, "pred_early_stop_freq": 4, "pred_early_stop_margin": 2.0}
+    b3 = lgb.train(p3, lgb.Dataset(X, label=y3), 40)
+    e3 = b3.predict(X)
+    f3 = b3.predict(X, pred_early_stop=False)
+    assert e3.shape == f3.shape == (1500, 3)
+    np.testing.assert_allclose(e3.sum(axis=1), 1.0, rtol=1e-12)
+    assert (np.abs(e3 - f3) > 1e-9).any() and (e3.argmax(axis=1) == f3.argmax(axis=1)).mean() > 0.99
+    # regression ignores it
+    br = lgb.train({"objective": "regression", "device_type": "cpu", "verbose": -1}, lgb.Dataset(X, label=X[:, 0]), 10)
+    np.testing.assert_array_equal(br.predict(X, pred_early_stop=True), br.predict(X))

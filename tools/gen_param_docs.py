@@ -103,6 +103,27 @@ NOTES = {
     "data_random_seed": "seed of the row sample for bin finding",
     "feature_pre_filter": "accepted for compatibility; single-valued features are always dropped",
     "iteration_offset": "first iteration index (tree-parallel forests: keeps every iteration's random streams)",
+    "top_k": "voting-parallel learner: features each rank votes for per leaf (CPU engine)",
+    "forcedsplits_filename": "JSON file of splits every tree starts with (`feature`, `threshold`, `left`, `right`)",
+    "early_stopping_min_delta": "an iteration counts as an improvement only if it beats the best score by this much",
+    "multi_error_top_k": "`multi_error` counts a row as right when its label is among the k best classes",
+    "auc_mu_weights": "`auc_mu`: num_class x num_class misclassification weights, row-major",
+    "saved_feature_importance_type": "importance block of saved models: 0 split counts, 1 total gains",
+    "monotone_constraints_method": "`basic`, `intermediate`, `advanced` accepted; one method: output ranges with midpoint separation",
+    "force_col_wise": "accepted for compatibility (no effect: one histogram layout per data shape)",
+    "force_row_wise": "accepted for compatibility (no effect)",
+    "histogram_pool_size": "accepted for compatibility (no effect: the pool holds every leaf's histogram)",
+    "gpu_platform_id": "accepted for compatibility (no effect)",
+    "gpu_use_dp": "accepted for compatibility (no effect: histograms are exact integers)",
+    "num_gpu": "accepted for compatibility; GPUs are used one process each (`parallel/`)",
+    "two_round": "accepted for compatibility (no effect)",
+    "precise_float_parser": "accepted for compatibility (no effect)",
+    "enable_bundle": "accepted for compatibility (no effect: dense storage, no feature bundling)",
+    "num_grad_quant_bins": "accepted for compatibility; gradients are quantised to 16 bits, see `quantized_grad`",
+    "stochastic_rounding": "accepted for compatibility; rounding is deterministic (seeded per row and iteration)",
+    "pred_early_stop": "prediction (binary / multiclass): stop adding trees for a row once its margin is wide enough",
+    "pred_early_stop_freq": "... checked every this many iterations",
+    "pred_early_stop_margin": "... against this margin (binary: 2|score|; multiclass: best minus second-best raw score)",
 }
 
 
