@@ -140,6 +140,7 @@ struct Config {
   int num_grad_quant_bins = 4;
   bool stochastic_rounding = true;
   // prediction (read by Booster.predict from the booster's parameters; the trainers ignore them)
+  bool reg_sqrt = false;       // objective=regression: fit sign(y) sqrt|y|, square the predictions back
   bool pred_early_stop = false;
   int pred_early_stop_freq = 10;
   double pred_early_stop_margin = 10.0;

@@ -57,8 +57,9 @@ class Engine {
   virtual int num_valid() const = 0;
   virtual int64_t num_rows(int which) const = 0;
 
-  // Sum of weight*label and sum of weight over the (global) training rows.
-  virtual void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) = 0;
+  // Sum of weight*label and sum of weight over the (global) training rows; sqrt_labels: of the labels that
+  // reg_sqrt fits (objective.hpp: sqrt_label).
+  virtual void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos, bool sqrt_labels) = 0;
   // scores = dataset init_score (or 0) + v, for training and validation data.
   virtual void reset_scores(double v) = 0;
   virtual void scale_scores(int which, double factor) = 0;

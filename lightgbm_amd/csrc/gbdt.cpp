@@ -56,7 +56,10 @@ void Booster::setup_objective() {
   obj_.poisson_max_delta = cfg_.poisson_max_delta_step;
   obj_.tweedie_rho = cfg_.tweedie_variance_power;
   obj_.multi_error_top_k = cfg_.multi_error_top_k;
-  if (o == "regression") { obj_.kind = kObjRegression; objective_str_ = "regression"; }
+  if (o == "regression") {
+    obj_.kind = cfg_.reg_sqrt ? kObjRegressionSqrt : kObjRegression;
+    objective_str_ = cfg_.reg_sqrt ? "regression sqrt" : "regression";
+  }
   else if (o == "regression_l1") { obj_.kind = kObjRegressionL1; objective_str_ = "regression_l1"; }
   else if (o == "huber") { obj_.kind = kObjHuber; objective_str_ = "huber"; }
   else if (o == "fair") { obj_.kind = kObjFair; objective_str_ = "fair"; }
@@ -99,10 +102,11 @@ double Booster::boost_from_average() {
   if (!cfg_.boost_from_average) return 0.0;
   if (!train_->root_init_score().empty()) return 0.0;
   double swy, sw, swp;
-  engine_->label_stats(&swy, &sw, &swp);
+  engine_->label_stats(&swy, &sw, &swp, obj_.kind == kObjRegressionSqrt);
   if (!(sw > 0.0)) return 0.0;
   switch (obj_.kind) {
     case kObjRegression:
+    case kObjRegressionSqrt:
     case kObjHuber:
     case kObjFair:
     case kObjRegressionL1:   // mean instead of the median: a constant start either way
@@ -168,7 +172,7 @@ void Booster::ensure_scores() {
   init_scores_.assign((size_t)K, 0.0);
   if (obj_.kind == kObjBinary) {
     double swy, sw, swp;
-    engine_->label_stats(&swy, &sw, &swp);
+    engine_->label_stats(&swy, &sw, &swp, false);
     double cp = swp, cn = sw - swp;
     if (cfg_.is_unbalance && cp > 0 && cn > 0) {
       if (cp > cn) { obj_.pos_weight = 1.0; obj_.neg_weight = cp / cn; }
@@ -395,8 +399,8 @@ void Booster::update_group(Booster* const* boosters, int n, int* finished) {
 namespace {
 bool pointwise_objective(int32_t kind) {
   switch (kind) {
-    case kObjRegression: case kObjHuber: case kObjFair: case kObjPoisson: case kObjBinary: case kObjCrossEntropy:
-    case kObjGamma: case kObjTweedie: return true;
+    case kObjRegression: case kObjRegressionSqrt: case kObjHuber: case kObjFair: case kObjPoisson: case kObjBinary:
+    case kObjCrossEntropy: case kObjGamma: case kObjTweedie: return true;
     default: return false;   // percentile leaf outputs, ranking, multiclass, custom
   }
 }

@@ -1339,8 +1339,8 @@ class HipEngine : public Engine {
   int num_valid() const override { return (int)valid_.size(); }
   int64_t num_rows(int which) const override { return which < 0 ? n_base_ : valid_[(size_t)which]->n; }
 
-  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) override {
-    k::label_sums(mir_->label.get(), weight_ptr(mir_), base_rows_.get(), n_base_, red_dev_.get(), stream_);
+  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos, bool sqrt_labels) override {
+    k::label_sums(mir_->label.get(), weight_ptr(mir_), base_rows_.get(), n_base_, sqrt_labels, red_dev_.get(), stream_);
     red_dev_.download(red_host_.get(), 3, stream_);
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     double b[3] = {red_host_[0], red_host_[1], red_host_[2]};

@@ -1657,13 +1657,14 @@ __global__ __launch_bounds__(256) void multi_metric_sum_kernel(int32_t metric, O
 
 __global__ __launch_bounds__(256) void label_sums_kernel(const float* __restrict__ label,
                                                          const float* __restrict__ weight,
-                                                         const int32_t* __restrict__ rows, int64_t n, double* out) {
+                                                         const int32_t* __restrict__ rows, int64_t n, int sqrt_labels,
+                                                         double* out) {
   __shared__ double scratch[4];
   double v[3] = {0.0, 0.0, 0.0};
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
     const double w = weight ? (double)weight[r] : 1.0;
-    v[0] += w * (double)label[r];
+    v[0] += w * (double)(sqrt_labels ? sqrt_label(label[r]) : label[r]);
     v[1] += w;
     if (label[r] > 0.0f) v[2] += w;
   }
@@ -2079,10 +2080,12 @@ void multiclass_gradients(const ObjectiveSpec& obj, const double* scores, int64_
   LGA_LAUNCH_CHECK();
 }
 
-void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s) {
+void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, bool sqrt_labels, double* out3,
+                hipStream_t s) {
   LGA_HIP_CHECK(hipMemsetAsync(out3, 0, 4 * sizeof(double), s));
   if (n <= 0) return;
-  hipLaunchKernelGGL(label_sums_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, label, weight, rows, n, out3);
+  hipLaunchKernelGGL(label_sums_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, label, weight, rows, n,
+                     sqrt_labels ? 1 : 0, out3);
   LGA_LAUNCH_CHECK();
 }
 

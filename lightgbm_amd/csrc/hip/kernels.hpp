@@ -377,7 +377,7 @@ void init_scores(double* scores, const double* init, const int32_t* rows, int64_
 constexpr int kReduceDoubles = 8 + 3 * 1024;
 void metric_sum(int32_t metric, const ObjectiveSpec& obj, const double* scores, const float* label,
                 const float* weight, const int32_t* rows, int64_t n, double* out2, hipStream_t s);
-void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, double* out3, hipStream_t s);
+void label_sums(const float* label, const float* weight, const int32_t* rows, int64_t n, bool sqrt_labels, double* out3, hipStream_t s);
 void gather_f64(const double* src, const int32_t* rows, int64_t n, double* dst, hipStream_t s);
 void gather_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s);
 void scatter_f32(const float* src, const int32_t* rows, int64_t n, float* dst, hipStream_t s);

@@ -551,13 +551,13 @@ class HostEngine : public Engine {
     return which < 0 ? (int64_t)base_.size() : (int64_t)valid_[(size_t)which].rows.size();
   }
 
-  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos) override {
+  void label_stats(double* sum_wy, double* sum_w, double* sum_w_pos, bool sqrt_labels) override {
     const auto& y = train_->root_label();
     const auto& w = train_->root_weight();
     double a = 0, b = 0, c = 0;
     for (int32_t r : base_) {
       double ww = w.empty() ? 1.0 : w[(size_t)r];
-      a += ww * y[(size_t)r];
+      a += ww * (sqrt_labels ? sqrt_label(y[(size_t)r]) : y[(size_t)r]);
       b += ww;
       if (y[(size_t)r] > 0.0f) c += ww;
     }

@@ -130,6 +130,7 @@ void Booster::load_model_from_string(const std::string& text) {
     for (size_t k = 1; k < tok.size(); ++k) {
       if (tok[k].rfind("sigmoid:", 0) == 0) cfg_.sigmoid = std::strtod(tok[k].c_str() + 8, nullptr);
       if (tok[k].rfind("num_class:", 0) == 0) cfg_.num_class = std::atoi(tok[k].c_str() + 10);
+      if (tok[k] == "sqrt") cfg_.reg_sqrt = true;
     }
     const std::string canon = Config::canonical_objective(name);
     if (canon == "multiclass" || canon == "multiclassova") {

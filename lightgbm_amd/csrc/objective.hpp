@@ -24,6 +24,7 @@ enum ObjectiveKind : int32_t {
   kObjMulticlassOva = 13,   // one binary (sigmoid) model per class
   kObjLambdarank = 14,      // ranking objectives: gradients per query on the host (ranking.hpp)
   kObjXendcg = 15,
+  kObjRegressionSqrt = 16,  // L2 on sign(y) sqrt|y| (reg_sqrt); predictions are squared back
 };
 
 enum MetricKind : int32_t {
@@ -60,12 +61,22 @@ struct ObjectiveSpec {
   int32_t pad_;
 };
 
+// reg_sqrt: the label the model is fitted to (rounded to float like every label; upstream LightGBM:
+// regression_objective.hpp, RegressionL2loss with sqrt_)
+LGA_HD float sqrt_label(float y) {
+  const double r = sqrt(fabs((double)y));
+  return (float)(y < 0.0f ? -r : r);
+}
+
 // label is the raw label; for binary any label > 0 is positive.
 LGA_HD void grad_hess(const ObjectiveSpec& o, double score, float label, float weight, float* g, float* h) {
   double gg, hh;
   switch (o.kind) {
     case kObjRegression: {
       gg = score - (double)label; hh = 1.0; break;
+    }
+    case kObjRegressionSqrt: {
+      gg = score - (double)sqrt_label(label); hh = 1.0; break;
     }
     case kObjRegressionL1: {
       double d = score - (double)label;
@@ -186,6 +197,7 @@ LGA_HD double transform_score(int32_t obj_kind, double sigmoid, double score) {
     case kObjPoisson:
     case kObjGamma:
     case kObjTweedie: return exp(score);
+    case kObjRegressionSqrt: return score < 0.0 ? -(score * score) : score * score;
     default: return score;
   }
 }

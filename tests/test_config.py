@@ -149,3 +149,28 @@ def test_pred_early_stop_keeps_confident_rows_short():
     # regression ignores it
     br = lgb.train({"objective": "regression", "device_type": "cpu", "verbose": -1}, lgb.Dataset(X, label=X[:, 0]), 10)
     np.testing.assert_array_equal(br.predict(X, pred_early_stop=True), br.predict(X))
+
+
+def test_reg_sqrt_fits_root_labels_and_squares_predictions():
+    """reg_sqrt (upstream: RegressionL2loss with sqrt_): the model is the one plain regression fits to
+    sign(y) sqrt|y|, predictions are squared back, metrics are taken on the original scale, and the model text
+    carries the flag."""
+    rng = np.random.RandomState(9)
+    X = rng.randn(2000, 5)
+    y = (np.exp(X[:, 0]) + 0.1 * rng.rand(2000)) * np.where(X[:, 1] > 1.5, -1.0, 1.0)
+    y = y.astype(np.float32).astype(np.float64)   # labels are held as floats: the root is taken of those
+    base = {"device_type": "cpu", "verbose": -1, "num_leaves": 15, "min_data_in_leaf": 5}
+    res = {}
+    b = lgb.train({**base, "objective": "regression", "reg_sqrt": True, "metric": "l2"}, lgb.Dataset(X, label=y), 30,
+                  valid_sets=[lgb.Dataset(X, label=y)], valid_names=["same"], evals_result=res, verbose_eval=False)
+    yt = (np.sign(y) * np.sqrt(np.abs(y))).astype(np.float32)
+    plain = lgb.train({**base, "objective": "regression"}, lgb.Dataset(X, label=yt), 30)
+    raw = b.predict(X, raw_score=True)
+    np.testing.assert_allclose(raw, plain.predict(X), rtol=1e-12, atol=1e-12)
+    pred = b.predict(X)
+    np.testing.assert_allclose(pred, np.sign(raw) * raw * raw, rtol=1e-12)
+    np.testing.assert_allclose(res["same"]["l2"][-1], np.mean((pred - y) ** 2), rtol=1e-9)
+    assert "objective=regression sqrt" in b.model_to_string()
+    again = lgb.Booster(model_str=b.model_to_string())
+    np.testing.assert_array_equal(again.predict(X), pred)
+    assert np.mean((pred - y) ** 2) < 0.5 * np.var(y)

@@ -286,7 +286,7 @@ def test_whole_tree_kernel_grows_the_cpu_trees(n, F, leaves, extra):
     np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
 
 
-@pytest.mark.parametrize("case", ["diamonds", "huber-nan-extra", "binary-bynode", "poisson-weights"])
+@pytest.mark.parametrize("case", ["diamonds", "huber-nan-extra", "binary-bynode", "reg-sqrt", "poisson-weights"])
 def test_boosting_chunks_on_the_device_equal_the_step_by_step_paths(case):
     """Small boosters run whole chunks of iterations on the device - one workgroup does gradients, bag, tree, leaf values,
     score updates and metric sums, with no host in between.  train() and cv() then give the CPU oracle's trees and,
@@ -309,6 +309,12 @@ def test_boosting_chunks_on_the_device_equal_the_step_by_step_paths(case):
         w = None
         p = {"objective": "binary", "num_leaves": 15, "learning_rate": 0.2, "metric": ["binary_logloss", "binary_error"],
              "feature_fraction_bynode": 0.6, "pos_bagging_fraction": 0.7, "neg_bagging_fraction": 0.9, "bagging_freq": 2}
+    elif case == "reg-sqrt":
+        X, y = make_regression(15000, 8, seed=4)
+        y = np.exp(np.clip(y / 3, -3, 3)) * np.where(X[:, 2] > 1.2, -1.0, 1.0)
+        w = None
+        p = {"objective": "regression", "reg_sqrt": True, "num_leaves": 31, "learning_rate": 0.15, "metric": ["l2", "l1"],
+             "min_data_in_leaf": 10}
     else:
         X, y = make_regression(9000, 5, seed=8)
         y = np.floor(np.exp(np.clip(y / 3, -3, 2)))
@@ -333,8 +339,9 @@ def test_boosting_chunks_on_the_device_equal_the_step_by_step_paths(case):
     for k, v in runs["cpu"][2].items():
         np.testing.assert_allclose(runs["chunks"][2][k], v, rtol=1e-9)
     b = runs["chunks"][0]
-    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X[:n_tr], raw_score=True, device="cpu"), atol=1e-9)
-    np.testing.assert_allclose(b._inner_predict(0, raw=True), b.predict(X[n_tr:], raw_score=True, device="cpu"), atol=1e-9)
+    every = b.num_trees()   # (the scores hold the trees grown after the best iteration too)
+    np.testing.assert_allclose(b._inner_predict(-1, raw=True), b.predict(X[:n_tr], raw_score=True, device="cpu", num_iteration=every), atol=1e-9)
+    np.testing.assert_allclose(b._inner_predict(0, raw=True), b.predict(X[n_tr:], raw_score=True, device="cpu", num_iteration=every), atol=1e-9)
 
 
 def test_grid_rows_are_batched_into_single_launches_with_the_same_table():

@@ -121,6 +121,7 @@ NOTES = {
     "enable_bundle": "accepted for compatibility (no effect: dense storage, no feature bundling)",
     "num_grad_quant_bins": "accepted for compatibility; gradients are quantised to 16 bits, see `quantized_grad`",
     "stochastic_rounding": "accepted for compatibility; rounding is deterministic (seeded per row and iteration)",
+    "reg_sqrt": "`objective=regression`: fit sign(y) sqrt|y| and square the predictions back; metrics on the original scale",
     "pred_early_stop": "prediction (binary / multiclass): stop adding trees for a row once its margin is wide enough",
     "pred_early_stop_freq": "... checked every this many iterations",
     "pred_early_stop_margin": "... against this margin (binary: 2|score|; multiclass: best minus second-best raw score)",
