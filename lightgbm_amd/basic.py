@@ -359,7 +359,8 @@ class Dataset:
         else:
             # host binning: category lookup, zeros that count as missing values, per-feature bin counts
             self._has_categorical = (bool(cat_idx) or str(get_param(params, "zero_as_missing", False)).lower() in ("true", "1")
-                                     or get_param(params, "max_bin_by_feature", None) not in (None, "", []))
+                                     or get_param(params, "max_bin_by_feature", None) not in (None, "", [])
+                                     or get_param(params, "forcedbins_filename", None) not in (None, ""))
             if cat_idx:
                 params["categorical_feature"] = cat_idx
             else:

@@ -2,6 +2,7 @@
 #include "binning_core.hpp"
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <map>
 #include <sstream>
 
@@ -16,8 +17,43 @@ std::vector<double> greedy_find_bounds(const std::vector<double>& distinct, cons
   return out;
 }
 
+namespace {
+// Bounds with the forced ones among them (upstream LightGBM: bin.cpp, FindBinWithPredefinedBin - the same idea, not
+// the same cuts: the forced bounds first, the rest of the budget spread over the intervals by their row counts).
+std::vector<double> bounds_with_forced(const std::vector<double>& distinct, const std::vector<int>& counts, int max_bin,
+                                       int64_t total_cnt, int min_data_in_bin, const std::vector<double>& forced_in) {
+  const double inf = std::numeric_limits<double>::infinity();
+  std::vector<double> forced;
+  for (double b : forced_in)
+    if (b == b && b < inf && b > -inf && (forced.empty() || b > forced.back())) forced.push_back(b);
+  if ((int)forced.size() > max_bin - 1) forced.resize((size_t)std::max(max_bin - 1, 0));
+  std::vector<double> out(forced);
+  int remaining = max_bin - (int)forced.size() - 1;
+  size_t lo = 0;
+  for (size_t k = 0; k <= forced.size() && remaining > 0 && total_cnt > 0; ++k) {
+    // distinct values in (forced[k-1], forced[k]]
+    size_t hi = lo;
+    int64_t cnt = 0;
+    while (hi < distinct.size() && (k == forced.size() || distinct[hi] <= forced[k])) cnt += counts[hi++];
+    const int extra = (int)((double)remaining * (double)cnt / (double)total_cnt);
+    if (extra >= 1 && hi - lo >= 2) {
+      std::vector<double> d(distinct.begin() + (std::ptrdiff_t)lo, distinct.begin() + (std::ptrdiff_t)hi);
+      std::vector<int> c(counts.begin() + (std::ptrdiff_t)lo, counts.begin() + (std::ptrdiff_t)hi);
+      std::vector<double> inner = greedy_find_bounds(d, c, extra + 1, cnt, min_data_in_bin);
+      for (size_t j = 0; j + 1 < inner.size(); ++j)
+        if (k == forced.size() || inner[j] < forced[k]) out.push_back(inner[j]);
+    }
+    lo = hi;
+  }
+  std::sort(out.begin(), out.end());
+  out.erase(std::unique(out.begin(), out.end()), out.end());
+  out.push_back(inf);
+  return out;
+}
+}  // namespace
+
 void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing,
-                          bool zero_as_missing) {
+                          bool zero_as_missing, const std::vector<double>* forced) {
   // strip NaN (and zeros when they count as missing)
   const bool zeros_missing = use_missing && zero_as_missing;
   size_t n_all = values.size();
@@ -36,7 +72,9 @@ void BinMapper::find_bins(std::vector<double>& values, int max_bin, int min_data
   missing = (use_missing && n_nan > 0) ? (zeros_missing ? MissingType::Zero : MissingType::NaN) : MissingType::None;
   int value_bins = max_bin - (missing != MissingType::None ? 1 : 0);
   if (value_bins < 1) value_bins = 1;
-  upper = greedy_find_bounds(distinct, counts, value_bins, (int64_t)values.size(), min_data_in_bin);
+  upper = (forced && !forced->empty())
+              ? bounds_with_forced(distinct, counts, value_bins, (int64_t)values.size(), min_data_in_bin, *forced)
+              : greedy_find_bounds(distinct, counts, value_bins, (int64_t)values.size(), min_data_in_bin);
   int nv = (int)upper.size();
   if (missing != MissingType::None) { missing_bin = nv; num_bin = nv + 1; }
   else { missing_bin = -1; num_bin = nv; }

@@ -28,8 +28,11 @@ struct BinMapper {
   // Build from a sample of one feature.  `values` may contain NaN; it is
   // modified (sorted).  total_sample_cnt is the number of sampled rows.
   // zero_as_missing: zeros (|v| <= 1e-35) share the missing bin with NaN (MissingType::Zero).
+  // forced: upper bounds the feature must have (forcedbins_filename; ascending).  They are taken first - as many as
+  // max_bin leaves room for - and the bins that remain are dealt to the intervals between them in proportion to
+  // the sampled rows each holds, cut the usual greedy way inside an interval.
   void find_bins(std::vector<double>& values, int max_bin, int min_data_in_bin, bool use_missing,
-                 bool zero_as_missing = false);
+                 bool zero_as_missing = false, const std::vector<double>* forced = nullptr);
   // Categorical form: the (max_bin - 1) most frequent categories that occur at least min_data_in_bin times
   // (ties: smaller category first) get a bin each.
   void find_bins_categorical(const std::vector<double>& values, int max_bin, int min_data_in_bin);

@@ -139,6 +139,7 @@ const ParamDef kParams[] = {
     P(enable_bundle, "is_enable_bundle,bundle", Bool, kNone, kNone),
     P(num_grad_quant_bins, "", Int, 2, kNone),
     P(stochastic_rounding, "", Bool, kNone, kNone),
+    P(forcedbins_filename, "", String, kNone, kNone),
     P(reg_sqrt, "", Bool, kNone, kNone),
     P(pred_early_stop, "", Bool, kNone, kNone),
     P(pred_early_stop_freq, "", Int, 1, kNone),

@@ -140,6 +140,7 @@ struct Config {
   int num_grad_quant_bins = 4;
   bool stochastic_rounding = true;
   // prediction (read by Booster.predict from the booster's parameters; the trainers ignore them)
+  std::string forcedbins_filename;   // JSON: [{"feature": 0, "bin_upper_bound": [0.3, 0.4]}, ...] - bounds those features must have
   bool reg_sqrt = false;       // objective=regression: fit sign(y) sqrt|y|, square the predictions back
   bool pred_early_stop = false;
   int pred_early_stop_freq = 10;

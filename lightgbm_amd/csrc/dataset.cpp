@@ -4,6 +4,8 @@
 #include <stdexcept>
 #include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <sstream>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -32,6 +34,64 @@ void Dataset::finish_mappers() {
   }
 }
 
+namespace {
+// forcedbins_filename: a JSON list of {"feature": <column>, "bin_upper_bound": [<ascending numbers>]} objects
+// (upstream LightGBM: examples/regression/forced_bins.json).  Returns one list of bounds per column.
+std::vector<std::vector<double>> load_forced_bins(const std::string& path, int ncol) {
+  std::ifstream in(path);
+  if (!in) throw std::runtime_error("forcedbins_filename: cannot read " + path);
+  std::stringstream buf;
+  buf << in.rdbuf();
+  const std::string t = buf.str();
+  size_t i = 0;
+  auto bad = [&](const char* what) { throw std::runtime_error(std::string("forcedbins_filename: ") + what + " near offset " + std::to_string(i)); };
+  auto ws = [&]() { while (i < t.size() && (t[i] == ' ' || t[i] == '\n' || t[i] == '\t' || t[i] == '\r')) ++i; };
+  auto eat = [&](char c) { ws(); if (i < t.size() && t[i] == c) { ++i; return true; } return false; };
+  auto number = [&]() {
+    ws();
+    char* end = nullptr;
+    const double v = std::strtod(t.c_str() + i, &end);
+    if (end == t.c_str() + i) bad("expected a number");
+    i = (size_t)(end - t.c_str());
+    return v;
+  };
+  std::vector<std::vector<double>> out((size_t)ncol);
+  if (!eat('[')) bad("expected [");
+  if (!eat(']')) {
+    do {
+      if (!eat('{')) bad("expected {");
+      int feature = -1;
+      std::vector<double> bounds;
+      do {
+        ws();
+        if (i >= t.size() || t[i] != '"') bad("expected a quoted key");
+        const size_t e = t.find('"', i + 1);
+        if (e == std::string::npos) bad("unterminated string");
+        const std::string key = t.substr(i + 1, e - i - 1);
+        i = e + 1;
+        if (!eat(':')) bad("expected :");
+        if (key == "feature") feature = (int)number();
+        else if (key == "bin_upper_bound") {
+          if (!eat('[')) bad("expected [");
+          if (!eat(']')) {
+            do bounds.push_back(number()); while (eat(','));
+            if (!eat(']')) bad("expected ]");
+          }
+        } else bad("unknown key (feature, bin_upper_bound)");
+      } while (eat(','));
+      if (!eat('}')) bad("expected }");
+      if (feature < 0 || feature >= ncol) throw std::runtime_error("forcedbins_filename: feature " + std::to_string(feature) + " does not exist");
+      std::sort(bounds.begin(), bounds.end());
+      out[(size_t)feature] = bounds;
+    } while (eat(','));
+    if (!eat(']')) bad("expected ]");
+  }
+  ws();
+  if (i != t.size()) bad("trailing text");
+  return out;
+}
+}  // namespace
+
 std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsample, int ncol, int64_t nrow,
                                               const Config& cfg) {
   auto ds = std::make_shared<Dataset>();
@@ -40,6 +100,8 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
   if (!cfg.max_bin_by_feature.empty() && (int)cfg.max_bin_by_feature.size() != ncol)
     throw std::runtime_error("max_bin_by_feature lists " + std::to_string(cfg.max_bin_by_feature.size()) +
                              " values, the data has " + std::to_string(ncol) + " columns");
+  std::vector<std::vector<double>> forced;
+  if (!cfg.forcedbins_filename.empty()) forced = load_forced_bins(cfg.forcedbins_filename, ncol);
 #pragma omp parallel for schedule(dynamic)
   for (int f = 0; f < ncol; ++f) {
     std::vector<double> col((size_t)nsample);
@@ -47,7 +109,8 @@ std::shared_ptr<Dataset> Dataset::from_sample(const double* sample, int64_t nsam
     const bool cat = std::find(cfg.categorical_feature.begin(), cfg.categorical_feature.end(), f) != cfg.categorical_feature.end();
     const int bins = cfg.max_bin_by_feature.empty() ? cfg.max_bin : cfg.max_bin_by_feature[(size_t)f];
     if (cat) ds->mappers_[f].find_bins_categorical(col, bins, cfg.min_data_in_bin);
-    else ds->mappers_[f].find_bins(col, bins, cfg.min_data_in_bin, cfg.use_missing, cfg.zero_as_missing);
+    else ds->mappers_[f].find_bins(col, bins, cfg.min_data_in_bin, cfg.use_missing, cfg.zero_as_missing,
+                                   forced.empty() ? nullptr : &forced[(size_t)f]);
   }
   ds->finish_mappers();
   return ds;

@@ -174,3 +174,40 @@ def test_reg_sqrt_fits_root_labels_and_squares_predictions():
     again = lgb.Booster(model_str=b.model_to_string())
     np.testing.assert_array_equal(again.predict(X), pred)
     assert np.mean((pred - y) ** 2) < 0.5 * np.var(y)
+
+
+def test_forced_bin_bounds_are_kept(tmp_path):
+    """forcedbins_filename: the listed upper bounds are among the feature's bin bounds (so a split can sit exactly
+    there), the bin budget still holds, other features are binned as before."""
+    import json
+    rng = np.random.RandomState(3)
+    X = rng.rand(4000, 3)
+    y = (X[:, 0] > 0.3333).astype(float) + 0.01 * rng.randn(4000)
+    path = tmp_path / "forced_bins.json"
+    path.write_text(json.dumps([{"feature": 0, "bin_upper_bound": [0.3333, 0.5, 0.9]}, {"feature": 2, "bin_upper_bound": [0.25]}]))
+    p = {"device_type": "cpu", "verbose": -1, "max_bin": 16, "min_data_in_bin": 1, "objective": "regression", "num_leaves": 4,
+         "min_data_in_leaf": 1}
+    plain = lgb.train(p, lgb.Dataset(X, label=y), 1)
+    forced = lgb.train({**p, "forcedbins_filename": str(path)}, lgb.Dataset(X, label=y), 1)
+
+    def thresholds(b, feature):
+        out = set()
+        def walk(n):
+            if "split_feature" in n:
+                if n["split_feature"] == feature:
+                    out.add(n["threshold"])
+                walk(n["left_child"]); walk(n["right_child"])
+        for t in b.dump_model()["tree_info"]:
+            walk(t["tree_structure"])
+        return out
+    assert 0.3333 in thresholds(forced, 0)            # the step sits on a forced bound ...
+    assert 0.3333 not in thresholds(plain, 0)         # ... that quantile binning does not have
+    d = lgb.Dataset(X, label=y, params={**p, "forcedbins_filename": str(path)}).construct()
+    # bin budget: at most max_bin bins per feature (bounds from the model's thresholds over many trees)
+    many = lgb.train({**p, "forcedbins_filename": str(path), "num_leaves": 31, "learning_rate": 0.5}, d, 40)
+    assert len(thresholds(many, 0)) <= 15 and len(thresholds(many, 2)) <= 15
+    assert {0.3333, 0.5, 0.9} & thresholds(many, 0) and len(thresholds(many, 1)) > 0
+    with pytest.raises(Exception, match="forcedbins_filename"):
+        bad = tmp_path / "bad.json"
+        bad.write_text('[{"feature": 7, "bin_upper_bound": [1]}]')
+        lgb.Dataset(X, label=y, params={**p, "forcedbins_filename": str(bad)}).construct()

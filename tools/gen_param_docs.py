@@ -121,6 +121,7 @@ NOTES = {
     "enable_bundle": "accepted for compatibility (no effect: dense storage, no feature bundling)",
     "num_grad_quant_bins": "accepted for compatibility; gradients are quantised to 16 bits, see `quantized_grad`",
     "stochastic_rounding": "accepted for compatibility; rounding is deterministic (seeded per row and iteration)",
+    "forcedbins_filename": "JSON list of `{\"feature\": column, \"bin_upper_bound\": [...]}`: bin bounds those features must have; the remaining bins are spread over the intervals between them by row count",
     "reg_sqrt": "`objective=regression`: fit sign(y) sqrt|y| and square the predictions back; metrics on the original scale",
     "pred_early_stop": "prediction (binary / multiclass): stop adding trees for a row once its margin is wide enough",
     "pred_early_stop_freq": "... checked every this many iterations",
