@@ -280,6 +280,17 @@ __device__ __forceinline__ int find_task_staged(const SplitTask* __restrict__ ta
   return lo;
 }
 
+// A workgroup's task descriptor as a COPY in registers.  Through a reference the compiler may keep a field only
+// until the next store - the descriptor sits in kernel-argument or global memory, which a store through some other
+// pointer could have changed - so every use after a store fetches the field again and waits for it: in the sides
+// kernel that was two dependent memory round trips per 64 rows.
+__device__ __forceinline__ SplitTask load_task(const SplitTask* __restrict__ staged, const InlineTasks& inl, int ti) {
+  SplitTask t;
+  if (staged) t = staged[ti];
+  else t = inl.t[ti];
+  return t;
+}
+
 // Pass 1 of the partition: ballot masks + left counts per 2048-row chunk.  A task that fits ONE
 // chunk is finished right here (ranks from the masks in LDS, scatter, child ranges), so rounds made
 // of small leaves need no second launch.  The workgroups also clear the histogram slots of the round.
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
     return;
   }
   const int ti = tasks ? chunk_task[wg] : find_task<true>(inl, wg);
-  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(tasks, inl, ti);
   const int c = wg - t.first_pchunk;
   const NodeRange p = nodes[t.parent_node];
   const int32_t* src = (p.buf ? a1 : a0) + p.begin;
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
   __shared__ int word_prefix[kWords];
   const int wg = blockIdx.x + chunk0;
   const int ti = tasks ? (chunk_task ? chunk_task[wg] : find_task_staged<true>(tasks, n_staged, wg)) : find_task<true>(inl, wg);
-  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(tasks, inl, ti);
   if (t.num_pchunk == 1) return;   // finished by pass 1
   const int c = wg - t.first_pchunk;
   const NodeRange p = nodes[t.parent_node];
@@ -518,7 +529,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   const int x = blockIdx.x;
   const int tile = tile_first + (int)blockIdx.y * tile_step;
   const int ti = tasks ? chunk_task[x] : find_task<false>(inl, x);
-  const SplitTask& t = tasks ? tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(tasks, inl, ti);
   const int c = x - t.first_hchunk;
   const int node = t.hist_child ? t.right_node : t.left_node;
   const NodeRange r = nodes[node];
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.y;
   const int ti = blockIdx.x >> 1, side = blockIdx.x & 1;
-  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(a.tasks, inl, ti);
   const int s = 2 * a.task0 + blockIdx.x;   // index among the round's scan tasks
   const bool direct = a.root || side == t.hist_child;
   const int node = a.root ? 0 : (side == 0 ? t.left_node : t.right_node);
@@ -762,7 +773,7 @@ __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wg = blockIdx.x;
   const int ti = a.tasks ? find_task_staged<true>(a.tasks, a.n_staged, wg) : find_task<true>(inl, wg);
-  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(a.tasks, inl, ti);
   const int c0 = wg - t.first_pchunk;
   if (c0 >= t.num_pchunk || (c0 % kFlagBlocks) != 0) return;
   const bool timed = a.phase_ticks && (wg & 255) == 0;   // LGA_GROW_TIMING: a sample of the workgroups, see grow_kernel
@@ -841,7 +852,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   __shared__ int32_t hist_rows[kGrowListRows];   // the histogram child's rows of this unit, compacted
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ti = a.tasks ? find_task_staged<false>(a.tasks, a.n_staged, blockIdx.x) : find_task<false>(inl, blockIdx.x);
-  const SplitTask& t = a.tasks ? a.tasks[ti] : inl.t[ti];
+  const SplitTask t = load_task(a.tasks, inl, ti);
   const int ridx = ti;                           // index among the round's tasks
   const int u = blockIdx.x - t.first_hchunk;
   const bool solo = !ROOT && t.num_pchunk == 0;  // the whole leaf is this workgroup's: sides, row movement, histogram
