@@ -200,17 +200,25 @@ def _auto_rows_in_flight(dtrain, rows: Sequence[Dict[str, Any]]) -> int:
     return 4 if dtrain.num_data() <= 500_000 else 1
 
 
-def _own_stream():
-    """Context of one row thread: on the HIP build the thread's boosters live on a stream of their own, so that the
-    rows in flight overlap on the device instead of queueing on the default stream."""
-    import contextlib
+def _callers_device():
+    """The GPU the calling thread works on (None: CPU build or no GPU).  A thread started later does not inherit it:
+    the current device is a per-thread setting that starts at device 0."""
     from . import _lib
     if not _lib.is_hip():
+        return None
+    import torch
+    return torch.cuda.current_device() if torch.cuda.is_available() else None
+
+
+def _own_stream(device):
+    """Context of one row thread: on the HIP build the thread's boosters live on a stream of their own - on
+    ``device``, the GPU of the thread that started the search - so that the rows in flight overlap on the device
+    instead of queueing on the default stream."""
+    import contextlib
+    if device is None:
         return contextlib.nullcontext()
     import torch
-    if not torch.cuda.is_available():
-        return contextlib.nullcontext()
-    return torch.cuda.stream(torch.cuda.Stream())
+    return torch.cuda.stream(torch.cuda.Stream(device=device))   # entering it makes `device` this thread's device
 
 
 def _run_rows(next_row: Callable[[], Optional[int]], run_one: Callable[[int], None], in_flight: int):
@@ -227,8 +235,10 @@ def _run_rows(next_row: Callable[[], Optional[int]], run_one: Callable[[int], No
     failed: List[BaseException] = []
     gate = threading.Lock()
 
+    device = _callers_device()
+
     def drain():
-        with _own_stream():
+        with _own_stream(device):
             _drain()
 
     def _drain():
