@@ -13,7 +13,7 @@ import os as _os
 # call, not at import - so setting it here covers every launcher that imports the package first.
 _os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-from .basic import Booster, Dataset, LightGBMError, default_device, params_to_string, register_logger, resolve_alias
+from .basic import Booster, Dataset, LightGBMError, Sequence, default_device, params_to_string, register_logger, resolve_alias
 from .callback import EarlyStopException, early_stopping, log_evaluation, print_evaluation, record_evaluation, reset_parameter
 from .engine import CVBooster, cv, make_folds, train
 
@@ -35,7 +35,7 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 __all__ = [
-    "Dataset", "Booster", "CVBooster", "LightGBMError", "train", "cv", "make_folds",
+    "Dataset", "Booster", "CVBooster", "LightGBMError", "Sequence", "train", "cv", "make_folds",
     "early_stopping", "log_evaluation", "print_evaluation", "record_evaluation", "reset_parameter",
     "EarlyStopException", "default_device", "params_to_string", "resolve_alias", "register_logger",
 ]

@@ -161,9 +161,39 @@ def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
 
+class Sequence:
+    """Rows served in batches (upstream LightGBM's ``lightgbm.Sequence``): subclass it with ``__len__`` and
+    ``__getitem__`` - an int gives one row, a slice a batch of rows - and pass one object, or a list of them, as the
+    ``data`` of a :class:`Dataset`.  The rows are read ``batch_size`` at a time into one matrix, which is then binned
+    like any other (this build keeps the whole binned matrix in memory anyway: 1 byte per value)."""
+    batch_size = 4096
+
+    def __getitem__(self, idx):
+        raise NotImplementedError("Sequence subclasses implement __getitem__ for ints and slices")
+
+    def __len__(self):
+        raise NotImplementedError("Sequence subclasses implement __len__")
+
+
+def _read_sequences(seqs) -> np.ndarray:
+    parts = []
+    for seq in seqs:
+        n, step = len(seq), max(int(getattr(seq, "batch_size", 4096) or 4096), 1)
+        for lo in range(0, n, step):
+            block = np.asarray(seq[lo:min(lo + step, n)], dtype=np.float64)
+            parts.append(block.reshape(1, -1) if block.ndim == 1 else block)
+    if not parts:
+        raise ValueError("empty Sequence")
+    return np.ascontiguousarray(np.vstack(parts))
+
+
 def _to_matrix(data) -> Tuple[Any, List[str] | None]:
     """Returns (2-D float32/float64 C- or F-contiguous ndarray | cuda tensor, column names or None)."""
     names = None
+    if isinstance(data, Sequence):
+        data = _read_sequences([data])
+    elif isinstance(data, (list, tuple)) and data and all(isinstance(d, Sequence) for d in data):
+        data = _read_sequences(data)
     if _is_torch(data):
         import torch
         if data.dim() != 2:

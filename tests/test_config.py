@@ -211,3 +211,27 @@ def test_forced_bin_bounds_are_kept(tmp_path):
         bad = tmp_path / "bad.json"
         bad.write_text('[{"feature": 7, "bin_upper_bound": [1]}]')
         lgb.Dataset(X, label=y, params={**p, "forcedbins_filename": str(bad)}).construct()
+
+
+def test_dataset_from_sequences_equals_the_matrix():
+    """lgb.Sequence objects (rows served in batches) - one, or a list that is stacked - give the dataset the matrix gives."""
+    class Rows(lgb.Sequence):
+        def __init__(self, m, batch_size):
+            self.m, self.batch_size, self.reads = m, batch_size, 0
+
+        def __len__(self):
+            return len(self.m)
+
+        def __getitem__(self, idx):
+            self.reads += 1
+            return self.m[idx]
+
+    rng = np.random.RandomState(2)
+    X = rng.randn(3000, 4)
+    y = X[:, 0] - X[:, 2] + 0.1 * rng.randn(3000)
+    p = {"device_type": "cpu", "verbose": -1, "num_leaves": 15}
+    want = lgb.train(p, lgb.Dataset(X, label=y), 10).model_to_string()
+    one = Rows(X, 700)
+    assert lgb.train(p, lgb.Dataset(one, label=y), 10).model_to_string() == want and one.reads == 5
+    parts = [Rows(X[:1000], 256), Rows(X[1000:], 4096)]
+    assert lgb.train(p, lgb.Dataset(parts, label=y), 10).model_to_string() == want
