@@ -1,7 +1,7 @@
 """Randomised CPU-oracle vs HIP-engine parity sweep.
 
 Every seed draws a dataset shape (crossing the engine's size gates: row lines at 2^18 rows, two rounds
-in flight at 2^19, tree-walk score update at 2^20; bags up to 2^16 rows take the whole-tree kernel and are
+in flight (when asked for) at 2^19, tree-walk score update at 2^20; bags up to 2^16 rows take the whole-tree kernel and are
 also trained with it switched off), a feature count (one or two 32-feature tiles),
 missing values, weights and a parameter set, trains a few iterations on both engines and compares the
 model text.  Regression objectives only: their gradients involve no transcendental function, so the
