@@ -878,7 +878,7 @@ def test_gpu_feature_parallel_equals_serial():
         assert trees_of(s) == trees_of(serial)
 
 
-def test_rccl_single_rank_communicator(tmp_path):
+def test_rccl_single_rank_communicator(tmp_path, monkeypatch):
     # RCCL itself needs one GPU per rank; with one GPU we can still bring a 1-rank communicator up and train through it
     import os, socket
     import torch.distributed as dist
@@ -892,6 +892,18 @@ def test_rccl_single_rank_communicator(tmp_path):
         a = lgb.train({**GPU, "tree_learner": "data"}, lgb.Dataset(X, label=y, params=GPU), 3, comm=comm)
         b = lgb.train(GPU, lgb.Dataset(X, label=y, params=GPU), 3)
         assert trees_of(a) == trees_of(b)
+        # a communicator of one rank normally means the serial learner; LGA_DP_KEEP_SINGLE_RANK keeps the distributed
+        # one, so the collectives (RCCL, one rank), the search hand-over behind them and the collective stream of two
+        # rounds in flight all run - with both exchanges, on data large enough for the row-line kernels
+        X, y = make_regression(300000, 28, seed=11)
+        p = {**GPU, "num_leaves": 63, "min_data_in_leaf": 5}
+        want = trees_of(lgb.train(p, lgb.Dataset(X, label=y, params=GPU), 4))
+        monkeypatch.setenv("LGA_DP_KEEP_SINGLE_RANK", "1")
+        for exchange, flight in (("allreduce", "1"), ("reduce_scatter", "1"), ("allreduce", "2"), ("reduce_scatter", "2")):
+            monkeypatch.setenv("LGA_DP_EXCHANGE", exchange)
+            monkeypatch.setenv("LGA_ROUNDS_IN_FLIGHT", flight)
+            got = lgb.train({**p, "tree_learner": "data"}, lgb.Dataset(X, label=y, params=GPU), 4, comm=comm)
+            assert trees_of(got) == want, (exchange, flight)
         comm.close()
     finally:
         dist.destroy_process_group()
