@@ -1,4 +1,4 @@
-"""Crosses objectives (regression, binary, multiclass, the two ranking objectives, L1, poisson) with boosting / sampling
+"""Crosses objectives (regression - plain and reg_sqrt -, binary, multiclass, the two ranking objectives, L1, poisson) with boosting / sampling
 variants and the tree-shape options (category sets, monotone and interaction constraints, path smoothing, ...)
 on one small dataset with categorical columns, zeros and NaNs: every combination has to train, predict finite
 values, keep its training scores equal to the predictor's and survive the model file.
@@ -25,7 +25,8 @@ ym = np.clip(np.round(rel + 1), 0, 2)
 base = {"device_type": sys.argv[1] if len(sys.argv) > 1 else "cpu", "verbose": -1, "num_leaves": 15, "min_data_in_leaf": 5}
 cases = []
 for obj, y, extra in (("lambdarank", yr, {}), ("rank_xendcg", yr, {}), ("regression", rel, {}), ("binary", yc, {}),
-                      ("multiclass", ym, {"num_class": 3}), ("regression_l1", rel, {}), ("poisson", np.abs(rel), {})):
+                      ("multiclass", ym, {"num_class": 3}), ("regression_l1", rel, {}), ("poisson", np.abs(rel), {}),
+                      ("regression", rel * np.abs(rel), {"reg_sqrt": True})):
     for mod in ({}, {"data_sample_strategy": "goss", "learning_rate": 0.5}, {"boosting": "dart"},
                 {"boosting": "rf", "bagging_fraction": 0.6, "bagging_freq": 1}, {"bagging_fraction": 0.5, "bagging_freq": 2, "feature_fraction": 0.6},
                 {"path_smooth": 5.0, "monotone_constraints": [1, 0, 0, 0, 0, 0]}, {"interaction_constraints": [[0, 1, 4], [2, 3, 5]], "extra_trees": True},
