@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 import lightgbm_amd as lgb
 shapes = [("MS-LTR-shaped", 2_270_000, 137), ("Yahoo-LTR-shaped", 473_000, 700), ("Bosch-shaped", 1_000_000, 968)]
+if len(sys.argv) > 1:   # one shape only (for a profiler run): wide_shapes.py Bosch
+    shapes = [s for s in shapes if s[0].startswith(sys.argv[1])]
 for name, n, f in shapes:
     g = torch.Generator(device="cuda").manual_seed(1)
     X = torch.randn(n, f, device="cuda", generator=g)
