@@ -1085,3 +1085,20 @@ def test_grid_search_with_worker_processes_on_the_gpu(tmp_path):
     assert again["score"].tolist() == spread["score"].tolist()
     workers_used = {__import__("json").loads(ln)["worker"] for ln in open(ck)}
     assert workers_used <= {"0"} and len(open(ck).readlines()) == len(grid)
+
+
+def test_forced_bins_and_reg_sqrt_on_the_device_engine(tmp_path):
+    """forcedbins_filename sends the boundary search to the host finder (the bins are uploaded afterwards) and
+    reg_sqrt is an objective kind of the shared header: the device engine grows the CPU engine's trees with both."""
+    import json
+    X, y = make_regression(30000, 6, seed=21)
+    y = np.exp(np.clip(y / 3, -3, 3))
+    path = tmp_path / "fb.json"
+    path.write_text(json.dumps([{"feature": 1, "bin_upper_bound": [-0.5, 0.0, 0.5]}, {"feature": 4, "bin_upper_bound": [1.25]}]))
+    p = {"objective": "regression", "reg_sqrt": True, "forcedbins_filename": str(path), "max_bin": 31, "num_leaves": 31,
+         "min_data_in_leaf": 5, "metric": "l2"}
+    a = lgb.train({**CPU, **p}, lgb.Dataset(X, label=y, params={**CPU, **p}), 8)
+    b = lgb.train({**GPU, **p}, lgb.Dataset(X, label=y, params={**GPU, **p}), 8)
+    assert trees_of(a) == trees_of(b)
+    assert "objective=regression sqrt" in b.model_to_string()
+    np.testing.assert_allclose(b.predict(X, device="gpu"), a.predict(X), rtol=1e-9, atol=1e-12)
