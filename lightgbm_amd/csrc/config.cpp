@@ -468,6 +468,10 @@ void Config::check() {
   if (d == "cpu") device_type = "cpu";
   else if (d == "gpu" || d == "hip" || d == "cuda" || d == "rocm") device_type = "gpu";
   else throw std::runtime_error("unknown device_type \"" + device_type + "\"");
+  // gpu_use_dp is upstream's switch for full-precision histograms on the device: here that is the 36-bit fixed-point
+  // form, unless the caller settled the histogram precision explicitly
+  if (gpu_use_dp && std::find(explicit_keys.begin(), explicit_keys.end(), "use_quantized_grad") == explicit_keys.end())
+    use_quantized_grad = false;
   if (boosting == "rf") {
     bool row_sub = bagging_freq > 0 && (bagging_fraction < 1.0 || pos_bagging_fraction < 1.0 || neg_bagging_fraction < 1.0);
     bool col_sub = feature_fraction < 1.0 || feature_fraction_bynode < 1.0;

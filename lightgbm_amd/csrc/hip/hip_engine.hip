@@ -264,7 +264,10 @@ class HipBackend : public TreeBackend {
     tree_kernel_rows_ = std::min<int64_t>(k::kTreeMaxRows, cfg.whole_tree_max_rows);
     if (const char* e = std::getenv("LGA_TREE_KERNEL_ROWS"))
       tree_kernel_rows_ = std::max<int64_t>(0, std::min<int64_t>(k::kTreeMaxRows, std::atoll(e)));
-    tree_kernel_on_ = tree_kernel_rows_ > 0;
+    // full-precision histograms (use_quantized_grad=false): the growth rounds carry them; the one-workgroup builds
+    // keep packed 16-bit records and stay out of it
+    wide_ = !cfg.use_quantized_grad;
+    tree_kernel_on_ = tree_kernel_rows_ > 0 && !wide_;
     // an explicit whole_tree_max_rows asks for the one-workgroup builds also for a booster that trains alone
     tree_kernel_forced_ = tree_kernel_on_ && std::find(cfg.explicit_keys.begin(), cfg.explicit_keys.end(), "whole_tree_max_rows") != cfg.explicit_keys.end();
     tree_renew_ = cfg.quant_train_renew_leaf ? 1 : 0;
@@ -566,6 +569,9 @@ class HipBackend : public TreeBackend {
   int64_t whole_trees_grown() const { return whole_trees_; }
   bool tree_timing() const { return tree_timing_; }
   bool renews_leaves() const { return tree_renew_ != 0; }
+  bool wide() const { return wide_; }
+  // bits between the histograms' scale (quant_scale) and the 36-bit scale of the leaf-value sums
+  int renew_extra_bits() const { return wide_ ? 0 : kWideExtraBits; }
   int num_features() const { return F_; }
   void set_quant_scale(QuantScale q) { qs_host_ = q; }
   // For descriptors filled outside begin_tree (boosting chunks): the tree's parameters and feature table.
@@ -781,6 +787,8 @@ class HipBackend : public TreeBackend {
     a.mask = x.mask.get(); a.chunk_left = x.chunk_left.get(); a.task_left = x.task_left.get();
     a.cat_sets = cat_sets_dev_.get();
     if (root) a.quant = root_quant_;
+    a.wide = wide_ ? 1 : 0;
+    a.qs = qs_dev_.get();
     a.phase_ticks = (!root && grow_timing_) ? grow_ticks() : nullptr;
     if (np > 0) {
       k::grow_flags(inl, a, np, st_);
@@ -869,7 +877,7 @@ class HipBackend : public TreeBackend {
         else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
       }
       k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_, packed_, lay_, round, F_,
-                   tile_first, tile_step, tile_count, st_);
+                   tile_first, tile_step, tile_count, wide_ ? qs_dev_.get() : nullptr, st_);
     }
     if (distributed()) { finish_distributed(x, tasks, root, round, dt, inl); return; }
     prof.mark(PhaseProfile::kComm, st_);
@@ -1172,6 +1180,7 @@ class HipBackend : public TreeBackend {
   unsigned tree_seq_ = 0;
   bool tree_prepared_ = false, tree_launched_ = false, tree_wide_valid_ = false;
   int tree_renew_ = 0;
+  bool wide_ = false;                 // full-precision (36-bit) histograms
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
   // LGA_GROW_TIMING=1: phase profile of the non-root growth kernels, printed when the backend goes away
@@ -1254,10 +1263,6 @@ class HipEngine : public Engine {
   HipEngine(std::shared_ptr<Dataset> train, const Config& cfg, Comm* comm, ParallelMode mode)
       : train_(train), cfg_(cfg), comm_(comm), grower_(cfg, train.get()) {
     if (train_->root_label().empty()) throw std::runtime_error("training data has no label");
-    if (!cfg.use_quantized_grad)
-      throw std::runtime_error("use_quantized_grad=false (36-bit gradient histograms) is served by the CPU engine: the device's "
-                               "histograms are packed 16-bit fixed point; set device_type=cpu, or keep the default - leaf "
-                               "values are renewed from 36-bit sums either way (quant_train_renew_leaf)");
     if (comm_ && comm_->host_only()) {
       staging_.reset(new StagingComm(comm_));
       comm_ = comm = staging_.get();
@@ -1579,7 +1584,7 @@ class HipEngine : public Engine {
       backend_->set_root_quant(gr(), he(), maxbits_.get());
     } else {
       k::quantize(gr(), he(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
-                  backend_->qs_device(), packed_.get(), stream_);
+                  backend_->qs_device(), packed_.get(), backend_->wide(), stream_);
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
     tree_begun_ = true;
@@ -1964,21 +1969,21 @@ class HipEngine : public Engine {
       leaf_of_row_.resize((size_t)N_);
       walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(),
                               mir_->tiles == 1 ? mir_->bins_rt.get() : nullptr, N_, base_or_null(), n_base_, gr(), he(),
-                              backend_->qs_device(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
+                              backend_->qs_device(), backend_->renew_extra_bits(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
       leaf_ids_valid_ = walked;
       leaf_ids_leaves_ = L;
     }
     if (!walked) {
       const int n_spans = upload_spans(nullptr);
       k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
-                   backend_->qs_device(), leaf_acc_.get(), stream_);
+                   backend_->qs_device(), backend_->renew_extra_bits(), leaf_acc_.get(), stream_);
     }
     sums->assign((size_t)2 * (size_t)L, 0);
     LGA_HIP_CHECK(hipMemcpyAsync(sums->data(), leaf_acc_.get(), sizeof(int64_t) * 2 * (size_t)L, hipMemcpyDeviceToHost, stream_));
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
     const QuantScale qs = backend_->quant_scale();
-    *kg = qs.kg + kWideExtraBits;
-    *kh = qs.kh + kWideExtraBits;
+    *kg = qs.kg + backend_->renew_extra_bits();
+    *kh = qs.kh + backend_->renew_extra_bits();
   }
 
   // raw device pointers (used by the bindings for zero-copy access)

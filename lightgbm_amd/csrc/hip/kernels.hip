@@ -223,16 +223,28 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
   }
 }
 
+// Full-precision histograms (WIDE): a row's 8-byte gradient word holds the float bit patterns themselves (gradient
+// high, hessian low); every histogram pass turns them into 36-bit fixed point on the way (quantize_wide at the
+// iteration's exponents + kWideExtraBits - the scale the kernel publishes), as the CPU engine's full-precision mode does.
+__device__ __forceinline__ unsigned long long float_pair_bits(float g, float h) {
+  return ((unsigned long long)__float_as_uint(g) << 32) | (unsigned long long)__float_as_uint(h);
+}
+__device__ __forceinline__ void wide_of(unsigned long long pk, int wkg, int wkh, long long& qg, long long& qh) {
+  qg = quantize_wide(__uint_as_float((unsigned)(pk >> 32)), wkg);
+  qh = quantize_wide(__uint_as_float((unsigned)(pk & 0xffffffffull)), wkh);
+}
+
+template <bool WIDE>
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ g, const float* __restrict__ h,
                                                        const int32_t* __restrict__ rows, int64_t n,
                                                        const uint32_t* __restrict__ maxbits, QuantScale* qs,
                                                        int64_t* __restrict__ packed) {
   const int kg = quant_exponent(__uint_as_float(maxbits[0]));
   const int kh = quant_exponent(__uint_as_float(maxbits[1]));
-  if (blockIdx.x == 0 && threadIdx.x == 0) { qs->kg = kg; qs->kh = kh; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { qs->kg = kg + (WIDE ? kWideExtraBits : 0); qs->kh = kh + (WIDE ? kWideExtraBits : 0); }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = rows ? rows[i] : i;
-    packed[r] = pack_gh(lga::quantize(g[r], kg), lga::quantize(h[r], kh));
+    packed[r] = WIDE ? (int64_t)float_pair_bits(g[r], h[r]) : pack_gh(lga::quantize(g[r], kg), lga::quantize(h[r], kh));
   }
 }
 
@@ -481,7 +493,9 @@ __device__ __forceinline__ int64_t* slot_header(const PoolLayout& L, const SlotR
 // `stagger` (any number that differs between the workgroups of a slot, e.g. the unit index) shifts where a workgroup
 // starts: the units of one leaf finish at about the same time, and without it all of them would add to the same
 // few cache lines at any moment.
-template <bool ROTATED>
+// WIDE: the LDS histogram is two planes of 64-bit cells, gradients at [0, kWidePlane), hessians behind them.
+constexpr int kWidePlane = kTileFeatures * kMaxBins;
+template <bool ROTATED, bool WIDE = false>
 __device__ __forceinline__ void flush_lds_hist(const unsigned long long* lds, int nf, int f0, const PoolLayout& L,
                                                const SlotRef& s, int nthreads, unsigned stagger = 0) {
   const int cells = nf * kMaxBins;
@@ -490,11 +504,21 @@ __device__ __forceinline__ void flush_lds_hist(const unsigned long long* lds, in
     int e = e0 + shift;
     if (e >= cells) e -= cells;
     const int fe = e >> 8, b = e & 255;
-    const unsigned long long v = ROTATED ? lds[(fe << 8) + ((b + 8 * fe) & 255)] : lds[e];
-    if (v != 0ull) {
-      unsigned long long* blk = reinterpret_cast<unsigned long long*>(feat_block(L, s, f0 + fe));
-      atomicAdd(&blk[b], (unsigned long long)(long long)(int32_t)(v >> 32));
-      atomicAdd(&blk[kMaxBins + b], v & 0xffffffffull);
+    const int cell = ROTATED ? (fe << 8) + ((b + 8 * fe) & 255) : e;
+    if (WIDE) {
+      const unsigned long long vg = lds[cell], vh = lds[kWidePlane + cell];
+      if ((vg | vh) != 0ull) {
+        unsigned long long* blk = reinterpret_cast<unsigned long long*>(feat_block(L, s, f0 + fe));
+        if (vg != 0ull) atomicAdd(&blk[b], vg);
+        if (vh != 0ull) atomicAdd(&blk[kMaxBins + b], vh);
+      }
+    } else {
+      const unsigned long long v = lds[cell];
+      if (v != 0ull) {
+        unsigned long long* blk = reinterpret_cast<unsigned long long*>(feat_block(L, s, f0 + fe));
+        atomicAdd(&blk[b], (unsigned long long)(long long)(int32_t)(v >> 32));
+        atomicAdd(&blk[kMaxBins + b], v & 0xffffffffull);
+      }
     }
   }
 }
@@ -519,13 +543,15 @@ struct QuantSource {
   QuantScale* qs_out;
 };
 
-__global__ __launch_bounds__(kHistThreads) void hist_kernel(
+template <bool WIDE>
+__global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl, int rows_per_chunk,
     const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, PoolLayout L, RoundSlots round,
-    int F, int tile_first, int tile_step) {
-  __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
-  __shared__ long long red[2][kHistThreads / kWave];
+    int F, int tile_first, int tile_step, const QuantScale* __restrict__ qs) {
+  constexpr int kThreads = WIDE ? kHistThreadsWide : kHistThreads;
+  __shared__ unsigned long long lds[(WIDE ? 2 : 1) * kTileFeatures * kMaxBins];   // 64 KiB (WIDE: 128 KiB, one workgroup of 16 waves per CU)
+  __shared__ long long red[2][kThreads / kWave];
   const int x = blockIdx.x;
   const int tile = tile_first + (int)blockIdx.y * tile_step;
   const int ti = tasks ? chunk_task[x] : find_task<false>(inl, x);
@@ -539,7 +565,12 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   if (lo >= r.count) return;   // the child turned out smaller than the grid was sized for
   const int hi = min(lo + rows_per_chunk, r.count);
   const int nf = min(kTileFeatures, F - tile * kTileFeatures);
-  for (int i = threadIdx.x; i < nf * kMaxBins; i += kHistThreads) lds[i] = 0ull;
+  for (int i = threadIdx.x; i < nf * kMaxBins; i += kThreads) {
+    lds[i] = 0ull;
+    if (WIDE) lds[kWidePlane + i] = 0ull;
+  }
+  int wkg = 0, wkh = 0;
+  if (WIDE) { wkg = qs->kg; wkh = qs->kh; }
   __syncthreads();
   const int32_t* rows = (r.buf ? a1 : a0) + r.begin;
   const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
@@ -547,13 +578,13 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
   // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
   // SIMD keep ~U x 3 memory requests per lane in flight.
   constexpr int U = 4;
-  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kHistThreads * U) {
+  for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kThreads * U) {
     int row[U];
     unsigned long long p[U];
     uint4 ra[U], rb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = i0 + u * kHistThreads;
+      const int i = i0 + u * kThreads;
       row[u] = i < hi ? rows[i] : -1;
       if (i < hi && !LGA_DEV_CHECK((unsigned)row[u] < (unsigned long long)N, kCheckHistRow, row[u], N)) row[u] = -1;
     }
@@ -568,21 +599,33 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] >= 0) {
-        sg += (long long)(int32_t)(p[u] >> 32);
-        sh += (long long)(p[u] & 0xffffffffull);
+        long long qg = 0, qh = 0;
+        if (WIDE) {
+          wide_of(p[u], wkg, wkh, qg, qh);
+          sg += qg;
+          sh += qh;
+        } else {
+          sg += (long long)(int32_t)(p[u] >> 32);
+          sh += (long long)(p[u] & 0xffffffffull);
+        }
         const unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
 #pragma unroll
         for (int k = 0; k < kTileFeatures; ++k) {
           if (k < nf) {
             unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-            atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+            if (WIDE) {
+              atomicAdd(&lds[k * kMaxBins + bin], (unsigned long long)qg);
+              atomicAdd(&lds[kWidePlane + k * kMaxBins + bin], (unsigned long long)qh);
+            } else {
+              atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+            }
           }
         }
       }
     }
   }
   __syncthreads();
-  flush_lds_hist<false>(lds, nf, tile * kTileFeatures, L, slot, kHistThreads);
+  flush_lds_hist<false, WIDE>(lds, nf, tile * kTileFeatures, L, slot, kThreads);
   if (blockIdx.y == 0) {
     // header: rows, sum g, sum h of this child (the first tile's workgroups see every row once)
     sg = wave_sum_i64(sg);
@@ -593,7 +636,7 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(
     if (threadIdx.x == 0) {
       long long tg = 0, th = 0;
 #pragma unroll
-      for (int w = 0; w < kHistThreads / kWave; ++w) { tg += red[0][w]; th += red[1][w]; }
+      for (int w = 0; w < kThreads / kWave; ++w) { tg += red[0][w]; th += red[1][w]; }
       add_slot_header(L, slot, hi - lo, tg, th);
     }
   }
@@ -838,12 +881,16 @@ __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks in
   if (timed && tid == 0) atomicAdd(&a.phase_ticks[12], 1ull);
 }
 
-template <bool ROOT, bool QUANT>
-__global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
-  constexpr int kWaves = kGrowThreads / kWave;
+// WIDE (full-precision histograms): the rows' gradient words are float bit patterns, converted to 36-bit fixed point in
+// every pass and added as TWO 64-bit LDS atomics per (row, feature) into separate gradient and hessian planes - 128 KiB
+// of LDS, so a CU holds one workgroup, which therefore has 16 waves instead of 8.  No cell can overflow.
+template <bool ROOT, bool QUANT, bool WIDE>
+__global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
+  constexpr int kThreads = WIDE ? kGrowThreadsWide : kGrowThreads;
+  constexpr int kWaves = kThreads / kWave;
   constexpr int kMaskWords = kSoloMaxRows / kWave;
-  constexpr int U1 = kSoloMaxRows / kGrowThreads;   // rows per lane of a (non-root) unit: all of them in one trip
-  __shared__ unsigned long long lds[kTileFeatures * kMaxBins];   // 64 KiB
+  constexpr int U1 = kSoloMaxRows / kThreads;   // rows per lane of a (non-root) unit: all of them in one trip
+  __shared__ unsigned long long lds[(WIDE ? 2 : 1) * kTileFeatures * kMaxBins];   // 64 KiB (WIDE: 128 KiB)
   __shared__ unsigned long long smask[kMaskWords];
   __shared__ int word_prefix[kMaskWords + 1];
   __shared__ int wave_tot[kWaves];
@@ -877,12 +924,21 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
       t_prev = now;
     }
   };
-  for (int i = tid; i < nf * kMaxBins; i += kGrowThreads) lds[i] = 0ull;
-  int kg = 0, kh = 0;
+  auto clear_lds = [&]() {
+    for (int i = tid; i < nf * kMaxBins; i += kThreads) {
+      lds[i] = 0ull;
+      if (WIDE) lds[kWidePlane + i] = 0ull;
+    }
+  };
+  clear_lds();
+  int kg = 0, kh = 0;   // WIDE: the exponents of the 36-bit form
   if (QUANT) {
-    kg = quant_exponent(__uint_as_float(a.quant.maxbits[0]));
-    kh = quant_exponent(__uint_as_float(a.quant.maxbits[1]));
+    kg = quant_exponent(__uint_as_float(a.quant.maxbits[0])) + (WIDE ? kWideExtraBits : 0);
+    kh = quant_exponent(__uint_as_float(a.quant.maxbits[1])) + (WIDE ? kWideExtraBits : 0);
     if (blockIdx.x == 0 && tid == 0) { a.quant.qs_out->kg = kg; a.quant.qs_out->kh = kh; }
+  } else if (WIDE) {
+    kg = a.qs->kg;
+    kh = a.qs->kh;
   }
   const bool hist_left = t.hist_child == 0;
   const uint4* lines = reinterpret_cast<const uint4*>(a.lines);
@@ -901,7 +957,8 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
         ra[k] = Lp[slot * 2];
         rb[k] = Lp[slot * 2 + 1];
         if (QUANT) {
-          pk[k] = (unsigned long long)pack_gh(lga::quantize(a.quant.g[row[k]], kg), lga::quantize(a.quant.h[row[k]], kh));
+          pk[k] = WIDE ? float_pair_bits(a.quant.g[row[k]], a.quant.h[row[k]])
+                       : (unsigned long long)pack_gh(lga::quantize(a.quant.g[row[k]], kg), lga::quantize(a.quant.h[row[k]], kh));
           reinterpret_cast<unsigned long long*>(const_cast<uint4*>(Lp))[12 + slot] = pk[k];
         } else {
           pk[k] = reinterpret_cast<const unsigned long long*>(Lp)[12 + slot];
@@ -913,8 +970,15 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     for (int k = 0; k < 4; ++k) {
       if (row[k] >= 0) {
         const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
-        sg += (long long)(int32_t)(pk[k] >> 32);
-        sh += (long long)(pk[k] & 0xffffffffull);
+        long long qg = 0, qh = 0;
+        if (WIDE) {
+          wide_of(pk[k], kg, kh, qg, qh);
+          sg += qg;
+          sh += qh;
+        } else {
+          sg += (long long)(int32_t)(pk[k] >> 32);
+          sh += (long long)(pk[k] & 0xffffffffull);
+        }
         // byte j of the record holds feature (j + row) mod 32: the lanes of a wave work on different
         // features at any moment, so a feature with three distinct values does not make 64 lanes queue on
         // three LDS words; the (bin + 8 f) rotation keeps equal bins of different features in different banks
@@ -924,7 +988,13 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
           const unsigned f = (j + rot) & 31u;
           if (f < (unsigned)nf) {
             const unsigned bn = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
-            atomicAdd(&lds[f * kMaxBins + ((bn + 8u * f) & 255u)], pk[k]);
+            const unsigned cell = f * kMaxBins + ((bn + 8u * f) & 255u);
+            if (WIDE) {
+              atomicAdd(&lds[cell], (unsigned long long)qg);
+              atomicAdd(&lds[kWidePlane + cell], (unsigned long long)qh);
+            } else {
+              atomicAdd(&lds[cell], pk[k]);
+            }
           }
         }
       }
@@ -955,18 +1025,18 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     for (int unit = u; unit == u || unit * a.unit_rows < p.count; unit += stride) {
       const int ulo = unit * a.unit_rows, uhi = min(ulo + a.unit_rows, p.count);
       if (unit != u) {
-        for (int i = tid; i < nf * kMaxBins; i += kGrowThreads) lds[i] = 0ull;
+        clear_lds();
         sg = 0; sh = 0;
       }
       __syncthreads();
       stamp(0);
       // (fetching trip i + 1 while trip i goes into the histogram was measured slower: 128 VGPRs with spills,
       // root pass 244 -> 260 us - the other waves of the CU already fill the gaps)
-      for (int sub = ulo; sub < uhi; sub += kSubRows) {
+      for (int sub = ulo; sub < uhi; sub += 4 * kThreads) {
         int row[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int pos = sub + k * kGrowThreads + tid;
+          const int pos = sub + k * kThreads + tid;
           row[k] = pos < uhi ? src[pos] : -1;
         }
         add_rows(row);
@@ -976,7 +1046,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
       stamp(3);
       reduce_sums(max(uhi - ulo, 0));
       stamp(4);
-      flush_lds_hist<true>(lds, nf, 0, L, fresh, kGrowThreads, (unsigned)unit);
+      flush_lds_hist<true, WIDE>(lds, nf, 0, L, fresh, kThreads, (unsigned)unit);
       if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
       __syncthreads();
       stamp(5);
@@ -992,7 +1062,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     int row[U1];
 #pragma unroll
     for (int k = 0; k < U1; ++k) {
-      const int pos = lo + k * kGrowThreads + tid;
+      const int pos = lo + k * kThreads + tid;
       row[k] = pos < hi ? src[pos] : -1;
       if (pos < hi && !LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N)) row[k] = -1;
     }
@@ -1003,7 +1073,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
 #pragma unroll
     for (int k = 0; k < U1; ++k) {
       mine[k] = 0ull;
-      if (lo + k * kGrowThreads < hi) {   // uniform: the whole stripe of 512 positions is outside otherwise
+      if (lo + k * kThreads < hi) {   // uniform: the whole stripe of kThreads positions is outside otherwise
         const bool left = row[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
         mine[k] = __ballot(left);
         if (lane == 0) smask[k * kWaves + wave] = mine[k];
@@ -1044,7 +1114,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     for (int w0 = 0; w0 < n_hist; w0 += kGrowListRows) {
 #pragma unroll
       for (int k = 0; k < U1; ++k) {
-        const int q = k * kGrowThreads + tid;   // position inside the unit
+        const int q = k * kThreads + tid;   // position inside the unit
         if (lo + q < hi) {
           const bool left = (mine[k] >> lane) & 1ull;
           if (left == hist_left) {
@@ -1056,11 +1126,11 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
       }
       __syncthreads();
       const int n_list = min(kGrowListRows, n_hist - w0);
-      for (int i0 = 0; i0 < n_list; i0 += 4 * kGrowThreads) {
+      for (int i0 = 0; i0 < n_list; i0 += 4 * kThreads) {
         int r4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int i = i0 + k * kGrowThreads + tid;
+          const int i = i0 + k * kThreads + tid;
           r4[k] = i < n_list ? hist_rows[i] : -1;
         }
         add_rows(r4);
@@ -1073,7 +1143,7 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
     {
       // the leaf fits this workgroup: move its rows right away - lefts to the front, rights behind, in order
       int32_t* dst = (p.buf ? a.a0_dst : a.a1_dst) + p.begin;
-      for (int pos = tid; pos < p.count; pos += kGrowThreads) {
+      for (int pos = tid; pos < p.count; pos += kThreads) {
         const int w = pos >> 6, l = pos & 63;
         const unsigned long long m = smask[w];
         const bool left = (m >> l) & 1ull;
@@ -1091,12 +1161,18 @@ __global__ __launch_bounds__(kGrowThreads, 4) void grow_kernel(InlineTasks inl, 
   stamp(3);
   reduce_sums(hist_left ? lefts : (hi - lo) - lefts);
   // the whole leaf was this workgroup's: the histogram goes to the slot as it is (no atomics, no zeroing)
-  for (int e = tid; e < nf * kMaxBins; e += kGrowThreads) {
+  for (int e = tid; e < nf * kMaxBins; e += kThreads) {
     const int fe = e >> 8, b = e & 255;
-    const unsigned long long v = lds[(fe << 8) + ((b + 8 * fe) & 255)];
+    const int cell = (fe << 8) + ((b + 8 * fe) & 255);
     int64_t* blk = feat_block(L, fresh, fe);
-    blk[b] = (int64_t)(int32_t)(v >> 32);
-    blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
+    if (WIDE) {
+      blk[b] = (int64_t)lds[cell];
+      blk[kMaxBins + b] = (int64_t)lds[kWidePlane + cell];
+    } else {
+      const unsigned long long v = lds[cell];
+      blk[b] = (int64_t)(int32_t)(v >> 32);
+      blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
+    }
   }
   if (tid == 0)
     for (int r = 0; r < L.ranks; ++r) {
@@ -1141,14 +1217,14 @@ constexpr int kLeafSumChunk = 4096;
 __global__ __launch_bounds__(256) void leaf_sums_kernel(const LeafSpan* __restrict__ spans, int n_spans,
                                                         const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
                                                         int64_t n_rows, const float* __restrict__ g,
-                                                        const float* __restrict__ h, const QuantScale* __restrict__ qs,
+                                                        const float* __restrict__ h, const QuantScale* __restrict__ qs, int extra_bits,
                                                         unsigned long long* __restrict__ acc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int32_t* begins = reinterpret_cast<int32_t*>(smem);
   __shared__ long long red[2][4];
   for (int i = threadIdx.x; i < n_spans; i += blockDim.x) begins[i] = spans[i].begin;
   __syncthreads();
-  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  const int kg = qs->kg + extra_bits, kh = qs->kh + extra_bits;
   const int64_t p0 = (int64_t)blockIdx.x * kLeafSumChunk;
   const int64_t p1 = p0 + kLeafSumChunk < n_rows ? p0 + kLeafSumChunk : n_rows;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1315,7 +1391,7 @@ __global__ __launch_bounds__(256) void walk_leaves_kernel(const TreeNodeDev* __r
                                                           const uint8_t* __restrict__ bins_fm, int64_t N,
                                                           const int32_t* __restrict__ rows, int64_t n,
                                                           const float* __restrict__ g, const float* __restrict__ h,
-                                                          const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                          const QuantScale* __restrict__ qs, int extra_bits, uint16_t* __restrict__ leaf_of_row,
                                                           unsigned long long* __restrict__ acc,
                                                           const uint64_t* __restrict__ node_sets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1326,7 +1402,7 @@ __global__ __launch_bounds__(256) void walk_leaves_kernel(const TreeNodeDev* __r
   for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
   __syncthreads();
   const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
-  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  const int kg = qs->kg + extra_bits, kh = qs->kh + extra_bits;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = rows ? rows[i] : i;
     if (!LGA_DEV_CHECK((unsigned long long)r < (unsigned long long)N, kCheckWalkRow, r, N)) continue;
@@ -1367,7 +1443,7 @@ __global__ __launch_bounds__(256) void walk_leaves_records_kernel(const TreeNode
                                                                   const uint4* __restrict__ recs, int64_t N,
                                                                   const int32_t* __restrict__ rows, int64_t n,
                                                                   const float* __restrict__ g, const float* __restrict__ h,
-                                                                  const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                                  const QuantScale* __restrict__ qs, int extra_bits, uint16_t* __restrict__ leaf_of_row,
                                                                   unsigned long long* __restrict__ acc,
                                                                   const uint64_t* __restrict__ node_sets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1379,7 +1455,7 @@ __global__ __launch_bounds__(256) void walk_leaves_records_kernel(const TreeNode
   for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
   __syncthreads();
   const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
-  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  const int kg = qs->kg + extra_bits, kh = qs->kh + extra_bits;
   for (int64_t base = (int64_t)blockIdx.x * (R * 256); base < n; base += (int64_t)gridDim.x * (R * 256)) {
     int64_t r[R];
     unsigned w[R][8];
@@ -1442,7 +1518,7 @@ __global__ __launch_bounds__(256) void walk_leaves_lds_kernel(const TreeNodeDev*
                                                               const uint4* __restrict__ recs, int64_t N,
                                                               const int32_t* __restrict__ rows, int64_t n,
                                                               const float* __restrict__ g, const float* __restrict__ h,
-                                                              const QuantScale* __restrict__ qs, uint16_t* __restrict__ leaf_of_row,
+                                                              const QuantScale* __restrict__ qs, int extra_bits, uint16_t* __restrict__ leaf_of_row,
                                                               unsigned long long* __restrict__ acc,
                                                               const uint64_t* __restrict__ node_sets) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1455,7 +1531,7 @@ __global__ __launch_bounds__(256) void walk_leaves_lds_kernel(const TreeNodeDev*
   for (int i = threadIdx.x; i < 2 * num_leaves; i += blockDim.x) sacc[i] = 0ull;
   __syncthreads();
   const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
-  const int kg = qs->kg + kWideExtraBits, kh = qs->kh + kWideExtraBits;
+  const int kg = qs->kg + extra_bits, kh = qs->kh + extra_bits;
   for (int64_t base = (int64_t)blockIdx.x * (R * 256); base < n; base += (int64_t)gridDim.x * (R * 256)) {
     int64_t r[R];
     float gv[R], hv[R];
@@ -1793,8 +1869,9 @@ void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint
 }
 
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
-              int64_t* packed, hipStream_t s) {
-  hipLaunchKernelGGL(quantize_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
+              int64_t* packed, bool wide, hipStream_t s) {
+  if (wide) hipLaunchKernelGGL(quantize_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
+  else hipLaunchKernelGGL(quantize_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1818,11 +1895,15 @@ void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                int rows_per_chunk, const NodeRange* nodes, const int32_t* a0, const int32_t* a1,
                const uint8_t* bins_rt, int64_t N, const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F,
-               int tile_first, int tile_step, int tile_count, hipStream_t s) {
+               int tile_first, int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s) {
   if (total_chunks <= 0 || tile_count <= 0) return;
   if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
-  hipLaunchKernelGGL(hist_kernel, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
-                     rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step);
+  if (wide_qs)
+    hipLaunchKernelGGL(hist_kernel<true>, dim3(total_chunks, tile_count), dim3(kHistThreadsWide), 0, s, tasks, chunk_task, inl,
+                       rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs);
+  else
+    hipLaunchKernelGGL(hist_kernel<false>, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
+                       rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs);
   LGA_LAUNCH_CHECK();
 }
 
@@ -1831,14 +1912,20 @@ void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool
   if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > kMaxRowsPerPass)
     throw std::runtime_error("growth round: bad unit size");
   if (a.F > kTileFeatures) throw std::runtime_error("row lines hold a single feature tile");
+  if (a.wide && !a.quant.g && !a.qs) throw std::runtime_error("full-precision growth round without its quantisation scale");
   if (root) {
-    if (a.quant.g)
-      hipLaunchKernelGGL((grow_kernel<true, true>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
+    if (a.quant.g && a.wide)
+      hipLaunchKernelGGL((grow_kernel<true, true, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
+    else if (a.quant.g)
+      hipLaunchKernelGGL((grow_kernel<true, true, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
+    else if (a.wide)
+      hipLaunchKernelGGL((grow_kernel<true, false, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
     else
-      hipLaunchKernelGGL((grow_kernel<true, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
+      hipLaunchKernelGGL((grow_kernel<true, false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
   } else {
     if (a.quant.g) throw std::runtime_error("fused quantisation belongs to the root pass");
-    hipLaunchKernelGGL((grow_kernel<false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
+    if (a.wide) hipLaunchKernelGGL((grow_kernel<false, false, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
+    else hipLaunchKernelGGL((grow_kernel<false, false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
   }
   LGA_LAUNCH_CHECK();
 }
@@ -1931,12 +2018,12 @@ void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int
 }
 
 void leaf_sums(const LeafSpan* spans, int n_spans, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
-               const float* g, const float* h, const QuantScale* qs, int64_t* acc, hipStream_t s) {
+               const float* g, const float* h, const QuantScale* qs, int extra_bits, int64_t* acc, hipStream_t s) {
   LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)n_leaves, s));
   if (n_rows <= 0 || n_spans <= 0) return;
   const size_t sm = ((size_t)n_spans * sizeof(int32_t) + 15) & ~(size_t)15;
   const int blocks = (int)((n_rows + kLeafSumChunk - 1) / kLeafSumChunk);
-  hipLaunchKernelGGL(leaf_sums_kernel, dim3(blocks), dim3(256), sm, s, spans, n_spans, a0, a1, n_rows, g, h, qs,
+  hipLaunchKernelGGL(leaf_sums_kernel, dim3(blocks), dim3(256), sm, s, spans, n_spans, a0, a1, n_rows, g, h, qs, extra_bits,
                      reinterpret_cast<unsigned long long*>(acc));
   LGA_LAUNCH_CHECK();
 }
@@ -1969,8 +2056,8 @@ void leaf_percentiles(const uint64_t* keys, int64_t n_rows, int n_leaves, double
 }
 
 bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
-                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
-                 int64_t* acc, const uint64_t* node_sets, hipStream_t s) {
+                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, int extra_bits,
+                 uint16_t* leaf_of_row, int64_t* acc, const uint64_t* node_sets, hipStream_t s) {
   const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)2 * (size_t)num_leaves * sizeof(unsigned long long);
   if (sm > 48 * 1024 || num_leaves > 65535) return false;   // the caller takes the per-leaf row lists instead
   LGA_HIP_CHECK(hipMemsetAsync(acc, 0, sizeof(int64_t) * 2 * (size_t)num_leaves, s));
@@ -1984,7 +2071,7 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
     const dim3 grid(grid_for(n, 256 * lds_rows, 4096));
     auto launch = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, grid, dim3(256), sm_rows, s, nodes, n_internal, num_leaves, reinterpret_cast<const uint4*>(records), N,
-                         rows, n, g, h, qs, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
+                         rows, n, g, h, qs, extra_bits, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
     };
     if (lds_rows == 2) launch(walk_leaves_lds_kernel<2>);
     else launch(walk_leaves_lds_kernel<4>);
@@ -1993,13 +2080,13 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
   }
   if (records) {
     hipLaunchKernelGGL(walk_leaves_records_kernel, dim3(grid_for(n, 1024, 2048)), dim3(256), sm, s, nodes, n_internal, num_leaves,
-                       reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, leaf_of_row,
+                       reinterpret_cast<const uint4*>(records), N, rows, n, g, h, qs, extra_bits, leaf_of_row,
                        reinterpret_cast<unsigned long long*>(acc), node_sets);
     LGA_LAUNCH_CHECK();
     return true;
   }
   hipLaunchKernelGGL(walk_leaves_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), sm, s, nodes, n_internal, num_leaves, bins_fm, N,
-                     rows, n, g, h, qs, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
+                     rows, n, g, h, qs, extra_bits, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
   LGA_LAUNCH_CHECK();
   return true;
 }

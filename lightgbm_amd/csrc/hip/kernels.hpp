@@ -12,6 +12,7 @@ namespace k {
 constexpr int kPartChunk = 2048;    // rows per partition workgroup (256 threads x 8)
 constexpr int kPartThreads = 256;
 constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
+constexpr int kHistThreadsWide = 1024;   // full-precision histograms: 128 KiB of LDS -> 1 workgroup of 16 waves per CU
 
 // Small rounds carry their task descriptors inside the kernel arguments.
 constexpr int kInlineTasks = 48;   // 48 x 64 B: leaves room for the round's other arguments in the 4 KiB kernel-argument block
@@ -87,8 +88,10 @@ void kth_largest(const float* v, int64_t n, int64_t k, uint32_t* scratch, float*
 void goss_amplify(float* g, float* h, int num_class, int64_t stride, const int32_t* rows, int64_t n,
                   const float* threshold, float multiplier, hipStream_t s);
 void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint32_t* maxbits, hipStream_t s);
+// wide (full-precision histograms): packed[row] = the float bit patterns (gradient high, hessian low) and *qs = the
+// exponents of their 36-bit fixed-point form (quantize_wide), which the histogram kernels apply on the way.
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
-              int64_t* packed, hipStream_t s);
+              int64_t* packed, bool wide, hipStream_t s);
 // Row lines (single feature tile): line r/3 = [3 x 32 bin bytes | 3 x 8-byte packed gradients | 8 spare];
 // the 32 bin bytes of row r are rotated by r (byte j = feature (j + r) mod 32).
 inline int64_t row_line_bytes(int64_t N) { return ((N + 2) / 3) * 128; }
@@ -128,10 +131,11 @@ struct FusedQuant {
   QuantScale* qs_out = nullptr;
 };
 // Feature-tile records + separate gradient array (data with more than one feature tile, feature-parallel).
+// wide_qs != nullptr: full-precision histograms - `packed` holds float bit patterns, *wide_qs their 36-bit exponents.
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks, int rows_per_chunk,
                const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
                const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F, int tile_first,
-               int tile_step, int tile_count, hipStream_t s);
+               int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s);
 
 // ---- fused growth round over row lines (single feature tile) ----
 // One launch decides every row's side for all leaves of the round and builds the smaller children's
@@ -140,6 +144,7 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 // no second launch).  A larger leaf is cut into units of `unit_rows` rows; its units add their LDS histograms
 // to the (zeroed) slot and grow_scatter moves the rows.  The split search follows as scan_blocks.
 constexpr int kGrowThreads = 512;
+constexpr int kGrowThreadsWide = 1024;   // full-precision histograms (GrowArgs::wide)
 constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
 constexpr int kSoloMaxRows = 8192;    // rows of a non-root unit / upper bound of the solo limit: sixteen rows per lane, one trip
 constexpr int kFlagBlocks = 1;        // blocks of kPartChunk rows a working workgroup of grow_flags_kernel takes (measured: 4 is slower - a big leaf's launch is one wave of workgroups either way, and fewer, longer workgroups only serialise it)
@@ -164,6 +169,8 @@ struct GrowArgs {
   int32_t* task_left;       // [task of the round]: rows that went left
   const uint64_t* cat_sets;
   FusedQuant quant;         // root pass: quantise the float gradients on the way (g != nullptr)
+  int32_t wide;             // 1: full-precision histograms - the lines' gradient words are float bit patterns, added as 36-bit fixed point
+  const QuantScale* qs;     // wide, non-root rounds: the exponents the root pass published
   unsigned long long* phase_ticks;   // LGA_GROW_TIMING: [8] sums of the workgroups' phase durations (100 MHz ticks), else null
 };
 // Sides of the rows of the multi-unit leaves (total_chunks blocks of kPartChunk rows): masks + left counts for grow_scatter.
@@ -337,9 +344,10 @@ void grow_trees(const TreeArgs* descs, int n_trees, int max_features, hipStream_
 void leaf_add(const LeafSpan* leaves, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
               double* scores, hipStream_t s);
 // Leaf-value renewal: acc[2 * leaf] / acc[2 * leaf + 1] = sums over the leaf's rows (spans over the bag arena, sorted
-// by begin) of quantize_wide(g, qs->kg + kWideExtraBits) / quantize_wide(h, qs->kh + kWideExtraBits).
+// by begin) of quantize_wide(g, qs->kg + extra_bits) / quantize_wide(h, qs->kh + extra_bits); extra_bits is
+// kWideExtraBits over 16-bit histograms and 0 when *qs already is the 36-bit scale (full-precision histograms).
 void leaf_sums(const LeafSpan* spans, int n_spans, int n_leaves, const int32_t* a0, const int32_t* a1, int64_t n_rows,
-               const float* g, const float* h, const QuantScale* qs, int64_t* acc, hipStream_t s);
+               const float* g, const float* h, const QuantScale* qs, int extra_bits, int64_t* acc, hipStream_t s);
 // Percentile leaf outputs (../percentile.hpp).  residual_keys: per in-bag row one sortable 64-bit key
 // (leaf id << 32 | order-preserving bits of float(label - score)), padding = ~0; leaf_percentiles: per leaf
 // the alpha-percentile of its (sorted) key segment and the segment length.  residual_items: the unsorted
@@ -359,8 +367,8 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 // walk_leaves returns false when the tree does not fit the kernel's LDS (nothing launched).
 // records != nullptr (data of ONE feature tile): the row-major 32-byte bin records; the walk then reads a row's bins once.
 bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
-                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, uint16_t* leaf_of_row,
-                 int64_t* acc, const uint64_t* node_sets, hipStream_t s);
+                 const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, int extra_bits,
+                 uint16_t* leaf_of_row, int64_t* acc, const uint64_t* node_sets, hipStream_t s);
 // leaf_value_add and the gradients of the next iteration (gradients()) in one pass.
 void leaf_value_add_gradients(const ObjectiveSpec& obj, const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves,
                               const int32_t* rows, int64_t n, double* scores, const float* label, const float* weight, float* g,

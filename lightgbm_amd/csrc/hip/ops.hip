@@ -50,6 +50,7 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
   }
   if (name == "histogram") {
     // ptrs: tasks, chunk_task, nodes, a0, a1, bins_rt, packed, pool, slot_table (2 words)
+    //       [, wide qs: full-precision pass - `packed` holds float bit patterns (g high, h low), *qs their 36-bit exponents]
     // ints: total_chunks, rows_per_chunk, N, F, tile_first, tile_step, tile_count, tiles
     // pool: one slot of `tiles` x 32 feature blocks [g 256 | h 256] + header
     if (nptr < 9 || nint < 8) return -1;
@@ -63,14 +64,15 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     L.slot_words = L.chunk_words;
     k::histogram((const SplitTask*)p[0], (const int32_t*)p[1], none, (int)a[0], (int)a[1], (const NodeRange*)p[2],
                  (const int32_t*)p[3], (const int32_t*)p[4], (const uint8_t*)p[5], a[2], (const int64_t*)p[6], L,
-                 k::RoundSlots{0, 1}, (int)a[3], (int)a[4], (int)a[5], (int)a[6], s);
+                 k::RoundSlots{0, 1}, (int)a[3], (int)a[4], (int)a[5], (int)a[6], nptr >= 10 ? (const QuantScale*)p[9] : nullptr, s);
     return 0;
   }
   if (name == "lines_histogram") {
     // Root pass of the fused growth kernel over row lines, histogram only (no split search).
     // ptrs: nodes (root range), rows, bins_rt (tile 0 records), packed, lines (scratch, row_line_bytes(N)), pool,
     //       slot_table, tickets (1 word, zero), g (float, for the fused quantisation) or null, h, maxbits, qs out
-    // ints: n_rows, N, F, unit_rows
+    // ints: n_rows, N, F, unit_rows [, wide: 1 = full-precision pass (packed = float bit patterns, qs = their 36-bit
+    //       exponents: written by the fused quantisation, read otherwise)]
     if (nptr < 12 || nint < 4) return -1;
     const int64_t n = a[0], N = a[1];
     k::build_row_lines((const uint8_t*)p[2], N, (uint8_t*)p[4], s);
@@ -95,6 +97,8 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     g.round = k::RoundSlots{0, 1};
     g.F = (int)a[2];
     g.unit_rows = unit_rows;
+    g.wide = (nint >= 5 && a[4]) ? 1 : 0;
+    g.qs = (const QuantScale*)p[11];
     if (p[8]) g.quant = k::FusedQuant{(const float*)p[8], (const float*)p[9], (const uint32_t*)p[10], (QuantScale*)p[11]};
     else k::store_line_gradients((uint8_t*)p[4], (const int64_t*)p[3], N, s);
     k::grow_round(inl, g, t.num_hchunk, true, s);

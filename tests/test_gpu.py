@@ -374,6 +374,19 @@ def test_randomised_parity_sweep(first):
         assert same, f"seed {seed}: {case}"
 
 
+@pytest.mark.parametrize("first", [0, 12, 24])
+def test_randomised_parity_sweep_full_precision(first):
+    """The same sweep with ``use_quantized_grad=false``: the device's full-precision histograms (float gradients turned
+    into 36-bit fixed point in every pass, two 64-bit LDS atomics per row and feature) give the CPU engine's
+    full-precision trees, bit for bit - single-tile row lines and multi-tile records alike."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import parity_sweep
+    for seed in range(first, first + 12):
+        same, case = parity_sweep.run_case(seed, 1_200_000, full=True)
+        assert same, f"seed {seed}: {case}"
+
+
 @pytest.mark.parametrize("onehot", [4, 64])
 def test_gpu_categorical_features_match_the_cpu_and_the_device_predictor_agrees(onehot):
     """onehot=4: the 40-category column is split on category SETS (histogram rows come back, the sorted search
@@ -567,9 +580,6 @@ def test_gpu_quantised_auc_matches_the_full_precision_cpu_learner():
                   lgb.Dataset(X[tr], label=y[tr], params={**p, "device_type": "cpu"}), 80)
     ag, ac = roc_auc_score(y[te], g.predict(X[te])), roc_auc_score(y[te], c.predict(X[te]))
     assert abs(ag - ac) <= 0.001, (ag, ac)
-    with pytest.raises(lgb.LightGBMError, match="CPU engine"):
-        lgb.train({**p, "device_type": "gpu", "use_quantized_grad": False},
-                  lgb.Dataset(X[:5000], label=y[:5000], params={**p, "device_type": "gpu"}), 1)
 
 
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])

@@ -8,7 +8,9 @@ model text.  Regression objectives only: their gradients involve no transcendent
 integer histograms - and with them the trees - are bit-identical.  The percentile-output objectives
 (regression_l1, quantile, mape) also cover the device ranking of leaf residuals.
 
-    python tools/parity_sweep.py [first_seed] [n_seeds] [max_rows]
+    python tools/parity_sweep.py [first_seed] [n_seeds] [max_rows] [full]
+
+``full``: both engines with full-precision (36-bit fixed-point) histograms, ``use_quantized_grad=false``.
 """
 from __future__ import annotations
 
@@ -107,9 +109,11 @@ def make_data(seed, n, F, opts):
     return X, y, w
 
 
-def run_case(seed: int, max_rows: int):
+def run_case(seed: int, max_rows: int, full: bool = False):
     import lightgbm_amd as lgb
     n, F, p, opts = draw_case(seed, max_rows)
+    if full:
+        p["use_quantized_grad"] = False      # the one-workgroup builds keep 16-bit records: growth rounds either way
     X, y, w = make_data(seed, n, F, opts)
     models = []
     rows = (n + 1) // 2 if opts["subset"] else n
@@ -135,10 +139,11 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 1_200_000
+    full = len(sys.argv) > 4 and sys.argv[4] == "full"
     bad = 0
     for seed in range(first, first + count):
         t0 = time.time()
-        ok, case = run_case(seed, max_rows)
+        ok, case = run_case(seed, max_rows, full)
         print(f"seed {seed}: {'ok' if ok else 'MISMATCH'} {time.time() - t0:.1f}s {case}", flush=True)
         bad += 0 if ok else 1
     print(f"{count - bad}/{count} identical", flush=True)
