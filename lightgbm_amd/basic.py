@@ -154,6 +154,30 @@ def _warn_unknown(params: Dict[str, Any]):
         _log_warning("Unknown parameter(s) ignored: " + ", ".join(sorted(unknown)), stacklevel=3)
 
 
+_no_effect_warned: set = set()
+
+
+def _warn_no_effect(params: Dict[str, Any]) -> None:
+    """Parameters that are accepted but change results in upstream LightGBM and not here: say so, once per setting."""
+    notes = []
+    m = str(get_param(params, "monotone_constraints_method", "basic")).lower()
+    if m in ("intermediate", "advanced"):
+        notes.append(("monotone_constraints_method=" + m,
+                      "monotone_constraints_method=%s is served by the basic method (same guarantee, more conservative splits)" % m))
+    q = get_param(params, "num_grad_quant_bins", None)
+    if q is not None and int(q) != 4:
+        notes.append(("num_grad_quant_bins", "num_grad_quant_bins has no effect: quantised histograms always use 16 bits "
+                                             "(use_quantized_grad=false selects full precision)"))
+    if str(get_param(params, "reg_sqrt", False)).lower() in ("true", "1"):
+        o = str(get_param(params, "objective", "regression")).lower()
+        if o not in ("regression", "regression_l2", "l2", "mean_squared_error", "mse", "l2_root", "root_mean_squared_error", "rmse"):
+            notes.append(("reg_sqrt+" + o, "reg_sqrt is honoured for objective=regression only; it has no effect with objective=%s" % o))
+    for key, msg in notes:
+        if key not in _no_effect_warned:
+            _no_effect_warned.add(key)
+            _log_warning(msg, stacklevel=4)
+
+
 # ----------------------------------------------------------------------------
 # data conversion
 # ----------------------------------------------------------------------------
@@ -771,6 +795,7 @@ class Booster:
                 raise TypeError("train_set must be a Dataset")
             p = _with_device(self.params)
             _warn_unknown(p)
+            _warn_no_effect(p)
             # the dataset decides where its bins live; keep the booster on the same device
             train_set.params = {**p, **train_set.params} if train_set._handle is None else train_set.params
             train_set.construct()

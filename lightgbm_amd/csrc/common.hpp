@@ -185,6 +185,28 @@ LGA_HD int32_t quantize(float v, int k) {
   return (int32_t)rintf(s);
 }
 
+// Unbiased rounding of the 16-bit form (stochastic_rounding=true): floor(s + u) with u uniform in [0, 1), drawn from
+// the counter-based generator below at (seed, stream, index) - the same draw on host and device, whatever the thread
+// layout, so both engines still grow the same trees.
+struct RoundingSpec {
+  uint64_t seed;
+  uint64_t stream;     // differs per tree
+  uint64_t salt;       // added to the row id (distributed learners: ranks draw different numbers for their local rows)
+  int32_t stochastic;  // 0: round to nearest
+  int32_t pad;
+};
+LGA_HD float rng_uniform(uint64_t seed, uint64_t stream, uint64_t index);
+// which: 0 gradient, 1 hessian
+LGA_HD int32_t quantize_with(float v, int k, const RoundingSpec& r, int which, uint64_t row) {
+  if (!r.stochastic) return quantize(v, k);
+  float s = ldexpf(v, k);
+  const float lim = (float)(1 << kQuantBits);
+  if (s > lim) s = lim;
+  if (s < -lim) s = -lim;
+  const double u = (double)rng_uniform(r.seed, r.stream * 2u + (uint64_t)which, r.salt + row);
+  return (int32_t)floor((double)s + u);
+}
+
 // Wide fixed point (leaf-value renewal, the CPU engine's full-precision histograms): kWideExtraBits more bits
 // than the packed form, i.e. |q| <= 2^36; int64 sums of up to 2^26 rows cannot overflow.
 constexpr int kWideExtraBits = 20;

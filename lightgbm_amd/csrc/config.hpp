@@ -138,7 +138,7 @@ struct Config {
   bool precise_float_parser = false;
   bool enable_bundle = true;
   int num_grad_quant_bins = 4;
-  bool stochastic_rounding = true;
+  bool stochastic_rounding = false;       // 16-bit histograms: unbiased floor(s + u) rounding instead of round-to-nearest
   // prediction (read by Booster.predict from the booster's parameters; the trainers ignore them)
   std::string forcedbins_filename;   // JSON: [{"feature": 0, "bin_upper_bound": [0.3, 0.4]}, ...] - bounds those features must have
   bool reg_sqrt = false;       // objective=regression: fit sign(y) sqrt|y|, square the predictions back

@@ -52,6 +52,10 @@ class Engine {
  public:
   virtual ~Engine() {}
   virtual const char* name() const = 0;
+  // Called at the top of any worker thread (OpenMP) that is about to drive this engine: a device engine makes its
+  // GPU the thread's current device - a new thread starts on device 0, where its allocations and launches would
+  // otherwise land, whatever device the engine was built on.
+  virtual void bind_thread() {}
   // which: -1 training data, >=0 validation set index
   virtual int add_valid(std::shared_ptr<Dataset> ds) = 0;
   virtual int num_valid() const = 0;

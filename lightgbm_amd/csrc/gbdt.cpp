@@ -523,6 +523,7 @@ int Booster::update_group_chunk(Booster* const* boosters, int n, int n_iters, bo
 #pragma omp parallel for schedule(dynamic, 1) if (n >= 8)
       for (int i = 0; i < n; ++i) {
         try {
+          if (boosters[i]->engine_) boosters[i]->engine_->bind_thread();
           body(i);
         } catch (const std::exception& e) {
 #pragma omp critical(lga_chunk_failure)

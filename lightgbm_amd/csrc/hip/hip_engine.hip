@@ -86,8 +86,15 @@ void* host_block_acquire(size_t bytes, bool mapped, size_t* capacity) {
 void host_block_release(void* p, size_t capacity, bool mapped) {
   if (!p) return;
   HostBlockCache& c = host_block_cache();
-  std::lock_guard<std::mutex> lock(c.mu);
-  c.free_blocks[mapped ? 1 : 0][capacity].push_back(p);
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto& v = c.free_blocks[mapped ? 1 : 0][capacity];
+    // keep a few blocks per size class (the boosters of a grid come and go by the dozen), free what exceeds that:
+    // page-locked memory must not grow to the peak of everything that ever lived at once
+    const size_t keep = capacity <= ((size_t)1 << 20) ? 64 : 4;
+    if (v.size() < keep) { v.push_back(p); return; }
+  }
+  (void)hipHostFree(p);
 }
 
 void set_current_stream(hipStream_t s) {
@@ -267,7 +274,8 @@ class HipBackend : public TreeBackend {
     // full-precision histograms (use_quantized_grad=false): the growth rounds carry them; the one-workgroup builds
     // keep packed 16-bit records and stay out of it
     wide_ = !cfg.use_quantized_grad;
-    tree_kernel_on_ = tree_kernel_rows_ > 0 && !wide_;
+    // (the one-workgroup builds round to nearest: stochastic rounding takes the growth rounds as well)
+    tree_kernel_on_ = tree_kernel_rows_ > 0 && !wide_ && !cfg.stochastic_rounding;
     // an explicit whole_tree_max_rows asks for the one-workgroup builds also for a booster that trains alone
     tree_kernel_forced_ = tree_kernel_on_ && std::find(cfg.explicit_keys.begin(), cfg.explicit_keys.end(), "whole_tree_max_rows") != cfg.explicit_keys.end();
     tree_renew_ = cfg.quant_train_renew_leaf ? 1 : 0;
@@ -326,8 +334,8 @@ class HipBackend : public TreeBackend {
   // Feature-tile records + a separate array of packed gradients.
   void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) { packed_ = packed_dev; hist_src_ = rows_src; lines_ = nullptr; }
   // Row lines only: the root pass quantises these float gradients itself (no separate quantisation kernel).
-  void set_root_quant(const float* g, const float* h, const uint32_t* maxbits) {
-    root_quant_ = k::FusedQuant{g, h, maxbits, qs_dev_.get()};
+  void set_root_quant(const float* g, const float* h, const uint32_t* maxbits, const RoundingSpec& rounding) {
+    root_quant_ = k::FusedQuant{g, h, maxbits, qs_dev_.get(), rounding};
   }
   QuantScale* qs_device() { return qs_dev_.get(); }
 
@@ -1268,6 +1276,7 @@ class HipEngine : public Engine {
       comm_ = comm = staging_.get();
     }
     stream_ = current_stream();
+    LGA_HIP_CHECK(hipGetDevice(&device_));
     mir_ = ensure_device_mirror(train_->root());
     N_ = train_->root_rows();
     upload_meta(train_->root(), mir_);
@@ -1312,7 +1321,18 @@ class HipEngine : public Engine {
     LGA_HIP_CHECK(hipStreamSynchronize(stream_));
   }
 
+  // Pinned and mapped blocks go back to a process-wide cache when the members below are destroyed: nothing enqueued
+  // on the stream may still read or write them by then.
+  ~HipEngine() override {
+    if (upload_ev_) { (void)hipEventSynchronize(upload_ev_); (void)hipEventDestroy(upload_ev_); }
+    (void)hipStreamSynchronize(stream_);
+  }
   const char* name() const override { return "hip"; }
+  void bind_thread() override {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != device_) LGA_HIP_CHECK(hipSetDevice(device_));
+  }
+  int device() const { return device_; }
 
   int add_valid(std::shared_ptr<Dataset> ds) override {
     if (ds->num_total_features() != train_->num_total_features())
@@ -1565,7 +1585,7 @@ class HipEngine : public Engine {
     have_max_ = false;   // the amplified rows may exceed the maxima taken with the gradients
   }
 
-  void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
+  void set_tree_index(int64_t i) override { tree_index_ = i; grower_.set_tree_index(i); }
   void update_split_config(const Config& c) override { grower_.update_split_config(c); }
   void set_group_size(int n) override { backend_->set_in_company(n >= 2); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
@@ -1579,12 +1599,13 @@ class HipEngine : public Engine {
     if (!have_max_) k::absmax(gr(), he(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
+    const RoundingSpec rounding = rounding_spec(cfg_, tree_index_, dist() ? comm_->rank() : 0);
     if (use_lines_) {
       backend_->set_lines(lines_.get());
-      backend_->set_root_quant(gr(), he(), maxbits_.get());
+      backend_->set_root_quant(gr(), he(), maxbits_.get(), rounding);
     } else {
       k::quantize(gr(), he(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
-                  backend_->qs_device(), packed_.get(), backend_->wide(), stream_);
+                  backend_->qs_device(), packed_.get(), backend_->wide(), rounding, stream_);
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
     tree_begun_ = true;
@@ -1645,7 +1666,7 @@ class HipEngine : public Engine {
     backend_->set_tree_params(base_meta, sp0);
     backend_->set_bag(bag_ptr_, bag_n_);
     backend_->set_lines(lines_.get());
-    backend_->set_root_quant(gr(), he(), maxbits_.get());
+    backend_->set_root_quant(gr(), he(), maxbits_.get(), RoundingSpec{});
     const int max_splits = cfg_.num_leaves - 1;
     const k::TreeLayout lay = k::tree_layout(max_splits);
     chunk_out_.resize((size_t)lay.bytes * (size_t)n_iters);
@@ -2133,10 +2154,12 @@ class HipEngine : public Engine {
   std::unique_ptr<StagingComm> staging_;
   TreeGrower grower_;
   hipStream_t stream_ = nullptr;
+  int device_ = 0;                 // the GPU this engine was built on (bind_thread)
   DeviceMirror* mir_ = nullptr;
   std::unique_ptr<HipBackend> backend_;
   int64_t N_ = 0, n_base_ = 0, bag_n_ = 0, oob_n_ = 0;
   int K_ = 1, cls_ = 0;
+  int64_t tree_index_ = 0;
   // rows == nullptr lets an elementwise kernel index rows directly (the training set is the whole root)
   const int32_t* base_or_null() const { return train_->used_indices() ? base_rows_.get() : nullptr; }
   const int32_t* bag_ptr_ = nullptr;

@@ -238,13 +238,14 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void quantize_kernel(const float* __restrict__ g, const float* __restrict__ h,
                                                        const int32_t* __restrict__ rows, int64_t n,
                                                        const uint32_t* __restrict__ maxbits, QuantScale* qs,
-                                                       int64_t* __restrict__ packed) {
+                                                       int64_t* __restrict__ packed, RoundingSpec rounding) {
   const int kg = quant_exponent(__uint_as_float(maxbits[0]));
   const int kh = quant_exponent(__uint_as_float(maxbits[1]));
   if (blockIdx.x == 0 && threadIdx.x == 0) { qs->kg = kg + (WIDE ? kWideExtraBits : 0); qs->kh = kh + (WIDE ? kWideExtraBits : 0); }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = rows ? rows[i] : i;
-    packed[r] = WIDE ? (int64_t)float_pair_bits(g[r], h[r]) : pack_gh(lga::quantize(g[r], kg), lga::quantize(h[r], kh));
+    packed[r] = WIDE ? (int64_t)float_pair_bits(g[r], h[r])
+                     : pack_gh(quantize_with(g[r], kg, rounding, 0, (uint64_t)r), quantize_with(h[r], kh, rounding, 1, (uint64_t)r));
   }
 }
 
@@ -958,7 +959,8 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
         rb[k] = Lp[slot * 2 + 1];
         if (QUANT) {
           pk[k] = WIDE ? float_pair_bits(a.quant.g[row[k]], a.quant.h[row[k]])
-                       : (unsigned long long)pack_gh(lga::quantize(a.quant.g[row[k]], kg), lga::quantize(a.quant.h[row[k]], kh));
+                       : (unsigned long long)pack_gh(quantize_with(a.quant.g[row[k]], kg, a.quant.rounding, 0, (uint64_t)row[k]),
+                                                     quantize_with(a.quant.h[row[k]], kh, a.quant.rounding, 1, (uint64_t)row[k]));
           reinterpret_cast<unsigned long long*>(const_cast<uint4*>(Lp))[12 + slot] = pk[k];
         } else {
           pk[k] = reinterpret_cast<const unsigned long long*>(Lp)[12 + slot];
@@ -1869,9 +1871,9 @@ void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint
 }
 
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
-              int64_t* packed, bool wide, hipStream_t s) {
-  if (wide) hipLaunchKernelGGL(quantize_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
-  else hipLaunchKernelGGL(quantize_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed);
+              int64_t* packed, bool wide, const RoundingSpec& rounding, hipStream_t s) {
+  if (wide) hipLaunchKernelGGL(quantize_kernel<true>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed, rounding);
+  else hipLaunchKernelGGL(quantize_kernel<false>, dim3(grid_for(n, 256)), dim3(256), 0, s, g, h, rows, n, maxbits, qs, packed, rounding);
   LGA_LAUNCH_CHECK();
 }
 

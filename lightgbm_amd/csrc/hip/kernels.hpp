@@ -91,7 +91,7 @@ void absmax(const float* g, const float* h, const int32_t* rows, int64_t n, uint
 // wide (full-precision histograms): packed[row] = the float bit patterns (gradient high, hessian low) and *qs = the
 // exponents of their 36-bit fixed-point form (quantize_wide), which the histogram kernels apply on the way.
 void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, const uint32_t* maxbits, QuantScale* qs,
-              int64_t* packed, bool wide, hipStream_t s);
+              int64_t* packed, bool wide, const RoundingSpec& rounding, hipStream_t s);
 // Row lines (single feature tile): line r/3 = [3 x 32 bin bytes | 3 x 8-byte packed gradients | 8 spare];
 // the 32 bin bytes of row r are rotated by r (byte j = feature (j + r) mod 32).
 inline int64_t row_line_bytes(int64_t N) { return ((N + 2) / 3) * 128; }
@@ -129,6 +129,7 @@ struct FusedQuant {
   const float* h = nullptr;
   const uint32_t* maxbits = nullptr;
   QuantScale* qs_out = nullptr;
+  RoundingSpec rounding{};   // 16-bit form only
 };
 // Feature-tile records + separate gradient array (data with more than one feature tile, feature-parallel).
 // wide_qs != nullptr: full-precision histograms - `packed` holds float bit patterns, *wide_qs their 36-bit exponents.

@@ -99,7 +99,7 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
     g.unit_rows = unit_rows;
     g.wide = (nint >= 5 && a[4]) ? 1 : 0;
     g.qs = (const QuantScale*)p[11];
-    if (p[8]) g.quant = k::FusedQuant{(const float*)p[8], (const float*)p[9], (const uint32_t*)p[10], (QuantScale*)p[11]};
+    if (p[8]) g.quant = k::FusedQuant{(const float*)p[8], (const float*)p[9], (const uint32_t*)p[10], (QuantScale*)p[11], RoundingSpec{}};
     else k::store_line_gradients((uint8_t*)p[4], (const int64_t*)p[3], N, s);
     k::grow_round(inl, g, t.num_hchunk, true, s);
     return 0;

@@ -18,11 +18,11 @@
 namespace lga {
 
 void quantize_rows_host(const float* g, const float* h, const int32_t* rows, int64_t n, QuantScale qs,
-                        int64_t* packed) {
+                        int64_t* packed, const RoundingSpec& rounding) {
 #pragma omp parallel for schedule(static) if (n > 65536)
   for (int64_t i = 0; i < n; ++i) {
     int64_t r = rows ? rows[i] : i;
-    packed[r] = pack_gh(quantize(g[r], qs.kg), quantize(h[r], qs.kh));
+    packed[r] = pack_gh(quantize_with(g[r], qs.kg, rounding, 0, (uint64_t)r), quantize_with(h[r], qs.kh, rounding, 1, (uint64_t)r));
   }
 }
 
@@ -688,7 +688,7 @@ class HostEngine : public Engine {
     }
   }
 
-  void set_tree_index(int64_t i) override { grower_.set_tree_index(i); }
+  void set_tree_index(int64_t i) override { tree_index_ = i; grower_.set_tree_index(i); }
   void update_split_config(const Config& c) override { grower_.update_split_config(c); }
   Tree train_tree(const std::vector<FeatureMeta>& meta) override {
     // quantisation scale from the largest |g| and h of the training rows
@@ -704,7 +704,8 @@ class HostEngine : public Engine {
     tree_qs_ = qs;
     backend_.set_bag(bag_.data(), (int64_t)bag_.size());
     if (cfg_.use_quantized_grad) {
-      quantize_rows_host(gc, hc, bag_.data(), (int64_t)bag_.size(), qs, packed_.data());
+      quantize_rows_host(gc, hc, bag_.data(), (int64_t)bag_.size(), qs, packed_.data(),
+                         rounding_spec(cfg_, tree_index_, dist() ? comm_->rank() : 0));
       backend_.set_gradients(packed_.data(), qs);
     } else {
       // full precision: the histograms take 36-bit fixed-point gradients (separate int64 arrays)
@@ -873,6 +874,7 @@ class HostEngine : public Engine {
   std::vector<double> scores_;
   std::vector<float> grad_, hess_;
   std::vector<int64_t> packed_, wide_g_, wide_h_;
+  int64_t tree_index_ = 0;
   QuantScale tree_qs_{0, 0};   // quantisation exponents of the tree being / just grown (16-bit form)
   std::vector<LeafPiece> leaf_nodes_;
   std::vector<int32_t> missing_bin_;

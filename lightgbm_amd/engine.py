@@ -124,7 +124,8 @@ def train(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round:
     if (get_param(params, "whole_tree_max_rows") is not None and int(get_param(params, "whole_tree_max_rows")) > 0 and
             _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host") and comm is None
             and fobj is None and feval is None and not cb_before and snapshot_freq <= 0 and not is_valid_contain_train
-            and len(booster.valid_sets) <= 1 and train_set.num_data() <= 65536):
+            and len(booster.valid_sets) <= 1 and train_set.num_data() <= 65536
+            and str(get_param(params, "boosting", "gbdt")).lower() != "dart"):     # (a dart iteration cannot be rolled back)
         chunk = 10 if need_eval else 50
     i = 0
     while chunk and i < num_boost_round:
@@ -430,7 +431,12 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
                 and max(len(tr) for tr, _ in folds) <= 65536 and int(get_param(params, "num_class", 1) or 1) <= 1
                 and str(get_param(params, "boosting", "gbdt")).lower() not in ("dart",)):
             lockstep_chunk = 10
-    lockstep = int(lockstep_chunk or 0) > 0 and fobj is None and feval is None and not eval_train_metric
+    # an explicit lockstep_chunk gives way where the chunked loop could not reproduce the plain one: iterations of a
+    # dart model cannot be rolled back after an early stop, and callbacks that act before an iteration would fire
+    # once per chunk
+    lockstep = (int(lockstep_chunk or 0) > 0 and fobj is None and feval is None and not eval_train_metric
+                and str(get_param(params, "boosting", "gbdt")).lower() != "dart"
+                and not any(getattr(c, "before_iteration", False) for c in callbacks))
     runner = _FoldRunner(len(folds), bool(concurrent_folds) and on_gpu and not lockstep)
 
     # The same folds come back for every row of a parameter grid: their (train, test) subsets - index lists over

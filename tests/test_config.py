@@ -78,18 +78,28 @@ def test_master_seed_settles_the_other_random_streams():
                           fit(seed=2, bagging_seed=9, feature_fraction_seed=9))   # explicit stream seeds win
 
 
-def test_upstream_parameters_without_a_choice_here_are_accepted_silently():
+def test_upstream_parameters_without_a_choice_here_are_accepted():
     """Switches between implementations this engine has one of (histogram orientation, OpenCL platform, bundling,
-    two-round loading, gradient quantisation bins) parse as known parameters and do not change the model."""
+    two-round loading, gradient quantisation bins) parse as known parameters and do not change the model; the ones
+    that change results upstream (num_grad_quant_bins, monotone_constraints_method) say once that they do not here."""
+    import warnings
+    from lightgbm_amd import basic
+    basic._no_effect_warned.clear()
     import lightgbm_amd as lgb
     from lightgbm_amd.utils.datasets import make_regression
     X, y = make_regression(1500, 5, seed=1)
     base = {"device_type": "cpu", "verbose": -1, "num_leaves": 7}
-    extra = {"force_col_wise": True, "histogram_pool_size": 512.0, "gpu_platform_id": 0, "gpu_use_dp": True, "num_gpu": 1,
+    extra = {"force_col_wise": True, "histogram_pool_size": 512.0, "gpu_platform_id": 0, "num_gpu": 1,
              "two_round": True, "enable_bundle": False, "num_grad_quant_bins": 8, "stochastic_rounding": False,
              "monotone_constraints_method": "advanced", "precise_float_parser": True}
     a = lgb.train(base, lgb.Dataset(X, label=y), 3)
-    b = lgb.train({**base, **extra}, lgb.Dataset(X, label=y), 3)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        b = lgb.train({**base, **extra}, lgb.Dataset(X, label=y), 3)
+        lgb.train({**base, **extra}, lgb.Dataset(X, label=y), 1)
+    said = [str(w.message) for w in caught]
+    assert sum("num_grad_quant_bins has no effect" in m for m in said) == 1
+    assert sum("served by the basic method" in m for m in said) == 1
     cut = lambda s: s[s.index("Tree=0"):s.index("end of trees")]
     assert cut(a.model_to_string()) == cut(b.model_to_string())
     assert "[monotone_constraints_method: advanced]" in b.model_to_string()

@@ -296,3 +296,23 @@ print("rank", rank, "done", flush=True)
                             "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                            capture_output=True, text=True, timeout=120, env={**os.environ, **extra})
         assert r.returncode == 0 and r.stdout.count("done") == 2, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """``python bench.py --gpus N`` without ``WORLD_SIZE`` in the environment starts N rank processes itself (before
+    touching any device) and passes rank 0's single result line through: it names N ranks and the communicator saw
+    N ranks.  Run here over gloo on the CPU engine; a rank that fails ends the others and the exit code says so."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LGA_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", "30000", "--steps", "2", "--warmup", "1",
+           "--leaves", "15", "--no-full-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["comm_ranks"] == 2 and out["config"]["parallelism"].startswith("dp2")
+    assert out["steps"] == 2 and out["value"] > 0 and out["config"]["precision"] == "full"
+    bad = subprocess.run(cmd + ["--extra", '{"num_leaves": "x"}'], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

@@ -664,6 +664,29 @@ def test_quantised_binary_auc_matches_full_precision():
     assert trees_of(quant) != trees_of(full)
 
 
+def test_stochastic_rounding_is_seeded_unbiased_and_changes_the_16_bit_trees():
+    """stochastic_rounding=true rounds the 16-bit gradients floor(s + u), u from the counter-based generator keyed by
+    (seed, tree, row): reproducible for a seed, different between seeds and from round-to-nearest, and the model is as
+    good; full-precision histograms do not round at that level, so the switch changes nothing there."""
+    X, y = _heavy_tailed(20000, 5)
+    p = {**CPU, "num_leaves": 31, "learning_rate": 0.1}
+    ds = lambda: lgb.Dataset(X, label=y)
+    near = lgb.train(p, ds(), 30)
+    s1 = lgb.train({**p, "stochastic_rounding": True, "seed": 1}, ds(), 30)
+    s1b = lgb.train({**p, "stochastic_rounding": True, "seed": 1}, ds(), 30)
+    s2 = lgb.train({**p, "stochastic_rounding": True, "seed": 2}, ds(), 30)
+    assert trees_of(s1) == trees_of(s1b)
+    assert trees_of(s1) != trees_of(near) and trees_of(s1) != trees_of(s2)
+    l2 = lambda b: float(np.mean((b.predict(X) - y) ** 2))
+    assert abs(l2(s1) - l2(near)) < 0.02 * l2(near)
+    f0 = lgb.train({**p, "use_quantized_grad": False}, ds(), 10)
+    f1 = lgb.train({**p, "use_quantized_grad": False, "stochastic_rounding": True}, ds(), 10)
+    assert trees_of(f0) == trees_of(f1)
+    # gpu_use_dp is upstream's switch for full-precision device histograms
+    f2 = lgb.train({**p, "gpu_use_dp": True}, ds(), 10)
+    assert trees_of(f0) == trees_of(f2)
+
+
 def test_forced_splits_start_every_tree(tmp_path):
     """forcedsplits_filename: the root splits on column 3 at 0.25, its left child on column 1 at -0.5, whatever the
     search would have chosen; growth below continues as usual (best-first over the remaining budget)."""

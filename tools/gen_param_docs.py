@@ -83,7 +83,7 @@ NOTES = {
     "cegb_penalty_split": "cost-effective gradient boosting: penalty per split, times the rows of the leaf",
     "cegb_penalty_feature_coupled": "cost-effective gradient boosting: per feature, a penalty paid by the first split on that feature in the whole model",
     "cegb_penalty_feature_lazy": "the per-row lazy penalty is not implemented: a list with a non-zero entry is refused",
-    "use_quantized_grad": "true: 16-bit fixed-point gradient histograms (the device engine's only form; bit-identical on both engines); false: CPU engine only, 36-bit gradient histograms - the full-precision reference the AUC parity record is measured against",
+    "use_quantized_grad": "true: 16-bit fixed-point gradient histograms (one packed 64-bit LDS atomic per row and feature on the device); false: full precision - the float gradients as 36-bit fixed point, summed exactly in 64-bit cells (two LDS atomics per row and feature; growth rounds only, the one-workgroup builds of small boosters keep 16 bits). Either way both engines, and any number of ranks, grow bit-identical trees",
     "quant_train_renew_leaf": "leaf values are recomputed from exact 36-bit sums of the float gradients of each leaf's rows (both engines; off: the values the 16-bit search produced)",
     "path_smooth": "> 0: a child's output is pulled towards its parent's, the more so the fewer rows it holds",
     "interaction_constraints": "groups of raw column indices, e.g. [0,1,2],[2,3]: a branch may only combine features of one group",
@@ -114,13 +114,13 @@ NOTES = {
     "force_row_wise": "accepted for compatibility (no effect)",
     "histogram_pool_size": "accepted for compatibility (no effect: the pool holds every leaf's histogram)",
     "gpu_platform_id": "accepted for compatibility (no effect)",
-    "gpu_use_dp": "accepted for compatibility (no effect: histograms are exact integers)",
+    "gpu_use_dp": "true selects full-precision histograms (`use_quantized_grad=false`) unless `use_quantized_grad` is given explicitly",
     "num_gpu": "accepted for compatibility; GPUs are used one process each (`parallel/`)",
     "two_round": "accepted for compatibility (no effect)",
     "precise_float_parser": "accepted for compatibility (no effect)",
     "enable_bundle": "accepted for compatibility (no effect: dense storage, no feature bundling)",
-    "num_grad_quant_bins": "accepted for compatibility; gradients are quantised to 16 bits, see `quantized_grad`",
-    "stochastic_rounding": "accepted for compatibility; rounding is deterministic (seeded per row and iteration)",
+    "num_grad_quant_bins": "no effect (a warning says so): the quantised form always has 16 bits, see `use_quantized_grad`",
+    "stochastic_rounding": "16-bit histograms: false (default) rounds gradients to nearest; true rounds floor(s + u) with u uniform in [0, 1) from the counter-based generator keyed by (`seed`, tree, row) - unbiased, reproducible, the same on both engines (growth rounds only)",
     "forcedbins_filename": "JSON list of `{\"feature\": column, \"bin_upper_bound\": [...]}`: bin bounds those features must have; the remaining bins are spread over the intervals between them by row count",
     "reg_sqrt": "`objective=regression`: fit sign(y) sqrt|y| and square the predictions back; metrics on the original scale",
     "pred_early_stop": "prediction (binary / multiclass): stop adding trees for a row once its margin is wide enough",

@@ -86,6 +86,9 @@ def draw_case(seed: int, max_rows: int):
         p["max_cat_to_onehot"] = 64            # one category against the rest, on the device
     if opts["categorical"] and "monotone_constraints" in p:
         p["monotone_constraints"][F - 2 if F > 1 else 0] = 0
+    if rng.rand() < 0.12:                      # (drawn last: the cases of earlier sweeps keep their settings)
+        p["stochastic_rounding"] = True
+        p["seed"] = int(rng.randint(1, 1000))
     return n, F, p, opts
 
 
