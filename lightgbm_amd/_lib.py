@@ -124,6 +124,8 @@ def load():
     want_hip = _gpu_visible()
     # LGA_DEBUG_LIB=1: the -DLGA_DEBUG build of the HIP core, whose kernels check indices instead of faulting
     hip_name = "_lga_hip_debug.so" if os.environ.get("LGA_DEBUG_LIB", "0") == "1" else "_lga_hip.so"
+    if os.environ.get("LGA_HIP_LIB"):      # development: another build of the HIP core next to this file (A/B timing)
+        hip_name = os.environ["LGA_HIP_LIB"]
     path = PKG / (hip_name if want_hip else "_lga_host.so")
     if not path.exists():
         if want_hip:

@@ -31,6 +31,10 @@ constexpr int kMaxBins = 256;          // bins are stored as uint8
 // kMaxRowsPerPass rows before flushing: 2^16 * 2^14 = 2^30 < 2^31.
 constexpr int kQuantBits = 16;
 constexpr int kMaxRowsPerPass = 16384;
+// The most a growth-round unit or histogram chunk may hold: 2^16 * 30720 < 2^31 still (|q| <= 2^16 exactly), and
+// the unsigned hessian half has twice that room.  Full-precision cells are 64 bits wide: no limit from overflow.
+constexpr int kMaxUnitRows = 30720;
+constexpr int kMaxUnitRowsWide = 1 << 18;
 constexpr int kSlotHeader = 8;         // int64 words appended to every histogram slot
 
 // ---- plain data ----------------------------------------------------------

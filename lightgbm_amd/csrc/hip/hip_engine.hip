@@ -267,13 +267,19 @@ class HipBackend : public TreeBackend {
     if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(kMaxRoundsInFlight, std::atoi(e)));
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
-    if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
     tree_kernel_rows_ = std::min<int64_t>(k::kTreeMaxRows, cfg.whole_tree_max_rows);
     if (const char* e = std::getenv("LGA_TREE_KERNEL_ROWS"))
       tree_kernel_rows_ = std::max<int64_t>(0, std::min<int64_t>(k::kTreeMaxRows, std::atoll(e)));
     // full-precision histograms (use_quantized_grad=false): the growth rounds carry them; the one-workgroup builds
     // keep packed 16-bit records and stay out of it
     wide_ = !cfg.use_quantized_grad;
+    // Units of a round's large leaves: about one workgroup slot's worth each (16-bit: two 512-thread workgroups per CU,
+    // 512 slots; full precision: one 1024-thread workgroup per CU, 256 slots) - fewer, longer units beat more, shorter
+    // ones (every unit clears and flushes a whole LDS histogram); measured over 256..2048 units on the 10.5 M x 28 shape.
+    target_units_ = wide_ ? 256 : 512;
+    if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
+    max_unit_rows_ = wide_ ? 65536 : kMaxUnitRows;
+    if (const char* e = std::getenv("LGA_MAX_UNIT_ROWS")) max_unit_rows_ = std::max(k::kSubRows, std::min(max_unit_rows_, std::atoi(e)));
     // (the one-workgroup builds round to nearest: stochastic rounding takes the growth rounds as well)
     tree_kernel_on_ = tree_kernel_rows_ > 0 && !wide_ && !cfg.stochastic_rounding;
     // an explicit whole_tree_max_rows asks for the one-workgroup builds also for a booster that trains alone
@@ -644,7 +650,7 @@ class HipBackend : public TreeBackend {
     int64_t c = (total_rows + chunks - 1) / chunks;
     c = ((c + 511) / 512) * 512;
     if (c < 1024) c = 1024;
-    if (c > kMaxRowsPerPass) c = kMaxRowsPerPass;
+    if (c > max_unit_rows_) c = max_unit_rows_;
     return (int)c;
   }
 
@@ -756,7 +762,7 @@ class HipBackend : public TreeBackend {
     }
     int64_t ur = (multi_rows + target_units_ - 1) / target_units_;
     ur = ((ur + k::kSubRows - 1) / k::kSubRows) * k::kSubRows;
-    ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, kMaxRowsPerPass));
+    ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, (max_unit_rows_ / k::kSubRows) * k::kSubRows));
     const int unit_rows = (int)ur;
     int np = 0;
     for (auto& t : tasks) {
@@ -1133,7 +1139,8 @@ class HipBackend : public TreeBackend {
   int capacity_splits_ = 0, max_batch_ = 0, max_pchunks_ = 0, max_hchunks_ = 0;
   int slots_dirty_ = 1;       // slots written since the pool was last cleared
   int solo_rows_ = 2048;      // leaves up to this many rows are one workgroup's (LGA_SOLO_ROWS)
-  int target_units_ = 640;    // units a round's multi-unit leaves are cut into (LGA_TARGET_UNITS)
+  int target_units_ = 512;    // units a round's multi-unit leaves are cut into (LGA_TARGET_UNITS)
+  int max_unit_rows_ = kMaxUnitRows;   // rows a unit / histogram chunk may hold (LGA_MAX_UNIT_ROWS lowers it)
   k::PoolLayout lay_{};
   k::ScanRange scan_range_{};
   DeviceBuffer<int64_t> pool_, slot_table_;

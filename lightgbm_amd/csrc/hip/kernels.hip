@@ -13,6 +13,7 @@
 //    place (parent - smaller child) on the way in.
 #include "kernels.hpp"
 #include <sstream>
+#include <type_traits>
 #include <string>
 #include "device.hpp"
 #include "wave_scan.hpp"
@@ -489,23 +490,67 @@ __device__ __forceinline__ int64_t* slot_header(const PoolLayout& L, const SlotR
   return s.base + (int64_t)r * s.rstride + (int64_t)L.fpr * (2 * kMaxBins);
 }
 
-// Adds a workgroup's LDS histogram (packed g:int32 | h:uint32 cells, features f0 .. f0 + nf - 1) to a slot.
-// ROTATED: cell (f, bin) sits at f * 256 + ((bin + 8 f) & 255) (row-line kernels).
+// ---- the workgroup histogram in LDS ----
+// Cell (feature f, bin b) sits at index b * 32 + f: the bank of an 8-byte cell is its index mod 16 (mod 32 for
+// reads), i.e. the FEATURE picks the bank, and the kernels make the lanes of a wave work on different features at
+// any moment - lane l takes the features of its row in the order l, l + 1, ... (mod 32) - so the lanes of every
+// 16-lane group of an LDS atomic hit 16 different banks whatever bins their rows hold: no bank conflicts and no
+// same-address collisions (a feature with three distinct values does not queue 64 lanes on three words).
+__device__ __forceinline__ int hist_cell(int f, int bin) { return (bin << 5) + f; }
+// WIDE (full precision): two planes of 64-bit cells, gradients at [0, kWidePlane), hessians behind them.
+constexpr int kWidePlane = kTileFeatures * kMaxBins;
+
+// The 32 bin bytes of a record (8 dwords) rotated left by d bytes: out byte j = in byte (j + d) mod 32.  A lane
+// rotates its row's record so that byte j holds the bin of feature (j + lane) mod 32; the loops over j then use
+// static register indices and shifts.
+__device__ __forceinline__ void rotate_record(unsigned (&w)[8], unsigned d) {
+  // three conditional stages (rotate by 4, 2, 1 dwords: 8 selects each), then one byte alignment per dword.
+  // Written out on scalars with constant indices: as loops over the arrays the compiler turns "select of two loads"
+  // into "load at a selected index" before it unrolls, and the arrays end up indexed dynamically - an eight-way
+  // compare-and-select chain per dword, four times the instructions.
+  const bool r4 = (d & 16u) != 0, r2 = (d & 8u) != 0, r1 = (d & 4u) != 0;
+  const unsigned a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3], a4 = w[4], a5 = w[5], a6 = w[6], a7 = w[7];
+  const unsigned b0 = r4 ? a4 : a0, b1 = r4 ? a5 : a1, b2 = r4 ? a6 : a2, b3 = r4 ? a7 : a3;
+  const unsigned b4 = r4 ? a0 : a4, b5 = r4 ? a1 : a5, b6 = r4 ? a2 : a6, b7 = r4 ? a3 : a7;
+  const unsigned c0 = r2 ? b2 : b0, c1 = r2 ? b3 : b1, c2 = r2 ? b4 : b2, c3 = r2 ? b5 : b3;
+  const unsigned c4 = r2 ? b6 : b4, c5 = r2 ? b7 : b5, c6 = r2 ? b0 : b6, c7 = r2 ? b1 : b7;
+  const unsigned e0 = r1 ? c1 : c0, e1 = r1 ? c2 : c1, e2 = r1 ? c3 : c2, e3 = r1 ? c4 : c3;
+  const unsigned e4 = r1 ? c5 : c4, e5 = r1 ? c6 : c5, e6 = r1 ? c7 : c6, e7 = r1 ? c0 : c7;
+  const unsigned s = d & 3u;
+  w[0] = __builtin_amdgcn_alignbyte(e1, e0, s);
+  w[1] = __builtin_amdgcn_alignbyte(e2, e1, s);
+  w[2] = __builtin_amdgcn_alignbyte(e3, e2, s);
+  w[3] = __builtin_amdgcn_alignbyte(e4, e3, s);
+  w[4] = __builtin_amdgcn_alignbyte(e5, e4, s);
+  w[5] = __builtin_amdgcn_alignbyte(e6, e5, s);
+  w[6] = __builtin_amdgcn_alignbyte(e7, e6, s);
+  w[7] = __builtin_amdgcn_alignbyte(e0, e7, s);
+}
+
+// Item i of a flush -> (feature, bin): the 64 lanes of a wave take an 8 x 8 tile (8 features x 8 consecutive bins),
+// so their LDS reads spread over 8 banks (4-way instead of 32-way for one feature's consecutive bins) and their
+// global accesses still form eight 64-byte segments.
+__device__ __forceinline__ void flush_item(int i, int& f, int& b) {
+  const int lo = i & 63, hi = i >> 6;
+  f = ((hi & 3) << 3) + (lo & 7);
+  b = ((hi >> 2) << 3) + (lo >> 3);
+}
+
+// Adds a workgroup's LDS histogram (features f0 .. f0 + nf - 1; packed g:int32 | h:uint32 cells, or - WIDE - two planes
+// of 64-bit cells) to a slot.
 // `stagger` (any number that differs between the workgroups of a slot, e.g. the unit index) shifts where a workgroup
 // starts: the units of one leaf finish at about the same time, and without it all of them would add to the same
 // few cache lines at any moment.
-// WIDE: the LDS histogram is two planes of 64-bit cells, gradients at [0, kWidePlane), hessians behind them.
-constexpr int kWidePlane = kTileFeatures * kMaxBins;
-template <bool ROTATED, bool WIDE = false>
+template <bool WIDE>
 __device__ __forceinline__ void flush_lds_hist(const unsigned long long* lds, int nf, int f0, const PoolLayout& L,
                                                const SlotRef& s, int nthreads, unsigned stagger = 0) {
-  const int cells = nf * kMaxBins;
-  const int shift = (int)((stagger * 1031u) % (unsigned)cells) & ~63;
-  for (int e0 = threadIdx.x; e0 < cells; e0 += nthreads) {
-    int e = e0 + shift;
-    if (e >= cells) e -= cells;
-    const int fe = e >> 8, b = e & 255;
-    const int cell = ROTATED ? (fe << 8) + ((b + 8 * fe) & 255) : e;
+  constexpr int kItems = kTileFeatures * kMaxBins;
+  const int shift = (int)((stagger * 1031u) & (unsigned)(kItems - 1)) & ~63;
+  for (int i0 = threadIdx.x; i0 < kItems; i0 += nthreads) {
+    int fe, b;
+    flush_item((i0 + shift) & (kItems - 1), fe, b);
+    if (fe >= nf) continue;
+    const int cell = hist_cell(fe, b);
     if (WIDE) {
       const unsigned long long vg = lds[cell], vh = lds[kWidePlane + cell];
       if ((vg | vh) != 0ull) {
@@ -566,10 +611,11 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
   if (lo >= r.count) return;   // the child turned out smaller than the grid was sized for
   const int hi = min(lo + rows_per_chunk, r.count);
   const int nf = min(kTileFeatures, F - tile * kTileFeatures);
-  for (int i = threadIdx.x; i < nf * kMaxBins; i += kThreads) {
+  for (int i = threadIdx.x; i < kTileFeatures * kMaxBins; i += kThreads) {
     lds[i] = 0ull;
     if (WIDE) lds[kWidePlane + i] = 0ull;
   }
+  const unsigned lane_rot = threadIdx.x & 31u;   // this lane takes features lane_rot, lane_rot + 1, ... (mod 32)
   int wkg = 0, wkh = 0;
   if (WIDE) { wkg = qs->kg; wkh = qs->kh; }
   __syncthreads();
@@ -609,24 +655,33 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
           sg += (long long)(int32_t)(p[u] >> 32);
           sh += (long long)(p[u] & 0xffffffffull);
         }
-        const unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+        unsigned w[8] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+        rotate_record(w, lane_rot);   // byte j = the bin of feature (j + lane) mod 32
+        auto add_features = [&](auto allf) {
 #pragma unroll
-        for (int k = 0; k < kTileFeatures; ++k) {
-          if (k < nf) {
-            unsigned bin = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-            if (WIDE) {
-              atomicAdd(&lds[k * kMaxBins + bin], (unsigned long long)qg);
-              atomicAdd(&lds[kWidePlane + k * kMaxBins + bin], (unsigned long long)qh);
-            } else {
-              atomicAdd(&lds[k * kMaxBins + bin], p[u]);
+          for (int j = 0; j < kTileFeatures; ++j) {
+            const unsigned f = (j + lane_rot) & 31u;
+            if (decltype(allf)::value || f < (unsigned)nf) {
+              const unsigned bin = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
+              const unsigned cell = (bin << 5) + f;
+              if (WIDE) {
+                atomicAdd(&lds[cell], (unsigned long long)qg);
+                atomicAdd(&lds[kWidePlane + cell], (unsigned long long)qh);
+              } else {
+                atomicAdd(&lds[cell], p[u]);
+              }
             }
           }
-        }
+        };
+        // a nearly full tile skips the per-step "does this lane's feature exist" test (see grow_kernel's ALLF); two
+        // copies of the loop behind one uniform branch - as a flag inside the loop the test stays per step
+        if (nf > 24) add_features(std::true_type{});
+        else add_features(std::false_type{});
       }
     }
   }
   __syncthreads();
-  flush_lds_hist<false, WIDE>(lds, nf, tile * kTileFeatures, L, slot, kThreads);
+  flush_lds_hist<WIDE>(lds, nf, tile * kTileFeatures, L, slot, kThreads);
   if (blockIdx.y == 0) {
     // header: rows, sum g, sum h of this child (the first tile's workgroups see every row once)
     sg = wave_sum_i64(sg);
@@ -885,7 +940,10 @@ __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks in
 // WIDE (full-precision histograms): the rows' gradient words are float bit patterns, converted to 36-bit fixed point in
 // every pass and added as TWO 64-bit LDS atomics per (row, feature) into separate gradient and hessian planes - 128 KiB
 // of LDS, so a CU holds one workgroup, which therefore has 16 waves instead of 8.  No cell can overflow.
-template <bool ROOT, bool QUANT, bool WIDE>
+// ALLF (a nearly full tile, F > 24): no per-step "does this lane's feature exist" test - the unused features' bin bytes
+// are zero in the lines, their adds land in cells (feature >= F, bin 0) that nothing ever reads, and 32 predicated
+// branches per row cost more than a few spare atomics (as a run-time flag the test stays in the loop: measured).
+template <bool ROOT, bool QUANT, bool WIDE, bool ALLF>
 __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void grow_kernel(InlineTasks inl, GrowArgs a) {
   constexpr int kThreads = WIDE ? kGrowThreadsWide : kGrowThreads;
   constexpr int kWaves = kThreads / kWave;
@@ -926,7 +984,7 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
     }
   };
   auto clear_lds = [&]() {
-    for (int i = tid; i < nf * kMaxBins; i += kThreads) {
+    for (int i = tid; i < kTileFeatures * kMaxBins; i += kThreads) {
       lds[i] = 0ull;
       if (WIDE) lds[kWidePlane + i] = 0ull;
     }
@@ -971,7 +1029,7 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (row[k] >= 0) {
-        const unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+        unsigned w[8] = {ra[k].x, ra[k].y, ra[k].z, ra[k].w, rb[k].x, rb[k].y, rb[k].z, rb[k].w};
         long long qg = 0, qh = 0;
         if (WIDE) {
           wide_of(pk[k], kg, kh, qg, qh);
@@ -981,16 +1039,16 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
           sg += (long long)(int32_t)(pk[k] >> 32);
           sh += (long long)(pk[k] & 0xffffffffull);
         }
-        // byte j of the record holds feature (j + row) mod 32: the lanes of a wave work on different
-        // features at any moment, so a feature with three distinct values does not make 64 lanes queue on
-        // three LDS words; the (bin + 8 f) rotation keeps equal bins of different features in different banks
-        const unsigned rot = (unsigned)row[k];
+        // byte j of the stored record holds feature (j + row) mod 32; rotated by (lane - row) it holds feature
+        // (j + lane) mod 32: the lanes of a wave then work on 32 different features at any moment, whatever rows
+        // they hold, and the feature is the bank (hist_cell): conflict-free LDS atomics
+        rotate_record(w, ((unsigned)lane - (unsigned)row[k]) & 31u);
 #pragma unroll
         for (int j = 0; j < kTileFeatures; ++j) {
-          const unsigned f = (j + rot) & 31u;
-          if (f < (unsigned)nf) {
+          const unsigned f = (j + (unsigned)lane) & 31u;
+          if (ALLF || f < (unsigned)nf) {
             const unsigned bn = (w[j >> 2] >> ((j & 3) * 8)) & 255u;
-            const unsigned cell = f * kMaxBins + ((bn + 8u * f) & 255u);
+            const unsigned cell = (bn << 5) + f;
             if (WIDE) {
               atomicAdd(&lds[cell], (unsigned long long)qg);
               atomicAdd(&lds[kWidePlane + cell], (unsigned long long)qh);
@@ -1000,6 +1058,7 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);   // one row at a time: interleaving the rows' rotations costs registers (spills)
     }
   };
   // rows, sum g, sum h of what the workgroup put into its histogram -> tot[]
@@ -1048,7 +1107,7 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
       stamp(3);
       reduce_sums(max(uhi - ulo, 0));
       stamp(4);
-      flush_lds_hist<true, WIDE>(lds, nf, 0, L, fresh, kThreads, (unsigned)unit);
+      flush_lds_hist<WIDE>(lds, nf, 0, L, fresh, kThreads, (unsigned)unit);
       if (tid == 0) add_slot_header(L, fresh, tot[0], tot[1], tot[2]);
       __syncthreads();
       stamp(5);
@@ -1163,9 +1222,11 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
   stamp(3);
   reduce_sums(hist_left ? lefts : (hi - lo) - lefts);
   // the whole leaf was this workgroup's: the histogram goes to the slot as it is (no atomics, no zeroing)
-  for (int e = tid; e < nf * kMaxBins; e += kThreads) {
-    const int fe = e >> 8, b = e & 255;
-    const int cell = (fe << 8) + ((b + 8 * fe) & 255);
+  for (int e = tid; e < kTileFeatures * kMaxBins; e += kThreads) {
+    int fe, b;
+    flush_item(e, fe, b);
+    if (fe >= nf) continue;
+    const int cell = hist_cell(fe, b);
     int64_t* blk = feat_block(L, fresh, fe);
     if (WIDE) {
       blk[b] = (int64_t)lds[cell];
@@ -1899,36 +1960,34 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
                const uint8_t* bins_rt, int64_t N, const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F,
                int tile_first, int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s) {
   if (total_chunks <= 0 || tile_count <= 0) return;
-  if (rows_per_chunk > kMaxRowsPerPass) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
-  if (wide_qs)
-    hipLaunchKernelGGL(hist_kernel<true>, dim3(total_chunks, tile_count), dim3(kHistThreadsWide), 0, s, tasks, chunk_task, inl,
+  if (rows_per_chunk > (wide_qs ? kMaxUnitRowsWide : kMaxUnitRows)) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
+  auto launch = [&](auto kernel, int threads) {
+    hipLaunchKernelGGL(kernel, dim3(total_chunks, tile_count), dim3(threads), 0, s, tasks, chunk_task, inl,
                        rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs);
-  else
-    hipLaunchKernelGGL(hist_kernel<false>, dim3(total_chunks, tile_count), dim3(kHistThreads), 0, s, tasks, chunk_task, inl,
-                       rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs);
+  };
+  if (wide_qs) launch(hist_kernel<true>, kHistThreadsWide);
+  else launch(hist_kernel<false>, kHistThreads);
   LGA_LAUNCH_CHECK();
 }
 
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s) {
   if (total_units <= 0) return;
-  if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > kMaxRowsPerPass)
+  if (a.unit_rows <= 0 || a.unit_rows % kSubRows != 0 || a.unit_rows > (a.wide ? kMaxUnitRowsWide : kMaxUnitRows))
     throw std::runtime_error("growth round: bad unit size");
   if (a.F > kTileFeatures) throw std::runtime_error("row lines hold a single feature tile");
   if (a.wide && !a.quant.g && !a.qs) throw std::runtime_error("full-precision growth round without its quantisation scale");
-  if (root) {
-    if (a.quant.g && a.wide)
-      hipLaunchKernelGGL((grow_kernel<true, true, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
-    else if (a.quant.g)
-      hipLaunchKernelGGL((grow_kernel<true, true, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
-    else if (a.wide)
-      hipLaunchKernelGGL((grow_kernel<true, false, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
-    else
-      hipLaunchKernelGGL((grow_kernel<true, false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
-  } else {
-    if (a.quant.g) throw std::runtime_error("fused quantisation belongs to the root pass");
-    if (a.wide) hipLaunchKernelGGL((grow_kernel<false, false, true>), dim3(total_units), dim3(kGrowThreadsWide), 0, s, inl, a);
-    else hipLaunchKernelGGL((grow_kernel<false, false, false>), dim3(total_units), dim3(kGrowThreads), 0, s, inl, a);
-  }
+  if (!root && a.quant.g) throw std::runtime_error("fused quantisation belongs to the root pass");
+  auto launch = [&](auto kernel, int threads) { hipLaunchKernelGGL(kernel, dim3(total_units), dim3(threads), 0, s, inl, a); };
+  const int tw = kGrowThreadsWide, tq = kGrowThreads;
+  const bool allf = a.F > 24, quant = a.quant.g != nullptr, wide = a.wide != 0;
+#define LGA_GROW_CASE(R, Q, W, A) if (root == R && quant == Q && wide == W && allf == A) launch(grow_kernel<R, Q, W, A>, W ? tw : tq);
+  LGA_GROW_CASE(true, true, true, true) LGA_GROW_CASE(true, true, true, false)
+  LGA_GROW_CASE(true, true, false, true) LGA_GROW_CASE(true, true, false, false)
+  LGA_GROW_CASE(true, false, true, true) LGA_GROW_CASE(true, false, true, false)
+  LGA_GROW_CASE(true, false, false, true) LGA_GROW_CASE(true, false, false, false)
+  LGA_GROW_CASE(false, false, true, true) LGA_GROW_CASE(false, false, true, false)
+  LGA_GROW_CASE(false, false, false, true) LGA_GROW_CASE(false, false, false, false)
+#undef LGA_GROW_CASE
   LGA_LAUNCH_CHECK();
 }
 

@@ -144,10 +144,13 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
 // finish: flags, row movement, histogram written straight to its slot (no atomics on global memory, no zeroing,
 // no second launch).  A larger leaf is cut into units of `unit_rows` rows; its units add their LDS histograms
 // to the (zeroed) slot and grow_scatter moves the rows.  The split search follows as scan_blocks.
-constexpr int kGrowThreads = 512;
+#ifndef LGA_GROW_THREADS
+#define LGA_GROW_THREADS 512
+#endif
+constexpr int kGrowThreads = LGA_GROW_THREADS;
 constexpr int kGrowThreadsWide = 1024;   // full-precision histograms (GrowArgs::wide)
 constexpr int kSubRows = 2048;        // rows per block of 32 mask words (4 rows per thread)
-constexpr int kSoloMaxRows = 8192;    // rows of a non-root unit / upper bound of the solo limit: sixteen rows per lane, one trip
+constexpr int kSoloMaxRows = 4096;    // upper bound of the solo limit: eight rows per lane (four with 1024 threads), one trip (the measured best limit is 2048; 8192 here cost sixteen row registers and spills)
 constexpr int kFlagBlocks = 1;        // blocks of kPartChunk rows a working workgroup of grow_flags_kernel takes (measured: 4 is slower - a big leaf's launch is one wave of workgroups either way, and fewer, longer workgroups only serialise it)
 constexpr int kGrowListRows = 3072;   // LDS list of a unit's histogram rows (worked off in windows of this many)
 struct GrowArgs {
@@ -164,7 +167,7 @@ struct GrowArgs {
   PoolLayout pool;
   RoundSlots round;
   int32_t F;
-  int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows; <= kSoloMaxRows, the root's <= kMaxRowsPerPass)
+  int32_t unit_rows;        // rows per unit of a multi-unit leaf (multiple of kSubRows; <= kMaxUnitRows, or kMaxUnitRowsWide with full-precision cells)
   uint64_t* mask;           // [mask block][32]: go-left bits of multi-unit leaves, read by grow_scatter
   int32_t* chunk_left;      // [mask block]
   int32_t* task_left;       // [task of the round]: rows that went left

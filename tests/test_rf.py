@@ -69,3 +69,53 @@ def test_forest_grown_in_parts_equals_the_forest_grown_in_one_go(freq):
     a, b = whole.model_to_string(), merged.model_to_string()
     assert a[a.index("Tree=0"):a.index("end of trees")] == b[b.index("Tree=0"):b.index("end of trees")]
     np.testing.assert_allclose(merged.predict(X), whole.predict(X), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_tree_parallel_forest_over_processes_equals_the_one_process_forest(P, tmp_path):
+    """bagging_boosting.ipynb:11 - bagged trees "are fitted in parallel": P processes (gloo) each grow their share of
+    the iterations on the full table, the parts are gathered and merged on every rank; the forest equals the one a
+    single process grows, tree for tree, and so do its predictions.  Also runs the 1 M x 50 example's multi-rank
+    path (rf tree-parallel, gbdt data-parallel) at a small size."""
+    import os, socket, subprocess, sys, textwrap
+    root = os.path.join(os.path.dirname(__file__), "..")
+    script = tmp_path / "forest_rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys
+        import numpy as np, torch.distributed as dist
+        sys.path.insert(0, %r)
+        import lightgbm_amd as lgb
+        from lightgbm_amd.parallel import train_forest_tree_parallel
+        from lightgbm_amd.utils.datasets import make_regression
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        CPU = {"device_type": "cpu", "verbose": -1}
+        X, y = make_regression(4000, 8, seed=12)
+        p = {**CPU, "boosting": "rf", "num_leaves": 31, "bagging_fraction": 0.63, "bagging_freq": 1,
+             "feature_fraction": 0.8, "min_data_in_leaf": 5}
+        merged = train_forest_tree_parallel(p, X, y, 13)
+        assert merged.num_trees() == 13
+        if rank == 0:
+            whole = lgb.train(p, lgb.Dataset(X, label=y, params=CPU), 13)
+            a, b = whole.model_to_string(), merged.model_to_string()
+            assert a[a.index("Tree=0"):a.index("end of trees")] == b[b.index("Tree=0"):b.index("end of trees")]
+            np.testing.assert_allclose(merged.predict(X), whole.predict(X), rtol=1e-12, atol=1e-12)
+        texts = [None] * world
+        dist.all_gather_object(texts, merged.model_to_string())
+        assert all(t == texts[0] for t in texts)
+        dist.destroy_process_group()
+        print("rank", rank, "ok", flush=True)
+    """) % root)
+
+    def launch(args):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}",
+                               "--master-addr", "127.0.0.1", "--master-port", str(port), *args],
+                              capture_output=True, text=True, timeout=280)
+    r = launch([str(script)])
+    assert r.returncode == 0 and r.stdout.count("ok") == P, r.stdout[-2000:] + r.stderr[-2000:]
+    if P == 2:
+        r = launch([os.path.join(root, "examples", "rf_vs_gbdt_1m.py"), "--rows", "20000", "--features", "10", "--trees", "8",
+                    "--leaves", "15", "--device", "cpu"])
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "tree-parallel, 2 ranks x 4 trees" in r.stdout and "data-parallel, 2 ranks x 10000 rows" in r.stdout, r.stdout
