@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--rows", type=int, default=400_000)
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--trees", type=int, default=20)
-    ap.add_argument("--leaves", type=int, default=63)
+    ap.add_argument("--leaves", type=int, default=255)
     ap.add_argument("--grid", type=int, default=0, help="evaluate this many grid points instead of one model")
     ap.add_argument("--device", default=lgb.default_device())
     args = ap.parse_args()
@@ -42,8 +42,9 @@ def main():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group("nccl" if args.device == "gpu" else "gloo")
     X, y = make_epsilon_like(args.rows, args.features, seed=7)       # the same data on every rank
-    base = {"objective": "binary", "num_leaves": args.leaves, "min_data_in_leaf": 50, "max_bin": 255,
-            "learning_rate": 0.1, "verbose": -1, "device_type": args.device}
+    # the settings of upstream's GPU benchmark: 255 leaves, 255 bins, min_data_in_leaf 1, min_sum_hessian_in_leaf 100
+    base = {"objective": "binary", "num_leaves": args.leaves, "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 100.0,
+            "max_bin": 255, "learning_rate": 0.1, "verbose": -1, "device_type": args.device}
     if args.grid <= 0:
         p = {**base, "tree_learner": "feature" if world > 1 else "serial", "metric": "auc"}
         from lightgbm_amd.parallel import default_comm
@@ -62,7 +63,7 @@ def main():
             comm.close()
     else:
         from lightgbm_amd.grid import expand_grid, grid_search_cv, grid_search_cv_distributed, rank_grid
-        grid = expand_grid(iteration=None, score=None, learning_rate=[0.2, 0.1], num_leaves=[15, 31, 63, 127],
+        grid = expand_grid(iteration=None, score=None, learning_rate=[0.2, 0.1], num_leaves=[31, 63, 127, 255],
                            min_data_in_leaf=[20, 100], lambda_l2=[0.0, 1.0], feature_fraction=[0.5, 1.0])
         grid = grid[: args.grid]
         t = time.time()

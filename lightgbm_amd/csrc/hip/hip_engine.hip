@@ -267,6 +267,8 @@ class HipBackend : public TreeBackend {
     if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(kMaxRoundsInFlight, std::atoi(e)));
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
+    scan_pairs_ = F_ > 4 * kTileFeatures;
+    if (const char* e = std::getenv("LGA_SCAN_PAIRS")) scan_pairs_ = std::atoi(e) != 0;
     tree_kernel_rows_ = std::min<int64_t>(k::kTreeMaxRows, cfg.whole_tree_max_rows);
     if (const char* e = std::getenv("LGA_TREE_KERNEL_ROWS"))
       tree_kernel_rows_ = std::max<int64_t>(0, std::min<int64_t>(k::kTreeMaxRows, std::atoll(e)));
@@ -925,6 +927,9 @@ class HipBackend : public TreeBackend {
       sa.range.group_size = g;
       sa.range.n_blocks = std::max(1, (owned + g - 1) / g);
     }
+    // wide data: the search is bound by the histogram bytes it moves - both children of a split in one workgroup
+    // read the fresh row once instead of twice (LGA_SCAN_PAIRS=0 / 1 overrides the width rule)
+    sa.pairs = (!root && scan_pairs_) ? 1 : 0;
     sa.my_rank = lay_.ranks > 1 ? comm_->rank() : 0;
     sa.node_totals = node_totals_.get();
     sa.scan_totals = x.scan_totals.get();
@@ -1196,6 +1201,7 @@ class HipBackend : public TreeBackend {
   bool tree_prepared_ = false, tree_launched_ = false, tree_wide_valid_ = false;
   int tree_renew_ = 0;
   bool wide_ = false;                 // full-precision (36-bit) histograms
+  bool scan_pairs_ = false;           // split search: both children of a split per workgroup (wide data)
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
   // LGA_GROW_TIMING=1: phase profile of the non-root growth kernels, printed when the backend goes away

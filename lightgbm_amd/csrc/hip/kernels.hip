@@ -681,7 +681,29 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
     }
   }
   __syncthreads();
-  flush_lds_hist<WIDE>(lds, nf, tile * kTileFeatures, L, slot, kThreads);
+  // A child that fits one chunk has this workgroup as the only writer of the tile's feature blocks: plain coalesced
+  // stores instead of two global atomics per non-empty cell (rounds of many small leaves on wide data were bound by
+  // those atomics: 16 k of them per workgroup whatever the row count).
+  const bool own_blocks = t.num_hchunk == 1;
+  if (own_blocks) {
+    for (int i = threadIdx.x; i < kTileFeatures * kMaxBins; i += kThreads) {
+      int fe, b;
+      flush_item(i, fe, b);
+      if (fe >= nf) continue;
+      const int cell = hist_cell(fe, b);
+      int64_t* blk = feat_block(L, slot, tile * kTileFeatures + fe);
+      if (WIDE) {
+        blk[b] = (int64_t)lds[cell];
+        blk[kMaxBins + b] = (int64_t)lds[kWidePlane + cell];
+      } else {
+        const unsigned long long v = lds[cell];
+        blk[b] = (int64_t)(int32_t)(v >> 32);
+        blk[kMaxBins + b] = (int64_t)(v & 0xffffffffull);
+      }
+    }
+  } else {
+    flush_lds_hist<WIDE>(lds, nf, tile * kTileFeatures, L, slot, kThreads);
+  }
   if (blockIdx.y == 0) {
     // header: rows, sum g, sum h of this child (the first tile's workgroups see every row once)
     sg = wave_sum_i64(sg);
@@ -693,7 +715,14 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
       long long tg = 0, th = 0;
 #pragma unroll
       for (int w = 0; w < kThreads / kWave; ++w) { tg += red[0][w]; th += red[1][w]; }
-      add_slot_header(L, slot, hi - lo, tg, th);
+      if (own_blocks) {
+        for (int rk = 0; rk < L.ranks; ++rk) {
+          int64_t* hdw = slot_header(L, slot, rk);
+          hdw[0] = hi - lo; hdw[1] = tg; hdw[2] = th;
+        }
+      } else {
+        add_slot_header(L, slot, hi - lo, tg, th);
+      }
     }
   }
 }
@@ -716,35 +745,48 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
   const int node = a.root ? 0 : (side == 0 ? t.left_node : t.right_node);
   const uint32_t key = a.root ? kRootNodeKey : child_node_key((uint32_t)t.parent_key, side);
   const SlotRef fresh = new_slot_ref(a.pool, a.round, t.new_slot);
-  const SlotRef self = direct ? fresh : old_slot_ref(a.pool, t.parent_slot);
-  int64_t tc, tg, th;
-  {
-    const int64_t* hd = slot_header(a.pool, fresh, a.my_rank);
-    tc = hd[0]; tg = hd[1]; th = hd[2];
-    if (!direct) {
-      const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
-      tc = pt[0] - tc; tg = pt[1] - tg; th = pt[2] - th;
-    }
+  // Everything the search needs from memory is requested before the first wait: the child's totals (and the parent's),
+  // the scales, the parent's slot address and the first feature's description, then that feature's cells - the leaf
+  // context's fp64 arithmetic runs while the cells are on their way.  In program order (totals, context, description,
+  // slot address, cells) a small round's search was four dependent memory round trips long; this way it is two.
+  const int group = a.range.group_first + b * a.range.group_step;
+  const int f0 = a.range.f_begin + group * a.range.group_size;
+  const int f1 = min(f0 + a.range.group_size, a.range.f_end);
+  const int f_first = f0 + wave;
+  const int64_t* hd = slot_header(a.pool, fresh, a.my_rank);
+  int64_t tc = hd[0], tg = hd[1], th = hd[2];
+  int64_t pc = 0, pg = 0, ph = 0;
+  if (!direct) {
+    const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
+    pc = pt[0]; pg = pt[1]; ph = pt[2];
   }
   const QuantScale q = *a.qs;
+  const SlotRef self = direct ? fresh : old_slot_ref(a.pool, t.parent_slot);
+  FeatureMeta m_first{};
+  if (f_first < f1) m_first = a.meta[f_first];
+  int64_t g[4], h[4], cg[4], ch[4];
+  const bool first_loaded = f_first < f1 && m_first.enabled;
+  if (first_loaded) {
+    const int bpl = bins_per_lane(m_first.num_bin);
+    load_feat_cells(feat_block(a.pool, self, f_first), lane, bpl, g, h);
+    if (!direct) load_feat_cells(feat_block(a.pool, fresh, f_first), lane, bpl, cg, ch);
+  }
+  if (!direct) { tc = pc - tc; tg = pg - tg; th = ph - th; }
   const LeafScanCtx ctx = node_scan_ctx(tg, th, tc, q, a.sp, node);
   const double ninf = -std::numeric_limits<double>::infinity();
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
-  const int group = a.range.group_first + b * a.range.group_step;
-  const int f0 = a.range.f_begin + group * a.range.group_size;
-  const int f1 = min(f0 + a.range.group_size, a.range.f_end);
-  for (int f = f0 + wave; f < f1; f += 8) {
-    const FeatureMeta m = a.meta[f];
+  for (int f = f_first; f < f1; f += 8) {
+    const FeatureMeta m = f == f_first ? m_first : a.meta[f];
     if (!m.enabled) continue;
-    int64_t g[4], h[4];
     int64_t* blk = feat_block(a.pool, self, f);
     const int bpl = bins_per_lane(m.num_bin);
-    load_feat_cells(blk, lane, bpl, g, h);
+    if (f != f_first) {
+      load_feat_cells(blk, lane, bpl, g, h);
+      if (!direct) load_feat_cells(feat_block(a.pool, fresh, f), lane, bpl, cg, ch);
+    }
     if (!direct) {
-      int64_t cg[4], ch[4];
-      load_feat_cells(feat_block(a.pool, fresh, f), lane, bpl, cg, ch);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
       store_feat_cells(blk, lane, bpl, g, h);
@@ -805,6 +847,128 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
     int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
     for (int i = threadIdx.x; i < n_left; i += 512) tl[i] = a.task_left[i];
     if (threadIdx.x == 0) *reinterpret_cast<QuantScale*>(tl + n_left) = q;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(a.host_out) = a.seq;
+  }
+}
+
+// The same search with BOTH children of a split in one workgroup (wide data, where the search is bound by the
+// histogram bytes it moves): per feature the fresh child's row and the parent's row are read once, the sibling is
+// derived in registers, written to the parent's slot (which it inherits) and both are searched - 3 slot-rows of
+// traffic per split and feature instead of 4 (the one-child form reads the fresh row twice).  Workgroup (t, b) takes
+// feature block b of task t; its results are scan tasks 2t + hist_child (the fresh child) and 2t + 1 - hist_child.
+__global__ __launch_bounds__(512) void scan_pairs_kernel(InlineTasks inl, ScanArgs a) {
+  __shared__ Cand wbest[2][8];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int ti = blockIdx.x;
+  const SplitTask t = load_task(a.tasks, inl, ti);
+  const SlotRef fresh = new_slot_ref(a.pool, a.round, t.new_slot);
+  const SlotRef parent = old_slot_ref(a.pool, t.parent_slot);
+  // k = 0: the child whose histogram was built; k = 1: its sibling
+  int64_t tc[2], tg[2], th[2];
+  int node[2], sidx[2];
+  uint32_t key[2];
+  {
+    const int64_t* hd = slot_header(a.pool, fresh, a.my_rank);
+    const int64_t* pt = a.node_totals + (int64_t)t.parent_node * 4;
+    tc[0] = hd[0]; tg[0] = hd[1]; th[0] = hd[2];
+    tc[1] = pt[0] - tc[0]; tg[1] = pt[1] - tg[0]; th[1] = pt[2] - th[0];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int side = k == 0 ? t.hist_child : 1 - t.hist_child;
+    node[k] = side == 0 ? t.left_node : t.right_node;
+    key[k] = child_node_key((uint32_t)t.parent_key, side);
+    sidx[k] = 2 * (a.task0 + ti) + side;
+  }
+  const QuantScale q = *a.qs;
+  const LeafScanCtx ctx0 = node_scan_ctx(tg[0], th[0], tc[0], q, a.sp, node[0]);
+  const LeafScanCtx ctx1 = node_scan_ctx(tg[1], th[1], tc[1], q, a.sp, node[1]);
+  const double ninf = -std::numeric_limits<double>::infinity();
+  double bg[2] = {ninf, ninf};
+  uint64_t bkey[2] = {~0ull, ~0ull};
+  int64_t blg[2] = {0, 0}, blh[2] = {0, 0};
+  const int group = a.range.group_first + b * a.range.group_step;
+  const int f0 = a.range.f_begin + group * a.range.group_size;
+  const int f1 = min(f0 + a.range.group_size, a.range.f_end);
+  for (int f = f0 + wave; f < f1; f += 8) {
+    const FeatureMeta m = a.meta[f];
+    if (!m.enabled) continue;
+    const int bpl = bins_per_lane(m.num_bin);
+    int64_t cg[4], ch[4], sg[4], sh[4];
+    int64_t* pblk = feat_block(a.pool, parent, f);
+    load_feat_cells(feat_block(a.pool, fresh, f), lane, bpl, cg, ch);
+    load_feat_cells(pblk, lane, bpl, sg, sh);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sg[j] -= cg[j]; sh[j] -= ch[j]; }
+    store_feat_cells(pblk, lane, bpl, sg, sh);
+    if (m.categorical == kCategoricalSorted) continue;
+    if (node_feature_on(a.sp, key[0], f, a.F) && node_allows(a.sp, node[0], f))
+      scan_cells_wave(f, lane, bpl, cg, ch, m, ctx0, a.sp, bg[0], bkey[0], blg[0], blh[0], key[0]);
+    if (node_feature_on(a.sp, key[1], f, a.F) && node_allows(a.sp, node[1], f))
+      scan_cells_wave(f, lane, bpl, sg, sh, m, ctx1, a.sp, bg[1], bkey[1], blg[1], blh[1], key[1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    wave_best(bg[k], bkey[k], blg[k], blh[k]);
+    if (lane == 0) wbest[k][wave] = Cand{bg[k], bkey[k], blg[k], blh[k]};
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_last = 0;
+    const int nb = a.range.n_blocks;
+    for (int k = 0; k < 2; ++k) {
+      for (int w = 1; w < 8; ++w) take_better(bg[k], bkey[k], blg[k], blh[k], wbest[k][w].gain, wbest[k][w].key, wbest[k][w].lg, wbest[k][w].lh);
+      if (b == 0) {
+        int64_t* nt = a.node_totals + (int64_t)node[k] * 4;
+        nt[0] = tc[k]; nt[1] = tg[k]; nt[2] = th[k]; nt[3] = 0;
+        int64_t* st = a.scan_totals + (int64_t)sidx[k] * 4;
+        st[0] = tc[k]; st[1] = tg[k]; st[2] = th[k]; st[3] = 0;
+      }
+      if (nb > 1) a.block_best[(int64_t)sidx[k] * nb + b] = Cand{bg[k], bkey[k], blg[k], blh[k]};
+    }
+    bool have_winner = true;
+    if (nb > 1) {
+      // one ticket per task serves both children (they always arrive together)
+      have_winner = release_and_ticket(&a.tickets[sidx[0]]) == (unsigned)(nb - 1);
+      if (have_winner) {
+        acquire_after_ticket();
+        a.tickets[sidx[0]] = 0u;
+        for (int k = 0; k < 2; ++k) {
+          bg[k] = ninf; bkey[k] = ~0ull; blg[k] = 0; blh[k] = 0;
+          for (int i = 0; i < nb; ++i) {
+            const Cand c = a.block_best[(int64_t)sidx[k] * nb + i];
+            take_better(bg[k], bkey[k], blg[k], blh[k], c.gain, c.key, c.lg, c.lh);
+          }
+        }
+      }
+    }
+    if (have_winner) {
+      if (a.best_out) {
+        for (int k = 0; k < 2; ++k) a.best_out[sidx[k]] = Cand{bg[k], bkey[k], blg[k], blh[k]};   // distributed: all-gather + merge_winners follow
+      } else {
+        for (int k = 0; k < 2; ++k) write_split(&a.results[sidx[k]], bg[k], bkey[k], blg[k], blh[k], tc[k], tg[k], th[k], q, a.sp);
+        if (release_and_ticket(a.done_counter) == (unsigned)(a.n_tasks - 1)) {
+          acquire_after_ticket();
+          *a.done_counter = 0u;
+          s_last = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  {
+    int64_t* out = reinterpret_cast<int64_t*>(a.host_out + kHostDataOffset);
+    const int64_t* res = reinterpret_cast<const int64_t*>(a.results);
+    const int words = a.n_scan * (int)(sizeof(SplitInfo) / 8);
+    for (int i = threadIdx.x; i < words; i += 512) out[i] = res[i];
+    int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
+    for (int i = threadIdx.x; i < a.n_tasks; i += 512) tl[i] = a.task_left[i];
+    if (threadIdx.x == 0) *reinterpret_cast<QuantScale*>(tl + a.n_tasks) = q;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(a.host_out) = a.seq;
@@ -2057,7 +2221,12 @@ void build_row_lines(const uint8_t* bins_rt_tile0, int64_t N, uint8_t* lines, hi
 void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hipStream_t s) {
   if (launch_scan <= 0) return;
   if (a.range.n_blocks < 1) throw std::runtime_error("split search needs at least one feature block");
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(launch_scan, a.range.n_blocks), dim3(512), 0, s, inl, a);
+  if (a.pairs && !a.root) {
+    if (launch_scan != 2 * a.n_tasks || a.task0 != 0) throw std::runtime_error("paired split search takes a round's tasks whole");
+    hipLaunchKernelGGL(scan_pairs_kernel, dim3(a.n_tasks, a.range.n_blocks), dim3(512), 0, s, inl, a);
+  } else {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(launch_scan, a.range.n_blocks), dim3(512), 0, s, inl, a);
+  }
   LGA_LAUNCH_CHECK();
 }
 

@@ -200,6 +200,7 @@ struct ScanArgs {
   int32_t n_scan;           // scan tasks of the whole round: 2 x tasks, or 1 (root)
   int32_t n_tasks;          // tasks of the whole round
   int32_t root;
+  int32_t pairs;            // 1: one workgroup searches both children of a split (scan_pairs_kernel; wide data)
   const FeatureMeta* meta;
   int32_t F;
   PoolLayout pool;

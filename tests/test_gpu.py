@@ -567,19 +567,26 @@ def test_gpu_binary_matches_cpu_quality_and_first_tree():
     assert abs(ec["training"]["binary_logloss"][-1] - eg["training"]["binary_logloss"][-1]) < 1e-3
 
 
-def test_gpu_quantised_auc_matches_the_full_precision_cpu_learner():
-    """The device learner (16-bit gradient histograms, leaf values from 36-bit sums) against the CPU engine with
-    36-bit gradient histograms on held-out rows of a Higgs-like task: |AUC difference| <= 0.001.
-    (bench/auc_parity.py runs the same comparison at 1 M rows x 200 trees of 255 leaves.)"""
+def test_gpu_auc_against_the_full_precision_cpu_learner_over_several_data_draws():
+    """Held-out AUC on a Higgs-like task over three data draws.  The device engine with full-precision histograms
+    (``use_quantized_grad=false``) takes the CPU full-precision learner's split decisions: the AUCs agree to 1e-9 on
+    every draw.  The 16-bit learner's MEAN difference stays inside 0.001 (single pairs of two boosting runs drift by
+    several 1e-4 at this size, so one pair says little).  The record at the benchmark's own size - 10.5 M rows, 500
+    trees, five draws - is profiles/r3/auc_parity_500trees.txt (bench/auc_parity_multi.py)."""
     from sklearn.metrics import roc_auc_score
-    X, y = make_higgs_like(250000, seed=21, device="numpy")
-    tr, te = slice(0, 200000), slice(200000, None)
-    p = {"objective": "binary", "num_leaves": 127, "learning_rate": 0.1, "min_sum_hessian_in_leaf": 20.0, "verbose": -1}
-    g = lgb.train({**p, "device_type": "gpu"}, lgb.Dataset(X[tr], label=y[tr], params={**p, "device_type": "gpu"}), 80)
-    c = lgb.train({**p, "device_type": "cpu", "use_quantized_grad": False},
-                  lgb.Dataset(X[tr], label=y[tr], params={**p, "device_type": "cpu"}), 80)
-    ag, ac = roc_auc_score(y[te], g.predict(X[te])), roc_auc_score(y[te], c.predict(X[te]))
-    assert abs(ag - ac) <= 0.001, (ag, ac)
+    diffs = []
+    for seed in (21, 22, 23):
+        X, y = make_higgs_like(250000, seed=seed, device="numpy")
+        tr, te = slice(0, 200000), slice(200000, None)
+        p = {"objective": "binary", "num_leaves": 127, "learning_rate": 0.1, "min_sum_hessian_in_leaf": 20.0, "verbose": -1}
+        auc = {}
+        for name, dev, quant in (("gpu q16", "gpu", True), ("gpu full", "gpu", False), ("cpu full", "cpu", False)):
+            q = {**p, "device_type": dev, "use_quantized_grad": quant}
+            b = lgb.train(q, lgb.Dataset(X[tr], label=y[tr], params=q), 80)
+            auc[name] = roc_auc_score(y[te], b.predict(X[te], device="cpu"))
+        assert abs(auc["gpu full"] - auc["cpu full"]) < 1e-9, (seed, auc)
+        diffs.append(auc["gpu q16"] - auc["cpu full"])
+    assert abs(np.mean(diffs)) <= 0.001 and max(abs(d) for d in diffs) <= 0.003, diffs
 
 
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
@@ -878,6 +885,46 @@ def test_gpu_data_parallel_over_feature_tiles_and_idle_owners(P, F, leaves, monk
         assert trees_of(s) == trees_of(serial)
 
 
+@pytest.mark.parametrize("exchange,precision", [("allreduce", "q16"), ("reduce_scatter", "q16"), ("allreduce", "full"), ("reduce_scatter", "full")])
+def test_gpu_data_parallel_with_shards_that_cross_the_size_gates_by_themselves(exchange, precision, monkeypatch):
+    """Four ranks with 330 k rows each (no size gate forced through the environment): every shard ALONE takes the
+    row-line kernels with multi-unit leaves, dense units and the tree-walk score update of its rank's engine, in both
+    exchanges and both histogram precisions; every rank ends with the serial learner's trees."""
+    monkeypatch.setenv("LGA_DP_EXCHANGE", exchange)
+    P, n = 4, 1_320_000
+    X, y = make_regression(n, 28, seed=31)
+    q = {"use_quantized_grad": precision == "q16"}
+    params = {**GPU, **q, "num_leaves": 127, "min_data_in_leaf": 20}
+    sample = X[:: max(1, n // 200000)]
+    serial = lgb.train(params, lgb.Dataset(X, label=y, bin_sample=sample, params=GPU), 5)
+    bounds = np.linspace(0, n, P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=sample, params=GPU)
+        return lgb.train({**params, "tree_learner": "data"}, d, 5, comm=comm).model_to_string()
+    for s in _run_ranks(P, rank):
+        assert trees_of(s) == trees_of(serial)
+
+
+@pytest.mark.parametrize("precision", ["q16", "full"])
+def test_gpu_feature_parallel_at_the_epsilon_width_with_eight_ranks(precision):
+    """BASELINE config 5's learner: 2000 dense features (63 feature tiles) dealt over EIGHT feature-parallel ranks
+    (loop-back communicator on one GPU; every rank holds all rows, histograms and searches its tiles, 32-byte winners
+    are all-gathered) at the GPU-benchmark settings (255 leaves, 255 bins, min_sum_hessian 100): the serial trees."""
+    from lightgbm_amd.utils.datasets import make_epsilon_like
+    X, y = make_epsilon_like(40000, 2000, seed=3)
+    X, y = X.numpy(), y.numpy()
+    params = {**GPU, "objective": "binary", "num_leaves": 255, "max_bin": 255, "min_data_in_leaf": 1,
+              "min_sum_hessian_in_leaf": 100.0, "use_quantized_grad": precision == "q16"}
+    # (the first iteration's gradients involve no device-specific exp() rounding either way: all ranks are this device)
+    serial = lgb.train(params, lgb.Dataset(X, label=y, params=params), 3)
+    res = _run_ranks(8, lambda r, c: lgb.train({**params, "tree_learner": "feature"},
+                                               lgb.Dataset(X, label=y, params=params), 3, comm=c).model_to_string())
+    for s in res:
+        assert trees_of(s) == trees_of(serial)
+
+
 def test_gpu_feature_parallel_equals_serial():
     X, y = make_regression(10000, 100, seed=9)
     params = {**GPU, "num_leaves": 31}
@@ -1074,6 +1121,18 @@ def test_multi_process_data_parallel_sharing_one_gpu(P, tmp_path):
     assert len(lines) == 1, r.stdout            # rank 0 alone reports
     out = json.loads(lines[0])
     assert out["n_gpus"] == P and out["steps"] == 4 and out["value"] > 0 and out["config"]["rows"] == 300000
+    if P == 2:
+        # without a launcher bench.py starts its rank processes itself (before touching the GPU)
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "300000", "--steps", "3",
+                            "--warmup", "1", "--no-full-run", "--precision", "q16"],
+                           capture_output=True, text=True, timeout=170, env=dict(env, LGA_BENCH_BACKEND="gloo"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["config"]["comm_ranks"] == 2 and out["config"]["precision"] == "q16"
+        assert "MI355X" in out["config"]["device"]
 
 
 def test_grid_search_with_worker_processes_on_the_gpu(tmp_path):
