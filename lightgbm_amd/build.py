@@ -30,7 +30,7 @@ HOST_SOURCES = [
 HOST_ONLY = ["engine_factory_host.cpp"]
 HIP_SOURCES = [
     "hip/kernels.hip", "hip/tree_kernel.hip", "hip/hip_engine.hip", "hip/predict.hip", "hip/binning.hip", "hip/rccl_comm.cpp",
-    "hip/engine_factory_hip.cpp", "hip/hip_api.hip", "hip/ops.hip", "hip/loopback_comm.hip", "hip/bin_find.hip", "hip/sort.hip", "hip/auc.hip", "hip/ranking.hip",
+    "hip/engine_factory_hip.cpp", "hip/hip_api.hip", "hip/ops.hip", "hip/loopback_comm.hip", "hip/bin_find.hip", "hip/sort.hip", "hip/auc.hip", "hip/ranking.hip", "hip/locality.hip",
 ]
 
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-parameter",

@@ -198,6 +198,7 @@ struct RoundingSpec {
   uint64_t salt;       // added to the row id (distributed learners: ranks draw different numbers for their local rows)
   int32_t stochastic;  // 0: round to nearest
   int32_t pad;
+  const int32_t* ext_ids;   // device engine with its rows in a private order: position -> the caller's row id (else null)
 };
 LGA_HD float rng_uniform(uint64_t seed, uint64_t stream, uint64_t index);
 // which: 0 gradient, 1 hessian
@@ -207,7 +208,7 @@ LGA_HD int32_t quantize_with(float v, int k, const RoundingSpec& r, int which, u
   const float lim = (float)(1 << kQuantBits);
   if (s > lim) s = lim;
   if (s < -lim) s = -lim;
-  const double u = (double)rng_uniform(r.seed, r.stream * 2u + (uint64_t)which, r.salt + row);
+  const double u = (double)rng_uniform(r.seed, r.stream * 2u + (uint64_t)which, r.salt + (r.ext_ids ? (uint64_t)(uint32_t)r.ext_ids[row] : row));
   return (int32_t)floor((double)s + u);
 }
 

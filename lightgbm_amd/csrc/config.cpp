@@ -121,6 +121,7 @@ const ParamDef kParams[] = {
     P(max_batch_leaves, "", Int, 0, kNone),
     P(whole_tree_max_rows, "gpu_whole_tree_max_rows", Int, 0, 65536),
     P(profile, "", Bool, kNone, kNone),
+    P(locality_order, "", Bool, kNone, kNone),
     P(device_bin_find, "", Bool, kNone, kNone),
     P(iteration_offset, "", Int, 0, kNone),
     P(early_stopping_min_delta, "", Double, 0, kNone),

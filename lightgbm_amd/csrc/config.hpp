@@ -122,6 +122,7 @@ struct Config {
   int max_batch_leaves = 0;   // 0: as many leaves per growth round as the budget allows
   int whole_tree_max_rows = 65536;   // device: bags up to this many rows are grown by the one-workgroup whole-tree kernel (0: never)
   bool profile = false;
+  bool locality_order = true;   // device engine, large single-tile data: private copies of the bins in a locality order of the rows
   int iteration_offset = 0;       // number the iterations from here: the random streams (bagging, feature
                                   // sampling) of iteration k are the same wherever that iteration is trained
   bool device_bin_find = true;   // device-resident raw matrices: find bin boundaries on the GPU

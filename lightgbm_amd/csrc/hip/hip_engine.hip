@@ -7,6 +7,7 @@
 #include "../cat_search.hpp"
 #include "../percentile.hpp"
 #include "sort.hpp"
+#include "locality.hpp"
 #include <algorithm>
 #include <dlfcn.h>
 #include <chrono>
@@ -604,9 +605,10 @@ class HipBackend : public TreeBackend {
 
   // Row partition used for bagging: base rows -> [bag | out-of-bag] in `out`; returns the bag size.
   int64_t bag_partition(const int32_t* base_rows, int64_t n, int32_t* out, double fraction, uint64_t seed,
-                        uint64_t iter, uint64_t salt) {
+                        uint64_t iter, uint64_t salt, const int32_t* ext_ids = nullptr) {
     k::BagParams bp{};
     bp.seed = seed; bp.iter = iter; bp.salt = salt; bp.fraction = (float)fraction;
+    bp.ext_ids = ext_ids;
     return sample_partition(base_rows, n, out, -1, bp);
   }
 
@@ -1295,7 +1297,26 @@ class HipEngine : public Engine {
     upload_meta(train_->root(), mir_);
     n_base_ = train_->num_data();
     base_rows_.resize((size_t)std::max<int64_t>(n_base_, 1));
-    if (train_->used_indices())
+    // Locality order (locality.hpp): large tables of one feature tile, trained whole, get private copies of their
+    // matrices in an order that keeps the rows of a deep leaf together.  From here on `mir_` is that private copy, a
+    // "root row" inside this engine is a position in it, and base_rows_ (dataset row -> root row) carries the mapping.
+    {
+      bool want = cfg.locality_order && n_base_ >= kLocalityMinRows;
+      if (const char* e = std::getenv("LGA_LOCALITY_ORDER")) want = std::atoi(e) != 0 && n_base_ > k::kTreeMaxRows;
+      want = want && !train_->used_indices() && train_->num_tiles() == 1 && train_->query_boundaries().empty() &&
+             mode != ParallelMode::Feature;
+      if (want) {
+        own_mir_.reset(new DeviceMirror());
+        locality_ = build_locality_mirror(*mir_, train_->feature_meta(), own_mir_.get(), &order_, stream_);
+        if (locality_) mir_ = own_mir_.get();
+        else own_mir_.reset();
+      }
+    }
+    if (locality_) {
+      LGA_HIP_CHECK(hipMemcpyAsync(base_rows_.get(), order_.int_of_ext.get(), sizeof(int32_t) * (size_t)n_base_, hipMemcpyDeviceToDevice, stream_));
+      iter_rows_.resize((size_t)n_base_);
+      k::iota(iter_rows_.get(), n_base_, stream_);
+    } else if (train_->used_indices())
       LGA_HIP_CHECK(hipMemcpyAsync(base_rows_.get(), train_->used_indices()->data(), sizeof(int32_t) * (size_t)n_base_,
                                    hipMemcpyHostToDevice, stream_));
     else
@@ -1312,10 +1333,17 @@ class HipEngine : public Engine {
       init_score_dev_.upload(train_->root_init_score().data(), train_->root_init_score().size(), stream_);
       has_init_ = true;
       init_per_class_ = (int64_t)train_->root_init_score().size() == (int64_t)K_ * N_ && K_ > 1;
+      if (locality_) {   // root order -> this engine's order, class by class
+        const size_t vectors = train_->root_init_score().size() / (size_t)N_;
+        DeviceBuffer<double> ordered(vectors * (size_t)N_);
+        for (size_t v = 0; v < vectors; ++v)
+          gather_rows_f64(init_score_dev_.get() + v * (size_t)N_, order_.ext_of_int.get(), N_, ordered.get() + v * (size_t)N_, stream_);
+        init_score_dev_ = std::move(ordered);
+      }
     }
     backend_.reset(new HipBackend(train_.get(), mir_, cfg, comm, mode, n_base_));
     if (backend_->mode() == ParallelMode::Data) grower_.set_row_shards(comm->size());
-    bag_ptr_ = base_rows_.get();
+    bag_ptr_ = all_rows();
     bag_n_ = n_base_;
     oob_n_ = 0;
     // Large single-tile datasets get a private copy of the bin records interleaved with the packed
@@ -1563,16 +1591,17 @@ class HipEngine : public Engine {
   }
 
   void resample(double fraction, uint64_t seed, uint64_t iter, double neg_fraction) override {
-    if (fraction >= 1.0 && (neg_fraction < 0.0 || neg_fraction >= 1.0)) { bag_ptr_ = base_rows_.get(); bag_n_ = n_base_; oob_n_ = 0; return; }
+    if (fraction >= 1.0 && (neg_fraction < 0.0 || neg_fraction >= 1.0)) { bag_ptr_ = all_rows(); bag_n_ = n_base_; oob_n_ = 0; return; }
     uint64_t salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
     if (neg_fraction >= 0.0) {
       k::BagParams bp{};
       bp.seed = seed; bp.iter = iter; bp.salt = salt; bp.fraction = (float)fraction;
       bp.label = mir_->label.get();
       bp.neg_fraction = (float)neg_fraction;
-      bag_n_ = backend_->sample_partition(base_rows_.get(), n_base_, bag_rows_.get(), -3, bp);
+      bp.ext_ids = ext_ids();
+      bag_n_ = backend_->sample_partition(all_rows(), n_base_, bag_rows_.get(), -3, bp);
     } else {
-      bag_n_ = backend_->bag_partition(base_rows_.get(), n_base_, bag_rows_.get(), fraction, seed, iter, salt);
+      bag_n_ = backend_->bag_partition(all_rows(), n_base_, bag_rows_.get(), fraction, seed, iter, salt, ext_ids());
     }
     bag_ptr_ = bag_rows_.get();
     oob_n_ = n_base_ - bag_n_;
@@ -1591,7 +1620,8 @@ class HipEngine : public Engine {
     bp.seed = seed; bp.iter = iter; bp.salt = dist() ? ((uint64_t)comm_->rank() << 40) : 0;
     bp.fraction = plan.keep_prob;
     bp.g = grad_.get(); bp.h = hess_.get(); bp.threshold = threshold; bp.num_class = K_; bp.stride = N_;
-    bag_n_ = backend_->sample_partition(base_rows_.get(), n_base_, bag_rows_.get(), -2, bp);
+    bp.ext_ids = ext_ids();
+    bag_n_ = backend_->sample_partition(all_rows(), n_base_, bag_rows_.get(), -2, bp);
     bag_ptr_ = bag_rows_.get();
     oob_n_ = n_base_ - bag_n_;
     k::goss_amplify(grad_.get(), hess_.get(), K_, N_, bag_ptr_, bag_n_, threshold, plan.multiplier, stream_);
@@ -1612,12 +1642,13 @@ class HipEngine : public Engine {
     if (!have_max_) k::absmax(gr(), he(), base_or_null(), n_base_, maxbits_.get(), stream_);
     if (dist()) comm_->allreduce_max_f32(reinterpret_cast<float*>(maxbits_.get()), 2, true, stream_);
     backend_->set_bag(bag_ptr_, bag_n_);
-    const RoundingSpec rounding = rounding_spec(cfg_, tree_index_, dist() ? comm_->rank() : 0);
+    RoundingSpec rounding = rounding_spec(cfg_, tree_index_, dist() ? comm_->rank() : 0);
+    rounding.ext_ids = ext_ids();
     if (use_lines_) {
       backend_->set_lines(lines_.get());
       backend_->set_root_quant(gr(), he(), maxbits_.get(), rounding);
     } else {
-      k::quantize(gr(), he(), bag_ptr_ == base_rows_.get() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
+      k::quantize(gr(), he(), bag_ptr_ == all_rows() ? base_or_null() : bag_ptr_, bag_n_, maxbits_.get(),
                   backend_->qs_device(), packed_.get(), backend_->wide(), rounding, stream_);
       backend_->set_packed(packed_.get(), mir_->bins_rt.get());
     }
@@ -2175,6 +2206,15 @@ class HipEngine : public Engine {
   int64_t tree_index_ = 0;
   // rows == nullptr lets an elementwise kernel index rows directly (the training set is the whole root)
   const int32_t* base_or_null() const { return train_->used_indices() ? base_rows_.get() : nullptr; }
+  // the training rows as a list for the kernels that walk them (the root's row list, the source of a bag): in the
+  // engine's own order when it has one (base_rows_ then maps dataset rows to it and is for gathers to the outside)
+  const int32_t* all_rows() const { return locality_ ? iter_rows_.get() : base_rows_.get(); }
+  const int32_t* ext_ids() const { return locality_ ? order_.ext_of_int.get() : nullptr; }
+  static constexpr int64_t kLocalityMinRows = 1 << 20;
+  bool locality_ = false;
+  std::unique_ptr<DeviceMirror> own_mir_;   // the private, reordered copies (mir_ points here then)
+  LocalityOrder order_;
+  DeviceBuffer<int32_t> iter_rows_;         // 0 .. n - 1
   const int32_t* bag_ptr_ = nullptr;
   DeviceBuffer<int32_t> base_rows_, bag_rows_;
   static constexpr int64_t kWalkMinRows = 1 << 20;

@@ -258,7 +258,7 @@ __device__ __forceinline__ bool goes_left(const SplitTask& t, const uint8_t* __r
   if (t.feature < 0) {
     if (t.feature == -2 && goss_weight(bag.g, bag.h, row, bag.num_class, bag.stride) >= *bag.threshold) return true;
     const float keep = (t.feature == -3 && !(bag.label[row] > 0.0f)) ? bag.neg_fraction : bag.fraction;
-    return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)row) < keep;
+    return rng_uniform(bag.seed, bag.iter, bag.salt + (uint64_t)(uint32_t)(bag.ext_ids ? bag.ext_ids[row] : row)) < keep;
   }
   int b = bins_fm[(int64_t)t.feature * N + row];
   if (t.default_left == kCategoricalTask) return b == t.threshold;

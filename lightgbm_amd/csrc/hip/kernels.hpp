@@ -114,6 +114,7 @@ struct BagParams {
   const float* label = nullptr;         // feature -3 (balanced bagging): rows with label > 0 stay with probability
   float neg_fraction = 0.0f;            // `fraction`, the others with `neg_fraction`
   const uint64_t* cat_sets = nullptr;   // growth rounds: kCatSetWords words per node, read for kCategoricalSetTask
+  const int32_t* ext_ids = nullptr;     // rows in a private order: position -> the caller's row id, which keys the random draws
 };
 // tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.
 // zero_ptr/zero_words: int64 range the partition workgroups clear on the way (the round's new histogram slots).

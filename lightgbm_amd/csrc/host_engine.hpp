@@ -25,6 +25,7 @@ inline RoundingSpec rounding_spec(const Config& cfg, int64_t tree_index, int ran
   r.seed = mix64((uint64_t)(uint32_t)cfg.seed * 0x9e3779b97f4a7c15ull + 0x51edull);
   r.stream = (uint64_t)tree_index;
   r.salt = (uint64_t)rank << 40;
+  r.ext_ids = nullptr;
   return r;
 }
 

@@ -589,6 +589,58 @@ def test_gpu_auc_against_the_full_precision_cpu_learner_over_several_data_draws(
     assert abs(np.mean(diffs)) <= 0.001 and max(abs(d) for d in diffs) <= 0.003, diffs
 
 
+@pytest.mark.parametrize("case", ["plain", "bagging", "goss", "weights_init", "custom", "stochastic", "multiclass", "full_dart"])
+def test_locality_order_changes_nothing_but_the_memory_layout(case, monkeypatch):
+    """The device engine's private locality order of the rows (on by default from 2^20 rows; forced here at 150 k):
+    the trees are the CPU engine's - which knows no such order - bit for bit, with bagging, GOSS and stochastic
+    rounding (their random streams stay keyed by the caller's row numbers), weights and initial scores (reordered on
+    the way in), custom gradients (scattered on the way in), multiclass score vectors and dart's tree replays; the
+    training scores come back in the caller's row order."""
+    rng = np.random.RandomState(17)
+    n = 150000
+    X = rng.randn(n, 9)
+    X[:, 8] = rng.randint(0, 4, size=n)
+    y = X[:, 0] * 1.5 + np.abs(X[:, 1]) - 0.7 * X[:, 2] * (X[:, 0] > 0) + 0.3 * (X[:, 8] == 2) + 0.1 * rng.randn(n)
+    p = {"num_leaves": 63, "min_data_in_leaf": 5, "boost_from_average": False, "learning_rate": 0.2}
+    kw, dkw, rounds = {}, {}, 5
+    if case == "bagging":
+        p.update(bagging_fraction=0.6, bagging_freq=1, feature_fraction=0.8)
+    elif case == "goss":
+        p.update(data_sample_strategy="goss", top_rate=0.2, other_rate=0.1, learning_rate=0.5)
+    elif case == "weights_init":
+        dkw = {"weight": 0.5 + rng.rand(n), "init_score": 0.3 * X[:, 3]}
+        p.update(objective="huber")
+    elif case == "custom":
+        kw = {"fobj": lambda preds, d: (preds - d.get_label() + 0.1 * np.sign(preds), np.full(len(preds), 1.25))}
+    elif case == "stochastic":
+        p.update(stochastic_rounding=True, seed=5, bagging_fraction=0.8, bagging_freq=2)
+    elif case == "multiclass":
+        y = (np.digitize(y, np.quantile(y, [0.33, 0.66]))).astype(float)
+        p.update(objective="multiclass", num_class=3)
+        rounds = 3
+    elif case == "full_dart":
+        p.update(use_quantized_grad=False, boosting="dart", drop_rate=0.5, skip_drop=0.0)
+        rounds = 7
+
+    def fit(dev):
+        base = {"device_type": dev, "verbose": -1}
+        d = lgb.Dataset(X, label=y, params=base, **dkw)
+        b = lgb.train({**base, **p}, d, rounds, keep_training_booster=True, **kw)
+        return b
+    a = fit("cpu")
+    monkeypatch.setenv("LGA_LOCALITY_ORDER", "1")
+    b = fit("gpu")
+    monkeypatch.setenv("LGA_LOCALITY_ORDER", "0")
+    c = fit("gpu")
+    assert trees_of(b) == trees_of(c)                       # the order changes nothing ...
+    if case != "multiclass":                                # (softmax goes through exp(): last-bit differences vs libm)
+        assert trees_of(a) == trees_of(b)                   # ... and the trees are the CPU engine's
+    raw_b, raw_c = b._inner_predict(-1, raw=True), c._inner_predict(-1, raw=True)
+    np.testing.assert_allclose(raw_b, raw_c, rtol=0, atol=1e-12)       # scores in the caller's row order
+    if case in ("plain", "bagging", "stochastic"):
+        np.testing.assert_allclose(raw_b, b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
+
+
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
 def test_gpu_multiclass_matches_cpu(objective):
     """num_class score / gradient vectors on the device: the first iteration (scores all zero, so the

@@ -97,6 +97,7 @@ NOTES = {
     "header": "command line, text data files: the first line holds column names",
     "max_batch_leaves": "leaves split per device round (0: as many as the speculative growth wants; 1 reproduces one-leaf-at-a-time growth)",
     "profile": "per-phase HIP-event timers, read with `Booster.profile()`",
+    "locality_order": "device engine, data of one feature tile with at least 2^20 rows and no row subset: the booster keeps private copies of the binned matrices in the order of a coarse key over the features whose bins explain the label best, so that the rows of a deep leaf sit in runs instead of being spread over the table (same trees, bit for bit; the random streams of bagging / GOSS / stochastic rounding stay keyed by the caller's row numbers)",
     "device_bin_find": "find bin boundaries on the device for GPU datasets (default on)",
     "deterministic": "always on: integer histograms make every run, engine and rank count give the same trees",
     "verbosity": "alias kept for LightGBM configs; see `verbose`",
