@@ -59,6 +59,21 @@ __device__ __forceinline__ void publish_max(uint32_t* target, float v) {
   const uint32_t bits = __float_as_uint(v);   // non-negative floats order like their bit patterns
   if (bits > __atomic_load_n(target, __ATOMIC_RELAXED)) atomicMax(target, bits);
 }
+// The two running maxima (|g|, h) of a 256-thread workgroup -> ONE atomic each per workgroup (thousands of waves
+// publishing to the same two words at once queue up behind each other for tens of microseconds: the fused score
+// update + gradients pass over a 1.3 M-row shard took 68 us with one atomic per wave, 30 us this way).
+__device__ __forceinline__ void publish_block_max(uint32_t* maxbits, float mg, float mh) {
+  __shared__ float wg_max[2][4];
+  mg = wave_max_f32(mg);
+  mh = wave_max_f32(mh);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { wg_max[0][wave] = mg; wg_max[1][wave] = mh; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    publish_max(&maxbits[0], fmaxf(fmaxf(wg_max[0][0], wg_max[0][1]), fmaxf(wg_max[0][2], wg_max[0][3])));
+    publish_max(&maxbits[1], fmaxf(fmaxf(wg_max[1][0], wg_max[1][1]), fmaxf(wg_max[1][2], wg_max[1][3])));
+  }
+}
 template <int WAVES>
 __device__ __forceinline__ double block_sum_f64(double v, double* lds_scratch) {
   v = wave_sum_f64(v);
@@ -118,12 +133,7 @@ __global__ __launch_bounds__(256) void gradients_kernel(ObjectiveSpec obj, const
       }
     }
   }
-  mg = wave_max_f32(mg);
-  mh = wave_max_f32(mh);
-  if ((threadIdx.x & 63) == 0) {
-    publish_max(&maxbits[0], mg);
-    publish_max(&maxbits[1], mh);
-  }
+  publish_block_max(maxbits, mg, mh);
 }
 
 __global__ __launch_bounds__(256) void multiclass_gradients_kernel(ObjectiveSpec obj, const double* __restrict__ scores,
@@ -216,12 +226,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ g
     mg = fmaxf(mg, fabsf(g[r]));
     mh = fmaxf(mh, h[r]);
   }
-  mg = wave_max_f32(mg);
-  mh = wave_max_f32(mh);
-  if ((threadIdx.x & 63) == 0) {
-    publish_max(&maxbits[0], mg);
-    publish_max(&maxbits[1], mh);
-  }
+  publish_block_max(maxbits, mg, mh);
 }
 
 // Full-precision histograms (WIDE): a row's 8-byte gradient word holds the float bit patterns themselves (gradient
@@ -1874,12 +1879,7 @@ __global__ __launch_bounds__(256) void leaf_value_add_gradients_kernel(Objective
       }
     }
   }
-  mg = wave_max_f32(mg);
-  mh = wave_max_f32(mh);
-  if ((threadIdx.x & 63) == 0) {
-    publish_max(&maxbits[0], mg);
-    publish_max(&maxbits[1], mh);
-  }
+  publish_block_max(maxbits, mg, mh);
 }
 
 __global__ __launch_bounds__(256) void scale_add_kernel(double* __restrict__ scores, const int32_t* __restrict__ rows,
@@ -2298,6 +2298,8 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
   static const int lds_rows = std::getenv("LGA_WALK_LDS") ? std::atoi(std::getenv("LGA_WALK_LDS")) : 2;
   if (records && (lds_rows == 2 || lds_rows == 4)) {
     const size_t sm_rows = sm + (size_t)lds_rows * 256 * 36;
+    // (every workgroup ends by adding its leaves' sums to the same 2 x num_leaves words, yet fewer, longer workgroups
+    // measure slower: 4096 -> 3.16, 1024 -> 3.22, 512 -> 3.34 ms per tree on the 10.5 M x 28 benchmark)
     const dim3 grid(grid_for(n, 256 * lds_rows, 4096));
     auto launch = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, grid, dim3(256), sm_rows, s, nodes, n_internal, num_leaves, reinterpret_cast<const uint4*>(records), N,
