@@ -268,6 +268,12 @@ class HipBackend : public TreeBackend {
     if (const char* e = std::getenv("LGA_ROUNDS_IN_FLIGHT")) n_ctx_ = prof.on ? 1 : std::max(1, std::min(kMaxRoundsInFlight, std::atoi(e)));
     if (const char* e = std::getenv("LGA_SOLO_ROWS"))
       solo_rows_ = std::max(k::kSubRows, std::min(k::kSoloMaxRows, std::atoi(e)));
+    single_pass_partition_ = !(std::getenv("LGA_TWO_PASS_PARTITION") && std::atoi(std::getenv("LGA_TWO_PASS_PARTITION")) != 0);
+    if (const char* e = std::getenv("LGA_PART_ROWS")) part_rows_forced_ = std::atoi(e);
+    if (part_rows_forced_ != 0 && part_rows_forced_ != 2048 && part_rows_forced_ != 4096 && part_rows_forced_ != 8192)
+      throw std::invalid_argument("LGA_PART_ROWS: 2048, 4096 or 8192");
+    if (const char* e = std::getenv("LGA_PART_ROWS4K_ABOVE")) part_rows4k_above_ = std::atoll(e);
+    if (const char* e = std::getenv("LGA_PART_ROWS8K_ABOVE")) part_rows8k_above_ = std::atoll(e);
     scan_pairs_ = F_ > 4 * kTileFeatures;
     if (const char* e = std::getenv("LGA_SCAN_PAIRS")) scan_pairs_ = std::atoi(e) != 0;
     tree_kernel_rows_ = std::min<int64_t>(k::kTreeMaxRows, cfg.whole_tree_max_rows);
@@ -298,6 +304,8 @@ class HipBackend : public TreeBackend {
         LGA_HIP_CHECK(hipEventCreateWithFlags(&x.ev_reduced, hipEventDisableTiming));
       }
       x.mask.resize((size_t)max_pchunks_ * (k::kPartChunk / 64));
+      x.part_cursor.resize(((size_t)max_batch_ + 1) * k::kPartCursorStride);
+      x.part_cursor.zero(stream_);
       x.chunk_left.resize((size_t)max_pchunks_);
       x.task_left.resize((size_t)max_batch_ + 1);
       x.stage_host.resize(stage_bytes_);
@@ -665,6 +673,7 @@ class HipBackend : public TreeBackend {
     bool owns_stream = false;
     hipEvent_t ev_ready = nullptr, ev_reduced = nullptr;   // hand-over to / from the collectives' stream
     DeviceBuffer<uint64_t> mask;
+    DeviceBuffer<unsigned long long> part_cursor;  // single-pass partition: the tasks' reservation cursors (zero between rounds)
     DeviceBuffer<int32_t> chunk_left, task_left;
     DeviceBuffer<char> stage_dev;
     PinnedBuffer<char> stage_host;
@@ -769,11 +778,18 @@ class HipBackend : public TreeBackend {
     ur = std::max<int64_t>(k::kSubRows, std::min<int64_t>(ur, (max_unit_rows_ / k::kSubRows) * k::kSubRows));
     const int unit_rows = (int)ur;
     int np = 0;
+    if (single_pass_partition_ && !root) {
+      // the blocks of one leaf reserve their room through one cursor: a round with a large leaf takes larger blocks
+      // (fewer atomics on that one address), a round of many middling leaves smaller ones (more workgroups per leaf)
+      int64_t largest = 0;
+      for (const auto& t : tasks) largest = std::max<int64_t>(largest, ranges_host_[(size_t)t.parent_node].count);
+      part_chunk_ = part_rows_forced_ ? part_rows_forced_ : largest > part_rows8k_above_ ? 8192 : largest > part_rows4k_above_ ? 4096 : 2048;
+    }
     for (auto& t : tasks) {
       const int64_t cnt = root ? bag_n_ : ranges_host_[(size_t)t.parent_node].count;
       const bool multi = root || cnt > solo_limit;
       t.first_pchunk = np;
-      t.num_pchunk = (multi && !root) ? ceil_div(cnt, k::kPartChunk) : 0;
+      t.num_pchunk = (multi && !root) ? ceil_div(cnt, part_chunk_) : 0;
       t.num_hchunk = multi ? std::max(1, ceil_div(hist_bound(t), unit_rows)) : 1;
       np += t.num_pchunk;
       if (np > max_pchunks_) throw std::runtime_error("chunk table overflow");
@@ -808,7 +824,11 @@ class HipBackend : public TreeBackend {
     a.wide = wide_ ? 1 : 0;
     a.qs = qs_dev_.get();
     a.phase_ticks = (!root && grow_timing_) ? grow_ticks() : nullptr;
-    if (np > 0) {
+    if (np > 0 && single_pass_partition_) {
+      a.part_cursor = x.part_cursor.get();
+      a.part_block_rows = part_chunk_;
+      k::grow_partition(inl, a, np, st_);
+    } else if (np > 0) {
       k::grow_flags(inl, a, np, st_);
       k::grow_scatter(staged, a.n_staged, inl, np, nodes_.get(), src0, arena_[1].get(), arena_[0].get(), arena_[1].get(),
                       x.mask.get(), x.chunk_left.get(), x.task_left.get(), st_);
@@ -1204,6 +1224,10 @@ class HipBackend : public TreeBackend {
   int tree_renew_ = 0;
   bool wide_ = false;                 // full-precision (36-bit) histograms
   bool scan_pairs_ = false;           // split search: both children of a split per workgroup (wide data)
+  int part_chunk_ = k::kPartChunk;    // rows per partition workgroup of the row-lines rounds (single pass: chosen per round)
+  int part_rows_forced_ = 0;          // LGA_PART_ROWS: rows per workgroup of the single-pass partition, 0 = by the round's largest leaf
+  int64_t part_rows4k_above_ = 1 << 20, part_rows8k_above_ = 1 << 22;
+  bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
   // LGA_GROW_TIMING=1: phase profile of the non-root growth kernels, printed when the backend goes away

@@ -1106,6 +1106,99 @@ __global__ __launch_bounds__(kPartThreads) void grow_flags_kernel(InlineTasks in
   if (timed && tid == 0) atomicAdd(&a.phase_ticks[12], 1ull);
 }
 
+// Single-pass partition of the multi-unit leaves (kernels.hpp: grow_partition).  A block of kPartChunk rows keeps its
+// rows in registers, counts its lefts and rights and reserves room for both with ONE 64-bit atomic add on its leaf's
+// cursor (lefts in the low word, rights in the high one): lefts fill the leaf's range from the front, rights from
+// the END backwards, so no block ever waits for another.  The block whose reservation completes the leaf's row count
+// knows the total of the lefts, writes the children's ranges and puts the cursor back to zero for the next round.
+template <int U, int T>   // rows per thread, threads
+__global__ __launch_bounds__(T) void grow_partition_kernel(InlineTasks inl, GrowArgs a) {
+  constexpr int kPartThreads = T, kPartChunk = U * T;   // shadow the two-launch partition's shape
+  constexpr int kWords = kPartChunk / kWave;
+  constexpr int kWaves = kPartThreads / kWave;
+  constexpr int kPerLane = (kWords + kWave - 1) / kWave;   // mask words a lane of the scanning wave sums
+  static_assert(kWords % kPerLane == 0 && kWords / kPerLane <= kWave, "one wave scans the block's mask words");
+  __shared__ unsigned long long smask[kWords];
+  __shared__ int word_prefix[kWords + 1];
+  __shared__ int s_before[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wg = blockIdx.x;
+  const int ti = a.tasks ? find_task_staged<true>(a.tasks, a.n_staged, wg) : find_task<true>(inl, wg);
+  const SplitTask t = load_task(a.tasks, inl, ti);
+  const int c = wg - t.first_pchunk;
+  if (c >= t.num_pchunk) return;
+  const NodeRange p = a.nodes[t.parent_node];
+  const int32_t* src = (p.buf ? a.a1 : a.a0) + p.begin;
+  int32_t* dst = (p.buf ? a.a0_dst : a.a1_dst) + p.begin;
+  const uint8_t* fcol = a.bins_fm + (int64_t)t.feature * a.N;
+  const int base = c * kPartChunk;
+  const int in_block = min(kPartChunk, p.count - base);
+  int row[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int pos = base + k * kPartThreads + tid;
+    row[k] = pos < p.count ? src[pos] : -1;
+    // a row id outside the table still has to be PLACED (the counts must add up to the leaf's): it goes right
+    if (row[k] >= 0) LGA_DEV_CHECK((unsigned)row[k] < (unsigned long long)a.N, kCheckPartitionRow, row[k], a.N);
+  }
+  int bin[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) bin[k] = (unsigned)row[k] < (unsigned)a.N ? (int)fcol[row[k]] : -1;
+  unsigned long long mine[U];
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const bool left = bin[k] >= 0 && bin_goes_left(t, bin[k], a.cat_sets);
+    mine[k] = __ballot(left);
+    if (lane == 0) smask[k * kWaves + wave] = mine[k];
+  }
+  __syncthreads();
+  if (tid < kWave) {
+    constexpr int kLanes = kWords / kPerLane;
+    int pcs[kPerLane], pc = 0;
+#pragma unroll
+    for (int q = 0; q < kPerLane; ++q) { pcs[q] = tid < kLanes ? __popcll(smask[tid * kPerLane + q]) : 0; pc += pcs[q]; }
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < kLanes; d <<= 1) {
+      const int o = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += o;
+    }
+    if (tid < kLanes) {
+      int run = incl - pc;
+#pragma unroll
+      for (int q = 0; q < kPerLane; ++q) { word_prefix[tid * kPerLane + q] = run; run += pcs[q]; }
+    }
+    if (tid == kLanes - 1) {
+      const int own = incl, own_right = in_block - own;
+      const unsigned long long before = atomicAdd(&a.part_cursor[ti * kPartCursorStride], (unsigned long long)own | ((unsigned long long)own_right << 32));
+      const int lb = (int)(before & 0xffffffffull), rb = (int)(before >> 32);
+      s_before[0] = lb;
+      s_before[1] = rb;
+      if (lb + rb + in_block == p.count) {   // the leaf's last reservation: this block knows the children's sizes
+        const int all = lb + own;
+        a.nodes[t.left_node] = NodeRange{p.begin, all, 1 - p.buf, 0};
+        a.nodes[t.right_node] = NodeRange{p.begin + all, p.count - all, 1 - p.buf, 0};
+        a.task_left[ti] = all;
+        a.part_cursor[ti * kPartCursorStride] = 0ull;
+      }
+    }
+  }
+  __syncthreads();
+  const int lefts_before = s_before[0], rights_before = s_before[1];
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    if (row[k] >= 0) {
+      const int w = k * kWaves + wave;
+      const int in_chunk = w * kWave + lane;
+      const bool left = (mine[k] >> lane) & 1ull;
+      const int lrank = word_prefix[w] + __popcll(mine[k] & below);
+      const int d = left ? lefts_before + lrank : p.count - 1 - (rights_before + (in_chunk - lrank));
+      if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = row[k];
+    }
+  }
+}
+
 // WIDE (full-precision histograms): the rows' gradient words are float bit patterns, converted to 36-bit fixed point in
 // every pass and added as TWO 64-bit LDS atomics per (row, feature) into separate gradient and hessian planes - 128 KiB
 // of LDS, so a CU holds one workgroup, which therefore has 16 waves instead of 8.  No cell can overflow.
@@ -2152,6 +2245,18 @@ void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool
   LGA_GROW_CASE(false, false, true, true) LGA_GROW_CASE(false, false, true, false)
   LGA_GROW_CASE(false, false, false, true) LGA_GROW_CASE(false, false, false, false)
 #undef LGA_GROW_CASE
+  LGA_LAUNCH_CHECK();
+}
+
+void grow_partition(const InlineTasks& inl, const GrowArgs& a, int total_chunks, hipStream_t s) {
+  if (total_chunks <= 0) return;
+  if (!a.part_cursor) throw std::runtime_error("single-pass partition without its cursors");
+  switch (a.part_block_rows) {
+    case 2048: hipLaunchKernelGGL((grow_partition_kernel<8, 256>), dim3(total_chunks), dim3(256), 0, s, inl, a); break;
+    case 4096: hipLaunchKernelGGL((grow_partition_kernel<16, 256>), dim3(total_chunks), dim3(256), 0, s, inl, a); break;
+    case 8192: hipLaunchKernelGGL((grow_partition_kernel<8, 1024>), dim3(total_chunks), dim3(1024), 0, s, inl, a); break;
+    default: throw std::runtime_error("single-pass partition: blocks of 2048, 4096 or 8192 rows");
+  }
   LGA_LAUNCH_CHECK();
 }
 

@@ -11,6 +11,7 @@ namespace k {
 
 constexpr int kPartChunk = 2048;    // rows per partition workgroup (256 threads x 8)
 constexpr int kPartThreads = 256;
+constexpr int kPartCursorStride = 16;   // 64-bit words between the reservation cursors of two tasks
 constexpr int kHistThreads = 512;   // 8 waves; 64 KiB LDS histogram -> 2 workgroups per CU
 constexpr int kHistThreadsWide = 1024;   // full-precision histograms: 128 KiB of LDS -> 1 workgroup of 16 waves per CU
 
@@ -177,9 +178,21 @@ struct GrowArgs {
   int32_t wide;             // 1: full-precision histograms - the lines' gradient words are float bit patterns, added as 36-bit fixed point
   const QuantScale* qs;     // wide, non-root rounds: the exponents the root pass published
   unsigned long long* phase_ticks;   // LGA_GROW_TIMING: [8] sums of the workgroups' phase durations (100 MHz ticks), else null
+  // single-pass partition (grow_partition): per task [rights reserved : 32 | lefts reserved : 32], zero between rounds,
+  // kPartCursorStride words apart (atomics on one 128-byte line queue up behind each other: measured, 32 leaves' cursors
+  // on 2 lines cost as much as one leaf's)
+  unsigned long long* part_cursor;
+  int32_t part_block_rows;           // 2048, 4096 or 8192 rows per workgroup
 };
 // Sides of the rows of the multi-unit leaves (total_chunks blocks of kPartChunk rows): masks + left counts for grow_scatter.
 void grow_flags(const InlineTasks& inl, const GrowArgs& a, int total_chunks, hipStream_t s);
+// Sides AND row movement of the multi-unit leaves in ONE launch (instead of grow_flags + grow_scatter): a block of
+// kPartChunk rows keeps its rows in registers, reserves room for its lefts and rights with one atomic add on the
+// leaf's cursor and moves its rows right away - lefts to the front of the leaf's range, rights to its END backwards
+// (the total of the lefts is only known to the block that reserves last, which writes the children's ranges).  The
+// blocks of a leaf land in the order of their reservations: nothing depends on the order of the rows inside a leaf
+// (the histograms are integer sums).
+void grow_partition(const InlineTasks& inl, const GrowArgs& a, int total_chunks, hipStream_t s);
 // root: the single task's "leaf" is node 0 and nothing is partitioned.  total_units = sum of the tasks' units.
 void grow_round(const InlineTasks& inl, const GrowArgs& a, int total_units, bool root, hipStream_t s);
 // Moves the rows of the multi-unit leaves of a grow_round launch (total_chunks mask blocks).

@@ -10,4 +10,5 @@ export TMPDIR=/tmp
 rm -rf /tmp/kt_$TAG && timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/kt_$TAG -o kt -- python $ROOT/bench.py --steps 32 --warmup 100 --no-full-run "$@" > "$OUT/bench.json" 2> /tmp/kt_$TAG.log
 DB="$(find /tmp/kt_$TAG -name '*.db' | sort | tail -1)"
 python $ROOT/tools/rocpd_stats.py "$DB" "$OUT/kernel_stats.csv" > /dev/null
+python $ROOT/tools/rocpd_rounds.py "$DB" "$OUT/rounds_last_tree.csv" > /dev/null || true
 head -12 "$OUT/kernel_stats.csv"
