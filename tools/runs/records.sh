@@ -1,17 +1,27 @@
 #!/bin/bash
-# The records named by the benchmark configurations, one GPU: bagging vs boosting on 1 M x 50, the Epsilon-shaped wide
-# data (serial, with a per-kernel trace), and the collection of tools/collect_profiles.sh.
+# The records of a round on one MI355X, written under gpurun_out/r3/final/ (copy what is to be kept into profiles/):
+#   tools/runs/records.sh            everything (about 4 minutes)
 set -e -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}
-OUT=$ROOT/gpurun_out/${1:-rec}
+OUT=$ROOT/gpurun_out/r3/final
 mkdir -p "$OUT"
-cd /tmp
-export TMPDIR=/tmp
-timeout -k 10 300 python -u $ROOT/examples/rf_vs_gbdt_1m.py > "$OUT/rf_vs_gbdt_1m.log" 2>&1 || { tail -20 "$OUT/rf_vs_gbdt_1m.log"; exit 1; }
-grep -v amdgpu.ids "$OUT/rf_vs_gbdt_1m.log" | tail -6
-timeout -k 10 400 python -u $ROOT/examples/epsilon_feature_parallel.py > "$OUT/epsilon_serial.log" 2>&1 || { tail -20 "$OUT/epsilon_serial.log"; exit 1; }
-grep -v amdgpu.ids "$OUT/epsilon_serial.log" | tail -6
-rm -rf /tmp/ktE && timeout -k 10 400 rocprofv3 --kernel-trace --stats -d /tmp/ktE -o kt -- python $ROOT/examples/epsilon_feature_parallel.py --trees 8 > /tmp/ktE.log 2>&1 || { tail -20 /tmp/ktE.log; exit 1; }
-python $ROOT/tools/rocpd_stats.py "$(find /tmp/ktE -name '*.db' | sort | tail -1)" "$OUT/kernel_stats_epsilon_8trees.csv" > /dev/null
-echo "epsilon kernel trace done"
-head -12 "$OUT/kernel_stats_epsilon_8trees.csv"
+cd "$ROOT"
+echo "== 500-tree benchmark, both precisions"
+timeout -k 10 300 python bench.py --steps 500 --warmup 5 > "$OUT/bench_1gpu_500trees.json"
+cut -c1-220 "$OUT/bench_1gpu_500trees.json"
+echo "== kernel statistics (32 trees after 100), full precision / 16-bit"
+bash tools/runs/kstats.sh final_full --no-other-precision > /dev/null
+bash tools/runs/kstats.sh final_q16 --precision q16 --no-other-precision > /dev/null
+bash tools/runs/kstats.sh final_shard_full --rows 1312500 --no-other-precision > /dev/null
+for t in final_full final_q16 final_shard_full; do
+  mkdir -p "$OUT/kstats_$t" && cp gpurun_out/r3/kstats_$t/* "$OUT/kstats_$t/"
+  echo "-- $t: $(cut -c1-200 gpurun_out/r3/kstats_$t/bench.json | grep -o '"ms_per_step": [0-9.]*')"; head -8 gpurun_out/r3/kstats_$t/kernel_stats.csv
+done
+echo "== LDS counters of the growth kernels"
+bash tools/runs/pmc_lds.sh final_full --no-other-precision > /dev/null
+cp gpurun_out/r3/pmc_final_full/pmc_sq_lds.csv "$OUT/pmc_sq_lds_full.csv"
+grep -E "grow_kernel.*(LDS_BANK_CONFLICT|ACTIVE_INST_LDS|INSTS_LDS)" "$OUT/pmc_sq_lds_full.csv" | head -8
+echo "== upstream's GPU-benchmark shapes"
+timeout -k 10 400 python tools/runs/wide_shapes.py --precision full > "$OUT/wide_shapes_full.txt"
+timeout -k 10 400 python tools/runs/wide_shapes.py --precision q16 > "$OUT/wide_shapes_q16.txt"
+cat "$OUT/wide_shapes_full.txt" "$OUT/wide_shapes_q16.txt" | cut -c1-110
