@@ -145,51 +145,6 @@ def main():
     lo = n_total * rank // world
     hi = n_total * (rank + 1) // world
     X, y = make_higgs_like(hi - lo, seed=1234 + rank, device="cuda" if on_gpu else "cpu")
-    if os.environ.get("LGA_BENCH_SORT_COLS"):
-        # experiment: rows stored in the order of a coarse key over some columns (the model does not depend on the row
-        # order; the memory locality of deep leaves does)
-        levels = int(os.environ.get("LGA_BENCH_SORT_LEVELS", "8"))
-        spec = os.environ["LGA_BENCH_SORT_COLS"]
-        if spec.startswith("model"):
-            # rows in the order of the leaves they fall into in the first k trees of a pilot model
-            import numpy as np
-            import lightgbm_amd as lgb0
-            k = int(spec[5:] or 2)
-            pp = {"objective": "binary", "num_leaves": 255, "max_bin": 255, "learning_rate": 0.1, "min_data_in_leaf": 1,
-                  "min_sum_hessian_in_leaf": 100.0, "verbose": -1, "device_type": "gpu"}
-            pilot = lgb0.train(pp, lgb0.Dataset(X, label=y, params=pp), k)
-            leaves = np.asarray(pilot.predict(X.cpu().numpy(), pred_leaf=True)).reshape(X.shape[0], -1)
-            key_np = np.zeros(X.shape[0], dtype=np.int64)
-            for j in range(leaves.shape[1]):
-                key_np = key_np * 256 + leaves[:, j]
-            order = torch.as_tensor(np.argsort(key_np, kind="stable"), device=X.device)
-            X, y = X[order].contiguous(), y[order].contiguous()
-            del pilot
-            cols = []
-        elif spec.startswith("auto"):
-            # the k columns whose 16-quantile bins explain most of the label's variance, best first
-            k = int(spec[4:] or 6)
-            sub = slice(None, None, 53)
-            ys = y[sub].float()
-            score = []
-            for c in range(X.shape[1]):
-                xs = X[sub, c].float()
-                q = torch.quantile(xs[::7], torch.linspace(0, 1, 17, device=X.device)[1:-1])
-                b = torch.bucketize(xs, q)
-                cnt = torch.bincount(b, minlength=16).float().clamp_min(1)
-                mean = torch.bincount(b, weights=ys, minlength=16) / cnt
-                score.append(float((cnt * (mean - ys.mean()) ** 2).sum()))
-            cols = sorted(range(X.shape[1]), key=lambda c: -score[c])[:k]
-            print("sort columns", cols, file=sys.stderr)
-        else:
-            cols = [int(c) for c in spec.split(",")]
-        key = torch.zeros(X.shape[0], dtype=torch.int64, device=X.device)
-        for c in cols:
-            q = torch.quantile(X[::97, c].float(), torch.linspace(0, 1, levels + 1, device=X.device)[1:-1])
-            key = key * levels + torch.bucketize(X[:, c].contiguous(), q)
-        if cols:
-            order = torch.argsort(key)
-            X, y = X[order].contiguous(), y[order].contiguous()
     params = {
         "objective": "binary", "num_leaves": args.leaves, "max_bin": 255, "learning_rate": 0.1,
         "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 100.0, "verbose": -1, "device_type": "gpu" if on_gpu else "cpu",
