@@ -116,6 +116,10 @@ class TreeGrower {
   double spec_lo_ = 0.2, spec_hi_ = 0.95;
   double spec_rows_lo_ = 131072.0, spec_rows_hi_ = 2097152.0;
   int row_shards_ = 1;
+  // A round costs its latency whatever it holds: one that the rules above leave nearly empty is filled with the best
+  // held-back leaves of at most fill_leaf_rows_ rows each, up to fill_rows_ rows in the round (LGA_FILL_ROWS,
+  // LGA_FILL_LEAF_ROWS; 0 rows: off).  Trees whose gains fall short of the previous tree's otherwise run one leaf per round.
+  double fill_rows_ = 524288.0, fill_leaf_rows_ = 131072.0;
   bool certain_splits_ = true;   // split leaves whose turn is certain ahead of time (LGA_CERTAIN_SPLITS=0: gain estimates only)
   double own_round_rows_ = 262144.0;   // leaves of at least this many rows (per rank) get a round of their own while places are free (LGA_OWN_ROUND_ROWS)
   bool spec_ratio_ = true;        // scale the previous cutoff by the ratio of the roots' best gains

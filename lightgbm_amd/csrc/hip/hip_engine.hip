@@ -10,6 +10,7 @@
 #include "locality.hpp"
 #include <algorithm>
 #include <dlfcn.h>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -473,6 +474,7 @@ class HipBackend : public TreeBackend {
   bool round_done(int ticket) override {
     if (distributed() || prof.on) return true;   // every rank replays the rounds in submission order
     const RoundCtx& x = ctx_[ticket];
+    if (x.direct && !x.root) return direct_done(x, 2 * (int)x.tasks.size());
     return *reinterpret_cast<const volatile unsigned*>(x.host_block.get()) == x.seq;
   }
 
@@ -685,6 +687,7 @@ class HipBackend : public TreeBackend {
     unsigned seq = 0;
     // the round in flight
     bool busy = false, root = false;
+    bool direct = false;   // the round's searches hand their results over one by one (ScanArgs::direct)
     std::vector<SplitTask> tasks;
     std::chrono::steady_clock::time_point t_begin, t_launched;
     unsigned* done_counter() const { return counters.get(); }
@@ -946,6 +949,8 @@ class HipBackend : public TreeBackend {
       const int want_blocks = std::max(1, 1024 / std::max(1, sa.n_scan));
       int g = (owned + want_blocks - 1) / want_blocks;
       g = std::max(8, ((g + 7) / 8) * 8);
+      // (ONE block per child for small rounds - no block ticket, no merge of the blocks' winners, a wave takes four
+      // features in turn - measured slower: 2.97 -> 3.04-3.17 ms per tree at 10.5 M rows, 1.67 -> 1.72-1.80 at 1.3 M)
       sa.range.group_size = g;
       sa.range.n_blocks = std::max(1, (owned + g - 1) / g);
     }
@@ -964,6 +969,8 @@ class HipBackend : public TreeBackend {
     sa.host_out = x.host_block.device_ptr();
     sa.done_counter = x.done_counter();
     sa.seq = x.seq;
+    sa.direct = (!root && !distributed() && direct_results_) ? 1 : 0;
+    x.direct = sa.direct != 0;
     return sa;
   }
 
@@ -1026,7 +1033,8 @@ class HipBackend : public TreeBackend {
     if (!x.busy) throw std::runtime_error("no round in flight on this context");
     const auto t_wait = std::chrono::steady_clock::now();
     TraceRange wait_range("lga.wait_round");
-    wait_flag(x);
+    if (x.direct && !x.root) wait_direct(x, 2 * (int)x.tasks.size());
+    else wait_flag(x);
     if (prof.on) {
       LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
       if (comm_stream_) LGA_HIP_CHECK(hipStreamSynchronize(comm_stream_));
@@ -1044,6 +1052,14 @@ class HipBackend : public TreeBackend {
     if (root) {
       std::memcpy(&qs_host_, tl, sizeof(QuantScale));
     } else {
+      // direct hand-over: a left child's exact row count IS the number of rows that went left
+      std::vector<int32_t> left_direct;
+      if (x.direct) {
+        left_direct.resize((size_t)B);
+        for (int i = 0; i < B; ++i) left_direct[(size_t)i] = (int32_t)infos[2 * i].total_cnt;
+        for (int i = 0; i < n_scan; ++i) infos[i].pad0 = 0;
+        tl = left_direct.data();
+      }
       for (int i = 0; i < B; ++i) {
         const SplitTask& t = x.tasks[(size_t)i];
         const NodeRange p = ranges_host_[(size_t)t.parent_node];
@@ -1133,6 +1149,19 @@ class HipBackend : public TreeBackend {
   // polls, so many boosters - cross-validation folds, grid rows - can wait on few cores.  The stream is
   // queried now and then so that a failed launch surfaces as an error instead of an endless wait.
   void wait_flag(RoundCtx& x) { wait_for(reinterpret_cast<volatile unsigned*>(x.host_block.get()), x.seq, x.stream); }
+  // direct hand-over (ScanArgs::direct): every result carries the round's sequence number once it is complete
+  void wait_direct(RoundCtx& x, int n_scan) {
+    const SplitInfo* res = reinterpret_cast<const SplitInfo*>(x.host_block.get() + k::kHostDataOffset);
+    for (int i = 0; i < n_scan; ++i)
+      wait_for(reinterpret_cast<volatile unsigned*>(const_cast<int32_t*>(&res[i].pad0)), x.seq, x.stream);
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  bool direct_done(const RoundCtx& x, int n_scan) const {
+    const SplitInfo* res = reinterpret_cast<const SplitInfo*>(x.host_block.get() + k::kHostDataOffset);
+    for (int i = 0; i < n_scan; ++i)
+      if (*reinterpret_cast<const volatile unsigned*>(&res[i].pad0) != x.seq) return false;
+    return true;
+  }
   static void wait_for(volatile unsigned* flag, unsigned seq, hipStream_t stream) {
     unsigned spins = 0;
     while (*flag != seq) {
@@ -1227,6 +1256,7 @@ class HipBackend : public TreeBackend {
   int part_chunk_ = k::kPartChunk;    // rows per partition workgroup of the row-lines rounds (single pass: chosen per round)
   int part_rows_forced_ = 0;          // LGA_PART_ROWS: rows per workgroup of the single-pass partition, 0 = by the round's largest leaf
   int64_t part_rows4k_above_ = 1 << 20, part_rows8k_above_ = 1 << 22;
+  bool direct_results_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 0);   // see ScanArgs::direct
   bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;

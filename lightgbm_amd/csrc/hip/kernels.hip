@@ -829,6 +829,11 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
     if (have_winner) {
       if (a.best_out) {
         a.best_out[s] = Cand{bg, bkey, blg, blh};   // distributed: all-gather + merge_winners follow
+      } else if (a.direct) {
+        SplitInfo* o = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset) + s;
+        write_split(o, bg, bkey, blg, blh, tc, tg, th, q, a.sp);
+        __threadfence_system();
+        *reinterpret_cast<volatile int32_t*>(&o->pad0) = (int32_t)a.seq;
       } else {
         write_split(&a.results[s], bg, bkey, blg, blh, tc, tg, th, q, a.sp);
         if (release_and_ticket(a.done_counter) == (unsigned)(a.n_scan - 1)) {
@@ -954,6 +959,11 @@ __global__ __launch_bounds__(512) void scan_pairs_kernel(InlineTasks inl, ScanAr
     if (have_winner) {
       if (a.best_out) {
         for (int k = 0; k < 2; ++k) a.best_out[sidx[k]] = Cand{bg[k], bkey[k], blg[k], blh[k]};   // distributed: all-gather + merge_winners follow
+      } else if (a.direct) {
+        SplitInfo* o = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
+        for (int k = 0; k < 2; ++k) write_split(&o[sidx[k]], bg[k], bkey[k], blg[k], blh[k], tc[k], tg[k], th[k], q, a.sp);
+        __threadfence_system();
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<volatile int32_t*>(&o[sidx[k]].pad0) = (int32_t)a.seq;
       } else {
         for (int k = 0; k < 2; ++k) write_split(&a.results[sidx[k]], bg[k], bkey[k], blg[k], blh[k], tc[k], tg[k], th[k], q, a.sp);
         if (release_and_ticket(a.done_counter) == (unsigned)(a.n_tasks - 1)) {

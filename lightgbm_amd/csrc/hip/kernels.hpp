@@ -233,6 +233,11 @@ struct ScanArgs {
   char* host_out;           // host-mapped result block
   unsigned* done_counter;
   unsigned seq;
+  // 1: every search hands its own result to the host - SplitInfo written straight into the host-mapped block, one
+  // system-scope fence, then `seq` into SplitInfo::pad0, which the host polls per result - instead of a second ticket,
+  // a last workgroup that copies everything, and one flag (three dependent memory round trips shorter).  The host
+  // then takes the left counts from the left children's total_cnt.  Not for the root, not for distributed learners.
+  int32_t direct;
 };
 // launch_scan: scan tasks of this launch (inl.count x 2, the staged tasks x 2, or 1 for the root)
 void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hipStream_t s);
