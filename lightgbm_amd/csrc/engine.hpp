@@ -151,6 +151,9 @@ class Engine {
   // of quantize_wide(g, kg) and quantize_wide(h, kh) (common.hpp), with kg / kh = the tree's quantisation
   // exponents + kWideExtraBits.  sums: [leaf][2] = (sum g, sum h).
   virtual void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) = 0;
+  // true: the trees' leaf values already come from those very sums (full-precision histograms: a node's histogram
+  // totals ARE the 36-bit sums over its rows), so renewing them would compute the same numbers again
+  virtual bool leaf_values_from_exact_sums() const { return false; }
   // Add (sign=+1) or remove (sign=-1) a tree's output by traversal of the binned rows.
   virtual void add_tree_by_traversal(int which, const Tree& tree, double sign) = 0;
 

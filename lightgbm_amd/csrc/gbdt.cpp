@@ -661,6 +661,7 @@ void Booster::renew_leaf_values_exact(Tree& tree) {
   if (!cfg_.quant_train_renew_leaf || tree.num_leaves <= 1) return;
   if (cfg_.path_smooth > 0.0) return;
   for (int m : cfg_.monotone_constraints) if (m != 0) return;
+  if (cfg_.forcedsplits_filename.empty() && engine_->leaf_values_from_exact_sums()) return;
   std::vector<int64_t> sums;
   int kg = 0, kh = 0;
   engine_->leaf_gradient_sums(tree, &sums, &kg, &kh);

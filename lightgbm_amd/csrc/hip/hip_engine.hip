@@ -1897,6 +1897,8 @@ class HipEngine : public Engine {
     TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
     ++score_version_;
+    // (leaf values that needed no renewal: nobody has walked the rows yet)
+    if (!leaf_ids_valid_ && leaf_values_from_exact_sums()) walk_rows_to_leaves(tree);
     if (leaf_ids_valid_ && leaf_ids_leaves_ == tree.num_leaves) {
       // the leaf of every row is known from the walk that took the leaf sums: the tree's structure has not changed
       // since, only its leaf values
@@ -2057,6 +2059,26 @@ class HipEngine : public Engine {
   void sum_over_ranks_i64(int64_t* v, size_t n) override {   // feature-parallel ranks all hold every row
     if (dist() && backend_->mode() == ParallelMode::Data) comm_->allreduce_sum_i64(v, n, false, stream_);
   }
+  // (LGA_RENEW_ALWAYS=1 keeps the renewal pass in full precision too: a check that it changes nothing)
+  bool leaf_values_from_exact_sums() const override { return backend_->wide() && !renew_always_; }
+  // Large data with every row in the bag: one walk over the rows in storage order yields every row's leaf - which turns
+  // the score update into a lookup - and the leaves' 36-bit gradient sums.
+  bool walk_rows_to_leaves(const Tree& tree) {
+    const int L = tree.num_leaves;
+    // (a walk costs one dependent bin read per level; LGA_WALK_DEPTH caps the row-weighted mean leaf depth it is taken for)
+    if (!(score_update_ != 1 && n_base_ >= kWalkMinRows && oob_n_ == 0 && bag_n_ == n_base_ && L > 1 &&
+          !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_))
+      return false;
+    leaf_acc_.resize((size_t)2 * (size_t)L);
+    const TreeOnDevice td = upload_tree(tree);
+    leaf_of_row_.resize((size_t)N_);
+    const bool walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(),
+                                       mir_->tiles == 1 ? mir_->bins_rt.get() : nullptr, N_, base_or_null(), n_base_, gr(), he(),
+                                       backend_->qs_device(), backend_->renew_extra_bits(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
+    leaf_ids_valid_ = walked;
+    leaf_ids_leaves_ = L;
+    return walked;
+  }
   void leaf_gradient_sums(const Tree& tree, std::vector<int64_t>* sums, int* kg, int* kh) override {
     TraceRange range("lga.leaf_sums");
     const int L = tree.num_leaves;
@@ -2080,18 +2102,7 @@ class HipEngine : public Engine {
     // Large data with every row in the bag: one walk over the rows in storage order yields the sums AND every row's
     // leaf, which turns the score update that follows into a lookup (add_trained_tree_to_train_scores).
     leaf_ids_valid_ = false;
-    bool walked = false;
-    // (a walk costs one dependent bin read per level; LGA_WALK_DEPTH caps the row-weighted mean leaf depth it is taken for)
-    if (score_update_ != 1 && n_base_ >= kWalkMinRows && oob_n_ == 0 && bag_n_ == n_base_ && L > 1 &&
-        !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_) {
-      const TreeOnDevice td = upload_tree(tree);
-      leaf_of_row_.resize((size_t)N_);
-      walked = k::walk_leaves(td.nodes, td.n_internal, td.num_leaves, mir_->bins_fm.get(),
-                              mir_->tiles == 1 ? mir_->bins_rt.get() : nullptr, N_, base_or_null(), n_base_, gr(), he(),
-                              backend_->qs_device(), backend_->renew_extra_bits(), leaf_of_row_.get(), leaf_acc_.get(), td.node_sets, stream_);
-      leaf_ids_valid_ = walked;
-      leaf_ids_leaves_ = L;
-    }
+    const bool walked = walk_rows_to_leaves(tree);
     if (!walked) {
       const int n_spans = upload_spans(nullptr);
       k::leaf_sums(span_dev_.get(), n_spans, L, backend_->arena(0), backend_->arena(1), bag_n_, gr(), he(),
@@ -2294,6 +2305,7 @@ class HipEngine : public Engine {
   DeviceBuffer<int64_t> packed_, leaf_acc_;
   DeviceBuffer<uint16_t> leaf_of_row_;   // leaf of every root row as the last walk for leaf sums left it
   bool leaf_ids_valid_ = false;
+  bool renew_always_ = std::getenv("LGA_RENEW_ALWAYS") && std::atoi(std::getenv("LGA_RENEW_ALWAYS")) != 0;
   int leaf_ids_leaves_ = 0;
   double walk_max_depth_ = std::getenv("LGA_WALK_DEPTH") ? std::atof(std::getenv("LGA_WALK_DEPTH")) : 1e9;   // measured: never worse than the per-leaf row lists
   DeviceBuffer<uint32_t> maxbits_, select_scratch_;

@@ -589,6 +589,32 @@ def test_gpu_auc_against_the_full_precision_cpu_learner_over_several_data_draws(
     assert abs(np.mean(diffs)) <= 0.001 and max(abs(d) for d in diffs) <= 0.003, diffs
 
 
+@pytest.mark.parametrize("case", ["walk", "bagging"])
+def test_full_precision_leaf_values_need_no_renewal(case, monkeypatch):
+    """With full-precision histograms a node's histogram totals ARE the 36-bit sums over its rows, so the device engine
+    skips the renewal pass (and the host round trip it costs): forcing the pass (LGA_RENEW_ALWAYS=1) gives the same
+    model, and so does the CPU engine, which always renews.  'walk': enough rows for the tree-walk score update."""
+    rng = np.random.RandomState(23)
+    n = 1_060_000 if case == "walk" else 120_000
+    X = rng.randn(n, 6).astype(np.float32)
+    y = (X[:, 0] + 0.5 * X[:, 1] * X[:, 2] + 0.3 * rng.randn(n) > 0).astype(np.float32)
+    p = {"objective": "binary", "num_leaves": 31, "min_data_in_leaf": 20, "learning_rate": 0.2, "use_quantized_grad": False,
+         "lambda_l2": 0.5, "verbose": -1}
+    if case == "bagging":
+        p.update(bagging_fraction=0.7, bagging_freq=1)
+
+    def fit(dev):
+        q = {**p, "device_type": dev}
+        return lgb.train(q, lgb.Dataset(X, label=y, params=q), 4)
+    monkeypatch.delenv("LGA_RENEW_ALWAYS", raising=False)
+    skipped = fit("gpu")
+    monkeypatch.setenv("LGA_RENEW_ALWAYS", "1")
+    renewed = fit("gpu")
+    monkeypatch.delenv("LGA_RENEW_ALWAYS", raising=False)
+    assert trees_of(skipped) == trees_of(renewed)
+    assert trees_of(skipped) == trees_of(fit("cpu"))
+
+
 @pytest.mark.parametrize("case", ["plain", "bagging", "goss", "weights_init", "custom", "stochastic", "multiclass", "full_dart"])
 def test_locality_order_changes_nothing_but_the_memory_layout(case, monkeypatch):
     """The device engine's private locality order of the rows (on by default from 2^20 rows; forced here at 150 k):
