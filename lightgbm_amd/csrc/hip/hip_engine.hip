@@ -350,7 +350,12 @@ class HipBackend : public TreeBackend {
   // Row lines (kernels.hpp: build_row_lines) carry the gradients themselves and take the fused growth rounds.
   void set_lines(uint8_t* lines) { lines_ = lines; packed_ = nullptr; hist_src_ = nullptr; }
   // Feature-tile records + a separate array of packed gradients.
-  void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) { packed_ = packed_dev; hist_src_ = rows_src; lines_ = nullptr; }
+  void set_packed(const int64_t* packed_dev, const uint8_t* rows_src) {
+    packed_ = packed_dev; hist_src_ = rows_src; lines_ = nullptr;
+    // several feature tiles: the partition moves the packed gradients along with the row ids (k::GradArenas)
+    if (ordered_grads_ && T_ >= 2 && gh_arena_[0].size() == 0)
+      for (int b = 0; b < 2; ++b) gh_arena_[b].resize(arena_[b].size());
+  }
   // Row lines only: the root pass quantises these float gradients itself (no separate quantisation kernel).
   void set_root_quant(const float* g, const float* h, const uint32_t* maxbits, const RoundingSpec& rounding) {
     root_quant_ = k::FusedQuant{g, h, maxbits, qs_dev_.get(), rounding};
@@ -901,12 +906,18 @@ class HipBackend : public TreeBackend {
     // copying the row list.  Only the root round and the round that splits the root ever touch node 0.
     const int32_t* src0 = (root || tasks[0].parent_node == 0) ? bag_ : arena_[0].get();
     prof.mark(PhaseProfile::kPartition, st_);
+    k::GradArenas grads{};
+    if (!root && gh_arena_[0].size() > 0) {
+      grads.by_row = packed_;
+      grads.arena[0] = gh_arena_[0].get();
+      grads.arena[1] = gh_arena_[1].get();
+    }
     if (!root) {
       k::BagParams part{};
       part.cat_sets = cat_sets_dev_.get();
       k::partition(dt, dpc, inl, np, any_multi, nodes_.get(), src0, arena_[1].get(), arena_[0].get(),
                    arena_[1].get(), mir_->bins_fm.get(), N_, x.mask.get(), x.chunk_left.get(), x.task_left.get(),
-                   part, pool_.get() + (size_t)round.first_slot * slot_words_, (int64_t)slot_words_ * B, st_);
+                   part, pool_.get() + (size_t)round.first_slot * slot_words_, (int64_t)slot_words_ * B, st_, grads);
     }
     prof.mark(PhaseProfile::kHist, st_);
     {
@@ -918,7 +929,7 @@ class HipBackend : public TreeBackend {
         else { tile_first = 0; tile_step = 1; tile_count = 1; }   // totals only
       }
       k::histogram(dt, dhc, inl, nh, hch, nodes_.get(), src0, arena_[1].get(), hist_src_, N_, packed_, lay_, round, F_,
-                   tile_first, tile_step, tile_count, wide_ ? qs_dev_.get() : nullptr, st_);
+                   tile_first, tile_step, tile_count, wide_ ? qs_dev_.get() : nullptr, st_, grads);
     }
     if (distributed()) { finish_distributed(x, tasks, root, round, dt, inl); return; }
     prof.mark(PhaseProfile::kComm, st_);
@@ -1203,6 +1214,8 @@ class HipBackend : public TreeBackend {
   DeviceBuffer<NodeRange> nodes_;
   DeviceBuffer<int64_t> node_totals_;
   DeviceBuffer<int32_t> arena_[2];
+  DeviceBuffer<int64_t> gh_arena_[2];   // the packed gradients in the order of the row arenas (data with several feature tiles)
+  bool ordered_grads_ = !(std::getenv("LGA_ORDERED_GRADS") && std::atoi(std::getenv("LGA_ORDERED_GRADS")) == 0);
   bool dp_allreduce_ = false;   // data-parallel exchange: whole histograms by all-reduce (narrow data) instead of reduce-scatter by feature
   static constexpr int kMaxRoundsInFlight = 4;
   RoundCtx ctx_[kMaxRoundsInFlight];

@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
     NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint8_t* __restrict__ bins_fm, int64_t N,
     uint64_t* __restrict__ mask, int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, BagParams bag,
-    int total_chunks, int64_t* __restrict__ zero_ptr, int64_t zero_words) {
+    int total_chunks, int64_t* __restrict__ zero_ptr, int64_t zero_words, GradArenas ga) {
   constexpr int kWords = kPartChunk / kWave;
   __shared__ unsigned long long smask[kWords];
   __shared__ int word_prefix[kWords + 1];
@@ -372,6 +372,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
   const int lefts = word_prefix[kWords];
   if (t.num_pchunk == 1) {
     int32_t* dst = (p.buf ? a0_dst : a1_dst) + p.begin;
+    const bool with_grads = ga.arena[0] != nullptr && t.feature >= 0;
+    const int64_t* gh_src = with_grads ? ga.arena[p.buf] + p.begin : nullptr;
+    int64_t* gh_dst = with_grads ? ga.arena[1 - p.buf] + p.begin : nullptr;
 #pragma unroll
     for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
       const int w = kk * (kPartThreads / kWave) + wave;
@@ -381,7 +384,10 @@ __global__ __launch_bounds__(kPartThreads) void partition_count_kernel(
         const bool left = (m >> lane) & 1ull;
         const int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
         const int d = left ? lrank : lefts + (in_chunk - lrank);
-        if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = myrow[kk];
+        if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) {
+          dst[d] = myrow[kk];
+          if (with_grads) gh_dst[d] = t.parent_node == 0 ? ga.by_row[myrow[kk]] : gh_src[in_chunk];
+        }
       }
     }
     if (threadIdx.x == 0) {
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl,
     NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0_src, const int32_t* __restrict__ a1_src,
     int32_t* __restrict__ a0_dst, int32_t* __restrict__ a1_dst, const uint64_t* __restrict__ mask,
-    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, int chunk0, int n_staged) {
+    const int32_t* __restrict__ chunk_left, int32_t* __restrict__ task_left, int chunk0, int n_staged, GradArenas ga) {
   constexpr int kWords = kPartChunk / kWave;   // 32 mask words per chunk
   __shared__ int red_before[kPartThreads / kWave], red_all[kPartThreads / kWave];
   __shared__ int word_prefix[kWords];
@@ -445,6 +451,9 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
   int32_t* dst = (p.buf ? a0_dst : a1_dst) + p.begin;   // the OTHER buffer
   const int base = c * kPartChunk;
   const int right_before = base - before;
+  const bool with_grads = ga.arena[0] != nullptr && t.feature >= 0;
+  const int64_t* gh_src = with_grads ? ga.arena[p.buf] + p.begin : nullptr;
+  int64_t* gh_dst = with_grads ? ga.arena[1 - p.buf] + p.begin : nullptr;
 #pragma unroll
   for (int kk = 0; kk < kPartChunk / kPartThreads; ++kk) {
     int w = kk * (kPartThreads / kWave) + wave;
@@ -455,7 +464,11 @@ __global__ __launch_bounds__(kPartThreads) void partition_scatter_kernel(
       int lrank = word_prefix[w] + __popcll(m & ((1ull << lane) - 1ull));
       int in_chunk = w * kWave + lane;
       int d = left ? (before + lrank) : (all + right_before + (in_chunk - lrank));
-      if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) dst[d] = src[pos];
+      if (LGA_DEV_CHECK((unsigned)d < (unsigned)p.count, kCheckPartitionTarget, d, p.count)) {
+        const int32_t row = src[pos];
+        dst[d] = row;
+        if (with_grads) gh_dst[d] = t.parent_node == 0 ? ga.by_row[row] : gh_src[pos];
+      }
     }
   }
   if (c == 0 && threadIdx.x == 0) {
@@ -599,7 +612,7 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
     const SplitTask* __restrict__ tasks, const int32_t* __restrict__ chunk_task, InlineTasks inl, int rows_per_chunk,
     const NodeRange* __restrict__ nodes, const int32_t* __restrict__ a0, const int32_t* __restrict__ a1,
     const uint8_t* __restrict__ bins_rt, int64_t N, const int64_t* __restrict__ packed, PoolLayout L, RoundSlots round,
-    int F, int tile_first, int tile_step, const QuantScale* __restrict__ qs) {
+    int F, int tile_first, int tile_step, const QuantScale* __restrict__ qs, GradArenas ga) {
   constexpr int kThreads = WIDE ? kHistThreadsWide : kHistThreads;
   __shared__ unsigned long long lds[(WIDE ? 2 : 1) * kTileFeatures * kMaxBins];   // 64 KiB (WIDE: 128 KiB, one workgroup of 16 waves per CU)
   __shared__ long long red[2][kThreads / kWave];
@@ -625,6 +638,8 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
   if (WIDE) { wkg = qs->kg; wkh = qs->kh; }
   __syncthreads();
   const int32_t* rows = (r.buf ? a1 : a0) + r.begin;
+  // the child's gradients in the order of its rows (GradArenas), or by row id
+  const int64_t* ordered = (ga.arena[0] != nullptr && node != 0) ? ga.arena[r.buf] + r.begin : nullptr;
   const uint4* recs = reinterpret_cast<const uint4*>(bins_rt + (int64_t)tile * N * kTileFeatures);
   long long sg = 0, sh = 0;
   // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
@@ -643,7 +658,7 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (row[u] >= 0) {
-        p[u] = (unsigned long long)packed[row[u]];
+        p[u] = (unsigned long long)(ordered ? ordered[i0 + u * kThreads] : packed[row[u]]);
         ra[u] = recs[(int64_t)row[u] * 2];
         rb[u] = recs[(int64_t)row[u] * 2 + 1];
       }
@@ -2208,29 +2223,31 @@ void quantize(const float* g, const float* h, const int32_t* rows, int64_t n, co
 void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                bool any_multi_chunk, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst,
                int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
-               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s) {
+               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s, const GradArenas& grads) {
   if (total_chunks <= 0) return;
+  if ((grads.arena[0] != nullptr) != (grads.arena[1] != nullptr) || (grads.arena[0] && !grads.by_row))
+    throw std::runtime_error("partition: incomplete gradient arenas");
   // zero_words is even (slot sizes are); one trailing workgroup clears 1024 x 16 bytes
   const int zero_blocks = (int)(((zero_words >> 1) + kPartThreads * 4 - 1) / (kPartThreads * 4));
   hipLaunchKernelGGL(partition_count_kernel, dim3(total_chunks + zero_blocks), dim3(kPartThreads), 0, s, tasks,
                      chunk_task, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, bins_fm, N, mask, chunk_left, task_left,
-                     bag, total_chunks, zero_ptr, zero_words);
+                     bag, total_chunks, zero_ptr, zero_words, grads);
   LGA_LAUNCH_CHECK();
   if (!any_multi_chunk) return;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, tasks, chunk_task, inl,
-                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0, 0);
+                     nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0, 0, grads);
   LGA_LAUNCH_CHECK();
 }
 
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                int rows_per_chunk, const NodeRange* nodes, const int32_t* a0, const int32_t* a1,
                const uint8_t* bins_rt, int64_t N, const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F,
-               int tile_first, int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s) {
+               int tile_first, int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s, const GradArenas& grads) {
   if (total_chunks <= 0 || tile_count <= 0) return;
   if (rows_per_chunk > (wide_qs ? kMaxUnitRowsWide : kMaxUnitRows)) throw std::runtime_error("histogram chunk exceeds the 32-bit LDS accumulator range");
   auto launch = [&](auto kernel, int threads) {
     hipLaunchKernelGGL(kernel, dim3(total_chunks, tile_count), dim3(threads), 0, s, tasks, chunk_task, inl,
-                       rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs);
+                       rows_per_chunk, nodes, a0, a1, bins_rt, N, packed, pool, round, F, tile_first, tile_step, wide_qs, grads);
   };
   if (wide_qs) launch(hist_kernel<true>, kHistThreadsWide);
   else launch(hist_kernel<false>, kHistThreads);
@@ -2282,7 +2299,7 @@ void grow_scatter(const SplitTask* staged, int n_staged, const InlineTasks& inl,
   if (total_chunks <= 0) return;
   hipLaunchKernelGGL(partition_scatter_kernel, dim3(total_chunks), dim3(kPartThreads), 0, s, staged,
                      (const int32_t*)nullptr, inl, nodes, a0_src, a1_src, a0_dst, a1_dst, mask, chunk_left, task_left, 0,
-                     n_staged);
+                     n_staged, GradArenas{});
   LGA_LAUNCH_CHECK();
 }
 

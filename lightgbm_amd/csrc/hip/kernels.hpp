@@ -117,12 +117,21 @@ struct BagParams {
   const uint64_t* cat_sets = nullptr;   // growth rounds: kCatSetWords words per node, read for kCategoricalSetTask
   const int32_t* ext_ids = nullptr;     // rows in a private order: position -> the caller's row id, which keys the random draws
 };
+// Ordered gradients (data with several feature tiles): the packed gradients of a node's rows in the order of its row
+// range - arena[b] runs parallel to row arena b - moved along with the row ids by the partition, so that the histogram
+// workgroups of EVERY tile read them as a stream instead of gathering 8 bytes (a 64-byte sector) per row and tile.
+// by_row: the gradients by row id, the source for the children of node 0, whose rows are the bag itself.
+struct GradArenas {
+  const int64_t* by_row = nullptr;
+  int64_t* arena[2] = {nullptr, nullptr};
+};
 // tasks == nullptr: descriptors come from `inl`.  any_multi_chunk tells whether pass 2 is needed.
 // zero_ptr/zero_words: int64 range the partition workgroups clear on the way (the round's new histogram slots).
 void partition(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks,
                bool any_multi_chunk, NodeRange* nodes, const int32_t* a0_src, const int32_t* a1_src, int32_t* a0_dst,
                int32_t* a1_dst, const uint8_t* bins_fm, int64_t N, uint64_t* mask, int32_t* chunk_left,
-               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s);
+               int32_t* task_left, BagParams bag, int64_t* zero_ptr, int64_t zero_words, hipStream_t s,
+               const GradArenas& grads = GradArenas{});
 
 // packed == nullptr: bins_rt points at row lines (see build_row_lines) that carry the gradients themselves.
 // quant (row lines, root pass): quantise the float gradients inside the pass and store them in the lines.
@@ -138,7 +147,8 @@ struct FusedQuant {
 void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTasks& inl, int total_chunks, int rows_per_chunk,
                const NodeRange* nodes, const int32_t* a0, const int32_t* a1, const uint8_t* bins_rt, int64_t N,
                const int64_t* packed, const PoolLayout& pool, RoundSlots round, int F, int tile_first,
-               int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s);
+               int tile_step, int tile_count, const QuantScale* wide_qs, hipStream_t s,
+               const GradArenas& grads = GradArenas{});   // grads.arena: the histogram children's gradients in row-range order
 
 // ---- fused growth round over row lines (single feature tile) ----
 // One launch decides every row's side for all leaves of the round and builds the smaller children's
