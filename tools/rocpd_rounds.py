@@ -15,6 +15,15 @@ def main():
         if "grid_x" in cols else [(*r, 0, 1) for r in db.execute(f"select {name_col}, start, end from kernels order by start")]
     roots = [i for i, r in enumerate(rows) if "grow_kernel<true" in r[0]]
     if len(roots) < 2:
+        # data with several feature tiles: a tree starts with the first histogram launch after the gradients
+        roots, armed = [], False
+        for i, r in enumerate(rows):
+            if "gradients" in r[0] or "quantize_kernel" in r[0]:
+                armed = True
+            elif armed and "hist_kernel" in r[0]:
+                roots.append(i)
+                armed = False
+    if len(roots) < 2:
         raise SystemExit("fewer than two trees in the trace")
     tree = rows[roots[-2]:roots[-1]]
     lines = ["round,partition_us,partition_workgroups,hist_us,hist_workgroups,scan_us"]
@@ -23,11 +32,11 @@ def main():
     for name, s, e, gx, wx in tree:
         us = (e - s) / 1e3
         wgs = gx // max(wx, 1)
-        if "grow_kernel<" in name:
+        if "grow_kernel<" in name or "hist_kernel" in name:
             if cur is None:
                 cur = {"p": 0.0, "pw": 0}
             cur["h"], cur["hw"] = us, wgs
-        elif "grow_flags" in name or "partition_scatter" in name or "grow_partition" in name:
+        elif "grow_flags" in name or "partition_scatter" in name or "grow_partition" in name or "partition_count" in name:
             if cur is None:
                 cur = {"p": 0.0, "pw": 0}
             cur["p"] += us

@@ -10,4 +10,5 @@ export TMPDIR=/tmp
 rm -rf /tmp/kt_$SHAPE && timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/kt_$SHAPE -o kt -- python $ROOT/tools/runs/wide_shapes.py $SHAPE "$@" > "$OUT/run.txt" 2> /tmp/kt_$SHAPE.log
 DB="$(find /tmp/kt_$SHAPE -name '*.db' | sort | tail -1)"
 python $ROOT/tools/rocpd_stats.py "$DB" "$OUT/kernel_stats.csv" > /dev/null
+python $ROOT/tools/rocpd_rounds.py "$DB" "$OUT/rounds_last_tree.csv" > /dev/null || true
 head -12 "$OUT/kernel_stats.csv"
