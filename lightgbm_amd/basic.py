@@ -168,11 +168,6 @@ def _warn_no_effect(params: Dict[str, Any]) -> None:
     if q is not None and int(q) != 4:
         notes.append(("num_grad_quant_bins", "num_grad_quant_bins has no effect: quantised histograms always use 16 bits "
                                              "(use_quantized_grad=false selects full precision)"))
-    t = str(get_param(params, "tree_learner", "serial")).lower()
-    if t in ("voting", "voting_parallel") and _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host"):
-        notes.append(("voting on the device", "tree_learner=voting: the device engine trains with the exact data-parallel learner "
-                      "(whole histograms summed over the ranks, which voting approximates); top_k has no effect. "
-                      "The vote itself is available with device_type=cpu"))
     if str(get_param(params, "reg_sqrt", False)).lower() in ("true", "1"):
         o = str(get_param(params, "objective", "regression")).lower()
         if o not in ("regression", "regression_l2", "l2", "mean_squared_error", "mse", "l2_root", "root_mean_squared_error", "rmse"):

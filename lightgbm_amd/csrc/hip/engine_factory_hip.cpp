@@ -9,9 +9,7 @@ std::unique_ptr<Engine> make_engine(std::shared_ptr<Dataset> train, const Config
                       : cfg.tree_learner == "data"  ? ParallelMode::Data
                       : cfg.tree_learner == "voting" ? ParallelMode::Voting
                                                     : ParallelMode::Serial;
-  // The device learner sums whole histograms by reduce-scatter over xGMI (exact, and what voting approximates):
-  // tree_learner=voting takes that learner on the device; the vote itself is the CPU engine's (host_engine.cpp).
-  if (cfg.device_type == "gpu") return make_hip_engine(train, cfg, comm, mode == ParallelMode::Voting ? ParallelMode::Data : mode);
+  if (cfg.device_type == "gpu") return make_hip_engine(train, cfg, comm, mode);
   engine_ensure_host_bins(train.get());
   return make_host_engine(train, cfg, comm, mode);
 }

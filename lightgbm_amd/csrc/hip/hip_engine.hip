@@ -194,6 +194,13 @@ class HipBackend : public TreeBackend {
     const bool keep_dist = comm_ && comm_->size() == 1 && keep_single && keep_single[0] == '1' && mode_ != ParallelMode::Serial;
     if (!comm_ || (comm_->size() <= 1 && !keep_dist)) mode_ = ParallelMode::Serial;
     else if (mode_ == ParallelMode::Serial) mode_ = ParallelMode::Data;
+    top_k_ = std::max(1, std::min(cfg.top_k, std::max(F_, 1)));
+    if (mode_ == ParallelMode::Voting &&
+        (F_ > k::kVoteMaxFeatures || comm_->size() * top_k_ > k::kVoteMaxVotes || std::min(F_, 2 * top_k_) > k::kVoteMaxSelected)) {
+      std::fprintf(stderr, "[lightgbm_amd] tree_learner=voting: %d features / %d ranks x top_k %d exceed the vote kernels' tables; "
+                           "training with the exact data-parallel learner\n", F_, comm_->size(), top_k_);
+      mode_ = ParallelMode::Data;
+    }
     // Histogram pool layout (kernels.hpp: PoolLayout): the data-parallel learner splits every slot into one
     // chunk per rank, so that one in-place reduce-scatter per round hands each rank the features it searches.
     // Narrow data (a slot of at most 512 KiB: up to four feature tiles) is summed WHOLE instead: one all-reduce per
@@ -414,6 +421,9 @@ class HipBackend : public TreeBackend {
     sorted_cat_.clear();
     for (int f = 0; f < (int)meta.size(); ++f)
       if (meta[(size_t)f].enabled && meta[(size_t)f].categorical == kCategoricalSorted) sorted_cat_.push_back(f);
+    if (mode_ == ParallelMode::Voting && !sorted_cat_.empty())
+      throw std::runtime_error("tree_learner=voting on the device does not search category sets (categorical features with more than "
+                               "max_cat_to_onehot categories): use tree_learner=data, or the CPU engine");
     if (!sorted_cat_.empty() && cat_sets_dev_.size() == 0) {
       const size_t n_nodes = (size_t)(2 * capacity_splits_ + 2);
       cat_sets_host_.resize(n_nodes * kCatSetWords);
@@ -680,6 +690,11 @@ class HipBackend : public TreeBackend {
     bool owns_stream = false;
     hipEvent_t ev_ready = nullptr, ev_reduced = nullptr;   // hand-over to / from the collectives' stream
     DeviceBuffer<uint64_t> mask;
+    // voting-parallel rounds (kernels.hpp: Vote)
+    DeviceBuffer<double> vote_gains;
+    DeviceBuffer<k::Vote> votes_local, votes_all;
+    DeviceBuffer<int32_t> vote_chosen;
+    DeviceBuffer<int64_t> vote_buf;
     DeviceBuffer<unsigned long long> part_cursor;  // single-pass partition: the tasks' reservation cursors (zero between rounds)
     DeviceBuffer<int32_t> chunk_left, task_left;
     DeviceBuffer<char> stage_dev;
@@ -1012,6 +1027,41 @@ class HipBackend : public TreeBackend {
     prof.mark(PhaseProfile::kScan, cs);
     const int n_scan = root ? 1 : 2 * B;
     k::ScanArgs sa = scan_args(x, root, B, round);
+    if (mode_ == ParallelMode::Voting) {
+      // PV-Tree (kernels.hpp: Vote): local search and votes, the votes all-gathered, the most voted features' local
+      // rows + the children's local totals all-reduced, the search in the summed rows
+      const int P = comm_->size(), kk = top_k_, n_sel = std::min(F_, 2 * kk);
+      const size_t per_child = (size_t)k::vote_words_per_child(n_sel);
+      const size_t cap = (size_t)(2 * max_batch_ + 2);
+      if (x.vote_gains.size() == 0) {
+        x.vote_gains.resize(cap * (size_t)std::max(F_, 1));
+        x.votes_local.resize(cap * (size_t)kk);
+        x.votes_all.resize(cap * (size_t)kk * (size_t)P);
+        x.vote_chosen.resize(cap * (size_t)n_sel);
+        x.vote_buf.resize(cap * per_child);
+      }
+      sa.tasks = staged;
+      sa.range = k::ScanRange{0, F_, 8, 0, 1, std::max(1, (F_ + 7) / 8)};
+      sa.my_rank = 0;
+      k::ScanArgs local = sa;   // the ranks' own searches: leaf-size limits scaled down by the number of ranks
+      local.sp.min_data_in_leaf = std::max(1, (int)(sp_.min_data_in_leaf / P));
+      local.sp.min_sum_hessian_in_leaf = sp_.min_sum_hessian_in_leaf / P;
+      k::vote_gains(inl, local, n_scan, x.vote_gains.get(), cs);
+      k::vote_topk(x.vote_gains.get(), n_scan, F_, kk, x.votes_local.get(), cs);
+      comm_->allgather_bytes(x.votes_local.get(), x.votes_all.get(), sizeof(k::Vote) * (size_t)n_scan * (size_t)kk, true, cs);
+      k::vote_select(inl, sa, x.votes_all.get(), P, n_scan, kk, n_sel, x.vote_chosen.get(), x.vote_buf.get(), cs);
+      comm_->allreduce_sum_i64(x.vote_buf.get(), (size_t)n_scan * per_child, true, cs);
+      k::vote_final(inl, sa, n_scan, x.vote_chosen.get(), x.vote_buf.get(), n_sel, x.best_local.get(), cs);
+      k::merge_winners(x.best_local.get(), 1, n_scan, root ? 0 : B, x.scan_totals.get(), qs_dev_.get(), sp_,
+                       x.task_left.get(), x.host_block.device_ptr(), x.seq, cs);
+      if (comm_stream_) {
+        LGA_HIP_CHECK(hipEventRecord(x.ev_reduced, comm_stream_));
+        LGA_HIP_CHECK(hipStreamWaitEvent(st_, x.ev_reduced, 0));
+      }
+      prof.mark(PhaseProfile::kFetch, st_);
+      prof.mark(PhaseProfile::kCount, st_);
+      return;
+    }
     if (mode_ == ParallelMode::Data && dp_allreduce_) {
       // every rank holds the summed histograms of every feature: the search and its hand-over are the serial ones,
       // and every rank arrives at the same splits by itself
@@ -1270,6 +1320,7 @@ class HipBackend : public TreeBackend {
   int part_rows_forced_ = 0;          // LGA_PART_ROWS: rows per workgroup of the single-pass partition, 0 = by the round's largest leaf
   int64_t part_rows4k_above_ = 1 << 20, part_rows8k_above_ = 1 << 22;
   bool direct_results_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 0);   // see ScanArgs::direct
+  int top_k_ = 20;                    // voting-parallel: features every rank votes for per searched child
   bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
   int64_t whole_trees_ = 0;
   bool tree_timing_ = std::getenv("LGA_TREE_TIMING") != nullptr;
@@ -1409,7 +1460,7 @@ class HipEngine : public Engine {
       }
     }
     backend_.reset(new HipBackend(train_.get(), mir_, cfg, comm, mode, n_base_));
-    if (backend_->mode() == ParallelMode::Data) grower_.set_row_shards(comm->size());
+    if (backend_->mode() == ParallelMode::Data || backend_->mode() == ParallelMode::Voting) grower_.set_row_shards(comm->size());
     bag_ptr_ = all_rows();
     bag_n_ = n_base_;
     oob_n_ = 0;
@@ -2070,7 +2121,8 @@ class HipEngine : public Engine {
     if (dist()) comm_->allreduce_sum_f64(v, n, false, stream_);
   }
   void sum_over_ranks_i64(int64_t* v, size_t n) override {   // feature-parallel ranks all hold every row
-    if (dist() && backend_->mode() == ParallelMode::Data) comm_->allreduce_sum_i64(v, n, false, stream_);
+    if (dist() && (backend_->mode() == ParallelMode::Data || backend_->mode() == ParallelMode::Voting))
+      comm_->allreduce_sum_i64(v, n, false, stream_);
   }
   // (LGA_RENEW_ALWAYS=1 keeps the renewal pass in full precision too: a check that it changes nothing)
   bool leaf_values_from_exact_sums() const override { return backend_->wide() && !renew_always_; }

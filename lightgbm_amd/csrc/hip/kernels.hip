@@ -12,6 +12,7 @@
 //    by shuffles, fp64 gains, wave arg-max; sibling histograms are derived in
 //    place (parent - smaller child) on the way in.
 #include "kernels.hpp"
+#include <climits>
 #include <sstream>
 #include <type_traits>
 #include <string>
@@ -1032,6 +1033,207 @@ __global__ __launch_bounds__(256) void merge_winners_kernel(const Cand* __restri
     *qo = q;
     __threadfence_system();
     *reinterpret_cast<volatile unsigned*>(host_out) = seq;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// voting-parallel search (kernels.hpp: Vote; the host form is host_engine.cpp: vote_and_search)
+// ---------------------------------------------------------------------------
+// What a searched child is, for every kernel of the vote: its node, its key, the slot that holds (or will hold) its
+// histogram, and whether that histogram was built (direct) or is the parent's minus the built sibling's.
+struct VoteChild {
+  SplitTask t;
+  int node;
+  uint32_t key;
+  bool direct;
+  SlotRef fresh, self;
+};
+__device__ __forceinline__ VoteChild vote_child(const ScanArgs& a, const InlineTasks& inl, int s) {
+  VoteChild c;
+  const int ti = s >> 1, side = s & 1;
+  c.t = load_task(a.tasks, inl, a.root ? 0 : ti);
+  c.direct = a.root || side == c.t.hist_child;
+  c.node = a.root ? 0 : (side == 0 ? c.t.left_node : c.t.right_node);
+  c.key = a.root ? kRootNodeKey : child_node_key((uint32_t)c.t.parent_key, side);
+  c.fresh = new_slot_ref(a.pool, a.round, c.t.new_slot);
+  c.self = c.direct ? c.fresh : old_slot_ref(a.pool, c.t.parent_slot);
+  return c;
+}
+
+__global__ __launch_bounds__(512) void vote_gains_kernel(InlineTasks inl, ScanArgs a, double* __restrict__ gains) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x, b = blockIdx.y;
+  const VoteChild c = vote_child(a, inl, s);
+  const int64_t* hd = slot_header(a.pool, c.fresh, 0);
+  int64_t tc = hd[0], tg = hd[1], th = hd[2];
+  if (!c.direct) {
+    const int64_t* pt = a.node_totals + (int64_t)c.t.parent_node * 4;
+    tc = pt[0] - tc; tg = pt[1] - tg; th = pt[2] - th;
+  }
+  const QuantScale q = *a.qs;
+  const LeafScanCtx ctx = node_scan_ctx(tg, th, tc, q, a.sp, c.node);
+  const double ninf = -std::numeric_limits<double>::infinity();
+  const int f0 = a.range.f_begin + b * a.range.group_size;
+  const int f1 = min(f0 + a.range.group_size, a.range.f_end);
+  for (int f = f0 + wave; f < f1; f += 8) {
+    const FeatureMeta m = a.meta[f];
+    double bg = ninf;
+    uint64_t bkey = ~0ull;
+    int64_t blg = 0, blh = 0;
+    if (m.enabled) {
+      int64_t* blk = feat_block(a.pool, c.self, f);
+      const int bpl = bins_per_lane(m.num_bin);
+      int64_t g[4], h[4];
+      load_feat_cells(blk, lane, bpl, g, h);
+      if (!c.direct) {
+        int64_t cg[4], ch[4];
+        load_feat_cells(feat_block(a.pool, c.fresh, f), lane, bpl, cg, ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
+        store_feat_cells(blk, lane, bpl, g, h);
+      }
+      if (node_feature_on(a.sp, c.key, f, a.F) && node_allows(a.sp, c.node, f) && m.categorical != kCategoricalSorted)
+        scan_cells_wave(f, lane, bpl, g, h, m, ctx, a.sp, bg, bkey, blg, blh, c.key);
+      wave_best(bg, bkey, blg, blh);
+    }
+    if (lane == 0) gains[(int64_t)s * a.F + f] = bg;
+  }
+  if (b == 0 && threadIdx.x == 0) {
+    int64_t* nt = a.node_totals + (int64_t)c.node * 4;   // LOCAL totals: what the children's siblings are derived from
+    nt[0] = tc; nt[1] = tg; nt[2] = th; nt[3] = 0;
+    int64_t* st = a.scan_totals + (int64_t)s * 4;
+    st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
+  }
+}
+
+// One wave per searched child: pick j is the best feature strictly AFTER pick j - 1 in the order (gain descending,
+// index ascending), so nothing has to be marked as taken.
+__global__ __launch_bounds__(64) void vote_topk_kernel(const double* __restrict__ gains, int F, int top_k, Vote* __restrict__ votes) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const double* g = gains + (int64_t)s * F;
+  const double ninf = -std::numeric_limits<double>::infinity();
+  double pg = std::numeric_limits<double>::infinity();
+  int pf = -1;
+  bool dry = false;
+  for (int j = 0; j < top_k; ++j) {
+    double bg = ninf;
+    int bf = INT_MAX;
+    if (!dry) {
+      for (int f = lane; f < F; f += 64) {
+        const double v = g[f];
+        if (!(v > ninf)) continue;
+        if (!(v < pg || (v == pg && f > pf))) continue;
+        if (v > bg || (v == bg && f < bf)) { bg = v; bf = f; }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const double og = shfl_xor_f64(bg, d);
+        const int of = __shfl_xor(bf, d, kWave);
+        if (og > bg || (og == bg && of < bf)) { bg = og; bf = of; }
+      }
+      dry = bf == INT_MAX;
+    }
+    if (lane == 0) votes[(int64_t)s * top_k + j] = dry ? Vote{-1, 0.0f} : Vote{bf, (float)bg};
+    pg = bg; pf = bf;
+  }
+}
+
+__global__ __launch_bounds__(256) void vote_select_kernel(InlineTasks inl, ScanArgs a, const Vote* __restrict__ all, int ranks, int n_scan,
+                                                          int top_k, int n_sel, int32_t* __restrict__ chosen, int64_t* __restrict__ buf) {
+  __shared__ int count[kVoteMaxFeatures];
+  __shared__ double weight[kVoteMaxFeatures];
+  __shared__ int cand[kVoteMaxVotes];
+  __shared__ int pick[kVoteMaxSelected];
+  __shared__ int n_cand;
+  const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  for (int f = tid; f < a.F; f += 256) { count[f] = 0; weight[f] = 0.0; }
+  __syncthreads();
+  if (tid == 0) {
+    // rank by rank, vote by vote: the sums of the voted gains are floating point, their order is part of the result
+    int nc = 0;
+    for (int r = 0; r < ranks; ++r)
+      for (int j = 0; j < top_k; ++j) {
+        const Vote v = all[((int64_t)r * n_scan + s) * top_k + j];
+        if (v.feature >= 0 && v.feature < a.F) {
+          if (count[v.feature]++ == 0) cand[nc++] = v.feature;
+          weight[v.feature] += (double)v.gain;
+        }
+      }
+    n_cand = nc;
+  }
+  __syncthreads();
+  if (tid < kWave) {
+    // a before b: more votes, then the larger sum of gains, then the lower index
+    auto before = [&](int x, int y) {
+      if (count[x] != count[y]) return count[x] > count[y];
+      if (weight[x] != weight[y]) return weight[x] > weight[y];
+      return x < y;
+    };
+    int prev = -1;
+    for (int j = 0; j < n_sel; ++j) {
+      int bf = -1;
+      for (int i = lane; i < n_cand; i += kWave) {
+        const int f = cand[i];
+        if (prev >= 0 && !before(prev, f)) continue;   // not after the previous pick (or the pick itself)
+        if (bf < 0 || before(f, bf)) bf = f;
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const int of = __shfl_xor(bf, d, kWave);
+        if (of >= 0 && (bf < 0 || before(of, bf))) bf = of;
+      }
+      if (lane == 0) pick[j] = bf;
+      if (bf < 0) {
+        for (int jj = j + 1 + lane; jj < n_sel; jj += kWave) pick[jj] = -1;
+        break;
+      }
+      prev = bf;
+    }
+  }
+  __syncthreads();
+  const VoteChild c = vote_child(a, inl, s);
+  int64_t* dst = buf + (int64_t)s * vote_words_per_child(n_sel);
+  if (tid < 4) dst[tid] = tid < 3 ? a.scan_totals[(int64_t)s * 4 + tid] : 0;
+  for (int j = 0; j < n_sel; ++j) {
+    const int f = pick[j];
+    if (tid == 0) chosen[(int64_t)s * n_sel + j] = f;
+    const int64_t* blk = f >= 0 ? feat_block(a.pool, c.self, f) : nullptr;
+    for (int i = tid; i < 2 * kMaxBins; i += 256) dst[4 + (int64_t)j * 2 * kMaxBins + i] = blk ? blk[i] : 0;
+  }
+}
+
+__global__ __launch_bounds__(512) void vote_final_kernel(InlineTasks inl, ScanArgs a, const int32_t* __restrict__ chosen,
+                                                         const int64_t* __restrict__ buf, int n_sel, Cand* __restrict__ best) {
+  __shared__ Cand wbest[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x;
+  const VoteChild c = vote_child(a, inl, s);
+  const int64_t* src = buf + (int64_t)s * vote_words_per_child(n_sel);
+  const int64_t tc = src[0], tg = src[1], th = src[2];   // summed over the ranks
+  const QuantScale q = *a.qs;
+  const LeafScanCtx ctx = node_scan_ctx(tg, th, tc, q, a.sp, c.node);
+  const double ninf = -std::numeric_limits<double>::infinity();
+  double bg = ninf;
+  uint64_t bkey = ~0ull;
+  int64_t blg = 0, blh = 0;
+  for (int j = wave; j < n_sel; j += 8) {
+    const int f = chosen[(int64_t)s * n_sel + j];
+    if (f < 0) continue;
+    const FeatureMeta m = a.meta[f];
+    if (m.categorical == kCategoricalSorted) continue;
+    const int bpl = bins_per_lane(m.num_bin);
+    int64_t g[4], h[4];
+    load_feat_cells(src + 4 + (int64_t)j * 2 * kMaxBins, lane, bpl, g, h);
+    scan_cells_wave(f, lane, bpl, g, h, m, ctx, a.sp, bg, bkey, blg, blh, c.key);
+  }
+  wave_best(bg, bkey, blg, blh);
+  if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 8; ++w) take_better(bg, bkey, blg, blh, wbest[w].gain, wbest[w].key, wbest[w].lg, wbest[w].lh);
+    best[s] = Cand{bg, bkey, blg, blh};
+    int64_t* st = a.scan_totals + (int64_t)s * 4;
+    st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
   }
 }
 
@@ -2251,6 +2453,32 @@ void histogram(const SplitTask* tasks, const int32_t* chunk_task, const InlineTa
   };
   if (wide_qs) launch(hist_kernel<true>, kHistThreadsWide);
   else launch(hist_kernel<false>, kHistThreads);
+  LGA_LAUNCH_CHECK();
+}
+
+void vote_gains(const InlineTasks& inl, const ScanArgs& a, int n_scan, double* gains, hipStream_t s) {
+  if (n_scan <= 0) return;
+  if (a.range.group_size != 8 || a.range.f_begin != 0 || a.range.f_end != a.F) throw std::runtime_error("vote: the local search covers every feature in groups of 8");
+  hipLaunchKernelGGL(vote_gains_kernel, dim3(n_scan, std::max(1, (a.F + 7) / 8)), dim3(512), 0, s, inl, a, gains);
+  LGA_LAUNCH_CHECK();
+}
+void vote_topk(const double* gains, int n_scan, int F, int top_k, Vote* votes, hipStream_t s) {
+  if (n_scan <= 0) return;
+  hipLaunchKernelGGL(vote_topk_kernel, dim3(n_scan), dim3(64), 0, s, gains, F, top_k, votes);
+  LGA_LAUNCH_CHECK();
+}
+void vote_select(const InlineTasks& inl, const ScanArgs& a, const Vote* all, int ranks, int n_scan, int top_k, int n_sel,
+                 int32_t* chosen, int64_t* buf, hipStream_t s) {
+  if (n_scan <= 0) return;
+  if (a.F > kVoteMaxFeatures || ranks * top_k > kVoteMaxVotes || n_sel > kVoteMaxSelected)
+    throw std::runtime_error("vote: more features, votes or selected features than the kernel's tables hold");
+  hipLaunchKernelGGL(vote_select_kernel, dim3(n_scan), dim3(256), 0, s, inl, a, all, ranks, n_scan, top_k, n_sel, chosen, buf);
+  LGA_LAUNCH_CHECK();
+}
+void vote_final(const InlineTasks& inl, const ScanArgs& a, int n_scan, const int32_t* chosen, const int64_t* buf, int n_sel,
+                Cand* best, hipStream_t s) {
+  if (n_scan <= 0) return;
+  hipLaunchKernelGGL(vote_final_kernel, dim3(n_scan), dim3(512), 0, s, inl, a, chosen, buf, n_sel, best);
   LGA_LAUNCH_CHECK();
 }
 

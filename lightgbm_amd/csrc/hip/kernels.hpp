@@ -257,6 +257,33 @@ void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hip
 void merge_winners(const Cand* gathered, int ranks, int n_scan, int n_left, const int64_t* scan_totals, const QuantScale* qs,
                    const SplitParams& sp, const int32_t* task_left, char* host_out, unsigned seq, hipStream_t s);
 
+// ---- voting-parallel search (PV-Tree; tree_learner=voting): rows sharded as for data-parallel, histograms LOCAL ----
+// Per round: (1) vote_gains - every rank searches its local histograms (siblings by local subtraction; `a.sp` carries
+// the leaf-size limits divided by the number of ranks) and records every feature's best local gain; (2) vote_topk -
+// its top_k features per searched child, by gain then lower index; the votes are all-gathered; (3) vote_select - per
+// child the 2 x top_k features with the most votes (ties: larger sum of the voted gains, added in rank order, then
+// lower index), the same on every rank, and their local histogram rows plus the child's local totals gathered into
+// one buffer, which is all-reduced; (4) vote_final - the split searched in the summed rows with the global totals
+// (`a.sp`: the real limits); merge_winners (one "rank") hands the results to the host.  Same arithmetic and the
+// same orders as host_engine.cpp: vote_and_search, so both engines grow the same trees.
+struct Vote {
+  int32_t feature;   // -1: no (further) feature with a valid split
+  float gain;
+};
+constexpr int kVoteMaxFeatures = 4096;   // per-feature vote tallies live in LDS
+constexpr int kVoteMaxVotes = 1024;      // ranks x top_k
+constexpr int kVoteMaxSelected = 128;    // 2 x top_k
+constexpr int64_t vote_words_per_child(int n_sel) { return 4 + (int64_t)n_sel * 2 * kMaxBins; }
+// gains: [n_scan][F] doubles (-inf: no valid split); a.range must cover every feature in groups of 8
+void vote_gains(const InlineTasks& inl, const ScanArgs& a, int n_scan, double* gains, hipStream_t s);
+void vote_topk(const double* gains, int n_scan, int F, int top_k, Vote* votes, hipStream_t s);
+// all: [rank][n_scan][top_k] votes; chosen: [n_scan][n_sel]; buf: [n_scan][vote_words_per_child(n_sel)]
+void vote_select(const InlineTasks& inl, const ScanArgs& a, const Vote* all, int ranks, int n_scan, int top_k, int n_sel,
+                 int32_t* chosen, int64_t* buf, hipStream_t s);
+// best: [n_scan] winners; a.scan_totals receives the GLOBAL totals of every child (node_totals keep the local ones)
+void vote_final(const InlineTasks& inl, const ScanArgs& a, int n_scan, const int32_t* chosen, const int64_t* buf, int n_sel,
+                Cand* best, hipStream_t s);
+
 // ---- whole tree in one launch (small data) ----
 // ONE workgroup grows a complete tree, strictly best-first, without the host: it gathers the bag's rows into
 // record arenas (row id, packed gradients, bin bytes - partitioned physically, so every later pass reads

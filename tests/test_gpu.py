@@ -944,6 +944,83 @@ def test_gpu_data_parallel_equals_serial(P, flight, lines, exchange, monkeypatch
         assert trees_of(s) == trees_of(serial)
 
 
+def _cpu_voting_ranks(P, X, y, sample, params, rounds):
+    """The CPU engine's voting-parallel learner over P thread ranks (the reference for the device's)."""
+    from lightgbm_amd.parallel import ThreadComm
+    comms = ThreadComm.make_group(P)
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+    out, err = [None] * P, [None] * P
+
+    def work(r):
+        try:
+            sl = slice(bounds[r], bounds[r + 1])
+            d = lgb.Dataset(X[sl], label=y[sl], bin_sample=sample, params=CPU)
+            out[r] = lgb.train({**CPU, **params}, d, rounds, comm=comms[r]).model_to_string()
+        except BaseException as e:   # noqa
+            err[r] = e
+            comms[r]._hub.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    [c.close() for c in comms]
+    return out
+
+
+@pytest.mark.parametrize("P,F,top_k,lines,precision", [(2, 10, 5, "0", "q16"), (3, 28, 3, "1", "q16"), (4, 70, 4, "0", "full"),
+                                                     (3, 28, 20, "1", "full")])
+def test_gpu_voting_parallel_equals_the_cpu_engines_vote(P, F, top_k, lines, precision, monkeypatch):
+    """PV-Tree on the device (local search, top_k votes per rank and child, the 2 x top_k most voted features' rows
+    summed, search in the summed rows): every rank grows the trees the CPU engine's voting learner grows over the same
+    shards - with few votes, over row lines and over feature tiles, in both histogram precisions - and with
+    2 x top_k >= F the serial trees."""
+    monkeypatch.setenv("LGA_ROW_LINES", lines)
+    X, y = make_regression(36000, F, seed=13)
+    sample = X[:20000]
+    q = {"use_quantized_grad": precision == "q16"}
+    params = {"num_leaves": 31, "min_data_in_leaf": 20, "tree_learner": "voting", "top_k": top_k, **q}
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=sample, params=GPU)
+        return lgb.train({**GPU, **params}, d, 6, comm=comm).model_to_string()
+    dev = _run_ranks(P, rank)
+    cpu = _cpu_voting_ranks(P, X, y, sample, params, 6)
+    for s in dev:
+        assert trees_of(s) == trees_of(cpu[0])
+    serial = lgb.train({**GPU, **q, "num_leaves": 31, "min_data_in_leaf": 20},
+                       lgb.Dataset(X, label=y, bin_sample=sample, params=GPU), 6)
+    if 2 * top_k >= F:
+        assert trees_of(dev[0]) == trees_of(serial)
+
+
+def test_gpu_voting_parallel_is_a_real_approximation_and_still_the_cpu_engines():
+    """Few votes on data whose features all carry a little signal (Higgs-shaped, 0/1 labels as a regression target so
+    that no exp() separates the engines): the trees differ from the serial learner's - the vote does restrict the
+    search - and equal the CPU engine's voting trees rank for rank."""
+    from lightgbm_amd.utils.datasets import make_higgs_like
+    X, y = make_higgs_like(30000, seed=5, device="numpy")
+    y = y.astype(np.float64)
+    sample = X[:20000]
+    P = 3
+    params = {"num_leaves": 31, "min_data_in_leaf": 20, "tree_learner": "voting", "top_k": 2, "learning_rate": 0.2}
+    bounds = np.linspace(0, len(y), P + 1).astype(int)
+
+    def rank(r, comm):
+        sl = slice(bounds[r], bounds[r + 1])
+        d = lgb.Dataset(X[sl], label=y[sl], bin_sample=sample, params=GPU)
+        return lgb.train({**GPU, **params}, d, 8, comm=comm).model_to_string()
+    dev = _run_ranks(P, rank)
+    cpu = _cpu_voting_ranks(P, X, y, sample, params, 8)
+    assert trees_of(dev[0]) == trees_of(dev[1]) == trees_of(dev[2]) == trees_of(cpu[0])
+    serial = lgb.train({**GPU, "num_leaves": 31, "min_data_in_leaf": 20, "learning_rate": 0.2},
+                       lgb.Dataset(X, label=y, bin_sample=sample, params=GPU), 8)
+    assert trees_of(dev[0]) != trees_of(serial)
+
+
 @pytest.mark.parametrize("P,F,leaves", [(2, 40, 31), (3, 70, 63), (8, 5, 15)])
 def test_gpu_data_parallel_over_feature_tiles_and_idle_owners(P, F, leaves, monkeypatch):
     """Reduce-scatter by feature: several feature tiles (records + gradient array instead of row lines), a

@@ -14,7 +14,7 @@ NOTES = {
     "boosting": "`gbdt`, `rf` (random forest: bagged trees on the initial gradients, averaged output), `dart`; `goss` is accepted and means `gbdt` with `data_sample_strategy=goss`",
     "objective": "`regression`, `regression_l1`, `huber`, `fair`, `poisson`, `quantile`, `mape`, `gamma`, `tweedie`, `binary`, `cross_entropy`, `multiclass`, `multiclassova`, `custom` (gradients from `fobj`)",
     "metric": "comma list; empty = the objective's own loss. `l2`, `rmse`, `l1`, `huber`, `fair`, `poisson`, `quantile`, `mape`, `gamma`, `gamma_deviance`, `tweedie`, `binary_logloss`, `binary_error`, `auc`, `cross_entropy`, `multi_logloss`, `multi_error`, `none`",
-    "tree_learner": "`serial`, `data` (rows sharded over ranks, one integer histogram all-reduce per growth round), `feature` (every rank scans its feature tiles, winners exchanged); `voting` is served by `data`",
+    "tree_learner": "`serial`, `data` (rows sharded over ranks, one integer histogram all-reduce per growth round), `feature` (every rank scans its feature tiles, winners exchanged), `voting` (rows sharded; per leaf the ranks vote for `top_k` features and only the 2 x `top_k` most voted features' histogram rows are summed)",
     "device_type": "`gpu` (HIP engine, default when a GPU is visible) or `cpu` (OpenMP engine, same numerics)",
     "num_iterations": "boosting rounds (`nrounds` in the R-style entry points)",
     "learning_rate": "shrinkage of every tree",
@@ -104,7 +104,7 @@ NOTES = {
     "data_random_seed": "seed of the row sample for bin finding",
     "feature_pre_filter": "accepted for compatibility; single-valued features are always dropped",
     "iteration_offset": "first iteration index (tree-parallel forests: keeps every iteration's random streams)",
-    "top_k": "voting-parallel learner: features each rank votes for per leaf (CPU engine)",
+    "top_k": "voting-parallel learner: features each rank votes for per leaf (both engines)",
     "forcedsplits_filename": "JSON file of splits every tree starts with (`feature`, `threshold`, `left`, `right`)",
     "early_stopping_min_delta": "an iteration counts as an improvement only if it beats the best score by this much",
     "multi_error_top_k": "`multi_error` counts a row as right when its label is among the k best classes",
