@@ -995,7 +995,8 @@ class HipBackend : public TreeBackend {
     sa.host_out = x.host_block.device_ptr();
     sa.done_counter = x.done_counter();
     sa.seq = x.seq;
-    sa.direct = (!root && !distributed() && direct_results_) ? 1 : 0;
+    // (data-parallel ranks that have summed whole histograms search like the serial learner, each for itself)
+    sa.direct = (!root && direct_results_ && (!distributed() || (mode_ == ParallelMode::Data && dp_allreduce_))) ? 1 : 0;
     x.direct = sa.direct != 0;
     return sa;
   }
@@ -1113,14 +1114,8 @@ class HipBackend : public TreeBackend {
     if (root) {
       std::memcpy(&qs_host_, tl, sizeof(QuantScale));
     } else {
-      // direct hand-over: a left child's exact row count IS the number of rows that went left
-      std::vector<int32_t> left_direct;
-      if (x.direct) {
-        left_direct.resize((size_t)B);
-        for (int i = 0; i < B; ++i) left_direct[(size_t)i] = (int32_t)infos[2 * i].total_cnt;
-        for (int i = 0; i < n_scan; ++i) infos[i].pad0 = 0;
-        tl = left_direct.data();
-      }
+      if (x.direct)
+        for (int i = 0; i < n_scan; ++i) infos[i].pad0 = 0;   // (the hand-over's sequence tag)
       for (int i = 0; i < B; ++i) {
         const SplitTask& t = x.tasks[(size_t)i];
         const NodeRange p = ranges_host_[(size_t)t.parent_node];

@@ -848,6 +848,10 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
       } else if (a.direct) {
         SplitInfo* o = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset) + s;
         write_split(o, bg, bkey, blg, blh, tc, tg, th, q, a.sp);
+        if (side == 0) {   // the left child's record travels with the task's LOCAL left count
+          int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
+          tl[a.task0 + ti] = a.task_left[a.task0 + ti];
+        }
         __threadfence_system();
         *reinterpret_cast<volatile int32_t*>(&o->pad0) = (int32_t)a.seq;
       } else {
@@ -978,6 +982,10 @@ __global__ __launch_bounds__(512) void scan_pairs_kernel(InlineTasks inl, ScanAr
       } else if (a.direct) {
         SplitInfo* o = reinterpret_cast<SplitInfo*>(a.host_out + kHostDataOffset);
         for (int k = 0; k < 2; ++k) write_split(&o[sidx[k]], bg[k], bkey[k], blg[k], blh[k], tc[k], tg[k], th[k], q, a.sp);
+        {
+          int32_t* tl = reinterpret_cast<int32_t*>(a.host_out + kHostDataOffset + sizeof(SplitInfo) * (size_t)a.n_scan);
+          tl[a.task0 + ti] = a.task_left[a.task0 + ti];
+        }
         __threadfence_system();
         for (int k = 0; k < 2; ++k) *reinterpret_cast<volatile int32_t*>(&o[sidx[k]].pad0) = (int32_t)a.seq;
       } else {

@@ -245,8 +245,8 @@ struct ScanArgs {
   unsigned seq;
   // 1: every search hands its own result to the host - SplitInfo written straight into the host-mapped block, one
   // system-scope fence, then `seq` into SplitInfo::pad0, which the host polls per result - instead of a second ticket,
-  // a last workgroup that copies everything, and one flag (three dependent memory round trips shorter).  The host
-  // then takes the left counts from the left children's total_cnt.  Not for the root, not for distributed learners.
+  // a last workgroup that copies everything, and one flag (three dependent memory round trips shorter).  A task's
+  // left count travels with its left child's record.  Not for the root, nor where winners are merged over ranks.
   int32_t direct;
 };
 // launch_scan: scan tasks of this launch (inl.count x 2, the staged tasks x 2, or 1 for the root)
