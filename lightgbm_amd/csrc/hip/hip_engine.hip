@@ -319,7 +319,8 @@ class HipBackend : public TreeBackend {
       x.stage_host.resize(stage_bytes_);
       x.stage_dev.resize(stage_bytes_);
       // host-mapped result block: [flag | SplitInfo x 2B | task_left x B | QuantScale]
-      x.host_block.resize(k::kHostDataOffset + sizeof(SplitInfo) * n_scan_max + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64);
+      x.blocks_off = (k::kHostDataOffset + sizeof(SplitInfo) * n_scan_max + sizeof(int32_t) * (size_t)(max_batch_ + 1) + 64 + 63) & ~(size_t)63;
+      x.host_block.resize(x.blocks_off + sizeof(k::BlockResult) * (size_t)k::kDirectBlocksMax);
       std::memset(x.host_block.get(), 0, x.host_block.size());
       // counters the kernels leave at zero: [round completion | per-scan-task block tickets]
       x.counters.resize(4 + n_scan_max);
@@ -707,7 +708,9 @@ class HipBackend : public TreeBackend {
     unsigned seq = 0;
     // the round in flight
     bool busy = false, root = false;
-    bool direct = false;   // the round's searches hand their results over one by one (ScanArgs::direct)
+    int direct = 0;        // the round's searches hand their results over one by one (ScanArgs::direct)
+    int direct_blocks = 1; // ... direct == 2: feature blocks per searched child
+    size_t blocks_off = 0; // ... and where their records start in the host block
     std::vector<SplitTask> tasks;
     std::chrono::steady_clock::time_point t_begin, t_launched;
     unsigned* done_counter() const { return counters.get(); }
@@ -997,7 +1000,10 @@ class HipBackend : public TreeBackend {
     sa.seq = x.seq;
     // (data-parallel ranks that have summed whole histograms search like the serial learner, each for itself)
     sa.direct = (!root && direct_results_ && (!distributed() || (mode_ == ParallelMode::Data && dp_allreduce_))) ? 1 : 0;
-    x.direct = sa.direct != 0;
+    if (sa.direct && direct_blocks_ && !sa.pairs && sa.n_scan * sa.range.n_blocks <= k::kDirectBlocksMax) sa.direct = 2;
+    sa.host_blocks = x.host_block.device_ptr() + x.blocks_off;
+    x.direct = sa.direct;
+    x.direct_blocks = sa.range.n_blocks;
     return sa;
   }
 
@@ -1095,7 +1101,8 @@ class HipBackend : public TreeBackend {
     if (!x.busy) throw std::runtime_error("no round in flight on this context");
     const auto t_wait = std::chrono::steady_clock::now();
     TraceRange wait_range("lga.wait_round");
-    if (x.direct && !x.root) wait_direct(x, 2 * (int)x.tasks.size());
+    if (x.direct == 2 && !x.root) merge_direct_blocks(x, 2 * (int)x.tasks.size());
+    else if (x.direct && !x.root) wait_direct(x, 2 * (int)x.tasks.size());
     else wait_flag(x);
     if (prof.on) {
       LGA_HIP_CHECK(hipStreamSynchronize(x.stream));
@@ -1212,7 +1219,52 @@ class HipBackend : public TreeBackend {
       wait_for(reinterpret_cast<volatile unsigned*>(const_cast<int32_t*>(&res[i].pad0)), x.seq, x.stream);
     std::atomic_thread_fence(std::memory_order_acquire);
   }
+  // ScanArgs::direct == 2: waits for every feature block's record, merges a child's blocks with the search's own
+  // total order and writes the SplitInfo records and left counts where the other hand-overs leave them.
+  void merge_direct_blocks(RoundCtx& x, int n_scan) {
+    const int nb = x.direct_blocks;
+    const k::BlockResult* br = reinterpret_cast<const k::BlockResult*>(x.host_block.get() + x.blocks_off);
+    for (int i = 0; i < n_scan * nb; ++i)
+      wait_for(reinterpret_cast<volatile unsigned*>(const_cast<int32_t*>(&br[i].tag)), x.seq, x.stream);
+    std::atomic_thread_fence(std::memory_order_acquire);
+    SplitInfo* out = reinterpret_cast<SplitInfo*>(x.host_block.get() + k::kHostDataOffset);
+    int32_t* tl = reinterpret_cast<int32_t*>(x.host_block.get() + k::kHostDataOffset + sizeof(SplitInfo) * (size_t)n_scan);
+    const double gunit = unit_of(qs_host_.kg), hunit = unit_of(qs_host_.kh);
+    const double ninf = -std::numeric_limits<double>::infinity();
+    SplitParams sp_host = sp_;   // (the node tables of sp_ are device pointers; a plain context reads none of them)
+    sp_host.node_bounds = nullptr;
+    sp_host.node_masks = nullptr;
+    sp_host.feature_scale = nullptr;
+    sp_host.feature_offset = nullptr;
+    for (int s = 0; s < n_scan; ++s) {
+      const k::BlockResult* b0 = br + (size_t)s * (size_t)nb;
+      double bg = b0->gain;
+      uint64_t bkey = b0->key;
+      int64_t blg = b0->lg, blh = b0->lh;
+      for (int b = 1; b < nb; ++b)
+        if (cand_better(b0[b].gain, b0[b].key, bg, bkey)) { bg = b0[b].gain; bkey = b0[b].key; blg = b0[b].lg; blh = b0[b].lh; }
+      SplitInfo& o = out[s];
+      o.total_cnt = b0->tc; o.total_g = b0->tg; o.total_h = b0->th; o.pad0 = 0;
+      if (bg == ninf) {
+        o.gain = ninf; o.feature = -1; o.threshold = 0; o.default_left = 0; o.left_g = 0; o.left_h = 0; o.left_cnt = 0;
+      } else {
+        o.gain = bg;
+        o.feature = (int32_t)(bkey >> 16);
+        o.threshold = (int32_t)((bkey >> 1) & 0x7fff);
+        o.default_left = (int32_t)(bkey & 1);
+        o.left_g = blg; o.left_h = blh;
+        o.left_cnt = est_count(blh, make_scan_ctx(b0->tg, b0->th, b0->tc, gunit, hunit, sp_host));
+      }
+      if ((s & 1) == 0) tl[s >> 1] = b0->left;
+    }
+  }
   bool direct_done(const RoundCtx& x, int n_scan) const {
+    if (x.direct == 2) {
+      const k::BlockResult* br = reinterpret_cast<const k::BlockResult*>(x.host_block.get() + x.blocks_off);
+      for (int i = 0; i < n_scan * x.direct_blocks; ++i)
+        if (*reinterpret_cast<const volatile unsigned*>(&br[i].tag) != x.seq) return false;
+      return true;
+    }
     const SplitInfo* res = reinterpret_cast<const SplitInfo*>(x.host_block.get() + k::kHostDataOffset);
     for (int i = 0; i < n_scan; ++i)
       if (*reinterpret_cast<const volatile unsigned*>(&res[i].pad0) != x.seq) return false;
@@ -1315,6 +1367,7 @@ class HipBackend : public TreeBackend {
   int part_rows_forced_ = 0;          // LGA_PART_ROWS: rows per workgroup of the single-pass partition, 0 = by the round's largest leaf
   int64_t part_rows4k_above_ = 1 << 20, part_rows8k_above_ = 1 << 22;
   bool direct_results_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 0);   // see ScanArgs::direct
+  bool direct_blocks_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 1);    // ... 1: never per block
   int top_k_ = 20;                    // voting-parallel: features every rank votes for per searched child
   bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
   int64_t whole_trees_ = 0;

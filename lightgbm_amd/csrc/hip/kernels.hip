@@ -829,7 +829,15 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
       st[0] = tc; st[1] = tg; st[2] = th; st[3] = 0;
     }
     bool have_winner = true;
-    if (nb > 1) {
+    if (a.direct == 2) {
+      BlockResult* o = reinterpret_cast<BlockResult*>(a.host_blocks) + ((int64_t)s * nb + b);
+      o->gain = bg; o->key = bkey; o->lg = blg; o->lh = blh;
+      o->tc = tc; o->tg = tg; o->th = th;
+      o->left = (b == 0 && side == 0 && !a.root) ? a.task_left[a.task0 + ti] : 0;
+      __threadfence_system();
+      *reinterpret_cast<volatile int32_t*>(&o->tag) = (int32_t)a.seq;
+      have_winner = false;
+    } else if (nb > 1) {
       a.block_best[(int64_t)s * nb + b] = Cand{bg, bkey, blg, blh};
       have_winner = release_and_ticket(&a.tickets[s]) == (unsigned)(nb - 1);
       if (have_winner) {

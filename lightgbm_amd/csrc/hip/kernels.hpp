@@ -247,8 +247,23 @@ struct ScanArgs {
   // system-scope fence, then `seq` into SplitInfo::pad0, which the host polls per result - instead of a second ticket,
   // a last workgroup that copies everything, and one flag (three dependent memory round trips shorter).  A task's
   // left count travels with its left child's record.  Not for the root, nor where winners are merged over ranks.
+  // 2: small rounds go one step further - every BLOCK of features hands its own winner to the host (BlockResult in
+  // `host_blocks`, [child][block]), which merges a child's blocks itself: no block ticket, no re-read of the blocks'
+  // winners either (two more round trips).
   int32_t direct;
+  char* host_blocks;
 };
+// One feature block's winner for one searched child, written by the block itself (ScanArgs::direct == 2).
+struct BlockResult {
+  double gain;
+  uint64_t key;
+  int64_t lg, lh;
+  int64_t tc, tg, th;   // the child's totals
+  int32_t left;         // block 0 of a left child: the task's local left count
+  int32_t tag;          // the round's sequence number, stored last
+};
+static_assert(sizeof(BlockResult) == 64, "one cache line per block result");
+constexpr int kDirectBlocksMax = 1024;   // children x blocks up to which a round's blocks report by themselves
 // launch_scan: scan tasks of this launch (inl.count x 2, the staged tasks x 2, or 1 for the root)
 void scan_blocks(const InlineTasks& inl, const ScanArgs& a, int launch_scan, hipStream_t s);
 
