@@ -2009,7 +2009,19 @@ class HipEngine : public Engine {
     TraceRange range("lga.score_update");
     const bool walk = score_update_ == 2 || (score_update_ == 0 && n_base_ >= kWalkMinRows);
     ++score_version_;
-    // (leaf values that needed no renewal: nobody has walked the rows yet)
+    // Leaf values that needed no renewal: nobody has walked the rows yet.  Then walk, score update and the next
+    // iteration's gradients are one pass (kernels.hpp: walk_update_gradients) ...
+    if (!leaf_ids_valid_ && leaf_values_from_exact_sums() && fused_walk_ && walk_pays(tree) && mir_->tiles == 1 && iteration_obj_ &&
+        K_ == 1 && !is_multiclass(iteration_obj_->kind) && fuse_gradients_) {
+      const TreeOnDevice td = upload_tree(tree);
+      if (k::walk_update_gradients(*iteration_obj_, td.nodes, td.n_internal, td.leaf_value, td.num_leaves, mir_->bins_rt.get(), N_,
+                                   base_or_null(), n_base_, sc(), mir_->label.get(), weight_ptr(mir_), grad_.get(), hess_.get(),
+                                   maxbits_.get(), td.node_sets, stream_)) {
+        grad_version_ = score_version_;
+        return;
+      }
+    }
+    // ... or, where that does not apply, a walk for the rows' leaves and a lookup pass
     if (!leaf_ids_valid_ && leaf_values_from_exact_sums()) walk_rows_to_leaves(tree);
     if (leaf_ids_valid_ && leaf_ids_leaves_ == tree.num_leaves) {
       // the leaf of every row is known from the walk that took the leaf sums: the tree's structure has not changed
@@ -2176,12 +2188,14 @@ class HipEngine : public Engine {
   bool leaf_values_from_exact_sums() const override { return backend_->wide() && !renew_always_; }
   // Large data with every row in the bag: one walk over the rows in storage order yields every row's leaf - which turns
   // the score update into a lookup - and the leaves' 36-bit gradient sums.
+  bool walk_pays(const Tree& tree) {
+    // (a walk costs one dependent bin read per level; LGA_WALK_DEPTH caps the row-weighted mean leaf depth it is taken for)
+    return score_update_ != 1 && n_base_ >= kWalkMinRows && oob_n_ == 0 && bag_n_ == n_base_ && tree.num_leaves > 1 &&
+           !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_;
+  }
   bool walk_rows_to_leaves(const Tree& tree) {
     const int L = tree.num_leaves;
-    // (a walk costs one dependent bin read per level; LGA_WALK_DEPTH caps the row-weighted mean leaf depth it is taken for)
-    if (!(score_update_ != 1 && n_base_ >= kWalkMinRows && oob_n_ == 0 && bag_n_ == n_base_ && L > 1 &&
-          !tree.split_feature_inner.empty() && tree.split_feature_inner[0] >= 0 && mean_leaf_depth(tree) <= walk_max_depth_))
-      return false;
+    if (!walk_pays(tree)) return false;
     leaf_acc_.resize((size_t)2 * (size_t)L);
     const TreeOnDevice td = upload_tree(tree);
     leaf_of_row_.resize((size_t)N_);
@@ -2418,6 +2432,7 @@ class HipEngine : public Engine {
   DeviceBuffer<int64_t> packed_, leaf_acc_;
   DeviceBuffer<uint16_t> leaf_of_row_;   // leaf of every root row as the last walk for leaf sums left it
   bool leaf_ids_valid_ = false;
+  bool fused_walk_ = !(std::getenv("LGA_FUSED_WALK") && std::atoi(std::getenv("LGA_FUSED_WALK")) == 0);
   bool renew_always_ = std::getenv("LGA_RENEW_ALWAYS") && std::atoi(std::getenv("LGA_RENEW_ALWAYS")) != 0;
   int leaf_ids_leaves_ = 0;
   double walk_max_depth_ = std::getenv("LGA_WALK_DEPTH") ? std::atof(std::getenv("LGA_WALK_DEPTH")) : 1e9;   // measured: never worse than the per-leaf row lists

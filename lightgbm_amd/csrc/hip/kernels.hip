@@ -2218,6 +2218,83 @@ __global__ __launch_bounds__(256) void leaf_value_add_gradients_kernel(Objective
   publish_block_max(maxbits, mg, mh);
 }
 
+// walk_leaves_lds_kernel's walk with leaf_value_add_gradients_kernel's work at the leaf (kernels.hpp: walk_update_gradients).
+template <int R>
+__global__ __launch_bounds__(256) void walk_update_kernel(ObjectiveSpec obj, const TreeNodeDev* __restrict__ nodes, int n_internal,
+                                                          const double* __restrict__ leaf_value, int num_leaves,
+                                                          const uint4* __restrict__ recs, int64_t N, const int32_t* __restrict__ rows, int64_t n,
+                                                          double* __restrict__ scores, const float* __restrict__ label,
+                                                          const float* __restrict__ weight, float* __restrict__ g, float* __restrict__ h,
+                                                          uint32_t* maxbits, const uint64_t* __restrict__ node_sets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kStride = 36;
+  int4* sn = reinterpret_cast<int4*>(smem);
+  double* lv = reinterpret_cast<double*>(smem + (size_t)n_internal * sizeof(TreeNodeDev));
+  unsigned char* sbins = reinterpret_cast<unsigned char*>(lv + num_leaves);   // [R * 256 rows][36 bytes], 4-byte aligned
+  const int4* gn = reinterpret_cast<const int4*>(nodes);
+  for (int i = threadIdx.x; i < n_internal; i += blockDim.x) sn[i] = gn[i];
+  for (int i = threadIdx.x; i < num_leaves; i += blockDim.x) lv[i] = leaf_value[i];
+  __syncthreads();
+  const TreeNodeDev* tn = reinterpret_cast<const TreeNodeDev*>(smem);
+  float mg = 0.f, mh = 0.f;
+  for (int64_t base = (int64_t)blockIdx.x * (R * 256); base < n; base += (int64_t)gridDim.x * (R * 256)) {
+    int64_t r[R];
+    double sc[R];
+    float lb[R], wt[R];
+    int node[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int64_t i = base + k * 256 + threadIdx.x;
+      r[k] = i < n ? (rows ? (int64_t)rows[i] : i) : -1;
+      if (r[k] >= 0 && !LGA_DEV_CHECK((unsigned long long)r[k] < (unsigned long long)N, kCheckWalkRow, r[k], N)) r[k] = -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      node[k] = (r[k] >= 0 && num_leaves > 1) ? 0 : ~0;
+      if (r[k] >= 0) {
+        const uint4 a = recs[r[k] * 2], b = recs[r[k] * 2 + 1];
+        unsigned* dst = reinterpret_cast<unsigned*>(sbins + (size_t)(k * 256 + (int)threadIdx.x) * kStride);   // only this lane reads it back
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w;
+        dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+        sc[k] = scores[r[k]];
+        lb[k] = label[r[k]];
+        wt[k] = weight ? weight[r[k]] : 1.0f;
+      }
+    }
+    bool more = true;
+    while (more) {
+      more = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        if (node[k] >= 0) {
+          const TreeNodeDev t = tn[node[k]];
+          const int b = sbins[(size_t)(k * 256 + (int)threadIdx.x) * kStride + ((unsigned)t.feature & 31u)];
+          const int thr = t.meta & 255, dl = (t.meta >> 8) & 1, mb = (t.meta >> 16) - 1;
+          const bool left = (t.meta & 1024) ? ((node_sets[(int64_t)node[k] * kCatSetWords + (b >> 6)] >> (b & 63)) & 1ull) != 0
+                            : (t.meta & 512) ? (b == thr) : ((b == mb) ? (dl != 0) : (b <= thr));
+          node[k] = left ? t.left : t.right;
+          if (!LGA_DEV_CHECK(node[k] < n_internal && ~node[k] < num_leaves, kCheckWalkNode, node[k], n_internal)) { node[k] = ~0; r[k] = -1; }
+          more = more || node[k] >= 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (r[k] >= 0) {
+        const double s_new = sc[k] + lv[min(~node[k], num_leaves - 1)];
+        scores[r[k]] = s_new;
+        float gg, hh;
+        grad_hess(obj, s_new, lb[k], wt[k], &gg, &hh);
+        g[r[k]] = gg;
+        h[r[k]] = hh;
+        mg = fmaxf(mg, fabsf(gg));
+        mh = fmaxf(mh, hh);
+      }
+    }
+  }
+  publish_block_max(maxbits, mg, mh);
+}
+
 __global__ __launch_bounds__(256) void scale_add_kernel(double* __restrict__ scores, const int32_t* __restrict__ rows,
                                                         int64_t n, double scale, double add) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2695,6 +2772,20 @@ bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const
   }
   hipLaunchKernelGGL(walk_leaves_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), sm, s, nodes, n_internal, num_leaves, bins_fm, N,
                      rows, n, g, h, qs, extra_bits, leaf_of_row, reinterpret_cast<unsigned long long*>(acc), node_sets);
+  LGA_LAUNCH_CHECK();
+  return true;
+}
+
+bool walk_update_gradients(const ObjectiveSpec& obj, const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
+                           const uint8_t* records, int64_t N, const int32_t* rows, int64_t n, double* scores, const float* label,
+                           const float* weight, float* g, float* h, uint32_t* maxbits, const uint64_t* node_sets, hipStream_t s) {
+  constexpr int kRows = 2;
+  const size_t sm = (size_t)n_internal * sizeof(TreeNodeDev) + (size_t)num_leaves * sizeof(double) + (size_t)kRows * 256 * 36;
+  if (!records || sm > 60 * 1024 || num_leaves > 65535) return false;
+  LGA_HIP_CHECK(hipMemsetAsync(maxbits, 0, 2 * sizeof(uint32_t), s));
+  if (n <= 0) return true;
+  hipLaunchKernelGGL(walk_update_kernel<kRows>, dim3(grid_for(n, 256 * kRows, 4096)), dim3(256), sm, s, obj, nodes, n_internal, leaf_value,
+                     num_leaves, reinterpret_cast<const uint4*>(records), N, rows, n, scores, label, weight, g, h, maxbits, node_sets);
   LGA_LAUNCH_CHECK();
   return true;
 }

@@ -445,6 +445,13 @@ void traverse_add(const TreeNodeDev* nodes, int n_internal, const double* leaf_v
 bool walk_leaves(const TreeNodeDev* nodes, int n_internal, int num_leaves, const uint8_t* bins_fm, const uint8_t* records, int64_t N,
                  const int32_t* rows, int64_t n, const float* g, const float* h, const QuantScale* qs, int extra_bits,
                  uint16_t* leaf_of_row, int64_t* acc, const uint64_t* node_sets, hipStream_t s);
+// The walk, the score update and the next iteration's gradients in ONE pass over the rows (leaf values known before
+// the walk: full-precision histograms, where nothing is renewed): a row's record is read once, walked to its leaf in
+// LDS, and its score, gradient and hessian are written right there - no leaf ids, no leaf sums, no second and third
+// pass.  Same arithmetic per row as leaf_value_add_gradients.  false: the tree does not fit the kernel's LDS.
+bool walk_update_gradients(const ObjectiveSpec& obj, const TreeNodeDev* nodes, int n_internal, const double* leaf_value, int num_leaves,
+                           const uint8_t* records, int64_t N, const int32_t* rows, int64_t n, double* scores, const float* label,
+                           const float* weight, float* g, float* h, uint32_t* maxbits, const uint64_t* node_sets, hipStream_t s);
 // leaf_value_add and the gradients of the next iteration (gradients()) in one pass.
 void leaf_value_add_gradients(const ObjectiveSpec& obj, const uint16_t* leaf_of_row, const double* leaf_value, int num_leaves,
                               const int32_t* rows, int64_t n, double* scores, const float* label, const float* weight, float* g,
