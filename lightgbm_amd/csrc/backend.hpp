@@ -55,6 +55,9 @@ class TreeBackend {
   // task i's left / right child.  The backend fills the chunk fields of the tasks.
   virtual void split_round(std::vector<SplitTask>& tasks, SplitInfo* infos) = 0;
   virtual QuantScale quant_scale() const = 0;
+  // The tree's last round has been waited for; nothing of the tree's histograms is read any more (the host goes on to
+  // assemble the tree: a backend may use the time).
+  virtual void tree_rounds_done() {}
   // Monotone constraints / path smoothing: the output range of a node and the node's own output, announced
   // before the round that creates the node is submitted (node 0 is unbounded, its output the plain optimum).
   // Never called when neither is active.

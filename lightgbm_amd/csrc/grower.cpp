@@ -668,6 +668,7 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
   }
   // rounds still in flight only carried speculation: their results are not needed, the device work is
   while (!flights.empty()) wait_oldest();
+  be.tree_rounds_done();
   stats_.materialized_splits = materialized;
   stats_.used_splits = (int)chosen.size();
   // the bar for the next tree: suffix minima of this tree's chosen gains (empty when the tree ran out of

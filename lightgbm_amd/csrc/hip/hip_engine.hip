@@ -454,6 +454,14 @@ class HipBackend : public TreeBackend {
     ++prof.trees;
   }
 
+  // The slots a tree has used are cleared as soon as its last round is in (while the host assembles the tree the
+  // device has nothing else to do); the next root round then only finds slot 0 to clear.
+  void tree_rounds_done() override {
+    if (slots_dirty_ <= 1) return;
+    LGA_HIP_CHECK(hipMemsetAsync(pool_.get() + slot_words_, 0, sizeof(int64_t) * (size_t)slot_words_ * (size_t)(slots_dirty_ - 1), stream_));
+    slots_dirty_ = 1;
+  }
+
   void root_round(SplitInfo* out) override {
     std::vector<SplitTask> tasks(1);
     SplitTask& t = tasks[0];
