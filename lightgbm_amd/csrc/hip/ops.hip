@@ -113,6 +113,27 @@ int run_op(const std::string& name, void** p, int nptr, const int64_t* a, int ni
                  (uint64_t*)p[6], (int32_t*)p[7], (int32_t*)p[8], k::BagParams{}, nullptr, 0, s);
     return 0;
   }
+  if (name == "grow_partition") {
+    // Single-pass partition of ONE multi-block leaf (node 0 -> nodes 1, 2).
+    // ptrs: task (one SplitTask), nodes, a0 (source rows), a1 (destination), bins_fm, cursor (>= 16 words, zero), task_left
+    // ints: total_chunks, N, rows per workgroup (2048, 4096 or 8192)
+    if (nptr < 7 || nint < 3) return -1;
+    k::InlineTasks inl{};
+    inl.count = 1;
+    LGA_HIP_CHECK(hipMemcpyAsync(&inl.t[0], p[0], sizeof(SplitTask), hipMemcpyDeviceToHost, s));
+    LGA_HIP_CHECK(hipStreamSynchronize(s));
+    k::GrowArgs g{};
+    g.nodes = (NodeRange*)p[1];
+    g.a0 = (const int32_t*)p[2]; g.a1 = (const int32_t*)p[3];
+    g.a0_dst = (int32_t*)p[2]; g.a1_dst = (int32_t*)p[3];
+    g.bins_fm = (const uint8_t*)p[4];
+    g.N = a[1];
+    g.part_cursor = (unsigned long long*)p[5];
+    g.part_block_rows = (int32_t)a[2];
+    g.task_left = (int32_t*)p[6];
+    k::grow_partition(inl, g, (int)a[0], s);
+    return 0;
+  }
   if (name == "scan") {
     // Split search of ONE leaf whose histogram sits in slot 0 of `pool` (feature blocks [g 256 | h 256] + header).
     // ptrs: meta, pool, slot_table (filled: {0, chunk_words}), node_totals, qs, split params (host), block_best,

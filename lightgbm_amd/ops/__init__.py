@@ -134,6 +134,36 @@ def lines_hist_build(bins_rt, rows, num_features: int, packed=None, g=None, h=No
     return G, H, hd, scales
 
 
+def partition_rows_single_pass(rows, bins_fm, feature: int, threshold: int, missing_bin: int = -1, default_left: bool = False,
+                               block_rows: int = 2048):
+    """The growth rounds' single-pass partition of ``rows`` (int32 [n]) by bins_fm[feature, row] <= threshold: lefts at
+    the front, rights behind them, in no particular order inside either.  Returns (new rows, n_left)."""
+    import torch
+    lib = _need_hip()
+    n = int(rows.numel())
+    N = int(bins_fm.shape[1])
+    nch = max(1, -(-n // block_rows))
+    task = np.zeros(17, dtype=np.int32)
+    task[0], task[1], task[2] = 0, 1, 2
+    task[3], task[4], task[5], task[6] = feature, threshold, int(default_left), missing_bin
+    task[10], task[11] = 0, nch
+    tasks = _i32(task)
+    nodes = _i32([0, n, 0, 0] + [0] * 8)
+    src = rows.contiguous().clone()
+    dst = torch.full_like(src, -1)
+    cursor = torch.zeros(32, dtype=torch.int64, device="cuda")
+    task_left = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _op(lib, "grow_partition",
+        [tasks.data_ptr(), nodes.data_ptr(), src.data_ptr(), dst.data_ptr(), bins_fm.data_ptr(), cursor.data_ptr(), task_left.data_ptr()],
+        [nch, N, block_rows])
+    torch.cuda.synchronize()
+    nd = nodes.cpu().numpy().reshape(3, 4)
+    nl = int(task_left.item())
+    assert nd[1, 1] == nl and nd[2, 0] == nl and nd[2, 1] == n - nl
+    assert int(cursor[0].item()) == 0          # the last block puts the cursor back for the next round
+    return dst, nl
+
+
 def partition_rows(rows, bins_fm, feature: int, threshold: int, missing_bin: int = -1, default_left: bool = False):
     """Stable partition of ``rows`` (int32 [n]) by bins_fm[feature, row] <= threshold.  Returns (new rows, n_left)."""
     import torch

@@ -116,6 +116,27 @@ def test_partition_kernel_is_a_stable_split(n):
         assert nl == int(left.sum())
 
 
+@pytest.mark.parametrize("n,block_rows", [(1, 2048), (4097, 2048), (100000, 2048), (100000, 4096), (300001, 8192)])
+def test_single_pass_partition_kernel_splits_exactly(n, block_rows):
+    """The growth rounds' single-pass partition (rows in registers, one reservation per workgroup, lefts forward and
+    rights backward): the left part holds exactly the rows that go left, the right part the others - as sets, the
+    order inside a child carries no meaning - and the children's ranges and the left count are what the split says."""
+    import torch
+    from lightgbm_amd import ops
+    rng = np.random.RandomState(n)
+    N = n + 500
+    fm = rng.randint(0, 40, size=(3, N)).astype(np.uint8)
+    rows = np.sort(rng.choice(N, size=n, replace=False)).astype(np.int32)
+    for (f, thr, mb, dl) in [(1, 17, -1, False), (2, 9, 39, True), (0, 0, 39, False), (1, 39, -1, False)]:
+        out, nl = ops.partition_rows_single_pass(torch.from_numpy(rows).cuda(), torch.from_numpy(fm).cuda(), f, thr, mb, dl, block_rows)
+        b = fm[f, rows]
+        left = np.where(b == mb, dl, b <= thr)
+        out = out.cpu().numpy()
+        assert nl == int(left.sum())
+        np.testing.assert_array_equal(np.sort(out[:nl]), rows[left])
+        np.testing.assert_array_equal(np.sort(out[nl:]), rows[~left])
+
+
 def _scan_reference(G, H, cnt, nb, mb, kg, kh, l1, l2, min_gain, min_h, min_data):
     gu, hu = 2.0 ** -kg, 2.0 ** -kh
     tg, th = int(G[0, :].sum()), int(H[0, :].sum())
