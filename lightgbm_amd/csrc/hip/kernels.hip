@@ -646,6 +646,13 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
   // U rows per lane and trip: every load of a trip is issued before its LDS atomics, so 4 waves per
   // SIMD keep ~U x 3 memory requests per lane in flight.
   constexpr int U = 4;
+  // (the row ids of trip i + 1 are requested before trip i's records: one memory round trip per trip instead of two)
+  int nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int i = lo + (int)threadIdx.x + u * kThreads;
+    nxt[u] = i < hi ? rows[i] : -1;
+  }
   for (int i0 = lo + threadIdx.x; i0 < hi; i0 += kThreads * U) {
     int row[U];
     unsigned long long p[U];
@@ -653,7 +660,9 @@ __global__ __launch_bounds__(WIDE ? kHistThreadsWide : kHistThreads) void hist_k
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = i0 + u * kThreads;
-      row[u] = i < hi ? rows[i] : -1;
+      row[u] = nxt[u];
+      const int in = i + kThreads * U;
+      nxt[u] = in < hi ? rows[in] : -1;
       if (i < hi && !LGA_DEV_CHECK((unsigned)row[u] < (unsigned long long)N, kCheckHistRow, row[u], N)) row[u] = -1;
     }
 #pragma unroll
@@ -1598,12 +1607,21 @@ __global__ __launch_bounds__(WIDE ? kGrowThreadsWide : kGrowThreads, 4) void gro
       stamp(0);
       // (fetching trip i + 1 while trip i goes into the histogram was measured slower: 128 VGPRs with spills,
       // root pass 244 -> 260 us - the other waves of the CU already fill the gaps)
+      // the row ids of trip i + 1 are requested before trip i's lines (four registers): a trip then waits for ONE
+      // memory round trip, its lines, instead of two dependent ones
+      int nxt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int pos = ulo + k * kThreads + tid;
+        nxt[k] = pos < uhi ? src[pos] : -1;
+      }
       for (int sub = ulo; sub < uhi; sub += 4 * kThreads) {
         int row[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int pos = sub + k * kThreads + tid;
-          row[k] = pos < uhi ? src[pos] : -1;
+          row[k] = nxt[k];
+          const int pos = sub + 4 * kThreads + k * kThreads + tid;
+          nxt[k] = pos < uhi ? src[pos] : -1;
         }
         add_rows(row);
         if (a.phase_ticks) { __builtin_amdgcn_s_waitcnt(0); stamp(2); }
