@@ -105,7 +105,7 @@ NOTES = {
     "feature_pre_filter": "accepted for compatibility; single-valued features are always dropped",
     "iteration_offset": "first iteration index (tree-parallel forests: keeps every iteration's random streams)",
     "top_k": "voting-parallel learner: features each rank votes for per leaf (both engines)",
-    "forcedsplits_filename": "JSON file of splits every tree starts with (`feature`, `threshold`, `left`, `right`)",
+    "forcedsplits_filename": "JSON file of splits every tree starts with (`feature`, `threshold`, `left`, `right`). A forced split is made whatever `min_data_in_leaf`, `min_sum_hessian_in_leaf` and its gain say (a child may even be empty: its value is then 0), rows with a missing value go right, and forcing ends on a branch at a categorical or unused feature, a threshold beyond the feature's last value bin, or the depth limit",
     "early_stopping_min_delta": "an iteration counts as an improvement only if it beats the best score by this much",
     "multi_error_top_k": "`multi_error` counts a row as right when its label is among the k best classes",
     "auc_mu_weights": "`auc_mu`: num_class x num_class misclassification weights, row-major",
