@@ -222,7 +222,12 @@ class HipBackend : public TreeBackend {
     slot_words_ = lay_.slot_words;
     int L = std::max(cfg.num_leaves, 2);
     max_batch_ = L - 1;
-    capacity_splits_ = 3 * (L - 1) + 1;
+    // Histogram slots for 4 x (L - 1) splits: a tree that wastes many speculative splits must not run out of them, or
+    // its last rounds are allowed one leaf each (with 3 x the 500-tree benchmark had trees of up to 99 rounds, with 4 x
+    // the worst has 50 and nothing hits the limit: 2.46 -> 2.42 ms per tree; LGA_POOL_FACTOR)
+    int pool_factor = 4;
+    if (const char* e = std::getenv("LGA_POOL_FACTOR")) pool_factor = std::max(2, std::min(8, std::atoi(e)));
+    capacity_splits_ = pool_factor * (L - 1) + 1;
     // keep the histogram pool below ~24 GiB
     while (capacity_splits_ > (L - 1) + 1 && (double)(capacity_splits_ + 1) * slot_words_ * 8.0 > 24.0 * (1u << 30))
       capacity_splits_ -= 1;
