@@ -299,6 +299,12 @@ class HipBackend : public TreeBackend {
     // 512 slots; full precision: one 1024-thread workgroup per CU, 256 slots) - fewer, longer units beat more, shorter
     // ones (every unit clears and flushes a whole LDS histogram); measured over 256..2048 units on the 10.5 M x 28 shape.
     target_units_ = wide_ ? 256 : 512;
+    {
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+        scan_wg_target_ = cus;
+      if (const char* e = std::getenv("LGA_SCAN_WGS")) scan_wg_target_ = std::max(1, std::atoi(e));
+    }
     if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
     max_unit_rows_ = wide_ ? 65536 : kMaxUnitRows;
     if (const char* e = std::getenv("LGA_MAX_UNIT_ROWS")) max_unit_rows_ = std::max(k::kSubRows, std::min(max_unit_rows_, std::atoi(e)));
@@ -988,7 +994,7 @@ class HipBackend : public TreeBackend {
       // feature blocks: one feature per wave (8 per workgroup) while the round is small - its search is pure
       // latency - growing to keep the launch near a thousand workgroups when it has hundreds of leaves
       const int owned = std::max(0, scan_range_.f_end - scan_range_.f_begin);
-      const int want_blocks = std::max(1, 1024 / std::max(1, sa.n_scan));
+      const int want_blocks = std::max(1, scan_wg_target_ / std::max(1, sa.n_scan));
       int g = (owned + want_blocks - 1) / want_blocks;
       g = std::max(8, ((g + 7) / 8) * 8);
       // (ONE block per child for small rounds - no block ticket, no merge of the blocks' winners, a wave takes four
@@ -1381,6 +1387,10 @@ class HipBackend : public TreeBackend {
   int64_t part_rows4k_above_ = 1 << 20, part_rows8k_above_ = 1 << 22;
   bool direct_results_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 0);   // see ScanArgs::direct
   bool direct_blocks_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 1);    // ... 1: never per block
+  // Workgroups a split search aims for: the search kernel keeps 8 waves of ~170 registers per CU - ONE workgroup - so a
+  // launch of more workgroups than CUs runs in shifts; rounds of many leaves give a wave several features in turn
+  // instead (measured on the 10.5 M x 28 benchmark: 1024 -> 256 workgroups 2.43 -> 2.38 ms per tree; LGA_SCAN_WGS)
+  int scan_wg_target_ = 256;
   int top_k_ = 20;                    // voting-parallel: features every rank votes for per searched child
   bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
   int64_t whole_trees_ = 0;

@@ -792,8 +792,9 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
   }
   const QuantScale q = *a.qs;
   const SlotRef self = direct ? fresh : old_slot_ref(a.pool, t.parent_slot);
-  FeatureMeta m_first{};
+  FeatureMeta m_first{}, m_next{};
   if (f_first < f1) m_first = a.meta[f_first];
+  if (f_first + 8 < f1) m_next = a.meta[f_first + 8];
   int64_t g[4], h[4], cg[4], ch[4];
   const bool first_loaded = f_first < f1 && m_first.enabled;
   if (first_loaded) {
@@ -807,22 +808,34 @@ __global__ __launch_bounds__(512) void scan_blocks_kernel(InlineTasks inl, ScanA
   double bg = ninf;
   uint64_t bkey = ~0ull;
   int64_t blg = 0, blh = 0;
+  // A wave that takes several features in turn (rounds of many leaves: few, long workgroups) requests the NEXT feature's
+  // cells before it works on the current one, and the description of the one after: one memory round trip per wave
+  // instead of one per feature.
+  FeatureMeta m = m_first;
   for (int f = f_first; f < f1; f += 8) {
-    const FeatureMeta m = f == f_first ? m_first : a.meta[f];
-    if (!m.enabled) continue;
-    int64_t* blk = feat_block(a.pool, self, f);
-    const int bpl = bins_per_lane(m.num_bin);
-    if (f != f_first) {
-      load_feat_cells(blk, lane, bpl, g, h);
-      if (!direct) load_feat_cells(feat_block(a.pool, fresh, f), lane, bpl, cg, ch);
+    const int fn = f + 8;
+    const FeatureMeta mn = m_next;
+    int64_t ng[4] = {0, 0, 0, 0}, nh[4] = {0, 0, 0, 0}, ncg[4] = {0, 0, 0, 0}, nch[4] = {0, 0, 0, 0};
+    if (fn < f1 && mn.enabled) {
+      const int nbpl = bins_per_lane(mn.num_bin);
+      load_feat_cells(feat_block(a.pool, self, fn), lane, nbpl, ng, nh);
+      if (!direct) load_feat_cells(feat_block(a.pool, fresh, fn), lane, nbpl, ncg, nch);
     }
-    if (!direct) {
+    if (fn + 8 < f1) m_next = a.meta[fn + 8];
+    if (m.enabled) {
+      int64_t* blk = feat_block(a.pool, self, f);
+      const int bpl = bins_per_lane(m.num_bin);
+      if (!direct) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
-      store_feat_cells(blk, lane, bpl, g, h);
+        for (int j = 0; j < 4; ++j) { g[j] -= cg[j]; h[j] -= ch[j]; }
+        store_feat_cells(blk, lane, bpl, g, h);
+      }
+      if (node_feature_on(a.sp, key, f, a.F) && node_allows(a.sp, node, f) && m.categorical != kCategoricalSorted)
+        scan_cells_wave(f, lane, bpl, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
     }
-    if (node_feature_on(a.sp, key, f, a.F) && node_allows(a.sp, node, f) && m.categorical != kCategoricalSorted)
-      scan_cells_wave(f, lane, bpl, g, h, m, ctx, a.sp, bg, bkey, blg, blh, key);
+    m = mn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g[j] = ng[j]; h[j] = nh[j]; cg[j] = ncg[j]; ch[j] = nch[j]; }
   }
   wave_best(bg, bkey, blg, blh);
   if (lane == 0) wbest[wave] = Cand{bg, bkey, blg, blh};
