@@ -428,10 +428,10 @@ Tree TreeGrower::grow_finish(TreeBackend& be, const std::vector<FeatureMeta>& me
     Flight f;
     f.tasks = std::move(tasks);
     if (dump_rounds) {
-      int64_t most = 0, sum = 0;
-      for (const SplitTask& t : f.tasks) { const int64_t r = nodes[(size_t)t.parent_node].best.total_cnt; most = std::max(most, r); sum += r; }
-      std::fprintf(stderr, "[grow dump] round %d: %zu leaves, %lld rows (largest %lld), %zu rounds already in flight, %zu splits chosen, at %.1f us\n",
-                   stats_.rounds, f.tasks.size(), (long long)sum, (long long)most, flights.size(), chosen.size(),
+      int64_t most = 0, sum = 0, hist = 0;
+      for (const SplitTask& t : f.tasks) { const int64_t r = nodes[(size_t)t.parent_node].best.total_cnt; most = std::max(most, r); sum += r; hist += t.hist_rows; }
+      std::fprintf(stderr, "[grow dump] round %d: %zu leaves, %lld rows (largest %lld), %lld rows to histogram, %zu rounds already in flight, %zu splits chosen, at %.1f us\n",
+                   stats_.rounds, f.tasks.size(), (long long)sum, (long long)most, (long long)hist, flights.size(), chosen.size(),
                    GrowTrace::us(t_enter, GrowTrace::clock::now()));
     }
     const auto t_call = GrowTrace::clock::now();
