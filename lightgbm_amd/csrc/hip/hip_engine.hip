@@ -302,7 +302,7 @@ class HipBackend : public TreeBackend {
     {
       int dev = 0, cus = 0;
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-        scan_wg_target_ = cus;
+        scan_wg_target_ = F_ > kTileFeatures ? 2 * cus : cus;
       if (const char* e = std::getenv("LGA_SCAN_WGS")) scan_wg_target_ = std::max(1, std::atoi(e));
     }
     if (const char* e = std::getenv("LGA_TARGET_UNITS")) target_units_ = std::max(1, std::atoi(e));
@@ -1389,7 +1389,9 @@ class HipBackend : public TreeBackend {
   bool direct_blocks_ = !(std::getenv("LGA_DIRECT_RESULTS") && std::atoi(std::getenv("LGA_DIRECT_RESULTS")) == 1);    // ... 1: never per block
   // Workgroups a split search aims for: the search kernel keeps 8 waves of ~170 registers per CU - ONE workgroup - so a
   // launch of more workgroups than CUs runs in shifts; rounds of many leaves give a wave several features in turn
-  // instead (measured on the 10.5 M x 28 benchmark: 1024 -> 256 workgroups 2.43 -> 2.38 ms per tree; LGA_SCAN_WGS)
+  // instead (measured on the 10.5 M x 28 benchmark: 1024 -> 256 workgroups 2.43 -> 2.38 ms per tree; LGA_SCAN_WGS).
+  // Data of several feature tiles searches hundreds of features per child and is bound by the histogram bytes it moves:
+  // two workgroups' worth per CU measured best there (1 M x 968: 8.2 ms per tree at 256, 6.9 at 512, 7.1 at 1024).
   int scan_wg_target_ = 256;
   int top_k_ = 20;                    // voting-parallel: features every rank votes for per searched child
   bool single_pass_partition_ = true; // row lines: sides + row movement of the large leaves in one launch (grow_partition)
