@@ -688,6 +688,35 @@ def test_locality_order_changes_nothing_but_the_memory_layout(case, monkeypatch)
         np.testing.assert_allclose(raw_b, b.predict(X, raw_score=True, device="cpu"), atol=1e-9)
 
 
+@pytest.mark.parametrize("width,precision", [(12, "full"), (12, "q16"), (70, "full")])
+def test_launch_shapes_and_pool_size_change_nothing_but_the_time(width, precision, monkeypatch):
+    """How a round is cut into workgroups is a matter of speed only: the split search with one workgroup per child (every
+    wave takes its features in turn, the next one's cells requested ahead) or with as many feature blocks as there are,
+    histogram units of the smallest and of the largest size, and a histogram pool with room for 2 x or 8 x
+    (num_leaves - 1) splits (a tree that runs out of slots finishes one leaf per round) all grow the CPU engine's trees.
+    300 k rows: the row-line rounds of single-tile data; 70 features: the feature-tile rounds."""
+    rng = np.random.RandomState(23)
+    n = 300000 if width <= 32 else 60000
+    X = rng.randn(n, width)
+    X[:, 3] = rng.randint(0, 3, size=n)
+    y = (X[:, 0] + 0.8 * X[:, 1] * X[:, 2] - 0.5 * np.abs(X[:, 4]) + 0.4 * (X[:, 3] == 1) + 0.5 * rng.randn(n) > 0).astype(float)
+    p = {"objective": "binary", "num_leaves": 127, "min_data_in_leaf": 1, "min_sum_hessian_in_leaf": 20.0,
+         "learning_rate": 0.2, "use_quantized_grad": precision == "q16", "verbose": -1}
+
+    def fit(dev):
+        base = {"device_type": dev, "verbose": -1}
+        return trees_of(lgb.train({**p, **base}, lgb.Dataset(X, label=y, params={**p, **base}), 4))
+    want = fit("cpu")
+    for env in ({"LGA_SCAN_WGS": "1"}, {"LGA_SCAN_WGS": "100000"}, {"LGA_TARGET_UNITS": "1"}, {"LGA_TARGET_UNITS": "4096"},
+                {"LGA_POOL_FACTOR": "2"}, {"LGA_POOL_FACTOR": "8", "LGA_SPEC_FLOOR": "0.0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = fit("gpu")
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got == want, env
+
+
 @pytest.mark.parametrize("objective", ["multiclass", "multiclassova"])
 def test_gpu_multiclass_matches_cpu(objective):
     """num_class score / gradient vectors on the device: the first iteration (scores all zero, so the
