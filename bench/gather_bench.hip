@@ -45,6 +45,15 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(const int* __restrict_
         if (LAYOUT == 2) {
           ra[u] = recs[(int64_t)row[u] * 2]; rb[u] = recs[(int64_t)row[u] * 2 + 1];
           p[u] = ((unsigned long long)(long long)(short)(rb[u].w >> 16) << 32) | (rb[u].w & 0xffffu);
+        } else if (LAYOUT == 3) {
+          // 128-byte lines whose first and third row sit in ONE 64-byte half each (bins + gradient word), the second row
+          // in what is left of both: 1.33 halves per row on average instead of 1.67
+          const unsigned line = div3((unsigned)row[u]), slot = (unsigned)row[u] - line * 3u;
+          const uint4* L = recs + (int64_t)line * 8;
+          const unsigned ia = slot == 0 ? 0u : (slot == 1 ? 3u : 4u), ib = slot == 0 ? 1u : (slot == 1 ? 7u : 5u);
+          const unsigned ip = slot == 0 ? 4u : (slot == 1 ? 13u : 12u);
+          ra[u] = L[ia]; rb[u] = L[ib];
+          p[u] = reinterpret_cast<const unsigned long long*>(L)[ip];
         } else if (LAYOUT == 1) {
           const unsigned line = div3((unsigned)row[u]), slot = (unsigned)row[u] - line * 3u;
           const uint4* L = recs + (int64_t)line * 8;
@@ -108,6 +117,19 @@ int main() {
     for (int b = 0; b < 32; ++b) h_lines[(size_t)line * 128 + slot * 32 + b] = h_rec[(size_t)r * 32 + b];
     reinterpret_cast<unsigned long long*>(&h_lines[(size_t)line * 128])[12 + slot] = h_packed[(size_t)r];
   }
+  std::vector<unsigned char> h_lines2((size_t)n_lines * 128, 0);
+  for (int64_t r = 0; r < N; ++r) {
+    const int64_t line = r / 3; const int slot = (int)(r % 3);
+    const int oa = slot == 0 ? 0 : (slot == 1 ? 48 : 64), ob = slot == 0 ? 16 : (slot == 1 ? 112 : 80), op = slot == 0 ? 32 : (slot == 1 ? 104 : 96);
+    for (int b = 0; b < 16; ++b) {
+      h_lines2[(size_t)line * 128 + oa + b] = h_rec[(size_t)r * 32 + b];
+      h_lines2[(size_t)line * 128 + ob + b] = h_rec[(size_t)r * 32 + 16 + b];
+    }
+    *reinterpret_cast<unsigned long long*>(&h_lines2[(size_t)line * 128 + op]) = h_packed[(size_t)r];
+  }
+  void* d_lines2;
+  CHECK(hipMalloc(&d_lines2, h_lines2.size()));
+  CHECK(hipMemcpy(d_lines2, h_lines2.data(), h_lines2.size(), hipMemcpyHostToDevice));
   void *d_rec, *d_lines; unsigned long long *d_packed, *d_out; int* d_rows;
   CHECK(hipMalloc(&d_rec, h_rec.size())); CHECK(hipMalloc(&d_lines, h_lines.size()));
   CHECK(hipMalloc(&d_packed, h_packed.size() * 8)); CHECK(hipMalloc(&d_out, 64)); CHECK(hipMalloc(&d_rows, N * 4));
@@ -129,7 +151,9 @@ int main() {
     double c = run<0, true>(d_rows, n, chunk, d_rec, d_packed, d_out);
     double e = run<1, true>(d_rows, n, chunk, d_lines, d_packed, d_out);
     double e2 = run<2, true>(d_rows, n, chunk, d_rec, d_packed, d_out);
-    printf("  1/%-5d %10d | %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f   rec32/full: %.1f ps/row\n", d, n, a, b, b2, c, e, e2, e2 * 1e6 / n);
+    double b3 = run<3, false>(d_rows, n, chunk, d_lines2, d_packed, d_out);
+    double e3 = run<3, true>(d_rows, n, chunk, d_lines2, d_packed, d_out);
+    printf("  1/%-5d %10d | %10.1f %10.1f %10.1f %10.1f %10.1f %10.1f   rec32/full: %.1f ps/row | halves/load %.1f halves/full %.1f\n", d, n, a, b, b2, c, e, e2, e2 * 1e6 / n, b3, e3);
   }
   return 0;
 }
