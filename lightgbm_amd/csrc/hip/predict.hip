@@ -138,6 +138,7 @@ struct QNode {
 };
 static_assert(sizeof(QNode) == 16, "QNode layout");
 constexpr size_t kQTileBytes = 20 * 1024;   // three 255-leaf trees
+constexpr int kQTileTrees = 64;             // trees a tile holds at most (their offsets wait in LDS too)
 
 // SETS: the model has category-set nodes (the common case without them compiles the lookup away)
 template <typename T, int R, bool SETS>
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
                                                                    double sigmoid, int raw, double* __restrict__ out,
                                                                    const uint32_t* __restrict__ cat_words) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_noff[kQTileTrees + 1], s_loff[kQTileTrees + 1];   // the tile's trees: first node / first leaf inside the tile
   constexpr int kRows = kPredThreads * R;
   T* xs = reinterpret_cast<T*>(smem);                                   // [nfeat][kRows]
   char* tile = smem + (((size_t)nfeat * kRows * sizeof(T) + 15) & ~(size_t)15);
@@ -178,30 +180,44 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
       double2* dst = reinterpret_cast<double2*>(sn);
       for (int i = threadIdx.x; i < nn; i += kPredThreads) dst[i] = src[i];
       for (int i = threadIdx.x; i < nl; i += kPredThreads) sl[i] = leaves[l0 + i];
+      for (int i = threadIdx.x; i <= t1 - t0; i += kPredThreads) { s_noff[i] = node_off[t0 + i] - n0; s_loff[i] = leaf_off[t0 + i] - l0; }
     }
     __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-      const int nb = node_off[t] - n0, lb = leaf_off[t] - l0;
-      const int tn = node_off[t + 1] - node_off[t];
-      int node[R];
+    // A lane walks the tile's trees one after the other WITHOUT waiting for the other lanes at every leaf: it adds the
+    // leaf's value and starts on its next tree at once, so a wave runs as long as its slowest lane needs for all the
+    // tile's trees together (sums of depths differ far less between rows than single depths do) instead of the
+    // deepest leaf of every tree.  The trees of a row are still added in order: the sums are the same bit for bit.
+    int tcur[R], node[R], nb[R], lb[R];
+    auto enter = [&](int j) {
+      // trees without a split are their one leaf
+      while (tcur[j] < t1 && s_noff[tcur[j] - t0 + 1] == s_noff[tcur[j] - t0]) { sum[j] += sl[s_loff[tcur[j] - t0]]; ++tcur[j]; }
+      if (tcur[j] < t1) { nb[j] = s_noff[tcur[j] - t0]; lb[j] = s_loff[tcur[j] - t0]; }
+      node[j] = 0;
+    };
+    bool any = false;
 #pragma unroll
-      for (int j = 0; j < R; ++j) node[j] = (tn > 0 && live[j]) ? 0 : ~0;
-      bool any = tn > 0;
-      while (any) {
-        any = false;
+    for (int j = 0; j < R; ++j) {
+      tcur[j] = live[j] ? t0 : t1;
+      nb[j] = 0; lb[j] = 0;
+      enter(j);
+      any = any || tcur[j] < t1;
+    }
+    while (any) {
+      any = false;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          if (node[j] >= 0) {
-            const QNode nd = sn[nb + node[j]];
-            const double v = (double)xs[(int)nd.feature * kRows + j * kPredThreads + threadIdx.x];
-            node[j] = go_left_dev<SETS>(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
-            any = any || node[j] >= 0;
+      for (int j = 0; j < R; ++j) {
+        if (tcur[j] < t1) {
+          const QNode nd = sn[nb[j] + node[j]];
+          const double v = (double)xs[(int)nd.feature * kRows + j * kPredThreads + threadIdx.x];
+          node[j] = go_left_dev<SETS>(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
+          if (node[j] < 0) {
+            sum[j] += sl[lb[j] + (~node[j])];
+            ++tcur[j];
+            enter(j);
           }
+          any = any || tcur[j] < t1;
         }
       }
-#pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (live[j]) sum[j] += sl[lb + (~node[j])];
     }
   }
 #pragma unroll
@@ -314,11 +330,24 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
     int max_leaves = 1;
     for (int t = 0; t < n_it; ++t) max_leaves = std::max(max_leaves, trees[(size_t)(start_iter + t)].num_leaves);
     const size_t biggest = (size_t)(max_leaves - 1) * sizeof(QNode) + (size_t)max_leaves * sizeof(double);
-    const size_t q_limit = std::max(kQTileBytes, biggest);
-    const size_t row_budget = 64 * 1024;
-    const int R = (size_t)nfeat * kPredThreads * 2 * esz <= row_budget ? 2
-                : (size_t)nfeat * kPredThreads * esz <= row_budget     ? 1 : 0;
-    if (R > 0 && max_leaves <= 32768 && nfeat <= 32767 && q_limit <= 40 * 1024 && n_it > 0) {
+    // How many workgroups a CU holds decides the throughput (a walk is a chain of LDS round trips; measured on 500 trees of
+    // 255 leaves over 28 columns: three workgroups of one row per lane 84 M rows/s, two workgroups of two rows per lane
+    // 63 M, two of one row 65 M): one row per lane, and the tree tile as large as still lets three workgroups - or,
+    // with a wide row tile, two, or one - share the CU's 160 KiB.  LGA_PRED_TILE_KB / LGA_PRED_ROWS override both.
+    const size_t cu_lds = 160 * 1024, slack = 1536;   // (the kernel's static arrays, allocation granularity)
+    const size_t xs1 = (((size_t)nfeat * kPredThreads * esz + 15) & ~(size_t)15);
+    int R = xs1 + biggest + slack <= cu_lds ? 1 : 0;
+    size_t q_limit = biggest;
+    if (R > 0) {
+      int wgs = 3;
+      while (wgs > 1 && xs1 + biggest + slack > cu_lds / (size_t)wgs) --wgs;
+      q_limit = std::max(biggest, std::min<size_t>(cu_lds / (size_t)wgs - xs1 - slack, 2 * kQTileBytes));
+    }
+    if (const char* e = std::getenv("LGA_PRED_ROWS")) {
+      if (std::atoi(e) == 2 && 2 * xs1 + biggest + slack <= cu_lds) { R = 2; q_limit = std::max(biggest, kQTileBytes); }
+    }
+    if (const char* e = std::getenv("LGA_PRED_TILE_KB")) q_limit = std::max(biggest, (size_t)std::max(4, std::atoi(e)) * 1024);
+    if (R > 0 && max_leaves <= 32768 && nfeat <= 32767 && q_limit + (size_t)R * xs1 + slack <= cu_lds && n_it > 0) {
       std::vector<QNode> nodes;
       std::vector<uint32_t> cat_words;
       std::vector<double> leaves;
@@ -328,7 +357,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
         const Tree& tr = trees[(size_t)(start_iter + t)];
         const int ni = tr.num_leaves - 1;
         const size_t bytes = (size_t)ni * sizeof(QNode) + (size_t)tr.num_leaves * sizeof(double);
-        if (tile_bytes + bytes > q_limit) { tile_begin.push_back(t); tile_bytes = 0; }
+        if (tile_bytes + bytes > q_limit || t - tile_begin.back() >= kQTileTrees) { tile_begin.push_back(t); tile_bytes = 0; }
         tile_bytes += bytes;
         for (int i = 0; i < ni; ++i) {
           QNode n;
