@@ -229,6 +229,80 @@ __global__ __launch_bounds__(kPredThreads) void predict_lds_kernel(const T* __re
   }
 }
 
+// Wider matrices: 64 rows per workgroup wait in LDS (transposed like above: a wave's 64 lanes are the 64 rows), and the
+// four waves walk FOUR DIFFERENT TREES of the tile for them at the same time - wave w takes the tile's trees w, w + 4,
+// ... - so a row tile a quarter the size keeps as many walks in flight.  The leaf values pass through LDS and the first
+// wave adds them to its rows' sums in tree order: the same sums, bit for bit, as one lane per row walking every tree.
+constexpr int kWideRows = 64;
+constexpr int kWideTileTrees = 16;   // trees per tile at most (their leaf values wait in LDS: 16 x 64 doubles)
+template <typename T, bool SETS>
+__global__ __launch_bounds__(kPredThreads) void predict_rows64_kernel(const T* __restrict__ X, int64_t nrow, int ncol, int nfeat,
+                                                                      const QNode* __restrict__ nodes,
+                                                                      const double* __restrict__ leaves,
+                                                                      const int32_t* __restrict__ node_off,
+                                                                      const int32_t* __restrict__ leaf_off,
+                                                                      const int32_t* __restrict__ tile_begin,
+                                                                      int n_tiles, int n_trees, int average, int obj_kind,
+                                                                      double sigmoid, int raw, double* __restrict__ out,
+                                                                      const uint32_t* __restrict__ cat_words) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_noff[kWideTileTrees + 1], s_loff[kWideTileTrees + 1];
+  __shared__ double vals[kWideTileTrees][kWideRows];
+  T* xs = reinterpret_cast<T*>(smem);                                   // [nfeat][64]
+  char* tile = smem + (((size_t)nfeat * kWideRows * sizeof(T) + 15) & ~(size_t)15);
+  const int64_t base = (int64_t)blockIdx.x * kWideRows;
+  const int row = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t block_vals = (int64_t)min((int64_t)kWideRows, nrow - base) * ncol;
+  for (int64_t i = threadIdx.x; i < block_vals; i += kPredThreads) {
+    const int r = (int)(i / ncol), c = (int)(i - (int64_t)r * ncol);
+    if (c < nfeat) xs[c * kWideRows + r] = X[base * ncol + i];
+  }
+  const bool live = base + row < nrow;
+  double sum = 0.0;
+  for (int tl = 0; tl < n_tiles; ++tl) {
+    const int t0 = tile_begin[tl], t1 = tile_begin[tl + 1];
+    const int n0 = node_off[t0], nn = node_off[t1] - n0;
+    const int l0 = leaf_off[t0], nl = leaf_off[t1] - l0;
+    QNode* sn = reinterpret_cast<QNode*>(tile);
+    double* sl = reinterpret_cast<double*>(tile + (size_t)nn * sizeof(QNode));
+    __syncthreads();   // the previous tile is done with (first pass: the rows are in place)
+    {
+      const double2* src = reinterpret_cast<const double2*>(nodes + n0);
+      double2* dst = reinterpret_cast<double2*>(sn);
+      for (int i = threadIdx.x; i < nn; i += kPredThreads) dst[i] = src[i];
+      for (int i = threadIdx.x; i < nl; i += kPredThreads) sl[i] = leaves[l0 + i];
+      for (int i = threadIdx.x; i <= t1 - t0; i += kPredThreads) { s_noff[i] = node_off[t0 + i] - n0; s_loff[i] = leaf_off[t0 + i] - l0; }
+    }
+    __syncthreads();
+    // this wave's trees of the tile, every lane at its own pace
+    int tcur = live ? t0 + wave : t1, node = 0, nb = 0, lb = 0;
+    auto enter = [&]() {
+      while (tcur < t1 && s_noff[tcur - t0 + 1] == s_noff[tcur - t0]) { vals[tcur - t0][row] = sl[s_loff[tcur - t0]]; tcur += 4; }
+      if (tcur < t1) { nb = s_noff[tcur - t0]; lb = s_loff[tcur - t0]; }
+      node = 0;
+    };
+    enter();
+    while (tcur < t1) {
+      const QNode nd = sn[nb + node];
+      const double v = (double)xs[(int)nd.feature * kWideRows + row];
+      node = go_left_dev<SETS>(v, nd.threshold, nd.dtype, cat_words) ? (int)nd.left : (int)nd.right;
+      if (node < 0) {
+        vals[tcur - t0][row] = sl[lb + (~node)];
+        tcur += 4;
+        enter();
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && live)
+      for (int t = 0; t < t1 - t0; ++t) sum += vals[t][row];
+  }
+  if (wave == 0 && live) {
+    double s = sum;
+    if (average && n_trees > 0) s /= (double)n_trees;
+    out[base + row] = raw ? s : transform_score(obj_kind, sigmoid, s);
+  }
+}
+
 // first parameter (const T* X) of a predictor kernel, for casting the untyped matrix pointer
 template <typename T, typename... A>
 const T* kernel_arg0(void (*)(const T*, A...));
@@ -336,18 +410,33 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
     // with a wide row tile, two, or one - share the CU's 160 KiB.  LGA_PRED_TILE_KB / LGA_PRED_ROWS override both.
     const size_t cu_lds = 160 * 1024, slack = 1536;   // (the kernel's static arrays, allocation granularity)
     const size_t xs1 = (((size_t)nfeat * kPredThreads * esz + 15) & ~(size_t)15);
-    int R = xs1 + biggest + slack <= cu_lds ? 1 : 0;
+    const size_t xs64 = (((size_t)nfeat * kWideRows * esz + 15) & ~(size_t)15), slack64 = slack + sizeof(double) * kWideTileTrees * kWideRows;
+    // 256 rows per workgroup while THREE such workgroups fit a CU (measured, 300 trees of 255 leaves: 28 columns 98 M
+    // rows/s against 77 M with the 64-row kernel, 45 columns 77 against 64, 60 columns - two workgroups - 63 against 78);
+    // else 64 rows and a tree per wave (predict_rows64_kernel) while that fits (200 columns: 43 M rows/s against 18.5 M
+    // with the feature values in global memory); else predict_kernel.  LGA_PRED_KERNEL=rows64 forces the second.
+    int R = xs1 + biggest + slack <= cu_lds / 3 ? 1 : 0;
+    if (const char* e = std::getenv("LGA_PRED_KERNEL")) { if (std::string(e) == "rows64") R = 0; }
+    const bool rows64 = R == 0 && xs64 + biggest + slack64 <= cu_lds;
+    if (R == 0 && !rows64 && xs1 + biggest + slack <= cu_lds) R = 1;
     size_t q_limit = biggest;
+    int max_tile_trees = kQTileTrees;
     if (R > 0) {
       int wgs = 3;
       while (wgs > 1 && xs1 + biggest + slack > cu_lds / (size_t)wgs) --wgs;
       q_limit = std::max(biggest, std::min<size_t>(cu_lds / (size_t)wgs - xs1 - slack, 2 * kQTileBytes));
+    } else if (rows64) {
+      int wgs = 3;
+      while (wgs > 1 && xs64 + biggest + slack64 > cu_lds / (size_t)wgs) --wgs;
+      q_limit = std::max(biggest, std::min<size_t>(cu_lds / (size_t)wgs - xs64 - slack64, 2 * kQTileBytes));
+      max_tile_trees = kWideTileTrees;
     }
     if (const char* e = std::getenv("LGA_PRED_ROWS")) {
       if (std::atoi(e) == 2 && 2 * xs1 + biggest + slack <= cu_lds) { R = 2; q_limit = std::max(biggest, kQTileBytes); }
     }
     if (const char* e = std::getenv("LGA_PRED_TILE_KB")) q_limit = std::max(biggest, (size_t)std::max(4, std::atoi(e)) * 1024);
-    if (R > 0 && max_leaves <= 32768 && nfeat <= 32767 && q_limit + (size_t)R * xs1 + slack <= cu_lds && n_it > 0) {
+    const bool fits = R > 0 ? q_limit + (size_t)R * xs1 + slack <= cu_lds : (rows64 && q_limit + xs64 + slack64 <= cu_lds);
+    if (fits && max_leaves <= 32768 && nfeat <= 32767 && n_it > 0) {
       std::vector<QNode> nodes;
       std::vector<uint32_t> cat_words;
       std::vector<double> leaves;
@@ -357,7 +446,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
         const Tree& tr = trees[(size_t)(start_iter + t)];
         const int ni = tr.num_leaves - 1;
         const size_t bytes = (size_t)ni * sizeof(QNode) + (size_t)tr.num_leaves * sizeof(double);
-        if (tile_bytes + bytes > q_limit || t - tile_begin.back() >= kQTileTrees) { tile_begin.push_back(t); tile_bytes = 0; }
+        if (tile_bytes + bytes > q_limit || t - tile_begin.back() >= max_tile_trees) { tile_begin.push_back(t); tile_bytes = 0; }
         tile_bytes += bytes;
         for (int i = 0; i < ni; ++i) {
           QNode n;
@@ -389,7 +478,7 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
       auto run = [&](auto kernel, size_t lds) {
         LGA_HIP_CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for_each_chunk([&](const void* x, int64_t n, double* o) {
-          const int rows_per_wg = kPredThreads * R;
+          const int rows_per_wg = R > 0 ? kPredThreads * R : kWideRows;
           dim3 grid((unsigned)((n + rows_per_wg - 1) / rows_per_wg));
           using XT = typename std::remove_pointer<decltype(kernel_arg0(kernel))>::type;
           hipLaunchKernelGGL(kernel, grid, dim3(kPredThreads), lds, s, (XT*)x, n, ncol, nfeat, d_nodes.get(),
@@ -398,7 +487,11 @@ void predict_class(const Booster& b, int K, int k, const void* data, bool on_dev
         });
       };
       const bool sets = !cat_words.empty();
-      if (dtype == 0 && R == 2) {
+      if (R == 0) {
+        const size_t lds = xs64 + q_limit;
+        if (dtype == 0) { if (sets) run(predict_rows64_kernel<float, true>, lds); else run(predict_rows64_kernel<float, false>, lds); }
+        else { if (sets) run(predict_rows64_kernel<double, true>, lds); else run(predict_rows64_kernel<double, false>, lds); }
+      } else if (dtype == 0 && R == 2) {
         if (sets) run(predict_lds_kernel<float, 2, true>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
         else run(predict_lds_kernel<float, 2, false>, lds_kernel_bytes<float, 2>(nfeat, q_limit));
       } else if (dtype == 0) {

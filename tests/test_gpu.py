@@ -886,6 +886,34 @@ def test_gpu_predictor_matches_host_predictor():
     np.testing.assert_allclose(rf.predict(X, device="gpu"), rf.predict(X, device="cpu"), atol=1e-12)
 
 
+@pytest.mark.parametrize("cols,force", [(12, ""), (12, "rows64"), (70, ""), (260, ""), (700, "")])
+def test_every_device_predictor_kernel_matches_the_host(cols, force, monkeypatch):
+    """The device predictor picks its kernel by the width of the matrix: 256 rows per workgroup in LDS (12 columns), 64
+    rows in LDS with one tree of the tile per wave (70 and 260 columns; forced for 12), feature values in global memory
+    (700 columns).  Each adds a row's trees in order, so all equal the host predictor; NaNs, a categorical column searched
+    over category sets, a 1-leaf tree (constant first iteration of a tiny learning rate), float32 and float64 matrices
+    and a row count that leaves the last workgroup part empty."""
+    rng = np.random.RandomState(cols)
+    n = 9000 + 37
+    X = rng.randn(n, cols)
+    X[:, 1] = rng.randint(0, 40, size=n)
+    X[rng.rand(n) < 0.05, 2] = np.nan
+    y = X[:, 0] + 0.5 * X[:, cols - 1] * X[:, 3] + 0.3 * (X[:, 1] % 5 == 2) + 0.2 * rng.randn(n)
+    p = {**GPU, "num_leaves": 63, "min_data_in_leaf": 5, "learning_rate": 0.2, "max_cat_to_onehot": 4,
+         "min_gain_to_split": 0.0}
+    b = lgb.train(p, lgb.Dataset(X, label=y, params=p, categorical_feature=[1]), 37)
+    if force:
+        monkeypatch.setenv("LGA_PRED_KERNEL", force)
+    for M in (X, X.astype(np.float32)):
+        host = b.predict(M, device="cpu")
+        np.testing.assert_allclose(b.predict(M, device="gpu"), host, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(b.predict(M[:65], device="gpu", num_iteration=5), b.predict(M[:65], device="cpu", num_iteration=5),
+                                   rtol=0, atol=1e-12)
+    yb = (y > np.median(y)).astype(float)
+    bb = lgb.train({**p, "objective": "binary", "min_sum_hessian_in_leaf": 1e9}, lgb.Dataset(X, label=yb, params=p), 3)   # 1-leaf trees
+    np.testing.assert_allclose(bb.predict(X, device="gpu"), bb.predict(X, device="cpu"), rtol=0, atol=1e-12)
+
+
 def test_gpu_cv_and_rstyle_grid_row():
     from lightgbm_amd.rstyle import lgb_cv, lgb_Dataset
     X, y = make_diamonds_like(20000, seed=4)
