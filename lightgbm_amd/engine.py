@@ -9,6 +9,7 @@
 """
 from __future__ import annotations
 
+import math
 import json
 
 import copy
@@ -322,7 +323,30 @@ def _agg_cv_result(raw_results: List[List[Tuple]], eval_train_metric: bool):
                 cvmap[key] = []
             metric_type[key] = one_line[3]
             cvmap[key].append(one_line[2])
-    return [("cv_agg", k, float(np.mean(cvmap[k])), metric_type[k], float(np.std(cvmap[k]))) for k in order]
+    out = []
+    for k in order:
+        mean, std = _mean_std(cvmap[k])
+        out.append(("cv_agg", k, mean, metric_type[k], std))
+    return out
+
+
+def _mean_std(v: List[float]) -> Tuple[float, float]:
+    """(numpy.mean(v), numpy.std(v)) of a handful of fold values by the operations numpy performs on so few elements - a
+    running sum in index order, squared deviations by multiplication - without its per-call overhead (a grid search
+    aggregates tens of thousands of five-element lists); longer lists go to numpy, whose pairwise summation they would
+    take there."""
+    n = len(v)
+    if n == 0 or n >= 8:
+        return float(np.mean(v)), float(np.std(v))
+    total = 0.0
+    for x in v:
+        total += x
+    mean = total / n
+    sq = 0.0
+    for x in v:
+        d = x - mean
+        sq += d * d
+    return mean, math.sqrt(sq / n)
 
 
 def cv(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_round: int = 100, folds=None, nfold: int = 5,
@@ -416,8 +440,19 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
         folds = [(np.flatnonzero(np.isin(qid, tr_q)), np.flatnonzero(np.isin(qid, te_q)))
                  for tr_q, te_q in make_folds(len(group), nfold, None, False, shuffle, seed)]
     else:
+        # the same folds are asked for again and again (every row of a grid search draws them with the same seed): a
+        # table keeps the last few draws, next to the label array they were drawn for
+        key = (n, nfold, bool(stratified), bool(shuffle), int(seed), bool(classification))
         label = train_set.get_label() if stratified else None
-        folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)
+        cache = train_set.__dict__.setdefault("_fold_draws", {})
+        hit = cache.get(key)
+        if hit is not None and (label is None or (hit[0] is not None and np.array_equal(hit[0], label))):
+            folds = hit[1]
+        else:
+            folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)
+            if len(cache) >= 4:
+                cache.clear()
+            cache[key] = (None if label is None else np.array(label, copy=True), folds)
 
     from . import _lib
     on_gpu = _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host")
