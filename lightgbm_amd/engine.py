@@ -427,6 +427,7 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
                                    "multiclassova", "multiclass_ova", "ova", "ovr")
     group = train_set.get_group()
     qid = np.repeat(np.arange(len(group)), group) if group is not None else None
+    drawn = None
     if folds is not None:
         if hasattr(folds, "split"):
             y = train_set.get_label()
@@ -452,7 +453,8 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
             folds = make_folds(n, nfold, label, stratified, shuffle, seed, classification)
             if len(cache) >= 4:
                 cache.clear()
-            cache[key] = (None if label is None else np.array(label, copy=True), folds)
+            cache[key] = hit = [None if label is None else np.array(label, copy=True), folds, None]
+        drawn = hit   # [label the folds were drawn for, folds, digest of the folds once somebody has needed it]
 
     from . import _lib
     on_gpu = _lib.is_hip() and str(get_param(params, "device_type", "gpu")).lower() not in ("cpu", "host")
@@ -478,12 +480,17 @@ def cv_steps(params: Optional[Dict[str, Any]], train_set: Dataset, num_boost_rou
     # the shared bins - are kept on the dataset and reused while the dataset parameters agree.
     fold_sets = None
     if fpreproc is None:
-        import hashlib
-        h = hashlib.sha1()
-        for tr_idx, te_idx in folds:
-            h.update(np.ascontiguousarray(te_idx, dtype=np.int64).tobytes())
-            h.update(b"|")
-        key = (h.hexdigest(), len(folds), json.dumps(train_set.params, sort_keys=True, default=str))
+        digest = drawn[2] if drawn is not None else None
+        if digest is None:
+            import hashlib
+            h = hashlib.sha1()
+            for tr_idx, te_idx in folds:
+                h.update(np.ascontiguousarray(te_idx, dtype=np.int64).tobytes())
+                h.update(b"|")
+            digest = h.hexdigest()
+            if drawn is not None:
+                drawn[2] = digest
+        key = (digest, len(folds), json.dumps(train_set.params, sort_keys=True, default=str))
         cache = train_set.__dict__.setdefault("_cv_fold_sets", {})
         fold_sets = cache.get(key)
         if fold_sets is None:
