@@ -139,7 +139,7 @@ def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable
     alive: Dict[int, List[Any]] = {}      # row -> [generator, pending request, start time]
     exhausted = False
     trace = os.environ.get("LGA_GRID_TRACE")
-    t_start = t_native = t_rows = 0.0
+    t_start = t_native = t_rows = t_first = 0.0
     n_calls = n_booster_iters = 0
     while True:
         t_a = time.perf_counter()
@@ -150,14 +150,16 @@ def _run_rows_batched(next_row: Callable[[], Optional[int]], start_row: Callable
                 break
             t0 = time.time()
             gen = start_row(i)
+            t_gen = time.perf_counter()
             try:
                 alive[i] = [gen, next(gen), t0]
             except StopIteration as stop:
                 finish_row(i, stop.value, time.time() - t0)
+            t_first += time.perf_counter() - t_gen
         if not alive:
             if trace:
                 print(f"[grid trace] {n_calls} native calls, {n_booster_iters} booster iterations: starting rows {t_start:.2f}s, "
-                      f"native calls {t_native:.2f}s, per-row processing {t_rows:.2f}s", flush=True)
+                      f"(of which up to the rows' first request {t_first:.2f}s), native calls {t_native:.2f}s, per-row processing {t_rows:.2f}s", flush=True)
             return
         ids = list(alive)
         n_iters = min(alive[i][1][1] for i in ids)
