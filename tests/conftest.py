@@ -5,6 +5,13 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+# Under pytest-xdist every worker would start one OpenMP team per core (this package's host engine, scikit-learn's
+# histogram boosting): N workers x all cores spin against each other and single tests take minutes instead of
+# seconds.  The workers share the cores instead; this has to happen before any OpenMP runtime is loaded.
+_workers = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "0") or 0)
+if _workers > 1 and "OMP_NUM_THREADS" not in os.environ:
+    os.environ["OMP_NUM_THREADS"] = str(max(1, (os.cpu_count() or 1) // _workers))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
