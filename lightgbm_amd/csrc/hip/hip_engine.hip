@@ -59,6 +59,7 @@ namespace {
 struct HostBlockCache {
   std::mutex mu;
   std::map<size_t, std::vector<void*>> free_blocks[2];   // [mapped][capacity]
+  size_t small_bytes = 0;                                // bytes of cached blocks of at most 1 MiB
   // blocks stay allocated until the process ends: the runtime may already be shutting down when statics die
 };
 HostBlockCache& host_block_cache() {
@@ -78,6 +79,7 @@ void* host_block_acquire(size_t bytes, bool mapped, size_t* capacity) {
     if (!v.empty()) {
       void* p = v.back();
       v.pop_back();
+      if (cap <= ((size_t)1 << 20)) c.small_bytes -= cap;
       return p;
     }
   }
@@ -91,10 +93,20 @@ void host_block_release(void* p, size_t capacity, bool mapped) {
   {
     std::lock_guard<std::mutex> lock(c.mu);
     auto& v = c.free_blocks[mapped ? 1 : 0][capacity];
-    // keep a few blocks per size class (the boosters of a grid come and go by the dozen), free what exceeds that:
-    // page-locked memory must not grow to the peak of everything that ever lived at once
-    const size_t keep = capacity <= ((size_t)1 << 20) ? 64 : 4;
-    if (v.size() < keep) { v.push_back(p); return; }
+    // Small blocks are kept up to a byte budget, large ones four per size class; what exceeds that is freed:
+    // page-locked memory must not grow to the peak of everything that ever lived at once.  The budget holds the
+    // blocks of the few hundred boosters a parameter grid keeps alive (a hipHostFree costs ~1.4 ms, and a grid
+    // releases its boosters by the hundred).
+    static const size_t budget = [] {
+      const char* e = std::getenv("LGA_HOST_CACHE_MB");
+      return (size_t)std::max(0, e ? std::atoi(e) : 512) << 20;
+    }();
+    const bool small = capacity <= ((size_t)1 << 20);
+    if (small ? c.small_bytes + capacity <= budget : v.size() < 4) {
+      v.push_back(p);
+      if (small) c.small_bytes += capacity;
+      return;
+    }
   }
   (void)hipHostFree(p);
 }
