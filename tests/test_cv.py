@@ -131,3 +131,39 @@ def test_register_logger_receives_the_messages():
     import pytest
     with pytest.raises(TypeError):
         lgb.register_logger(object())
+
+
+def test_fold_statistics_in_plain_python_equal_numpys_bit_for_bit():
+    """cv aggregates its handful of fold values without numpy's per-call overhead (engine._mean_std); the table of a
+    grid search must not depend on that shortcut."""
+    from lightgbm_amd.engine import _mean_std
+    rng = np.random.default_rng(5)
+    for _ in range(20000):
+        n = int(rng.integers(1, 12))
+        v = (rng.standard_normal(n) * 10.0 ** rng.integers(-6, 6)).tolist()
+        m, s = _mean_std(v)
+        assert m == float(np.mean(v)) and s == float(np.std(v))
+
+
+def test_cached_fold_draws_follow_the_labels_and_the_arguments():
+    """cv keeps the folds it drew on the dataset (a grid search draws the same folds for every row); new labels,
+    another seed or another fold count must draw anew, and a repeated call must give the same numbers."""
+    X, y = make_regression(600, 5, seed=3)
+    params = {"objective": "regression", "num_leaves": 7, "min_data_in_leaf": 5, "verbose": -1, "device_type": "cpu"}
+    d = lgb.Dataset(X, label=y, params=params, free_raw_data=False)
+    a = lgb.cv(params, d, num_boost_round=5, nfold=3, stratified=False, seed=1)
+    assert len(d._fold_draws) == 1
+    b = lgb.cv(params, d, num_boost_round=5, nfold=3, stratified=False, seed=1)
+    assert a == b and len(d._fold_draws) == 1
+    c = lgb.cv(params, d, num_boost_round=5, nfold=3, stratified=False, seed=2)
+    assert len(d._fold_draws) == 2 and c != a
+    lgb.cv(params, d, num_boost_round=5, nfold=4, stratified=False, seed=1)
+    assert len(d._fold_draws) == 3
+    # the same arguments on a fresh dataset: what the cache returns is what a first draw gives
+    d2 = lgb.Dataset(X, label=y, params=params, free_raw_data=False)
+    assert lgb.cv(params, d2, num_boost_round=5, nfold=3, stratified=False, seed=1) == a
+    # new labels under the same key: drawn (and computed) anew
+    d.set_label(y[::-1].copy())
+    e = lgb.cv(params, d, num_boost_round=5, nfold=3, stratified=False, seed=1)
+    d3 = lgb.Dataset(X, label=y[::-1].copy(), params=params, free_raw_data=False)
+    assert e == lgb.cv(params, d3, num_boost_round=5, nfold=3, stratified=False, seed=1)
