@@ -470,6 +470,39 @@ def test_index_checking_build_catches_a_bad_row_and_passes_clean_runs():
     assert r.returncode == 0 and "CAUGHT" in r.stdout and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("budget", ["0", "1"])
+def test_the_page_locked_block_cache_is_a_matter_of_time_only(budget):
+    """Released boosters leave their page-locked host blocks in a process-wide cache up to a byte budget
+    (LGA_HOST_CACHE_MB, read once per process).  With no budget every release frees its blocks at once, with 1 MiB the
+    cache overflows after a few boosters: waves of boosters that come and go - a grid search's pattern - train the
+    same models either way."""
+    import json, os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, json, numpy as np
+        sys.path.insert(0, %r)
+        import lightgbm_amd as lgb
+        rng = np.random.RandomState(3)
+        X = rng.randn(20000, 6); y = X[:, 0] * X[:, 1] + np.sin(X[:, 2]) + 0.1 * rng.randn(20000)
+        p = {"objective": "regression", "num_leaves": 31, "verbose": -1, "device_type": "gpu", "bagging_fraction": 0.8,
+             "bagging_freq": 2, "min_data_in_leaf": 20}
+        d = lgb.Dataset(X, label=y, params=p, free_raw_data=False)
+        out = []
+        for wave in range(3):     # every cv creates 5 fold boosters and drops them
+            r = lgb.cv({**p, "learning_rate": 0.1 + 0.05 * wave}, d, num_boost_round=12, nfold=5, stratified=False, seed=1)
+            out.append(r[sorted(r)[0]])
+        b = lgb.train(p, d, 5)
+        out.append(b.predict(X[:50], device="cpu").tolist())
+        print("RESULT" + json.dumps(out))
+    """) % (os.path.join(os.path.dirname(__file__), ".."),)
+
+    def run(env):
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=170)
+        assert r.returncode == 0 and "RESULT" in r.stdout, r.stdout + r.stderr
+        return json.loads(r.stdout[r.stdout.index("RESULT") + 6:])
+    base = {k: v for k, v in os.environ.items() if k != "LGA_HOST_CACHE_MB"}
+    assert run(dict(base, LGA_HOST_CACHE_MB=budget)) == run(base)
+
+
 @pytest.mark.parametrize("lines,flight", [("0", "1"), ("1", "1"), ("1", "2"), ("0", "2"), ("1", "4")])
 def test_row_line_layout_grows_the_same_trees(lines, flight, monkeypatch):
     """The large-data paths - bin records interleaved with the packed gradients, two (or four: large leaves then get
